@@ -1,0 +1,217 @@
+/* orc_cloud.c -- oracle restatement of the OpenFOAM-side particle path (TEST INFRASTRUCTURE ONLY).
+ *
+ *   orc_ergun_wenyu_jd       : lammpsFoam/dragModels/ErgunWenYu/ErgunWenYu.C:86-145
+ *   orc_syamlal_obrien_jd    : lammpsFoam/dragModels/SyamlalOBrien/SyamlalOBrien.C:85-144
+ *   orc_drag_on_particles    : lammpsFoam/enhancedCloud.C:56-76 (alpha), :83-109 (Ur), :112-257 (forces)
+ *   orc_particle_to_eulerian : lammpsFoam/enhancedCloud.C:911-980
+ *   orc_calc_tc_fields       : lammpsFoam/enhancedCloud.C:316-441
+ *   orc_adjust_timestep      : lammpsFoam/softParticleCloud.C:209-261
+ *   orc_cell_owner           : the cell that OpenFOAM's tracking (softParticle.C:102-151, [3P]
+ *                              particle::trackToFace) ends in, for ONE uniform blockMesh hex block
+ *                              whose cells are numbered ix + nx*(iy + ny*iz) [3P blockMesh ordering]
+ *
+ * OpenFOAM constants [3P]: ROOTVSMALL = 1e-150 (double precision), pi = constant::mathematical::pi.
+ * Fields are plain arrays: scalars [n], vectors AoS [3*n].
+ */
+#include <math.h>
+#include <stddef.h>
+#include "sedifoam_oracle.h"
+
+#define ROOTVSMALL 1.0e-150
+#define FOAM_PI 3.14159265358979323846
+
+static double dmax(double a, double b) { return a > b ? a : b; }
+
+void orc_ergun_wenyu_jd(int n, const double *Ur, const double *alpha, const double *pd,
+                        double nuf, double rhof, double *Jd)
+{
+  int i;
+  for (i = 0; i < n; i++) {
+    double beta = dmax(1.0 - alpha[i], ROOTVSMALL);                 /* :104 */
+    double bp = pow(beta, -2.65);                                   /* :105 */
+    double Re = dmax(beta * Ur[i] * pd[i] / nuf, ROOTVSMALL);       /* :106 */
+    double Cds = 24.0 * (1.0 + 0.15 * pow(Re, 0.687)) / Re;         /* :107 */
+    if (Re > 1000.0) Cds = 0.44;                                    /* :111-114 */
+    double K = 0.75 * Cds * rhof * Ur[i] * bp / pd[i];              /* :118 Wen-Yu */
+    if (beta <= 0.8) {                                              /* :124-131 Ergun */
+      double bd = beta * pd[i];
+      K = 150.0 * alpha[i] * nuf * rhof / (bd * bd) + 1.75 * rhof * Ur[i] / (beta * pd[i]);
+    }
+    Jd[i] = K;
+  }
+}
+
+void orc_syamlal_obrien_jd(int n, const double *Ur, const double *alpha, const double *pd,
+                           double nuf, double rhof, double *Jd)
+{
+  int i;
+  for (i = 0; i < n; i++) {
+    double beta = dmax(1.0 - alpha[i], ROOTVSMALL);                 /* :105 */
+    double Ai = pow(beta, 4.14);                                    /* :106 */
+    double Bi = 0.8 * pow(beta, 1.28);                              /* :107 */
+    if (beta > 0.85) Bi = pow(beta, 2.65);                          /* :111-114 */
+    double Re = dmax(Ur[i] * pd[i] / nuf, ROOTVSMALL);              /* :117 */
+    double a = 0.06 * Re;
+    double Vr = 0.5 * (Ai - 0.06 * Re + sqrt(a * a + 0.12 * Re * (2.0 * Bi - Ai) + Ai * Ai)); /* :119-124 */
+    double s = 0.63 + 4.8 * sqrt(Vr / Re);
+    double Cds = s * s;                                             /* :126 */
+    Jd[i] = 0.75 * Cds * rhof * Ur[i] / (pd[i] * (Vr * Vr));        /* :143 */
+  }
+}
+
+void orc_cell_owner(int n, const double *x, const double origin[3], const double dx[3],
+                    const int ncell[3], int *cell)
+{
+  int i, k;
+  for (i = 0; i < n; i++) {
+    int c[3], inside = 1;
+    for (k = 0; k < 3; k++) {
+      double s = (x[3 * i + k] - origin[k]) / dx[k];
+      double fl = floor(s);
+      if (fl < 0.0 || fl >= (double)ncell[k]) inside = 0;
+      c[k] = (int)fl;
+    }
+    cell[i] = inside ? c[0] + ncell[0] * (c[1] + ncell[1] * c[2]) : -1;
+  }
+}
+
+void orc_drag_on_particles(const orc_cloud_flags *fl, int dragModel, int n, const int *cell,
+                           const double *pos, const double *d, const double *U,
+                           const double *UOld, const double *gamma, const double *UfSmoothed,
+                           const double *gradp, const double *DDtUf, const double *curlU,
+                           double *Uri, double *magUri, double *Jd, double *pDrag,
+                           double *pDuDt)
+{
+  int i, k;
+  /* updateParticleUr :83-109 ; updateParticleAlpha :56-76 (alpha buffered in pDuDt[0..n)) */
+  for (i = 0; i < n; i++) {
+    int c = cell[i];
+    if (c < 0) {
+      Uri[3 * i] = Uri[3 * i + 1] = Uri[3 * i + 2] = 0.0;
+      magUri[i] = 0.0;
+      continue;
+    }
+    for (k = 0; k < 3; k++) Uri[3 * i + k] = UfSmoothed[3 * c + k] - U[3 * i + k];
+    magUri[i] = sqrt(Uri[3 * i] * Uri[3 * i] + Uri[3 * i + 1] * Uri[3 * i + 1] +
+                     Uri[3 * i + 2] * Uri[3 * i + 2]);
+  }
+  /* Jd_ = drag_->Jd(magUri_) :129, with pAlpha_ = gamma[cell] and pDia_ = d */
+  for (i = 0; i < n; i++) {
+    double a = (cell[i] >= 0) ? gamma[cell[i]] : 0.0;
+    if (dragModel == 0) orc_ergun_wenyu_jd(1, &magUri[i], &a, &d[i], fl->nub, fl->rhob, &Jd[i]);
+    else orc_syamlal_obrien_jd(1, &magUri[i], &a, &d[i], fl->nub, fl->rhob, &Jd[i]);
+  }
+  for (i = 0; i < n; i++) {
+    int c = cell[i];
+    double F[3] = {0.0, 0.0, 0.0};
+    for (k = 0; k < 3; k++) pDrag[3 * i + k] = pDuDt[3 * i + k] = 0.0; /* :125-126 */
+    if (c < 0) continue;                                            /* :141 */
+    double Vol = FOAM_PI * d[i] * d[i] * d[i] / 6.0;                /* softParticle.H:270-273 */
+    double alpha = gamma[c];
+    for (k = 0; k < 3; k++) pDuDt[3 * i + k] = DDtUf[3 * c + k];    /* :155 */
+    if (fl->particleDrag)                                           /* :157-162 */
+      for (k = 0; k < 3; k++) F[k] += Jd[i] * (1.0 - alpha) * Vol * Uri[3 * i + k];
+    if (fl->particlePressureGrad)                                   /* :163-168 */
+      for (k = 0; k < 3; k++) F[k] += -gradp[3 * c + k] * Vol;
+    if (fl->particleBuoyancy)                                       /* :169-173 */
+      for (k = 0; k < 3; k++) F[k] += -fl->gravity[k] * fl->rhob * Vol;
+    if (fl->particleAddedMass) {                                    /* :175-188 */
+      double acc[3], m = 0.0;
+      for (k = 0; k < 3; k++) {
+        double dupdt = (U[3 * i + k] - UOld[3 * i + k]) / fl->deltaT;
+        acc[k] = DDtUf[3 * c + k] - dupdt;
+        m += acc[k] * acc[k];
+      }
+      m = sqrt(m);
+      if (m > 10)
+        for (k = 0; k < 3; k++) acc[k] = acc[k] / (m + ROOTVSMALL) * 10;
+      for (k = 0; k < 3; k++) F[k] += 0.5 * fl->rhob * Vol * acc[k];
+    }
+    if (fl->particleLift) {                                         /* :189-196 */
+      const double *w = &curlU[3 * c];
+      const double *u = &Uri[3 * i];
+      double cr[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2],
+                      u[0] * w[1] - u[1] * w[0]};
+      double magw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      for (k = 0; k < 3; k++)
+        F[k] += 1.6 * fl->rhob * sqrt(fl->nub) * (d[i] * d[i]) * cr[k] / sqrt(magw + ROOTVSMALL);
+    }
+    if (fl->lubricationForce) {                                     /* :235-248 (y wall at 0) */
+      double distMin = 0.0001 * d[i], distMax = 0.1 * d[i];
+      double distWall = pos[3 * i + 1] - 0.5 * d[i];
+      double pVel = U[3 * i + 1];
+      if (distWall < distMax && distWall > distMin)
+        F[1] += 6 * 3.1416 * fl->nub * fl->rhob * (-pVel) / distWall * (d[i] * d[i]) / 4.0 * 1.0;
+    }
+    for (k = 0; k < 3; k++) pDrag[3 * i + k] = F[k];
+  }
+}
+
+void orc_particle_to_eulerian(int n, const int *cell, const double *d, const double *U,
+                              int ncells, const double *V, double *gamma, double *Ue)
+{
+  int i, c, k;
+  for (c = 0; c < ncells; c++) {
+    gamma[c] = 0.0;
+    Ue[3 * c] = Ue[3 * c + 1] = Ue[3 * c + 2] = 0.0;                /* :914-915 */
+  }
+  for (i = 0; i < n; i++) {                                         /* :918-928 */
+    double Vol = FOAM_PI * d[i] * d[i] * d[i] / 6.0;
+    c = cell[i];
+    if (c < 0) continue; /* such particles were already dropped from the cloud (softParticle.C:177-184) */
+    gamma[c] += Vol;
+    for (k = 0; k < 3; k++) Ue[3 * c + k] += Vol * U[3 * i + k];
+  }
+  for (c = 0; c < ncells; c++) {
+    gamma[c] /= V[c];                                               /* :930 */
+    for (k = 0; k < 3; k++) Ue[3 * c + k] /= V[c];                  /* :941 */
+    if (gamma[c] > ROOTVSMALL)                                      /* :955-962 */
+      for (k = 0; k < 3; k++) Ue[3 * c + k] /= gamma[c];
+  }
+}
+
+void orc_calc_tc_fields(int n, const int *cell, const double *d, const double *U,
+                        const double *Jd, int ncells, const double *V, const double *gamma,
+                        const double *UfSmoothed, double *Asrc, double *Omega)
+{
+  int i, c, k;
+  for (c = 0; c < ncells; c++) {
+    Omega[c] = 0.0;
+    Asrc[3 * c] = Asrc[3 * c + 1] = Asrc[3 * c + 2] = 0.0;          /* :318-320 */
+  }
+  for (i = 0; i < n; i++) {                                         /* :364-389 */
+    c = cell[i];
+    if (c < 0) continue;
+    double Vol = FOAM_PI * d[i] * d[i] * d[i] / 6.0;
+    double omg = Vol * Jd[i] / V[c];
+    Omega[c] += omg;
+    for (k = 0; k < 3; k++) Asrc[3 * c + k] += omg * (U[3 * i + k] - UfSmoothed[3 * c + k]);
+  }
+  for (c = 0; c < ncells; c++) {
+    Omega[c] *= 0;                                                  /* :391 */
+    for (k = 0; k < 3; k++) {
+      Asrc[3 * c + k] = Asrc[3 * c + k] * (1 - gamma[c]);           /* :407-408 */
+      Asrc[3 * c + k] /= (1 - gamma[c]);                            /* :415-416 */
+    }
+  }
+}
+
+int orc_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double *dtLampAdj,
+                        int *solidStepsPerDt, int *subCycles, int *subSteps)
+{
+  double dnSub = round(deltaT / dtLampIn);                          /* :216 */
+  if (dnSub == 0) dnSub++;                                          /* :217 */
+  int sc = subCycles_in;
+  int steps = ((int)dnSub / sc) * sc;                               /* :219-221 */
+  *dtLampAdj = deltaT / dnSub;                                      /* :224 */
+  if (sc >= steps) {                                                /* :229-234 */
+    sc = steps;
+    *subSteps = 1;
+  } else {
+    *subSteps = steps / sc;                                         /* :237-238 */
+    if (steps % sc != 0) return -1;
+  }
+  *solidStepsPerDt = steps;
+  *subCycles = sc;
+  return 0;
+}
