@@ -1,0 +1,273 @@
+/* sedifoam_amd.h -- C-ABI of libsedifoam_amd.so: the MI355X-native (gfx950, HIP) replacement of
+ * sediFoam's per-step CFD-DEM particle hot path.
+ *
+ * Three groups of entry points, all `extern "C"`, plain pointers and sizes, int status returns
+ * (0 = ok, <0 = error; text via sf_last_error()).  Paths cited are relative to the reference
+ * checkout (xiaoh/sediFoam).
+ *
+ *  (1) sf_lammps_*  : the patched LAMMPS C library interface the OpenFOAM side binds
+ *                     (interfaceToLammps/library.h:29-63).  Same argument meaning, same AoS
+ *                     host buffers (xyz-interleaved doubles, int32 ids/tags, caller allocates).
+ *                     With SEDIFOAM_AMD_LAMMPS_NAMES defined before including this header the
+ *                     reference's own names (lammps_open, lammps_step, ...) are provided as
+ *                     inline forwards so softParticleCloud.C compiles against it unchanged.
+ *  (2) sfk_*        : per-kernel entry points on DEVICE pointers, one per reference
+ *                     PairStyle / FixStyle / dragModel / cloud method on the hot path.
+ *  (3) sf_cloud_*   : the enhancedCloud surface (lammpsFoam/enhancedCloud.H:183-249) on
+ *                     device-resident fields, driving (1) without host marshalling.
+ *  (4) sf_dem_*     : fine-grained stepping + halo pack/unpack used by the one-process-per-GPU
+ *                     driver (ghost-particle exchange over RCCL, sedifoam_amd/halo.py).
+ *
+ * All device work is issued on the engine's own HIP stream; functions that hand data to the
+ * host synchronise that stream before returning.  One engine per process per GPU; calls on one
+ * engine must come from one host thread at a time (same rule as the reference: single-threaded
+ * per MPI rank).
+ */
+#ifndef SEDIFOAM_AMD_H
+#define SEDIFOAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *sf_last_error(void);
+/* 0 if a HIP device is usable; never falls back to a CPU path */
+int sf_device_check(void);
+const char *sf_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) LAMMPS library surface -- interfaceToLammps/library.h:29-63, library.cpp:40-621
+ * ---------------------------------------------------------------------------------------- */
+
+/* library.h:29 lammps_open(int, char**, MPI_Comm, void**): `comm` is carried opaquely (this
+ * library needs no MPI: one engine per process, ranks are wired up by sf_dem_* below). */
+int sf_lammps_open(int argc, char **argv, intptr_t comm, void **ptr);
+/* library.h:30 */
+int sf_lammps_close(void *ptr);
+/* library.h:31  run every line of an input script (library.cpp:63-67) */
+int sf_lammps_file(void *ptr, const char *path);
+/* library.h:32  one input-script command (library.cpp:73-77).  Understood commands are the ones
+ * the reference's in.lammps files use: units, atom_style sphere, atom_modify, boundary, newton,
+ * communicate, processors, read_data (or sf_dem_create_atoms), neighbor, neigh_modify, pair_style {gran/hertzFix/history,
+ * gran/hooke/history, lubricate/poly, hybrid/overlay}, pair_coeff, timestep, velocity all set,
+ * fix {nve/sphere, gravity, fdrag, wall/gran, wall/granFix, cohesive}, run, thermo*, dump and
+ * group (accepted, no effect).  returns NULL like LAMMPS, or an error string. */
+const char *sf_lammps_command(void *ptr, const char *line);
+/* library.h:34 (debug barrier) -- a stream synchronise here */
+int sf_lammps_sync(void *ptr);
+/* library.h:35 */
+int sf_lammps_get_global_n(void *ptr);
+/* library.h:38  np_[nprocs]: atoms owned by each rank (this rank's slot filled; caller reduces) */
+int sf_lammps_get_initial_np(void *ptr, int *np_);
+/* library.h:40-42  diam = 2 r; rho = 3 m / (4 pi' r^3) with the reference's pi' (library.cpp:200) */
+int sf_lammps_get_initial_info(void *ptr, double *coords, double *velos, double *diam,
+                               double *rho_, int *tag_, int *lmpCpuId_, int *type_);
+/* library.h:45 */
+int sf_lammps_get_local_n(void *ptr);
+/* library.h:48  {xlo,xhi,ylo,yhi,zlo,zhi} of this rank's sub-domain */
+int sf_lammps_get_local_domain(void *ptr, double *domain_);
+/* library.h:51-52 */
+int sf_lammps_get_local_info(void *ptr, double *coords, double *velos_, int *foamCpuId_,
+                             int *lmpCpuId_, int *tag_);
+/* library.h:55-56  rows matched to atoms by tag (library.cpp:344-366); DuDt accepted and
+ * ignored exactly as the reference does (library.cpp:314-367 never reads it) */
+int sf_lammps_put_local_info(void *ptr, int nLocalIn, const double *fdrag, const double *DuDt,
+                             const int *foamCpuIdIn, const int *tagIn);
+/* library.h:58  "run n pre no post no" (library.cpp:372-386) */
+int sf_lammps_step(void *ptr, int n);
+/* library.h:59-60 */
+int sf_lammps_set_timestep(void *ptr, double dt_i);
+double sf_lammps_get_timestep(void *ptr);
+/* library.h:61-63 (particle injection / removal; tag[] is double in the reference) */
+int sf_lammps_create_particle(void *ptr, int npAdd, const double *position, const double *tag,
+                              double diameter, double rho, int type, const double *vel);
+int sf_lammps_delete_particle(void *ptr, const int *deleteList, int nDelete);
+
+/* Atoms without a data file: what `read_data` would have loaded (atom_style sphere rows:
+ * tag type diameter density x y z).  mass = 4/3 pi r^3 rho like LAMMPS read_data. */
+int sf_dem_create_atoms(void *ptr, int n, const double *x /*3n*/, const double *v /*3n|NULL*/,
+                        const double *omega /*3n|NULL*/, const double *diameter,
+                        const double *density, const int *tag /*n|NULL*/, const int *type /*n|NULL*/);
+int sf_dem_set_box(void *ptr, const double lo[3], const double hi[3]);
+
+/* ------------------------------------------------------------------------------------------
+ * (4) fine-grained DEM stepping, device access and ghost-particle halo
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int nlocal, nghost, capacity, max_neigh_used, max_neigh_cap;
+  long long nbuilds, nsteps;
+  long long npairs_full; /* sum of numneigh over owned atoms (full list) */
+} sf_dem_info;
+int sf_dem_get_info(void *ptr, sf_dem_info *out);
+/* device pointers into the engine's state (valid until the next rebuild / step):
+ *   xr, vm, om : double4 records (x,y,z,radius) (vx,vy,vz,rmass) (wx,wy,wz,0)
+ *   fdrag      : component-major [3][capacity] doubles ; tag/type : int32 [capacity] */
+typedef struct {
+  void *xr, *vm, *om, *force, *torque;
+  double *fdrag, *DuDt, *vOld;
+  int *tag, *type, *foamCpuId;
+  int nlocal, nghost, capacity;
+  void *stream; /* hipStream_t */
+} sf_dem_device_view;
+int sf_dem_device_view_get(void *ptr, sf_dem_device_view *out);
+/* forces/torques of owned atoms to host AoS (3n each, engine order) with tags */
+int sf_dem_get_forces(void *ptr, double *f, double *torque, double *omega, int *tag);
+/* touching pairs (tag_i < tag_j, shear oriented i->j) ; returns count or <0 */
+long long sf_dem_get_history(void *ptr, long long max, int *tag_i, int *tag_j, double *shear);
+/* per-atom wall shear of wall fix w, AoS 3n in engine order */
+int sf_dem_get_wall_shear(void *ptr, int w, double *shear);
+
+/* sub-domain decomposition (1-D slabs along x; rank r owns [sublo, subhi) of the global box).
+ * left/right < 0 : no neighbour on that side (wall or self-periodic handled internally). */
+int sf_dem_set_subdomain(void *ptr, int rank, int nranks, double sublo, double subhi);
+/* step phases (what sf_lammps_step does internally, exposed for the multi-rank driver) */
+int sf_dem_run_begin(void *ptr);            /* initial_integrate with the stored forces */
+int sf_dem_substep(void *ptr, int last);    /* fused force + final [+ next initial] kernel */
+int sf_dem_need_rebuild(void *ptr);         /* 1 if any owned atom moved > skin/2 (synchronises) */
+int sf_dem_setup(void *ptr);                /* first run's setup: forces with shearupdate = 0 */
+int sf_dem_rebuild_begin(void *ptr);        /* shear history -> partner tags; forget ghosts */
+int sf_dem_rebuild_sort(void *ptr);         /* pbc + sort owned atoms by bin (after migration) */
+int sf_dem_rebuild_finish(void *ptr);       /* periodic ghosts (y,z), bins, full list, history */
+/* halo: side 0 = towards -x neighbour, 1 = towards +x.  Buffers are DEVICE doubles.
+ * border records (on rebuild)  : 13 doubles / atom (x y z r vx vy vz m wx wy wz tag type)
+ * forward records (every step) : 9 doubles / atom  (x y z vx vy vz wx wy wz)
+ * migrate records (on rebuild) : variable, see DESIGN.md */
+long long sf_dem_border_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_atoms);
+int sf_dem_border_unpack(void *ptr, int side, const double *dev_buf, long long natoms);
+long long sf_dem_forward_pack(void *ptr, int side, double xshift, double *dev_buf);
+int sf_dem_forward_unpack(void *ptr, int side, const double *dev_buf, long long natoms);
+long long sf_dem_migrate_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_doubles);
+int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
+int sf_dem_migrate_record_doubles(void *ptr);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) per-kernel entry points (device pointers; stream = hipStream_t or NULL)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  double kn, kt, gamman, gammat, xmu;
+  int dampflag;
+} sfk_gran_params;
+/* PairGranHertzFixHistory::settings  pair_gran_hertzFix_history.cpp:293-317 */
+int sfk_gran_settings(sfk_gran_params *p, double kn, int kt_null, double kt, double gamman,
+                      int gammat_null, double gammat, double xmu, int dampflag, double nktv2p);
+
+/* PairGranHertzFixHistory::compute  pair_gran_hertzFix_history.cpp:45-287 on a LAMMPS-shaped
+ * half list in CSR form (rows = owned atoms ilist[ii]; first[inum+1]; jlist; touch; shear[3*])
+ * and AoS atom arrays (double[n][3]) -- what a PairStyle adapter holds after flattening
+ * NeighList.  hertz = 1: gran/hertzFix/history, 0: gran/hooke/history.  f/torque are
+ * accumulated (+=) with FP64 atomics for the j side when j < nlocal. */
+int sfk_pair_gran_history_compute(int hertz, const sfk_gran_params *p, double dt, int shearupdate,
+                                  int nlocal, int inum, const int *ilist, const int *first,
+                                  const int *jlist, int *touch, double *shear, const double *x,
+                                  const double *v, const double *omega, const double *radius,
+                                  const double *rmass, const int *mask, int freeze_group_bit,
+                                  double *f, double *torque, void *stream);
+/* FixCohe::post_force  fix_cohesive.cpp:138-263 (half list, CSR) */
+int sfk_fix_cohesive_post_force(double ah, double lam, double smin, double smax, int opt,
+                                int nlocal, int newton_pair, const int *ilist, const int *first,
+                                const int *jlist, const double *x, const double *radius,
+                                const int *mask, int groupbit, double *f, void *stream);
+/* PairLubricatePoly::compute  pair_lubricate_poly.cpp:65-444 (full list, CSR, no shearing) */
+typedef struct {
+  double mu;
+  int flaglog, flagfld, flagHI, flagVF;
+  double cut_inner, cut_global, R0, RT0, RS0, vxmu2f;
+} sfk_lub_params;
+int sfk_pair_lubricate_poly_compute(const sfk_lub_params *p, int inum, const int *ilist,
+                                    const int *first, const int *jlist, const double *x,
+                                    const double *v, const double *omega, const double *radius,
+                                    double *f, double *torque, void *stream);
+/* FixFluidDrag::post_force  fix_fluid_drag.cpp:114-164 (AoS [n][3]) */
+int sfk_fix_fluid_drag_post_force(int nlocal, double dt, double carrier_rho, const double *v,
+                                  const double *rmass, const double *radius, const int *mask,
+                                  int groupbit, const double *ffluiddrag, const double *DuDt,
+                                  double *vOld, double *f, void *stream);
+/* dragModel::Jd  ErgunWenYu.C:86-145 (model 0) / SyamlalOBrien.C:85-144 (model 1) */
+int sfk_drag_model_jd(int model, int n, const double *Ur, const double *alpha, const double *pd,
+                      double nuf, double rhof, double *Jd, void *stream);
+/* cell owner of a uniform blockMesh hex block (the result of softParticle::move tracking,
+ * softParticle.C:102-151): cell = ix + nx*(iy + ny*iz), -1 outside.  x AoS [n][3] */
+int sfk_cell_owner(int n, const double *x, const double origin[3], const double dx[3],
+                   const int ncell[3], int *cell, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (3) enhancedCloud surface -- lammpsFoam/enhancedCloud.H:183-249, enhancedCloud.C
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  /* constant/cloudProperties + transportProperties keys read at enhancedCloud.C:573-608 */
+  int dragModel;          /* 0 ErgunWenYu, 1 SyamlalOBrien  (cloudProperties: dragModel) */
+  int subCycles;
+  int particleDrag, particlePressureGrad, particleBuoyancy, particleAddedMass, particleLift,
+      lubricationForce;
+  double gravity[3];      /* cloudProperties: g */
+  double rhob, nub;       /* transportProperties */
+  double maxPossibleAlpha;
+} sf_cloud_props;
+/* uniform hex block mesh (blockMeshDict: hex (...) (nx ny nz) simpleGrading (1 1 1)) */
+typedef struct {
+  double origin[3], dx[3];
+  int n[3];
+} sf_cloud_mesh;
+
+int sf_cloud_create(void *lmp, const sf_cloud_mesh *mesh, const sf_cloud_props *props,
+                    double deltaT, void **cloud);
+int sf_cloud_destroy(void *cloud);
+/* fluid-side inputs, host AoS [ncells][3] (Uf, DDtUf, gradp = fvc::grad(p), curlU = fvc::curl(Uf));
+ * any pointer may be NULL = keep previous (zero initially) */
+int sf_cloud_set_fluid(void *cloud, const double *Uf, const double *DDtUf, const double *gradp,
+                       const double *curlU);
+/* enhancedCloud::evolve()  enhancedCloud.C:669-787 */
+int sf_cloud_evolve(void *cloud);
+/* enhancedCloud::calcTcFields()  enhancedCloud.C:316-441 */
+int sf_cloud_calc_tc_fields(void *cloud);
+/* accessors: gamma (alpha) [ncells], Ue [ncells][3], Asrc [ncells][3], Omega [ncells] to host */
+int sf_cloud_get_fields(void *cloud, double *gamma, double *Ue, double *Asrc, double *Omega);
+/* per-particle results of the last evolve sub-cycle in tag order (n = particle count):
+ * cell [n], pDrag [n][3], Jd [n] ; any may be NULL */
+int sf_cloud_get_particles(void *cloud, int *tag, int *cell, double *pDrag, double *Jd);
+int sf_cloud_particle_count(void *cloud);
+/* softParticleCloud::adjustLampTimestep  softParticleCloud.C:209-261 (done by sf_cloud_create;
+ * exposed for tests) */
+int sf_cloud_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double *dtLampAdj,
+                             int *solidStepsPerDt, int *subCycles, int *subSteps);
+/* timers in the reference's buckets (writeCPUTime.H:1-19): seconds since creation */
+typedef struct {
+  double evolve, calcTc, dragOnParticles, lammps, particleMove, scatter;
+} sf_cloud_timers;
+int sf_cloud_get_timers(void *cloud, sf_cloud_timers *t);
+
+#ifdef __cplusplus
+}
+#endif
+
+#ifdef SEDIFOAM_AMD_LAMMPS_NAMES
+/* drop-in spelling of interfaceToLammps/library.h for softParticleCloud.C */
+static inline void lammps_open(int a, char **b, intptr_t c, void **p) { sf_lammps_open(a, b, c, p); }
+static inline void lammps_close(void *p) { sf_lammps_close(p); }
+static inline void lammps_file(void *p, char *s) { sf_lammps_file(p, s); }
+static inline char *lammps_command(void *p, char *s) { return (char *)sf_lammps_command(p, s); }
+static inline void lammps_sync(void *p) { sf_lammps_sync(p); }
+static inline int lammps_get_global_n(void *p) { return sf_lammps_get_global_n(p); }
+static inline void lammps_get_initial_np(void *p, int *n) { sf_lammps_get_initial_np(p, n); }
+static inline void lammps_get_initial_info(void *p, double *c, double *v, double *d, double *r,
+                                           int *t, int *l, int *ty)
+{ sf_lammps_get_initial_info(p, c, v, d, r, t, l, ty); }
+static inline int lammps_get_local_n(void *p) { return sf_lammps_get_local_n(p); }
+static inline void lammps_get_local_domain(void *p, double *d) { sf_lammps_get_local_domain(p, d); }
+static inline void lammps_get_local_info(void *p, double *c, double *v, int *f, int *l, int *t)
+{ sf_lammps_get_local_info(p, c, v, f, l, t); }
+static inline void lammps_put_local_info(void *p, int n, double *fd, double *du, int *f, int *t)
+{ sf_lammps_put_local_info(p, n, fd, du, f, t); }
+static inline void lammps_step(void *p, int n) { sf_lammps_step(p, n); }
+static inline void lammps_set_timestep(void *p, double dt) { sf_lammps_set_timestep(p, dt); }
+static inline double lammps_get_timestep(void *p) { return sf_lammps_get_timestep(p); }
+static inline void lammps_create_particle(void *p, int n, double *x, double *t, double d,
+                                          double r, int ty, double *v)
+{ sf_lammps_create_particle(p, n, x, t, d, r, ty, v); }
+static inline void lammps_delete_particle(void *p, int *l, int n) { sf_lammps_delete_particle(p, l, n); }
+#endif
+
+#endif /* SEDIFOAM_AMD_H */

@@ -1,0 +1,59 @@
+"""Build libsedifoam_amd.so in-tree with hipcc for gfx950 (no GPU needed: hipcc cross-compiles)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libsedifoam_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "sedifoam_amd.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    objs = []
+    for src in _sources():
+        obj = os.path.join(OBJDIR, src[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(CSRC, src)] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+        return r
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

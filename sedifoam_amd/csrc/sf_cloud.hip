@@ -1,0 +1,645 @@
+// sf_cloud.hip -- the OpenFOAM-side particle path on device-resident state:
+//   dragModel::Jd      lammpsFoam/dragModels/ErgunWenYu/ErgunWenYu.C:86-145,
+//                      lammpsFoam/dragModels/SyamlalOBrien/SyamlalOBrien.C:85-144
+//   enhancedCloud      lammpsFoam/enhancedCloud.C: updateParticleAlpha :56-76, updateParticleUr :83-109,
+//                      updateDragOnParticles :112-257, calcTcFields :316-441, evolve :669-787,
+//                      particleToEulerianField :911-980
+//   adjustLampTimestep lammpsFoam/softParticleCloud.C:209-261
+//   cell owner         result of softParticle::move tracking (softParticle.C:102-151) on a uniform hex block
+//
+// Particles are NOT copied into a cloud-side list: every kernel reads the DEM engine's double4 records
+// (same order, same HBM), the drag force is written straight into fix fdrag's array, so the reference's
+// assemble/transpose/flatten/tag-sort marshalling (softParticleCloud.C:716-846, 970-1089) has no
+// counterpart here.
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include "../../include/sedifoam_amd.h"
+#include "sf_handles.h"
+
+namespace sf {
+
+constexpr double kRootVSmall = 1.0e-150;  // OpenFOAM ROOTVSMALL (double precision)
+
+__device__ __forceinline__ double jd_ergun_wenyu(double Ur, double alpha, double pd, double nuf, double rhof)
+{
+  const double beta = fmax(1.0 - alpha, kRootVSmall);
+  const double bp = pow(beta, -2.65);
+  const double Re = fmax(beta * Ur * pd / nuf, kRootVSmall);
+  double Cds = 24.0 * (1.0 + 0.15 * pow(Re, 0.687)) / Re;
+  if (Re > 1000.0) Cds = 0.44;
+  double K = 0.75 * Cds * rhof * Ur * bp / pd;  // Wen-Yu
+  if (beta <= 0.8) {                            // Ergun
+    const double bd = beta * pd;
+    K = 150.0 * alpha * nuf * rhof / (bd * bd) + 1.75 * rhof * Ur / (beta * pd);
+  }
+  return K;
+}
+
+__device__ __forceinline__ double jd_syamlal_obrien(double Ur, double alpha, double pd, double nuf, double rhof)
+{
+  const double beta = fmax(1.0 - alpha, kRootVSmall);
+  const double Ai = pow(beta, 4.14);
+  double Bi = 0.8 * pow(beta, 1.28);
+  if (beta > 0.85) Bi = pow(beta, 2.65);
+  const double Re = fmax(Ur * pd / nuf, kRootVSmall);
+  const double a = 0.06 * Re;
+  const double Vr = 0.5 * (Ai - 0.06 * Re + sqrt(a * a + 0.12 * Re * (2.0 * Bi - Ai) + Ai * Ai));
+  const double s = 0.63 + 4.8 * sqrt(Vr / Re);
+  return 0.75 * (s * s) * rhof * Ur / (pd * (Vr * Vr));
+}
+
+__device__ __forceinline__ double jd_model(int model, double Ur, double alpha, double pd, double nuf, double rhof)
+{
+  return model == 0 ? jd_ergun_wenyu(Ur, alpha, pd, nuf, rhof) : jd_syamlal_obrien(Ur, alpha, pd, nuf, rhof);
+}
+
+__global__ __launch_bounds__(256) void k_jd(int model, int n, const double* Ur, const double* alpha,
+                                            const double* pd, double nuf, double rhof, double* Jd)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Jd[i] = jd_model(model, Ur[i], alpha[i], pd[i], nuf, rhof);
+}
+
+struct MeshDev {
+  double origin[3], dx[3];
+  int n[3];
+  int ncells;
+};
+
+__device__ __forceinline__ int cell_of(const MeshDev& m, double x, double y, double z)
+{
+  const double fx = floor((x - m.origin[0]) / m.dx[0]);
+  const double fy = floor((y - m.origin[1]) / m.dx[1]);
+  const double fz = floor((z - m.origin[2]) / m.dx[2]);
+  if (fx < 0.0 || fx >= (double)m.n[0] || fy < 0.0 || fy >= (double)m.n[1] || fz < 0.0 || fz >= (double)m.n[2])
+    return -1;
+  return (int)fx + m.n[0] * ((int)fy + m.n[1] * (int)fz);
+}
+
+__global__ __launch_bounds__(256) void k_cell_owner_aos(int n, const double* x, MeshDev m, int* cell)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cell[i] = cell_of(m, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+}
+
+struct CloudFlagsDev {
+  int dragModel, particleDrag, particlePressureGrad, particleBuoyancy, particleAddedMass, particleLift,
+      lubricationForce;
+  double g[3], rhob, nub, deltaT;
+};
+
+// updateParticleUr + updateParticleAlpha + Jd + updateDragOnParticles, one owned atom per lane.
+// pDrag goes straight into fix fdrag's [3][cap] array (what lammps_put_local_info would copy).
+__global__ __launch_bounds__(256) void k_drag_on_particles(
+    int n, size_t cap, const double4* xr, const double4* vm, const int* tag, MeshDev m, CloudFlagsDev fl,
+    const double* gamma, const double* UfS, const double* gradp, const double* DDtUf, const double* curlU,
+    double* UOld_bytag, int maxtag, int first_call, int* cell_out, double* Jd_out, double* fdrag, double* DuDt)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 x = xr[i], v = vm[i];
+  const int c = cell_of(m, x.x, x.y, x.z);
+  cell_out[i] = c;
+  const int t = tag[i];
+  double F[3] = {0.0, 0.0, 0.0};
+  double jd = 0.0;
+  const double U[3] = {v.x, v.y, v.z};
+  double uold[3] = {v.x, v.y, v.z};
+  if (t >= 1 && t <= maxtag) {
+    if (!first_call)
+      for (int k = 0; k < 3; k++) uold[k] = UOld_bytag[(size_t)k * maxtag + (t - 1)];
+    for (int k = 0; k < 3; k++) UOld_bytag[(size_t)k * maxtag + (t - 1)] = U[k];  // setPositionVeloCpuId: UOld = U
+  }
+  double dudt[3] = {0.0, 0.0, 0.0};
+  if (c >= 0) {
+    const double d = 2.0 * x.w;
+    const double Vol = kPi * d * d * d / 6.0;  // softParticle.H:270-273
+    const double alpha = gamma[c];
+    double Uri[3];
+    for (int k = 0; k < 3; k++) Uri[k] = UfS[3 * c + k] - U[k];
+    const double mag = sqrt(Uri[0] * Uri[0] + Uri[1] * Uri[1] + Uri[2] * Uri[2]);
+    jd = jd_model(fl.dragModel, mag, alpha, d, fl.nub, fl.rhob);
+    for (int k = 0; k < 3; k++) dudt[k] = DDtUf[3 * c + k];
+    if (fl.particleDrag)
+      for (int k = 0; k < 3; k++) F[k] += jd * (1.0 - alpha) * Vol * Uri[k];
+    if (fl.particlePressureGrad)
+      for (int k = 0; k < 3; k++) F[k] += -gradp[3 * c + k] * Vol;
+    if (fl.particleBuoyancy)
+      for (int k = 0; k < 3; k++) F[k] += -fl.g[k] * fl.rhob * Vol;
+    if (fl.particleAddedMass) {
+      double acc[3], mm = 0.0;
+      for (int k = 0; k < 3; k++) {
+        acc[k] = DDtUf[3 * c + k] - (U[k] - uold[k]) / fl.deltaT;
+        mm += acc[k] * acc[k];
+      }
+      mm = sqrt(mm);
+      if (mm > 10)
+        for (int k = 0; k < 3; k++) acc[k] = acc[k] / (mm + kRootVSmall) * 10;
+      for (int k = 0; k < 3; k++) F[k] += 0.5 * fl.rhob * Vol * acc[k];
+    }
+    if (fl.particleLift) {
+      const double w0 = curlU[3 * c], w1 = curlU[3 * c + 1], w2 = curlU[3 * c + 2];
+      const double cr[3] = {Uri[1] * w2 - Uri[2] * w1, Uri[2] * w0 - Uri[0] * w2, Uri[0] * w1 - Uri[1] * w0};
+      const double magw = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+      for (int k = 0; k < 3; k++)
+        F[k] += 1.6 * fl.rhob * sqrt(fl.nub) * (d * d) * cr[k] / sqrt(magw + kRootVSmall);
+    }
+    if (fl.lubricationForce) {
+      const double distMin = 0.0001 * d, distMax = 0.1 * d;
+      const double distWall = x.y - 0.5 * d;
+      if (distWall < distMax && distWall > distMin)
+        F[1] += 6 * 3.1416 * fl.nub * fl.rhob * (-U[1]) / distWall * (d * d) / 4.0 * 1.0;
+    }
+  }
+  Jd_out[i] = jd;
+  for (int k = 0; k < 3; k++) {
+    fdrag[(size_t)k * cap + i] = F[k];
+    DuDt[(size_t)k * cap + i] = dudt[k];
+  }
+}
+
+// sort keys for the particle -> cell scatter: cell id (outside = ncells, sorts last)
+__global__ __launch_bounds__(256) void k_cell_keys(int n, const double4* xr, MeshDev m, unsigned* keys, int* idx)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 x = xr[i];
+  const int c = cell_of(m, x.x, x.y, x.z);
+  keys[i] = (unsigned)(c < 0 ? m.ncells : c);
+  idx[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_cell_ranges(const unsigned* keys, int n, int* cstart, int* cend)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned b = keys[i];
+  if (i == 0 || keys[i - 1] != b) cstart[b] = i;
+  if (i == n - 1 || keys[i + 1] != b) cend[b] = i + 1;
+}
+
+// particleToEulerianField: one cell per lane walks its (cell-sorted) particles -- deterministic,
+// no atomics.  gamma = sum Vol / V ; Ue = sum Vol U / V, then Ue /= gamma where gamma > ROOTVSMALL.
+__global__ __launch_bounds__(256) void k_particle_to_eulerian(int ncells, const int* cstart, const int* cend,
+                                                              const int* order, const double4* xr,
+                                                              const double4* vm, const double* V, double* gamma,
+                                                              double* Ue)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  double g = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
+  for (int k = cstart[c]; k < cend[c]; k++) {
+    const int i = order[k];
+    const double d = 2.0 * xr[i].w;
+    const double Vol = kPi * d * d * d / 6.0;
+    const double4 v = vm[i];
+    g += Vol;
+    u0 += Vol * v.x;
+    u1 += Vol * v.y;
+    u2 += Vol * v.z;
+  }
+  const double Vc = V[c];
+  g /= Vc;
+  u0 /= Vc;
+  u1 /= Vc;
+  u2 /= Vc;
+  if (g > kRootVSmall) {
+    u0 /= g;
+    u1 /= g;
+    u2 /= g;
+  }
+  gamma[c] = g;
+  Ue[3 * c] = u0;
+  Ue[3 * c + 1] = u1;
+  Ue[3 * c + 2] = u2;
+}
+
+// calcTcFields: Asrc[c] = sum (Vol Jd / V)(U - UfSmoothed[c]) ; Omega accumulated then zeroed (:391)
+__global__ __launch_bounds__(256) void k_calc_tc(int ncells, const int* cstart, const int* cend, const int* order,
+                                                 const double4* xr, const double4* vm, const double* V,
+                                                 const double* gamma, const double* UfS, int dragModel,
+                                                 double nub, double rhob, double* Asrc, double* Omega,
+                                                 double* Jd_out)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  const double alpha = gamma[c];
+  const double uf[3] = {UfS[3 * c], UfS[3 * c + 1], UfS[3 * c + 2]};
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int k = cstart[c]; k < cend[c]; k++) {
+    const int i = order[k];
+    const double d = 2.0 * xr[i].w;
+    const double Vol = kPi * d * d * d / 6.0;
+    const double4 v = vm[i];
+    const double r0 = uf[0] - v.x, r1 = uf[1] - v.y, r2 = uf[2] - v.z;
+    const double mag = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    const double jd = jd_model(dragModel, mag, alpha, d, nub, rhob);
+    Jd_out[i] = jd;
+    const double omg = Vol * jd / V[c];
+    a0 += omg * (v.x - uf[0]);
+    a1 += omg * (v.y - uf[1]);
+    a2 += omg * (v.z - uf[2]);
+  }
+  const double w = 1 - alpha;
+  Asrc[3 * c] = a0 * w / w;
+  Asrc[3 * c + 1] = a1 * w / w;
+  Asrc[3 * c + 2] = a2 * w / w;
+  Omega[c] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_cap_alpha(int ncells, double* gamma, double maxAlpha)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncells && gamma[c] > maxAlpha) gamma[c] = maxAlpha;
+}
+
+int adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double* dtLampAdj, int* solidStepsPerDt,
+                    int* subCycles, int* subSteps)
+{
+  double dnSub = std::round(deltaT / dtLampIn);  // softParticleCloud.C:216
+  if (dnSub == 0) dnSub++;
+  int sc = subCycles_in;
+  const int steps = ((int)dnSub / sc) * sc;      // :219-221
+  *dtLampAdj = deltaT / dnSub;                   // :224
+  if (sc >= steps) {                             // :229-234
+    sc = steps;
+    *subSteps = 1;
+  } else {
+    *subSteps = steps / sc;                      // :237-238
+    if (steps % sc != 0) return -1;              // FatalError :239-247
+  }
+  *solidStepsPerDt = steps;
+  *subCycles = sc;
+  return 0;
+}
+
+class Cloud {
+ public:
+  Cloud(SfLammps* lmp, const sf_cloud_mesh& mesh, const sf_cloud_props& props, double deltaT)
+      : lmp_(lmp), props_(props), deltaT_(deltaT)
+  {
+    for (int k = 0; k < 3; k++) {
+      mesh_.origin[k] = mesh.origin[k];
+      mesh_.dx[k] = mesh.dx[k];
+      mesh_.n[k] = mesh.n[k];
+    }
+    mesh_.ncells = mesh.n[0] * mesh.n[1] * mesh.n[2];
+    if (mesh_.ncells <= 0) fail("cloud mesh has no cells");
+    DemEngine& e = lmp_->eng;
+    s_ = e.stream();
+    // adjustLampTimestep
+    double dtadj;
+    int steps;
+    if (adjust_timestep(deltaT, e.timestep(), props.subCycles < 1 ? 1 : props.subCycles, &dtadj, &steps,
+                        &subCycles_, &subSteps_) != 0)
+      fail("softParticleCloud::adjustLampTimestep() Time step adjustment error.");
+    e.set_timestep(dtadj);
+    const size_t nc = (size_t)mesh_.ncells;
+    auto alloc = [&](double*& p, size_t n) {
+      SF_HIP(hipMalloc(&p, sizeof(double) * n));
+      SF_HIP(hipMemsetAsync(p, 0, sizeof(double) * n, s_));
+    };
+    alloc(V_, nc);
+    alloc(gamma_, nc);
+    alloc(Ue_, 3 * nc);
+    alloc(Asrc_, 3 * nc);
+    alloc(Omega_, nc);
+    alloc(Uf_, 3 * nc);
+    alloc(DDtUf_, 3 * nc);
+    alloc(gradp_, 3 * nc);
+    alloc(curlU_, 3 * nc);
+    SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
+    std::vector<double> hV(nc, mesh.dx[0] * mesh.dx[1] * mesh.dx[2]);
+    SF_HIP(hipMemcpyAsync(V_, hV.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+    if (!e.is_setup()) e.setup();  // lammps_step(0) at construction, softParticleCloud.C:189
+    particle_to_eulerian();        // enhancedCloud.C:635
+    SF_HIP(hipStreamSynchronize(s_));
+  }
+
+  ~Cloud()
+  {
+    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_})
+      if (p) (void)hipFree(p);
+    for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_})
+      if (p) (void)hipFree(p);
+  }
+
+  void set_fluid(const double* Uf, const double* DDtUf, const double* gradp, const double* curlU)
+  {
+    const size_t nb = sizeof(double) * 3 * (size_t)mesh_.ncells;
+    if (Uf) SF_HIP(hipMemcpyAsync(Uf_, Uf, nb, hipMemcpyHostToDevice, s_));
+    if (DDtUf) SF_HIP(hipMemcpyAsync(DDtUf_, DDtUf, nb, hipMemcpyHostToDevice, s_));
+    if (gradp) SF_HIP(hipMemcpyAsync(gradp_, gradp, nb, hipMemcpyHostToDevice, s_));
+    if (curlU) SF_HIP(hipMemcpyAsync(curlU_, curlU, nb, hipMemcpyHostToDevice, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+  }
+
+  void evolve()
+  {
+    const double t0 = now();
+    DemEngine& e = lmp_->eng;
+    // UfSmoothed_ = Uf_ (diffusion smoothing is the "next" row N1)
+    for (int k = 0; k < subCycles_; k++) {
+      double t1 = now();
+      drag_on_particles();
+      t_.dragOnParticles += sync_now() - t1;
+      t1 = now();
+      e.run(subSteps_);  // lammpsEvolveForward without the host round trip
+      t_.lammps += sync_now() - t1;
+      // Cloud::move: the new cell owner is recomputed from the DEM positions wherever it is used
+      if (k == 0) {
+        t1 = now();
+        particle_to_eulerian();
+        t_.scatter += sync_now() - t1;
+      }
+    }
+    t_.evolve += sync_now() - t0;
+  }
+
+  void calc_tc_fields()
+  {
+    const double t0 = now();
+    DemEngine& e = lmp_->eng;
+    const int n = e.nlocal();
+    ensure_particle_arrays();
+    // liftDragCoeffs.H:6-14: alpha capped before calcTcFields
+    if (props_.maxPossibleAlpha > 0.0)
+      k_cap_alpha<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, gamma_, props_.maxPossibleAlpha);
+    sort_by_cell(n);
+    k_calc_tc<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_, cstart_ + mesh_.ncells + 1, idx2_,
+                                                         e.d_xr(), e.d_vm(), V_, gamma_, Uf_, props_.dragModel,
+                                                         props_.nub, props_.rhob, Asrc_, Omega_, Jd_);
+    t_.calcTc += sync_now() - t0;
+  }
+
+  void get_fields(double* gamma, double* Ue, double* Asrc, double* Omega)
+  {
+    const size_t nc = (size_t)mesh_.ncells;
+    if (gamma) SF_HIP(hipMemcpyAsync(gamma, gamma_, sizeof(double) * nc, hipMemcpyDeviceToHost, s_));
+    if (Ue) SF_HIP(hipMemcpyAsync(Ue, Ue_, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, s_));
+    if (Asrc) SF_HIP(hipMemcpyAsync(Asrc, Asrc_, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, s_));
+    if (Omega) SF_HIP(hipMemcpyAsync(Omega, Omega_, sizeof(double) * nc, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+  }
+
+  // results of the last drag evaluation, sorted by tag
+  void get_particles(int* tag, int* cell, double* pDrag, double* Jd)
+  {
+    DemEngine& e = lmp_->eng;
+    const int n = e.nlocal();
+    if (!n) return;
+    ensure_particle_arrays();
+    std::vector<int> ht(n), hc(n);
+    std::vector<double> hj(n), hf(3 * (size_t)n);
+    SF_HIP(hipMemcpyAsync(ht.data(), e.d_tag(), sizeof(int) * n, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipMemcpyAsync(hc.data(), cell_, sizeof(int) * n, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipMemcpyAsync(hj.data(), Jd_, sizeof(double) * n, hipMemcpyDeviceToHost, s_));
+    for (int k = 0; k < 3; k++)
+      SF_HIP(hipMemcpyAsync(hf.data() + (size_t)k * n, e.d_fdrag() + (size_t)k * e.capacity(), sizeof(double) * n,
+                            hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return ht[a] < ht[b]; });
+    for (int r = 0; r < n; r++) {
+      const int i = order[r];
+      if (tag) tag[r] = ht[i];
+      if (cell) cell[r] = hc[i];
+      if (Jd) Jd[r] = hj[i];
+      if (pDrag)
+        for (int k = 0; k < 3; k++) pDrag[3 * r + k] = hf[(size_t)k * n + i];
+    }
+  }
+
+  int particle_count() const { return lmp_->eng.nlocal(); }
+  const sf_cloud_timers& timers() const { return t_; }
+
+ private:
+  static double now()
+  {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  double sync_now()
+  {
+    SF_HIP(hipStreamSynchronize(s_));
+    return now();
+  }
+
+  void ensure_particle_arrays()
+  {
+    DemEngine& e = lmp_->eng;
+    const size_t cap = e.capacity();
+    if (cap > pcap_) {
+      auto re = [&](void** p, size_t bytes) {
+        if (*p) SF_HIP(hipFree(*p));
+        SF_HIP(hipMalloc(p, bytes));
+        SF_HIP(hipMemsetAsync(*p, 0, bytes, s_));
+      };
+      re((void**)&Jd_, sizeof(double) * cap);
+      re((void**)&cell_, sizeof(int) * cap);
+      re((void**)&keys_, sizeof(unsigned) * cap);
+      re((void**)&keys2_, sizeof(unsigned) * cap);
+      re((void**)&idx_, sizeof(int) * cap);
+      re((void**)&idx2_, sizeof(int) * cap);
+      pcap_ = cap;
+    }
+    const int mt = e.max_tag();
+    if (mt > maxtag_) {
+      double* nu = nullptr;
+      const int newmax = mt + mt / 4 + 16;
+      SF_HIP(hipMalloc(&nu, sizeof(double) * 3 * (size_t)newmax));
+      SF_HIP(hipMemsetAsync(nu, 0, sizeof(double) * 3 * (size_t)newmax, s_));
+      if (UOld_) {
+        for (int k = 0; k < 3; k++)
+          SF_HIP(hipMemcpyAsync(nu + (size_t)k * newmax, UOld_ + (size_t)k * maxtag_, sizeof(double) * maxtag_,
+                                hipMemcpyDeviceToDevice, s_));
+        SF_HIP(hipStreamSynchronize(s_));
+        SF_HIP(hipFree(UOld_));
+      }
+      UOld_ = nu;
+      maxtag_ = newmax;
+    }
+  }
+
+  CloudFlagsDev flags() const
+  {
+    CloudFlagsDev f;
+    f.dragModel = props_.dragModel;
+    f.particleDrag = props_.particleDrag;
+    f.particlePressureGrad = props_.particlePressureGrad;
+    f.particleBuoyancy = props_.particleBuoyancy;
+    f.particleAddedMass = props_.particleAddedMass;
+    f.particleLift = props_.particleLift;
+    f.lubricationForce = props_.lubricationForce;
+    for (int k = 0; k < 3; k++) f.g[k] = props_.gravity[k];
+    f.rhob = props_.rhob;
+    f.nub = props_.nub;
+    f.deltaT = deltaT_;
+    return f;
+  }
+
+  void drag_on_particles()
+  {
+    DemEngine& e = lmp_->eng;
+    const int n = e.nlocal();
+    if (!n) return;
+    ensure_particle_arrays();
+    k_drag_on_particles<<<div_up(n, 256), 256, 0, s_>>>(n, e.capacity(), e.d_xr(), e.d_vm(), e.d_tag(), mesh_,
+                                                        flags(), gamma_, Uf_, gradp_, DDtUf_, curlU_, UOld_,
+                                                        maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, e.d_fdrag(),
+                                                        e.d_DuDt());
+    first_drag_ = false;
+  }
+
+  void sort_by_cell(int n)
+  {
+    DemEngine& e = lmp_->eng;
+    const int nc = mesh_.ncells;
+    SF_HIP(hipMemsetAsync(cstart_, 0, sizeof(int) * 2 * ((size_t)nc + 1), s_));
+    if (!n) return;
+    k_cell_keys<<<div_up(n, 256), 256, 0, s_>>>(n, e.d_xr(), mesh_, keys_, idx_);
+    int bits = 1;
+    while ((1 << bits) <= nc) bits++;
+    sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_, keys2_, idx_, idx2_, n, bits, s_);
+    k_cell_ranges<<<div_up(n, 256), 256, 0, s_>>>(keys2_, n, cstart_, cstart_ + nc + 1);
+  }
+
+  void particle_to_eulerian()
+  {
+    DemEngine& e = lmp_->eng;
+    const int n = e.nlocal();
+    ensure_particle_arrays();
+    sort_by_cell(n);
+    k_particle_to_eulerian<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_,
+                                                                      cstart_ + mesh_.ncells + 1, idx2_, e.d_xr(),
+                                                                      e.d_vm(), V_, gamma_, Ue_);
+  }
+
+  SfLammps* lmp_;
+  sf_cloud_props props_;
+  double deltaT_;
+  MeshDev mesh_{};
+  hipStream_t s_ = nullptr;
+  int subCycles_ = 1, subSteps_ = 1;
+  double *V_ = nullptr, *gamma_ = nullptr, *Ue_ = nullptr, *Asrc_ = nullptr, *Omega_ = nullptr;
+  double *Uf_ = nullptr, *DDtUf_ = nullptr, *gradp_ = nullptr, *curlU_ = nullptr;
+  double *Jd_ = nullptr, *UOld_ = nullptr;
+  int *cstart_ = nullptr, *cell_ = nullptr, *idx_ = nullptr, *idx2_ = nullptr;
+  unsigned *keys_ = nullptr, *keys2_ = nullptr;
+  void* sort_tmp_ = nullptr;
+  size_t sort_tmp_bytes_ = 0, pcap_ = 0;
+  int maxtag_ = 0;
+  bool first_drag_ = true;
+  sf_cloud_timers t_{};
+};
+
+}  // namespace sf
+
+using sf::Cloud;
+
+extern "C" {
+
+int sf_cloud_create(void* lmp, const sf_cloud_mesh* mesh, const sf_cloud_props* props, double deltaT, void** cloud)
+{
+  SF_API_BEGIN
+  if (!lmp) sf::fail("null engine handle");
+  *cloud = new Cloud(static_cast<sf::SfLammps*>(lmp), *mesh, *props, deltaT);
+  SF_API_END(0)
+}
+
+int sf_cloud_destroy(void* cloud)
+{
+  SF_API_BEGIN
+  delete static_cast<Cloud*>(cloud);
+  SF_API_END(0)
+}
+
+int sf_cloud_set_fluid(void* cloud, const double* Uf, const double* DDtUf, const double* gradp, const double* curlU)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->set_fluid(Uf, DDtUf, gradp, curlU);
+  SF_API_END(0)
+}
+
+int sf_cloud_evolve(void* cloud)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->evolve();
+  SF_API_END(0)
+}
+
+int sf_cloud_calc_tc_fields(void* cloud)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->calc_tc_fields();
+  SF_API_END(0)
+}
+
+int sf_cloud_get_fields(void* cloud, double* gamma, double* Ue, double* Asrc, double* Omega)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->get_fields(gamma, Ue, Asrc, Omega);
+  SF_API_END(0)
+}
+
+int sf_cloud_get_particles(void* cloud, int* tag, int* cell, double* pDrag, double* Jd)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->get_particles(tag, cell, pDrag, Jd);
+  SF_API_END(0)
+}
+
+int sf_cloud_particle_count(void* cloud)
+{
+  SF_API_BEGIN
+  const int n = static_cast<Cloud*>(cloud)->particle_count();
+  SF_API_END(n)
+}
+
+int sf_cloud_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double* dtLampAdj,
+                             int* solidStepsPerDt, int* subCycles, int* subSteps)
+{
+  return sf::adjust_timestep(deltaT, dtLampIn, subCycles_in, dtLampAdj, solidStepsPerDt, subCycles, subSteps);
+}
+
+int sf_cloud_get_timers(void* cloud, sf_cloud_timers* t)
+{
+  SF_API_BEGIN
+  *t = static_cast<Cloud*>(cloud)->timers();
+  SF_API_END(0)
+}
+
+int sfk_drag_model_jd(int model, int n, const double* Ur, const double* alpha, const double* pd, double nuf,
+                      double rhof, double* Jd, void* stream)
+{
+  SF_API_BEGIN
+  if (model != 0 && model != 1) sf::fail("Unknown dragModel type %d (valid: 0 ErgunWenYu, 1 SyamlalOBrien)", model);
+  if (n > 0) {
+    sf::k_jd<<<sf::div_up(n, 256), 256, 0, (hipStream_t)stream>>>(model, n, Ur, alpha, pd, nuf, rhof, Jd);
+    SF_HIP(hipGetLastError());
+  }
+  SF_API_END(0)
+}
+
+int sfk_cell_owner(int n, const double* x, const double origin[3], const double dx[3], const int ncell[3],
+                   int* cell, void* stream)
+{
+  SF_API_BEGIN
+  sf::MeshDev m;
+  for (int k = 0; k < 3; k++) {
+    m.origin[k] = origin[k];
+    m.dx[k] = dx[k];
+    m.n[k] = ncell[k];
+  }
+  m.ncells = ncell[0] * ncell[1] * ncell[2];
+  if (n > 0) {
+    sf::k_cell_owner_aos<<<sf::div_up(n, 256), 256, 0, (hipStream_t)stream>>>(n, x, m, cell);
+    SF_HIP(hipGetLastError());
+  }
+  SF_API_END(0)
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+// sf_dem.h -- device-resident DEM engine: what `lammps_step(n)` does to the particles, on one GPU.
+//
+// State layout in HBM (all FP64, capacity `cap` particle slots = owned atoms then ghost atoms):
+//   xr[2], vm[2], om[2] : double4 records (x,y,z,radius) (vx,vy,vz,rmass) (wx,wy,wz,0), ping-pong:
+//                         sub-step k reads buffer k&1 (own row coalesced, neighbour rows gathered) and
+//                         writes buffer (k+1)&1, so force, final_integrate(k) and initial_integrate(k+1)
+//                         fuse into ONE kernel with no read/write hazard.
+//   neigh   [M][cap] int32 : full neighbour list, slot-major (lane i reads consecutive addresses);
+//                            bit 30 of an entry = "touching" flag (LAMMPS keeps it in a separate
+//                            touch[] array, pair_gran_hertzFix_history.cpp:135,212)
+//   shear   [M][3][cap] f64: per-slot shear history, same slot-major layout
+//   fdrag/DuDt/vOld [3][cap], wall shear [nwall][3][cap], xhold [3][cap], force/torque double4.
+// The list is FULL (every owned atom lists all its neighbours; each contact is evaluated from both
+// sides, bit-for-bit antisymmetric) so no atomics are needed and results are run-to-run
+// deterministic.  This is the reference's own `newton off` semantics for owned-ghost pairs
+// (pair_gran_hertzFix_history.cpp:273) applied to every pair.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sf_common.h"
+#include "sf_physics.h"
+
+namespace sf {
+
+constexpr int kNeighMask = 0x3FFFFFFF;
+constexpr int kTouchBit = 0x40000000;
+constexpr int kMaxWalls = 6;
+
+enum Flag {
+  F_TRIGGER = 0,    // smallest sub-step index whose new positions exceeded skin/2 (INT_MAX: none)
+  F_NEIGH_OVER,     // max numneigh wanted when the per-atom slot count M overflowed
+  F_GHOST_COUNT,    // ghost atoms appended so far in this rebuild
+  F_GHOST_OVER,     // capacity overflow during ghost creation
+  F_MAXNEIGH,       // max numneigh of the built list
+  F_LOST,           // atoms outside a non-periodic box (bins clamp them; reported)
+  F_SEND_COUNT,     // scratch counter for halo packing
+  F_SEND_COUNT2,
+  F_NFLAGS = 16
+};
+
+struct WallParams {
+  int dim;
+  double lo, hi;
+  GranParams gp;
+};
+
+struct DemPtrs {
+  const double4* xr_in;
+  const double4* vm_in;
+  const double4* om_in;
+  double4* xr_out;
+  double4* vm_out;
+  double4* om_out;
+  double4* force;
+  double4* torque;
+  int* neigh;
+  int* numneigh;
+  double* shear;
+  double* fdrag;
+  double* DuDt;
+  double* vOld;
+  double* wshear;          // [nwall][3][cap]
+  unsigned char* wtouch;   // [cap] bit w = touching wall w
+  const double* xhold;     // [3][cap]
+  const int* mask;
+  int* flags;
+};
+
+struct StepParams {
+  int nlocal, cap, mode;   // mode 0: force + final + next initial ; 1: last (force + final, store f) ; 2: setup
+  int kstep;
+  double dt, trigger_sq;
+  GranParams gran;
+  CoheParams cohe;
+  LubParams lub;
+  int nwalls;
+  WallParams wall[kMaxWalls];
+  int have_gravity;
+  double gacc[3];
+  int have_fdrag;
+  double carrier_rho;
+  int have_nve;
+  int freeze_bit;
+};
+
+struct BinGrid {
+  double lo[3], inv[3];
+  int n[3];
+  int nbins;
+};
+
+class DemEngine {
+ public:
+  DemEngine();
+  ~DemEngine();
+
+  // ---- configuration (input-script surface) ----
+  void set_box(const double lo[3], const double hi[3]);
+  void set_periodic(int px, int py, int pz);
+  void create_atoms(int n, const double* x, const double* v, const double* omega,
+                    const double* diameter, const double* density, const int* tag, const int* type);
+  void set_pair_gran(int style, double kn, bool kt_null, double kt, double gamman, bool gammat_null,
+                     double gammat, double xmu, int dampflag);
+  void set_pair_lubricate(double mu, int flaglog, int flagfld, double cut_inner, double cut_global,
+                          int flagHI, int flagVF);
+  void set_cohesive(double ah, double lam, double smin, double smax, int opt);
+  void set_gravity(double mag, double gx, double gy, double gz);
+  void set_fdrag(double carrier_rho);
+  void add_wall(int dim, bool lo_null, double lo, bool hi_null, double hi, double kn, bool kt_null,
+                double kt, double gamman, bool gammat_null, double gammat, double xmu, int dampflag,
+                bool granfix);
+  void set_nve_sphere() { have_nve_ = true; }
+  void set_skin(double s) { skin_ = s; }
+  void set_timestep(double dt) { dt_ = dt; }
+  double timestep() const { return dt_; }
+  void set_max_neigh(int m);
+  void set_velocity_all(double vx, double vy, double vz);
+  void set_subdomain(int rank, int nranks, double sublo, double subhi);
+
+  // ---- stepping ----
+  void setup();            // first run: build list, forces with shearupdate = 0
+  void run(int nsteps);    // "run n pre no post no"
+  void run_begin();
+  void substep(bool last);
+  bool need_rebuild();
+  void rebuild_begin();
+  void rebuild_sort();
+  void rebuild_finish();
+
+  // ---- data exchange ----
+  int nlocal() const { return nlocal_; }
+  int nghost() const { return nghost_; }
+  int rank() const { return rank_; }
+  int nranks() const { return nranks_; }
+  void sublo_hi(double out[6]) const;
+  void get_local_info(double* x, double* v, int* foamCpuId, int* tag);
+  void get_initial_info(double* x, double* v, double* diam, double* rho, int* tag, int* type);
+  void put_local_info(int n, const double* fdrag, const int* foamCpuId, const int* tagIn);
+  void get_forces(double* f, double* torque, double* omega, int* tag);
+  long long get_history(long long max, int* tag_i, int* tag_j, double* shear);
+  void get_wall_shear(int w, double* shear);
+  void create_particles(int np, const double* pos, const double* tag, double diameter, double rho,
+                        int type, const double* vel);
+  void delete_particles(const int* tags, int n);
+
+  // halo (device buffers)
+  long long border_pack(int side, double xshift, double* buf, long long max_atoms);
+  void border_unpack(int side, const double* buf, long long natoms);
+  long long forward_pack(int side, double xshift, double* buf);
+  void forward_unpack(int side, const double* buf, long long natoms);
+  long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
+  void migrate_unpack(const double* buf, long long ndoubles);
+  int migrate_record_doubles() const;
+
+  // device view for the cloud
+  hipStream_t stream() const { return stream_; }
+  size_t capacity() const { return cap_; }
+  const double4* d_xr() const { return xr_[cur_].as<double4>(); }
+  const double4* d_vm() const { return vm_[cur_].as<double4>(); }
+  const double4* d_om() const { return om_[cur_].as<double4>(); }
+  double4* d_force() const { return force_.as<double4>(); }
+  double4* d_torque() const { return torque_.as<double4>(); }
+  double* d_fdrag() const { return fdrag_.as<double>(); }
+  double* d_DuDt() const { return DuDt_.as<double>(); }
+  double* d_vOld() const { return vOld_.as<double>(); }
+  int* d_tag() const { return tag_.as<int>(); }
+  int* d_type() const { return type_.as<int>(); }
+  int* d_foamCpuId() const { return foamCpuId_.as<int>(); }
+  int max_tag() const { return max_tag_; }
+
+  long long nbuilds() const { return nbuilds_; }
+  long long nsteps() const { return nsteps_; }
+  int max_neigh_used() const { return max_neigh_used_; }
+  int max_neigh_cap() const { return M_; }
+  long long npairs_full();
+  bool is_setup() const { return setup_done_; }
+  double cutneighmax() const;
+  double last_substep_ms() const { return last_substep_ms_; }
+
+ private:
+  void ensure_capacity(size_t need);
+  void alloc_all(size_t cap);
+  void grow_neigh(int newM);
+  DemPtrs ptrs(int in_buf) const;
+  StepParams step_params(int mode, int kstep) const;
+  void launch_substep(int in_buf, int mode, int kstep);
+  void launch_ghost_forward(int buf, int kstep);
+  void launch_initial_integrate();
+  void rebuild();          // rebuild_begin + rebuild_finish
+  void make_periodic_ghosts();
+  void bin_and_build();
+  void read_flags();
+  void reset_flag(int idx, int value);
+  void compute_grid();
+  double max_radius();
+  void sync() const { SF_HIP(hipStreamSynchronize(stream_)); }
+
+  hipStream_t stream_ = nullptr;
+  size_t cap_ = 0;
+  int nlocal_ = 0, nghost_ = 0, next_ghost_ = 0;   // next_ghost_: external ghosts appended by border_unpack
+  int cur_ = 0;
+  int M_ = 32;
+  int max_neigh_used_ = 0;
+  int max_tag_ = 0;
+  bool setup_done_ = false, have_list_ = false;
+  long long nbuilds_ = 0, nsteps_ = 0;
+  double last_substep_ms_ = 0.0;
+
+  // domain
+  double boxlo_[3] = {0, 0, 0}, boxhi_[3] = {1, 1, 1};
+  int periodic_[3] = {0, 0, 0};
+  int rank_ = 0, nranks_ = 1;
+  double sublo_x_ = 0.0, subhi_x_ = 1.0;
+  bool have_subdomain_ = false;
+  double skin_ = 0.0, dt_ = 0.0;
+  double rmax_ = 0.0;
+
+  // styles
+  GranParams gran_{};
+  CoheParams cohe_{};
+  LubParams lub_{};
+  int nwalls_ = 0;
+  WallParams walls_[kMaxWalls];
+  bool have_gravity_ = false, have_fdrag_ = false, have_nve_ = false;
+  double gacc_[3] = {0, 0, 0};
+  double carrier_rho_ = 0.0;
+
+  // device arrays (rows x cap)
+  DevArray xr_[2], vm_[2], om_[2], force_, torque_;
+  DevArray tag_, type_, mask_, foamCpuId_;
+  DevArray fdrag_, DuDt_, vOld_, xhold_;
+  DevArray wshear_, wtouch_;
+  DevArray gsrc_, gshift_;
+  DevArray neigh_, numneigh_, shear_;
+  DevArray neigh_old_, numneigh_old_, shear_old_, ptag_;
+  DevArray tmp4_, tmpd_, tmpi_;        // gather scratch
+  DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
+  int* cell_start_ = nullptr;          // [4][nbins]: local start/end, ghost start/end
+  size_t cell_alloc_ = 0;
+  int* tagmap_ = nullptr;
+  size_t tagmap_alloc_ = 0;
+  void* sort_tmp_ = nullptr;
+  size_t sort_tmp_bytes_ = 0;
+  int* d_flags_ = nullptr;
+  int* h_flags_ = nullptr;             // pinned
+  std::vector<DevArray*> per_atom_;    // registry for capacity growth
+  BinGrid grid_{};
+  // halo bookkeeping: send lists for forward comm [side] (device index arrays) and ghost slot ranges
+  DevArray sendlist_[2];
+  long long nsend_[2] = {0, 0};
+  int recv_first_[2] = {0, 0}, recv_count_[2] = {0, 0};
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+};
+
+// sf_sort.hip
+void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
+                    int* vals_out, int n, int end_bit, hipStream_t s);
+void sort_pairs_u64(void*& tmp, size_t& tmp_bytes, unsigned long long* keys_in,
+                    unsigned long long* keys_out, int* vals_in, int* vals_out, int n, int end_bit,
+                    hipStream_t s);
+
+}  // namespace sf

@@ -1,0 +1,893 @@
+// sf_dem.hip -- host side of the device-resident DEM engine (see sf_dem.h for the HBM layout).
+//
+// Sub-step driver = LAMMPS 1Feb14 Verlet::run as the reference invokes it through
+// lammps_step() (interfaceToLammps/library.cpp:372-386, "run n pre no post no") [3P].
+#include "sf_dem.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "sf_dem_kernels.h"
+
+namespace sf {
+
+std::string& last_error()
+{
+  static thread_local std::string e;
+  return e;
+}
+
+void set_error(const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+}
+
+void fail(const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw Error(buf);
+}
+
+static double hertz_beta(double gamman)
+{
+  // pair_gran_hertzFix_history.cpp:195-196 evaluated once (a pure function of gamman)
+  const double lg = std::log(gamman) / std::log(std::exp(1.0));
+  return -(lg) / std::sqrt(lg * lg + kPi * kPi);
+}
+
+static void gran_settings(GranParams& p, int style, double kn, bool kt_null, double kt, double gamman,
+                          bool gammat_null, double gammat, double xmu, int dampflag, double nktv2p)
+{
+  p.style = style;
+  p.kn = kn;
+  p.kt = kt_null ? kn * 2.0 / 7.0 : kt;
+  p.gamman = gamman;
+  p.gammat = gammat_null ? 0.5 * gamman : gammat;
+  p.xmu = xmu;
+  p.dampflag = dampflag;
+  if (dampflag == 0) p.gammat = 0.0;
+  if (p.kn < 0.0 || p.kt < 0.0 || p.gamman < 0.0 || p.gammat < 0.0 || p.xmu < 0.0 || p.xmu > 10000.0 ||
+      dampflag < 0 || dampflag > 1)
+    fail("Illegal pair_style command");
+  p.kn /= nktv2p;
+  p.kt /= nktv2p;
+  p.beta = (style == 2 && gamman > 0.0) ? hertz_beta(gamman) : 0.0;
+}
+
+DemEngine::DemEngine()
+{
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    fail("sedifoam_amd: no HIP device available (%s) -- this library has no CPU path",
+         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  SF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  SF_HIP(hipMalloc(&d_flags_, sizeof(int) * F_NFLAGS));
+  SF_HIP(hipHostMalloc(&h_flags_, sizeof(int) * F_NFLAGS));
+  SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
+  SF_HIP(hipEventCreate(&ev0_));
+  SF_HIP(hipEventCreate(&ev1_));
+  memset(&gran_, 0, sizeof(gran_));
+  memset(&cohe_, 0, sizeof(cohe_));
+  memset(&lub_, 0, sizeof(lub_));
+  per_atom_ = {&xr_[0], &xr_[1], &vm_[0], &vm_[1], &om_[0], &om_[1], &force_, &torque_, &tag_, &type_,
+               &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
+               &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
+               &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
+               &sendlist_[0], &sendlist_[1]};
+}
+
+DemEngine::~DemEngine()
+{
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (DevArray* a : per_atom_) a->release();
+  if (cell_start_) (void)hipFree(cell_start_);
+  if (tagmap_) (void)hipFree(tagmap_);
+  if (sort_tmp_) (void)hipFree(sort_tmp_);
+  if (d_flags_) (void)hipFree(d_flags_);
+  if (h_flags_) (void)hipHostFree(h_flags_);
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void DemEngine::alloc_all(size_t cap)
+{
+  hipStream_t s = stream_;
+  for (int b = 0; b < 2; b++) {
+    xr_[b].alloc(sizeof(double4), 1, cap, s);
+    vm_[b].alloc(sizeof(double4), 1, cap, s);
+    om_[b].alloc(sizeof(double4), 1, cap, s);
+  }
+  force_.alloc(sizeof(double4), 1, cap, s);
+  torque_.alloc(sizeof(double4), 1, cap, s);
+  tag_.alloc(sizeof(int), 1, cap, s);
+  type_.alloc(sizeof(int), 1, cap, s);
+  mask_.alloc(sizeof(int), 1, cap, s);
+  foamCpuId_.alloc(sizeof(int), 1, cap, s);
+  fdrag_.alloc(sizeof(double), 3, cap, s);
+  DuDt_.alloc(sizeof(double), 3, cap, s);
+  vOld_.alloc(sizeof(double), 3, cap, s);
+  xhold_.alloc(sizeof(double), 3, cap, s);
+  wshear_.alloc(sizeof(double), 3 * kMaxWalls, cap, s);
+  wtouch_.alloc(sizeof(unsigned char), 1, cap, s);
+  gsrc_.alloc(sizeof(int), 1, cap, s);
+  gshift_.alloc(sizeof(double), 3, cap, s);
+  neigh_.alloc(sizeof(int), M_, cap, s);
+  numneigh_.alloc(sizeof(int), 1, cap, s);
+  shear_.alloc(sizeof(double), 3 * M_, cap, s);
+  neigh_old_.alloc(sizeof(int), M_, cap, s);
+  numneigh_old_.alloc(sizeof(int), 1, cap, s);
+  shear_old_.alloc(sizeof(double), 3 * M_, cap, s);
+  ptag_.alloc(sizeof(int), M_, cap, s);
+  tmp4_.alloc(sizeof(double4), 1, cap, s);
+  tmpd_.alloc(sizeof(double), 3 * kMaxWalls, cap, s);
+  tmpi_.alloc(sizeof(int), 1, cap, s);
+  keys_.alloc(sizeof(unsigned), 1, cap, s);
+  keys_alt_.alloc(sizeof(unsigned), 1, cap, s);
+  perm_.alloc(sizeof(int), 1, cap, s);
+  perm_alt_.alloc(sizeof(int), 1, cap, s);
+  keys64_.alloc(sizeof(unsigned long long), 1, cap, s);
+  keys64_alt_.alloc(sizeof(unsigned long long), 1, cap, s);
+  sendlist_[0].alloc(sizeof(int), 1, cap, s);
+  sendlist_[1].alloc(sizeof(int), 1, cap, s);
+  cap_ = cap;
+}
+
+void DemEngine::ensure_capacity(size_t need)
+{
+  if (need <= cap_) return;
+  size_t newcap = need + need / 4 + 1024;
+  if (cap_ == 0) {
+    alloc_all(newcap);
+    return;
+  }
+  for (DevArray* a : per_atom_) a->grow(newcap, stream_);
+  cap_ = newcap;
+}
+
+void DemEngine::grow_neigh(int newM)
+{
+  // re-allocate the slot-major arrays with more rows (old rows keep their place)
+  auto regrow = [&](DevArray& a, int rows_per_slot) {
+    DevArray n;
+    n.alloc(a.elem, rows_per_slot * newM, cap_, stream_);
+    SF_HIP(hipMemcpyAsync(n.ptr, a.ptr, a.elem * (size_t)a.rows * cap_, hipMemcpyDeviceToDevice, stream_));
+    sync();
+    a.release();
+    a = n;
+  };
+  regrow(neigh_, 1);
+  regrow(shear_, 3);
+  regrow(neigh_old_, 1);
+  regrow(shear_old_, 3);
+  regrow(ptag_, 1);
+  M_ = newM;
+}
+
+void DemEngine::set_max_neigh(int m)
+{
+  if (m < 4) m = 4;
+  if (cap_ == 0) M_ = m;
+  else if (m > M_) grow_neigh(m);
+}
+
+void DemEngine::set_box(const double lo[3], const double hi[3])
+{
+  for (int k = 0; k < 3; k++) {
+    boxlo_[k] = lo[k];
+    boxhi_[k] = hi[k];
+  }
+  if (!have_subdomain_) {
+    sublo_x_ = lo[0];
+    subhi_x_ = hi[0];
+  }
+}
+
+void DemEngine::set_periodic(int px, int py, int pz)
+{
+  periodic_[0] = px;
+  periodic_[1] = py;
+  periodic_[2] = pz;
+}
+
+void DemEngine::set_subdomain(int rank, int nranks, double sublo, double subhi)
+{
+  rank_ = rank;
+  nranks_ = nranks;
+  sublo_x_ = sublo;
+  subhi_x_ = subhi;
+  have_subdomain_ = true;
+}
+
+void DemEngine::sublo_hi(double out[6]) const
+{
+  out[0] = sublo_x_;
+  out[1] = subhi_x_;
+  out[2] = boxlo_[1];
+  out[3] = boxhi_[1];
+  out[4] = boxlo_[2];
+  out[5] = boxhi_[2];
+}
+
+void DemEngine::create_atoms(int n, const double* x, const double* v, const double* omega,
+                             const double* diameter, const double* density, const int* tag, const int* type)
+{
+  if (setup_done_) fail("create_atoms after setup: use lammps_create_particle");
+  const int n0 = nlocal_;
+  ensure_capacity((size_t)(n0 + n) + (size_t)(n0 + n) / 2 + 4096);
+  std::vector<double4> hx(n), hv(n), hw(n);
+  std::vector<int> ht(n), hty(n), hm(n, 1);
+  for (int i = 0; i < n; i++) {
+    const double r = 0.5 * diameter[i];
+    // [3P] read_data, atom_style sphere: rmass = 4 pi/3 r^3 density
+    const double m = 4.0 * kPi / 3.0 * r * r * r * density[i];
+    hx[i] = {x[3 * i], x[3 * i + 1], x[3 * i + 2], r};
+    hv[i] = {v ? v[3 * i] : 0.0, v ? v[3 * i + 1] : 0.0, v ? v[3 * i + 2] : 0.0, m};
+    hw[i] = {omega ? omega[3 * i] : 0.0, omega ? omega[3 * i + 1] : 0.0, omega ? omega[3 * i + 2] : 0.0, 0.0};
+    ht[i] = tag ? tag[i] : n0 + i + 1;
+    hty[i] = type ? type[i] : 1;
+    max_tag_ = std::max(max_tag_, ht[i]);
+    rmax_ = std::max(rmax_, r);
+  }
+  auto up = [&](DevArray& a, const void* src, size_t bytes, size_t off) {
+    SF_HIP(hipMemcpyAsync((char*)a.ptr + off, src, bytes, hipMemcpyHostToDevice, stream_));
+  };
+  up(xr_[cur_], hx.data(), sizeof(double4) * n, sizeof(double4) * n0);
+  up(vm_[cur_], hv.data(), sizeof(double4) * n, sizeof(double4) * n0);
+  up(om_[cur_], hw.data(), sizeof(double4) * n, sizeof(double4) * n0);
+  up(tag_, ht.data(), sizeof(int) * n, sizeof(int) * n0);
+  up(type_, hty.data(), sizeof(int) * n, sizeof(int) * n0);
+  up(mask_, hm.data(), sizeof(int) * n, sizeof(int) * n0);
+  sync();
+  nlocal_ = n0 + n;
+}
+
+void DemEngine::set_pair_gran(int style, double kn, bool kt_null, double kt, double gamman, bool gammat_null,
+                              double gammat, double xmu, int dampflag)
+{
+  gran_settings(gran_, style, kn, kt_null, kt, gamman, gammat_null, gammat, xmu, dampflag, 1.0);
+  // wall/granFix follows the pair style (fix_wall_granFix.cpp:217-229)
+  for (int w = 0; w < nwalls_; w++) {
+    walls_[w].gp.style = style;
+    walls_[w].gp.beta = (style == 2 && walls_[w].gp.gamman > 0.0) ? hertz_beta(walls_[w].gp.gamman) : 0.0;
+  }
+}
+
+void DemEngine::set_pair_lubricate(double mu, int flaglog, int flagfld, double cut_inner, double cut_global,
+                                   int flagHI, int flagVF)
+{
+  lub_.enabled = 1;
+  lub_.mu = mu;
+  lub_.flaglog = flaglog;
+  lub_.flagfld = flagfld;
+  lub_.cut_inner = cut_inner;
+  lub_.cut_global = cut_global;
+  lub_.flagHI = flagHI;
+  lub_.flagVF = flagVF;
+  lub_.vxmu2f = 1.0;
+}
+
+void DemEngine::set_cohesive(double ah, double lam, double smin, double smax, int opt)
+{
+  if (opt != 0 && opt != 1) fail("invalid option for cohesive force model");  // fix_cohesive.cpp:262
+  cohe_ = {ah, lam, smin, smax, opt, 1};
+}
+
+void DemEngine::set_gravity(double mag, double gx, double gy, double gz)
+{
+  const double len = std::sqrt(gx * gx + gy * gy + gz * gz);
+  have_gravity_ = true;
+  gacc_[0] = len > 0 ? mag * (gx / len) : 0.0;
+  gacc_[1] = len > 0 ? mag * (gy / len) : 0.0;
+  gacc_[2] = len > 0 ? mag * (gz / len) : 0.0;
+}
+
+void DemEngine::set_fdrag(double carrier_rho)
+{
+  have_fdrag_ = true;
+  carrier_rho_ = carrier_rho;
+}
+
+void DemEngine::add_wall(int dim, bool lo_null, double lo, bool hi_null, double hi, double kn, bool kt_null,
+                         double kt, double gamman, bool gammat_null, double gammat, double xmu, int dampflag,
+                         bool granfix)
+{
+  if (nwalls_ >= kMaxWalls) fail("too many wall fixes (max %d)", kMaxWalls);
+  if (periodic_[dim]) fail("Cannot use wall in periodic dimension");  // fix_wall_granFix.cpp:143-148
+  if (!granfix && gran_.style == 2)
+    fail("Fix wall/gran is incompatible with Pair style");  // stock wall/gran does not know hertzFix
+  WallParams& W = walls_[nwalls_++];
+  W.dim = dim;
+  W.lo = lo_null ? -1.0e20 : lo;
+  W.hi = hi_null ? 1.0e20 : hi;
+  gran_settings(W.gp, gran_.style ? gran_.style : 1, kn, kt_null, kt, gamman, gammat_null, gammat, xmu,
+                dampflag, 1.0);
+}
+
+void DemEngine::set_velocity_all(double vx, double vy, double vz)
+{
+  if (!nlocal_) return;
+  k_set_velocity<<<div_up(nlocal_, 256), 256, 0, stream_>>>(vm_[cur_].as<double4>(), nlocal_, vx, vy, vz);
+}
+
+double DemEngine::max_radius() { return rmax_; }
+
+double DemEngine::cutneighmax() const
+{
+  double c = 0.0;
+  if (gran_.style) c = 2.0 * rmax_ + (cohe_.enabled ? cohe_.smax : 0.0);
+  if (lub_.enabled && lub_.cut_global > c) c = lub_.cut_global;
+  return c + skin_;
+}
+
+void DemEngine::reset_flag(int idx, int value)
+{
+  h_flags_[idx] = value;
+  SF_HIP(hipMemcpyAsync(d_flags_ + idx, h_flags_ + idx, sizeof(int), hipMemcpyHostToDevice, stream_));
+}
+
+void DemEngine::read_flags()
+{
+  SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
+  sync();
+}
+
+DemPtrs DemEngine::ptrs(int in_buf) const
+{
+  DemPtrs P;
+  const int ob = in_buf ^ 1;
+  P.xr_in = xr_[in_buf].as<double4>();
+  P.vm_in = vm_[in_buf].as<double4>();
+  P.om_in = om_[in_buf].as<double4>();
+  P.xr_out = xr_[ob].as<double4>();
+  P.vm_out = vm_[ob].as<double4>();
+  P.om_out = om_[ob].as<double4>();
+  P.force = force_.as<double4>();
+  P.torque = torque_.as<double4>();
+  P.neigh = neigh_.as<int>();
+  P.numneigh = numneigh_.as<int>();
+  P.shear = shear_.as<double>();
+  P.fdrag = fdrag_.as<double>();
+  P.DuDt = DuDt_.as<double>();
+  P.vOld = vOld_.as<double>();
+  P.wshear = wshear_.as<double>();
+  P.wtouch = wtouch_.as<unsigned char>();
+  P.xhold = xhold_.as<double>();
+  P.mask = mask_.as<int>();
+  P.flags = d_flags_;
+  return P;
+}
+
+StepParams DemEngine::step_params(int mode, int kstep) const
+{
+  StepParams S;
+  memset(&S, 0, sizeof(S));
+  S.nlocal = nlocal_;
+  S.cap = (int)cap_;
+  S.mode = mode;
+  S.kstep = kstep;
+  S.dt = dt_;
+  S.trigger_sq = (0.5 * skin_) * (0.5 * skin_);
+  S.gran = gran_;
+  S.cohe = cohe_;
+  S.lub = lub_;
+  S.nwalls = nwalls_;
+  for (int w = 0; w < nwalls_; w++) S.wall[w] = walls_[w];
+  S.have_gravity = have_gravity_;
+  for (int k = 0; k < 3; k++) S.gacc[k] = gacc_[k];
+  S.have_fdrag = have_fdrag_;
+  S.carrier_rho = carrier_rho_;
+  S.have_nve = have_nve_;
+  S.freeze_bit = 0;
+  return S;
+}
+
+template <int STYLE>
+static void launch_substep_style(bool cohe, bool lub, dim3 grid, hipStream_t s, const DemPtrs& P,
+                                 const StepParams& S)
+{
+  if (cohe && lub) k_substep<STYLE, true, true><<<grid, 256, 0, s>>>(P, S);
+  else if (cohe) k_substep<STYLE, true, false><<<grid, 256, 0, s>>>(P, S);
+  else if (lub) k_substep<STYLE, false, true><<<grid, 256, 0, s>>>(P, S);
+  else k_substep<STYLE, false, false><<<grid, 256, 0, s>>>(P, S);
+}
+
+void DemEngine::launch_substep(int in_buf, int mode, int kstep)
+{
+  if (!nlocal_) return;
+  const DemPtrs P = ptrs(in_buf);
+  const StepParams S = step_params(mode, kstep);
+  const dim3 grid(div_up(nlocal_, 256));
+  const bool cohe = cohe_.enabled, lub = lub_.enabled;
+  switch (gran_.style) {
+    case 2: launch_substep_style<2>(cohe, lub, grid, stream_, P, S); break;
+    case 1: launch_substep_style<1>(cohe, lub, grid, stream_, P, S); break;
+    default: launch_substep_style<0>(cohe, lub, grid, stream_, P, S); break;
+  }
+  SF_HIP(hipGetLastError());
+}
+
+void DemEngine::launch_ghost_forward(int buf, int kstep)
+{
+  if (!nghost_) return;
+  k_ghost_forward<<<div_up(nghost_, 256), 256, 0, stream_>>>(
+      xr_[buf].as<double4>(), vm_[buf].as<double4>(), om_[buf].as<double4>(), gsrc_.as<int>(),
+      gshift_.as<double>(), nlocal_, nghost_, cap_, d_flags_, kstep);
+}
+
+void DemEngine::launch_initial_integrate()
+{
+  if (!nlocal_ || !have_nve_) return;
+  k_initial_integrate<<<div_up(nlocal_, 256), 256, 0, stream_>>>(
+      xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), force_.as<double4>(),
+      torque_.as<double4>(), xhold_.as<double>(), d_flags_, nlocal_, cap_, dt_,
+      (0.5 * skin_) * (0.5 * skin_));
+}
+
+// ------------------------------------------------------------------------------------------------
+// neighbour rebuild
+// ------------------------------------------------------------------------------------------------
+void DemEngine::compute_grid()
+{
+  const double cut = cutneighmax();
+  if (!(cut > 0.0)) fail("neighbor cutoff is zero: define a pair style and/or `neighbor <skin> bin`");
+  double lo[3] = {sublo_x_, boxlo_[1], boxlo_[2]};
+  double hi[3] = {subhi_x_, boxhi_[1], boxhi_[2]};
+  grid_.nbins = 1;
+  for (int k = 0; k < 3; k++) {
+    const bool ext = periodic_[k] || (k == 0 && nranks_ > 1);
+    const double l = ext ? lo[k] - cut : lo[k];
+    const double h = ext ? hi[k] + cut : hi[k];
+    int n = (int)((h - l) / cut);
+    n = std::max(1, std::min(n, 1 << 9));
+    grid_.lo[k] = l;
+    grid_.n[k] = n;
+    grid_.inv[k] = n / (h - l);
+    grid_.nbins *= n;
+  }
+  if ((size_t)grid_.nbins > cell_alloc_) {
+    if (cell_start_) SF_HIP(hipFree(cell_start_));
+    cell_alloc_ = (size_t)grid_.nbins + grid_.nbins / 8;
+    SF_HIP(hipMalloc(&cell_start_, sizeof(int) * 4 * cell_alloc_));
+  }
+}
+
+void DemEngine::rebuild_begin()
+{
+  if (!nlocal_ && !nghost_) return;
+  compute_grid();
+  if (have_list_ && nlocal_)
+    k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
+                                                              tag_.as<int>(), ptag_.as<int>(), nlocal_, cap_,
+                                                              max_neigh_used_);
+  nghost_ = 0;
+  next_ghost_ = 0;
+  nsend_[0] = nsend_[1] = 0;
+  recv_count_[0] = recv_count_[1] = 0;
+}
+
+void DemEngine::rebuild_sort()
+{
+  if (!nlocal_) return;
+  PbcParams pb;
+  for (int k = 0; k < 3; k++) {
+    pb.lo[k] = boxlo_[k];
+    pb.hi[k] = boxhi_[k];
+    // x is wrapped here only when this GPU owns the whole periodic length; with several slabs the
+    // wrap is applied by the migration shift
+    pb.wrap[k] = periodic_[k] && !(k == 0 && nranks_ > 1);
+  }
+  const int nb = div_up(nlocal_, 256);
+  k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
+                                      perm_.as<int>(), d_flags_);
+  int bits = 1;
+  while ((1 << bits) < grid_.nbins) bits++;
+  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
+                 perm_alt_.as<int>(), nlocal_, bits, stream_);
+  const int* perm = perm_alt_.as<int>();
+  // physically re-order every per-atom array of the owned atoms
+  auto g4 = [&](DevArray& a) {
+    k_gather4<<<nb, 256, 0, stream_>>>(tmp4_.as<double4>(), a.as<double4>(), perm, nlocal_);
+    SF_HIP(hipMemcpyAsync(a.ptr, tmp4_.ptr, sizeof(double4) * nlocal_, hipMemcpyDeviceToDevice, stream_));
+  };
+  auto gd = [&](DevArray& a, int rows) {
+    k_gather_rows<double><<<nb, 256, 0, stream_>>>(tmpd_.as<double>(), a.as<double>(), perm, nlocal_, rows, cap_);
+    k_copy_rows<double><<<nb, 256, 0, stream_>>>(a.as<double>(), tmpd_.as<double>(), nlocal_, rows, cap_);
+  };
+  auto gi = [&](DevArray& a) {
+    k_gather_rows<int><<<nb, 256, 0, stream_>>>(tmpi_.as<int>(), a.as<int>(), perm, nlocal_, 1, cap_);
+    SF_HIP(hipMemcpyAsync(a.ptr, tmpi_.ptr, sizeof(int) * nlocal_, hipMemcpyDeviceToDevice, stream_));
+  };
+  g4(xr_[cur_]);
+  g4(vm_[cur_]);
+  g4(om_[cur_]);
+  g4(force_);
+  g4(torque_);
+  gi(tag_);
+  gi(type_);
+  gi(mask_);
+  gi(foamCpuId_);
+  gd(fdrag_, 3);
+  if (carrier_rho_ != 0.0) {
+    gd(DuDt_, 3);
+    gd(vOld_, 3);
+  }
+  if (nwalls_) {
+    gd(wshear_, 3 * nwalls_);
+    k_gather_rows<unsigned char><<<nb, 256, 0, stream_>>>((unsigned char*)tmpi_.ptr, wtouch_.as<unsigned char>(),
+                                                          perm, nlocal_, 1, cap_);
+    SF_HIP(hipMemcpyAsync(wtouch_.ptr, tmpi_.ptr, nlocal_, hipMemcpyDeviceToDevice, stream_));
+  }
+  if (have_list_) {
+    // old list rows travel with their atom: partner tags -> neigh_old_, shear -> shear_old_
+    k_gather_rows<int><<<nb, 256, 0, stream_>>>(numneigh_old_.as<int>(), numneigh_.as<int>(), perm, nlocal_, 1, cap_);
+    k_gather_rows<int><<<nb, 256, 0, stream_>>>(neigh_old_.as<int>(), ptag_.as<int>(), perm, nlocal_,
+                                                max_neigh_used_, cap_);
+    k_gather_rows<double><<<nb, 256, 0, stream_>>>(shear_old_.as<double>(), shear_.as<double>(), perm, nlocal_,
+                                                   3 * max_neigh_used_, cap_);
+  }
+  // sorted bin keys -> cell ranges of owned atoms
+  SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
+  k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
+                                                   cell_start_ + cell_alloc_);
+}
+
+void DemEngine::make_periodic_ghosts()
+{
+  // external ghosts (other GPUs) were appended by border_unpack: slots [nlocal, nlocal+next_ghost_)
+  nghost_ = next_ghost_;
+  const double cut = cutneighmax();
+  for (int attempt = 0; attempt < 4; attempt++) {
+    reset_flag(F_GHOST_COUNT, next_ghost_);
+    reset_flag(F_GHOST_OVER, 0);
+    int nall0 = nlocal_ + next_ghost_;
+    bool over = false;
+    for (int dim = 0; dim < 3; dim++) {
+      if (!periodic_[dim]) continue;
+      if (dim == 0 && nranks_ > 1) continue;  // x images come from the neighbour GPUs
+      GhostPtrs G{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
+                  type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
+      if (nall0)
+        k_make_ghosts<<<div_up(nall0, 256), 256, 0, stream_>>>(G, nlocal_, nall0, dim, boxlo_[dim], boxhi_[dim],
+                                                               cut, cap_, d_flags_);
+      read_flags();
+      if (h_flags_[F_GHOST_OVER]) {
+        over = true;
+        // count how many we would need and grow
+        ensure_capacity((size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] * 2 + 1024);
+        break;
+      }
+      nall0 = nlocal_ + h_flags_[F_GHOST_COUNT];
+    }
+    if (!over) {
+      nghost_ = nall0 - nlocal_;
+      return;
+    }
+  }
+  fail("ghost creation: capacity could not be grown");
+}
+
+void DemEngine::bin_and_build()
+{
+  if (!nlocal_) {
+    have_list_ = true;
+    return;
+  }
+  int* cellLS = cell_start_;
+  int* cellLE = cell_start_ + cell_alloc_;
+  int* cellGS = cell_start_ + 2 * cell_alloc_;
+  int* cellGE = cell_start_ + 3 * cell_alloc_;
+  if (nghost_) {
+    k_ghost_keys<<<div_up(nghost_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), tag_.as<int>(), nlocal_,
+                                                            nghost_, grid_, keys64_.as<unsigned long long>(),
+                                                            perm_.as<int>(), d_flags_);
+    sort_pairs_u64(sort_tmp_, sort_tmp_bytes_, keys64_.as<unsigned long long>(),
+                   keys64_alt_.as<unsigned long long>(), perm_.as<int>(), perm_alt_.as<int>(), nghost_, 64,
+                   stream_);
+    k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
+        keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE);
+  }
+  for (int attempt = 0; attempt < 3; attempt++) {
+    reset_flag(F_NEIGH_OVER, 0);
+    reset_flag(F_MAXNEIGH, 0);
+    BuildParams B;
+    B.nlocal = nlocal_;
+    B.M = M_;
+    B.Mold = max_neigh_used_;
+    B.cap = cap_;
+    B.skin_gran = gran_.style ? skin_ + (cohe_.enabled ? cohe_.smax : 0.0) : -1.0;
+    B.cut_lub = lub_.enabled ? lub_.cut_global + skin_ : 0.0;
+    B.g = grid_;
+    k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
+        B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
+        have_list_ ? numneigh_old_.as<int>() : nullptr, neigh_old_.as<int>(), shear_old_.as<double>(),
+        neigh_.as<int>(), numneigh_.as<int>(), shear_.as<double>(), d_flags_);
+    read_flags();
+    if (h_flags_[F_NEIGH_OVER] > M_) {
+      // more neighbours than slots: widen the slot-major arrays and build again.  The old-history
+      // arrays keep their first rows, so the re-injection still finds every partner.
+      grow_neigh(h_flags_[F_NEIGH_OVER] + 4);
+      continue;
+    }
+    break;
+  }
+  if (h_flags_[F_NEIGH_OVER] > M_) fail("neighbor list overflow (%d > %d slots)", h_flags_[F_NEIGH_OVER], M_);
+  if (h_flags_[F_LOST] == 1) {
+    reset_flag(F_LOST, 0);
+    fail("Lost atoms: an atom left the (non-periodic) simulation box");  // thermo_modify lost error
+  }
+  max_neigh_used_ = h_flags_[F_MAXNEIGH];
+  k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
+                                                           cap_);
+  have_list_ = true;
+  nbuilds_++;
+}
+
+void DemEngine::rebuild_finish()
+{
+  make_periodic_ghosts();
+  bin_and_build();
+  reset_flag(F_TRIGGER, INT_MAX);
+}
+
+void DemEngine::rebuild()
+{
+  rebuild_begin();
+  rebuild_sort();
+  rebuild_finish();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stepping
+// ------------------------------------------------------------------------------------------------
+void DemEngine::setup()
+{
+  if (!have_nve_ && nlocal_) { /* allowed: static atoms */ }
+  if (lub_.enabled) {
+    // PairLubricatePoly::init_style pair_lubricate_poly.cpp:514-559: volume fraction constants
+    std::vector<double4> hx(nlocal_);
+    if (nlocal_)
+      SF_HIP(hipMemcpyAsync(hx.data(), xr_[cur_].ptr, sizeof(double4) * nlocal_, hipMemcpyDeviceToHost, stream_));
+    sync();
+    double volP = 0.0;
+    for (int i = 0; i < nlocal_; i++) volP += (4.0 / 3.0) * kPi * std::pow(hx[i].w, 3.0);
+    const double vol_T = (boxhi_[0] - boxlo_[0]) * (boxhi_[1] - boxlo_[1]) * (boxhi_[2] - boxlo_[2]);
+    double vol_f = volP / vol_T;
+    if (!lub_.flagVF) vol_f = 0;
+    const double mu = lub_.mu;
+    if (lub_.flaglog == 0) {
+      lub_.R0 = 6 * kPi * mu * (1.0 + 2.16 * vol_f);
+      lub_.RT0 = 8 * kPi * mu;
+      lub_.RS0 = 20.0 / 3.0 * kPi * mu * (1.0 + 3.33 * vol_f + 2.80 * vol_f * vol_f);
+    } else {
+      lub_.R0 = 6 * kPi * mu * (1.0 + 2.725 * vol_f - 6.583 * vol_f * vol_f);
+      lub_.RT0 = 8 * kPi * mu * (1.0 + 0.749 * vol_f - 2.469 * vol_f * vol_f);
+      lub_.RS0 = 20.0 / 3.0 * kPi * mu * (1.0 + 3.64 * vol_f - 6.95 * vol_f * vol_f);
+    }
+  }
+  have_list_ = false;
+  if (nranks_ == 1) rebuild();
+  // (multi-rank: the driver has already run rebuild_begin / migrate / sort / borders / finish)
+  reset_flag(F_TRIGGER, INT_MAX);
+  launch_substep(cur_, 2, 0);
+  launch_ghost_forward(cur_ ^ 1, 0);
+  cur_ ^= 1;
+  sync();
+  setup_done_ = true;
+}
+
+void DemEngine::run_begin()
+{
+  reset_flag(F_TRIGGER, INT_MAX);
+  launch_initial_integrate();
+  launch_ghost_forward(cur_, 0);
+}
+
+void DemEngine::substep(bool last)
+{
+  launch_substep(cur_, last ? 1 : 0, 0);
+  launch_ghost_forward(cur_ ^ 1, 0);
+  cur_ ^= 1;
+  nsteps_++;
+}
+
+bool DemEngine::need_rebuild()
+{
+  read_flags();
+  return h_flags_[F_TRIGGER] != INT_MAX;
+}
+
+void DemEngine::run(int nsteps)
+{
+  if (!setup_done_) setup();
+  if (nsteps <= 0) return;
+  if (nranks_ > 1) fail("sf_lammps_step on a decomposed domain: drive the sub-steps through sf_dem_*");
+  reset_flag(F_TRIGGER, INT_MAX);
+  launch_initial_integrate();
+  launch_ghost_forward(cur_, 0);
+  int k = 0;
+  SF_HIP(hipEventRecord(ev0_, stream_));
+  while (k < nsteps) {
+    const int base = cur_;
+    for (int s = k; s < nsteps; s++) {
+      const int in_buf = (base + (s - k)) & 1;
+      launch_substep(in_buf, (s == nsteps - 1) ? 1 : 0, s);
+      launch_ghost_forward(in_buf ^ 1, s);
+    }
+    read_flags();
+    const int trig = h_flags_[F_TRIGGER];
+    if (trig == INT_MAX) {
+      cur_ = (base + (nsteps - k)) & 1;
+      k = nsteps;
+    } else {
+      // sub-steps k..trig ran; the list went stale for sub-step trig+1 (trig = -1: for sub-step 0)
+      const int done = trig + 1 - k;
+      cur_ = (base + done) & 1;
+      k = trig + 1;
+      rebuild();
+    }
+  }
+  SF_HIP(hipEventRecord(ev1_, stream_));
+  sync();
+  float ms = 0.f;
+  SF_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+  last_substep_ms_ = ms / nsteps;
+  nsteps_ += nsteps;
+}
+
+// ------------------------------------------------------------------------------------------------
+// data exchange (lammps_* surface)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ScratchD {
+  double* p = nullptr;
+  explicit ScratchD(size_t n) { SF_HIP(hipMalloc(&p, sizeof(double) * (n ? n : 1))); }
+  ~ScratchD() { (void)hipFree(p); }
+};
+struct ScratchI {
+  int* p = nullptr;
+  explicit ScratchI(size_t n) { SF_HIP(hipMalloc(&p, sizeof(int) * (n ? n : 1))); }
+  ~ScratchI() { (void)hipFree(p); }
+};
+}  // namespace
+
+void DemEngine::get_local_info(double* x, double* v, int* foamCpuId, int* tag)
+{
+  const int n = nlocal_;
+  if (!n) return;
+  ScratchD dx(3 * (size_t)n), dv(3 * (size_t)n);
+  k_pack_info<<<div_up(n, 256), 256, 0, stream_>>>(d_xr(), d_vm(), d_om(), d_force(), d_torque(), n, dx.p, dv.p,
+                                                   nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (x) SF_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (v) SF_HIP(hipMemcpyAsync(v, dv.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (foamCpuId)
+    SF_HIP(hipMemcpyAsync(foamCpuId, foamCpuId_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
+  if (tag) SF_HIP(hipMemcpyAsync(tag, tag_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
+  sync();
+}
+
+void DemEngine::get_initial_info(double* x, double* v, double* diam, double* rho, int* tag, int* type)
+{
+  const int n = nlocal_;
+  if (!n) return;
+  ScratchD dx(3 * (size_t)n), dv(3 * (size_t)n), dd(n), dr(n);
+  k_pack_info<<<div_up(n, 256), 256, 0, stream_>>>(d_xr(), d_vm(), d_om(), d_force(), d_torque(), n, dx.p, dv.p,
+                                                   nullptr, nullptr, nullptr, dd.p, dr.p);
+  if (x) SF_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (v) SF_HIP(hipMemcpyAsync(v, dv.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (diam) SF_HIP(hipMemcpyAsync(diam, dd.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+  if (rho) SF_HIP(hipMemcpyAsync(rho, dr.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+  if (tag) SF_HIP(hipMemcpyAsync(tag, tag_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
+  if (type) SF_HIP(hipMemcpyAsync(type, type_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
+  sync();
+}
+
+void DemEngine::get_forces(double* f, double* torque, double* omega, int* tag)
+{
+  const int n = nlocal_;
+  if (!n) return;
+  ScratchD df(3 * (size_t)n), dt(3 * (size_t)n), dw(3 * (size_t)n);
+  k_pack_info<<<div_up(n, 256), 256, 0, stream_>>>(d_xr(), d_vm(), d_om(), d_force(), d_torque(), n, nullptr,
+                                                   nullptr, dw.p, df.p, dt.p, nullptr, nullptr);
+  if (f) SF_HIP(hipMemcpyAsync(f, df.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (torque) SF_HIP(hipMemcpyAsync(torque, dt.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (omega) SF_HIP(hipMemcpyAsync(omega, dw.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (tag) SF_HIP(hipMemcpyAsync(tag, tag_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
+  sync();
+}
+
+void DemEngine::put_local_info(int n, const double* fdrag, const int* foamCpuId, const int* tagIn)
+{
+  if (!have_fdrag_) fail("lammps_put_local_info: no `fix ... fdrag` defined");  // library.cpp:324-333 derefs NULL
+  if (n != nlocal_)
+    fprintf(stderr, "Incoming drag not consistent with local particle number.\nIncoming drag is: %5d, local "
+                    "particle number is: %5d.\n", n, nlocal_);  // library.cpp:335-341 (prints, continues)
+  const int m = std::min(n, nlocal_);
+  if (!m) return;
+  if ((size_t)max_tag_ > tagmap_alloc_) {
+    if (tagmap_) SF_HIP(hipFree(tagmap_));
+    tagmap_alloc_ = (size_t)max_tag_ + max_tag_ / 4 + 16;
+    SF_HIP(hipMalloc(&tagmap_, sizeof(int) * tagmap_alloc_));
+  }
+  SF_HIP(hipMemsetAsync(tagmap_, 0xff, sizeof(int) * tagmap_alloc_, stream_));
+  k_tag_map<<<div_up(nlocal_, 256), 256, 0, stream_>>>(tag_.as<int>(), nlocal_, tagmap_, max_tag_);
+  ScratchD din(3 * (size_t)m);
+  ScratchI dtag(m), dcpu(m);
+  SF_HIP(hipMemcpyAsync(din.p, fdrag, sizeof(double) * 3 * m, hipMemcpyHostToDevice, stream_));
+  SF_HIP(hipMemcpyAsync(dtag.p, tagIn, sizeof(int) * m, hipMemcpyHostToDevice, stream_));
+  if (foamCpuId) SF_HIP(hipMemcpyAsync(dcpu.p, foamCpuId, sizeof(int) * m, hipMemcpyHostToDevice, stream_));
+  k_put_fdrag<<<div_up(m, 256), 256, 0, stream_>>>(din.p, dtag.p, foamCpuId ? dcpu.p : nullptr, m, tagmap_,
+                                                   max_tag_, fdrag_.as<double>(), foamCpuId_.as<int>(), cap_,
+                                                   d_flags_);
+  read_flags();
+  if (h_flags_[F_LOST] == 2) {
+    reset_flag(F_LOST, 0);
+    fail("lammps_put_local_info: incoming tag not owned by this rank");
+  }
+}
+
+long long DemEngine::npairs_full()
+{
+  if (!nlocal_ || !have_list_) return 0;
+  unsigned long long* d = nullptr;
+  SF_HIP(hipMalloc(&d, sizeof(unsigned long long)));
+  SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), stream_));
+  k_count_pairs<<<div_up(nlocal_, 256), 256, 0, stream_>>>(numneigh_.as<int>(), nlocal_, d);
+  unsigned long long h = 0;
+  SF_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream_));
+  sync();
+  (void)hipFree(d);
+  return (long long)h;
+}
+
+long long DemEngine::get_history(long long max, int* tag_i, int* tag_j, double* shear)
+{
+  if (!nlocal_ || !have_list_) return 0;
+  unsigned long long* d = nullptr;
+  SF_HIP(hipMalloc(&d, sizeof(unsigned long long)));
+  SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), stream_));
+  ScratchI ti(max), tj(max);
+  ScratchD sh(3 * (size_t)max);
+  k_collect_history<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
+                                                               shear_.as<double>(), tag_.as<int>(), nlocal_, cap_,
+                                                               d, max, ti.p, tj.p, sh.p);
+  unsigned long long h = 0;
+  SF_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream_));
+  sync();
+  (void)hipFree(d);
+  const long long n = std::min<long long>((long long)h, max);
+  if (n > 0) {
+    SF_HIP(hipMemcpy(tag_i, ti.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    SF_HIP(hipMemcpy(tag_j, tj.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    SF_HIP(hipMemcpy(shear, sh.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  }
+  return (long long)h;
+}
+
+void DemEngine::get_wall_shear(int w, double* shear)
+{
+  if (w < 0 || w >= nwalls_) fail("no such wall fix %d", w);
+  const int n = nlocal_;
+  std::vector<double> row((size_t)n);
+  std::vector<unsigned char> wt((size_t)n);
+  SF_HIP(hipMemcpyAsync(wt.data(), wtouch_.ptr, n, hipMemcpyDeviceToHost, stream_));
+  sync();
+  for (int c = 0; c < 3; c++) {
+    SF_HIP(hipMemcpy(row.data(), wshear_.as<double>() + (size_t)(3 * w + c) * cap_, sizeof(double) * n,
+                     hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) shear[3 * i + c] = (wt[i] & (1u << w)) ? row[i] : 0.0;
+  }
+}
+
+}  // namespace sf

@@ -1,0 +1,612 @@
+// sf_dem_kernels.h -- HIP kernels of the DEM engine (gfx950, wave64, FP64).  Included by sf_dem.hip.
+//
+// Hot kernel: k_substep = PairGranHertzFixHistory::compute (pair_gran_hertzFix_history.cpp:45-287)
+//   + FixCohe::post_force (fix_cohesive.cpp:138-263) + PairLubricatePoly::compute
+//   (pair_lubricate_poly.cpp:194-407) + FixFluidDrag::post_force (fix_fluid_drag.cpp:114-164)
+//   + FixWallGranFix::post_force (fix_wall_granFix.cpp:247-345) + [3P] gravity and the two
+//   nve/sphere half-kicks, for one owned atom per lane.
+#pragma once
+#include <climits>
+
+#include "sf_dem.h"
+
+namespace sf {
+
+__device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
+
+// ------------------------------------------------------------------------------------------------
+// fused DEM sub-step
+// ------------------------------------------------------------------------------------------------
+template <int STYLE, bool COHE, bool LUB>
+__global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
+{
+  // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
+  // (the host rebuilds and relaunches from that sub-step)
+  if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S.nlocal) return;
+  const size_t cap = (size_t)S.cap;
+  const bool shearupdate = (S.mode != 2);
+
+  const double4 xi4 = P.xr_in[i];
+  const double4 vi4 = P.vm_in[i];
+  const double4 wi4 = P.om_in[i];
+  const Vec3 xi = v3(xi4), vi = v3(vi4), wi = v3(wi4);
+  const double radi = xi4.w, mi = vi4.w;
+
+  Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
+  const int nn = P.numneigh[i];
+  const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
+
+  for (int s = 0; s < nn; s++) {
+    const size_t slot = (size_t)s * cap + i;
+    const int jraw = P.neigh[slot];
+    const int j = jraw & kNeighMask;
+    const double4 xj4 = P.xr_in[j];
+    const Vec3 del = xi - v3(xj4);
+    const double rsq = dot(del, del);
+    const double radj = xj4.w;
+    const double radsum = radi + radj;
+    bool have_vw = false;
+    double4 vj4 = {0, 0, 0, 0}, wj4 = {0, 0, 0, 0};
+
+    if (STYLE != 0) {
+      if (rsq >= radsum * radsum) {
+        // unset non-touching neighbours (:131-139); the stale shear is ignored once the bit is clear
+        if (jraw & kTouchBit) P.neigh[slot] = j;
+      } else {
+        vj4 = P.vm_in[j];
+        wj4 = P.om_in[j];
+        have_vw = true;
+        ContactIn c;
+        c.del = del;
+        c.rsq = rsq;
+        c.r = sqrt(rsq);
+        c.rinv = 1.0 / c.r;
+        c.vr = vi - v3(vj4);
+        c.wsum = {radi * wi.x + radj * wj4.x, radi * wi.y + radj * wj4.y, radi * wi.z + radj * wj4.z};
+        const double mj = vj4.w;
+        c.meff = mi * mj / (mi + mj);
+        c.overlap = radsum - c.r;
+        c.reff = (radsum - c.r) * radi * radj / radsum;
+        Vec3 sh = {0.0, 0.0, 0.0};
+        const size_t sbase = (size_t)(3 * s) * cap + i;
+        if (jraw & kTouchBit) {
+          sh.x = P.shear[sbase];
+          sh.y = P.shear[sbase + cap];
+          sh.z = P.shear[sbase + 2 * cap];
+        }
+        ContactOut o;
+        gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
+        P.shear[sbase] = sh.x;
+        P.shear[sbase + cap] = sh.y;
+        P.shear[sbase + 2 * cap] = sh.z;
+        if (!(jraw & kTouchBit)) P.neigh[slot] = j | kTouchBit;
+        F = F + o.F;
+        T = T - radi * o.tor;
+      }
+    }
+    if (COHE) {
+      // fix cohesive is skipped during setup (FixCohe::setup() never runs, fix_cohesive.cpp:117)
+      const double rc = radsum + S.cohe.smax;
+      if (S.mode != 2 && rsq < rc * rc) {
+        const double r = sqrt(rsq);
+        const double cc = cohesive_ccel(S.cohe, r, radsum) * (1 / r);
+        F = F + Vec3{del.x * cc, del.y * cc, del.z * cc};
+      }
+    }
+    if (LUB) {
+      if (S.lub.flagHI && rsq < lub_cutsq) {
+        if (!have_vw) {
+          vj4 = P.vm_in[j];
+          wj4 = P.om_in[j];
+        }
+        lubricate_poly_pair(S.lub, del, rsq, radi, radj, vi, v3(vj4), wi, v3(wj4), F, T);
+      }
+    }
+  }
+  if (LUB) {
+    if (S.lub.flagfld) {  // isotropic FLD terms, pair_lubricate_poly.cpp:213-220
+      const double a = S.lub.vxmu2f * S.lub.R0 * radi;
+      const double b = S.lub.vxmu2f * S.lub.RT0 * (radi * radi * radi);
+      F = F - a * vi;
+      T = T - b * wi;
+    }
+  }
+
+  // ---- post_force fixes, in script order gravity -> fdrag -> walls ----
+  if (S.have_gravity) F = F + Vec3{mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
+  if (S.have_fdrag) {
+    Vec3 fd = {P.fdrag[i], P.fdrag[cap + i], P.fdrag[2 * cap + i]};
+    if (S.carrier_rho != 0.0) {
+      const double rho = 3.0 * mi / (4.0 * kPiTypo * radi * radi * radi);
+      const Vec3 vo = {P.vOld[i], P.vOld[cap + i], P.vOld[2 * cap + i]};
+      const Vec3 du = {P.DuDt[i], P.DuDt[cap + i], P.DuDt[2 * cap + i]};
+      const double k = S.carrier_rho / rho * 0.5 * mi;
+      fd.x += k * (du.x - (vi.x - vo.x) / S.dt);
+      fd.y += k * (du.y - (vi.y - vo.y) / S.dt);
+      fd.z += k * (du.z - (vi.z - vo.z) / S.dt);
+      P.vOld[i] = vi.x;
+      P.vOld[cap + i] = vi.y;
+      P.vOld[2 * cap + i] = vi.z;
+    }
+    F = F + fd;
+  }
+  if (S.nwalls) {
+    unsigned wt = P.wtouch[i], wt_new = 0;
+    for (int w = 0; w < S.nwalls; w++) {
+      const WallParams& W = S.wall[w];
+      const double xc = (W.dim == 0) ? xi.x : (W.dim == 1) ? xi.y : xi.z;
+      const double del1 = xc - W.lo, del2 = W.hi - xc;
+      const double d = (del1 < del2) ? del1 : -del2;
+      const double rsq = d * d;
+      if (rsq > radi * radi) continue;   // shear reset = touch bit cleared
+      ContactIn c;
+      c.del = {W.dim == 0 ? d : 0.0, W.dim == 1 ? d : 0.0, W.dim == 2 ? d : 0.0};
+      c.rsq = rsq;
+      c.r = sqrt(rsq);
+      c.rinv = 1.0 / c.r;
+      c.vr = vi;
+      c.wsum = radi * wi;
+      c.meff = mi;
+      c.overlap = radi - c.r;
+      c.reff = (radi - c.r) * radi;
+      const size_t wb = ((size_t)(3 * w)) * cap + i;
+      Vec3 sh = {0.0, 0.0, 0.0};
+      if (wt & (1u << w)) {
+        sh.x = P.wshear[wb];
+        sh.y = P.wshear[wb + cap];
+        sh.z = P.wshear[wb + 2 * cap];
+      }
+      ContactOut o;
+      if (W.gp.style == 2) hertz_history_law(W.gp, S.dt, shearupdate, c, sh, o);
+      else hooke_history_law(W.gp, S.dt, shearupdate, c, sh, o);
+      P.wshear[wb] = sh.x;
+      P.wshear[wb + cap] = sh.y;
+      P.wshear[wb + 2 * cap] = sh.z;
+      wt_new |= (1u << w);
+      F = F + o.F;
+      T = T - radi * o.tor;
+    }
+    if (wt_new != wt) P.wtouch[i] = (unsigned char)wt_new;
+  }
+
+  // ---- integrate: final(k) [+ initial(k+1)]  ([3P] FixNVESphere, dtf = dt/2, INERTIA = 0.4) ----
+  Vec3 vn = vi, wn = wi, xn = xi;
+  if (S.mode != 2 && S.have_nve) {
+    const double dtf = 0.5 * S.dt;
+    const double dtfm = dtf / mi;
+    const double dtirot = (dtf / 0.4) / (radi * radi * mi);
+    vn = vn + dtfm * F;
+    wn = wn + dtirot * T;
+    if (S.mode == 0) {
+      vn = vn + dtfm * F;
+      xn = xn + S.dt * vn;
+      wn = wn + dtirot * T;
+      const double dx = xn.x - P.xhold[i], dy = xn.y - P.xhold[cap + i], dz = xn.z - P.xhold[2 * cap + i];
+      if (dx * dx + dy * dy + dz * dz > S.trigger_sq) atomicMin(&P.flags[F_TRIGGER], S.kstep);
+    }
+  }
+  P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
+  P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
+  P.om_out[i] = {wn.x, wn.y, wn.z, 0.0};
+  if (S.mode != 0) {
+    P.force[i] = {F.x, F.y, F.z, 0.0};
+    P.torque[i] = {T.x, T.y, T.z, 0.0};
+  }
+}
+
+// first half-kick of a run with the forces stored by the previous run's last sub-step
+__global__ __launch_bounds__(256) void k_initial_integrate(double4* xr, double4* vm, double4* om,
+                                                           const double4* force, const double4* torque,
+                                                           const double* xhold, int* flags, int nlocal,
+                                                           size_t cap, double dt, double trigger_sq)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  double4 x = xr[i], v = vm[i], w = om[i];
+  const double4 f = force[i], t = torque[i];
+  const double dtf = 0.5 * dt;
+  const double dtfm = dtf / v.w;
+  const double dtirot = (dtf / 0.4) / (x.w * x.w * v.w);
+  v.x += dtfm * f.x;
+  v.y += dtfm * f.y;
+  v.z += dtfm * f.z;
+  x.x += dt * v.x;
+  x.y += dt * v.y;
+  x.z += dt * v.z;
+  w.x += dtirot * t.x;
+  w.y += dtirot * t.y;
+  w.z += dtirot * t.z;
+  xr[i] = x;
+  vm[i] = v;
+  om[i] = w;
+  const double dx = x.x - xhold[i], dy = x.y - xhold[cap + i], dz = x.z - xhold[2 * cap + i];
+  if (dx * dx + dy * dy + dz * dz > trigger_sq) atomicMin(&flags[F_TRIGGER], -1);
+}
+
+// [3P] Comm::forward_comm for images owned by this GPU: ghost = root atom + accumulated shift
+__global__ __launch_bounds__(256) void k_ghost_forward(double4* xr, double4* vm, double4* om,
+                                                       const int* gsrc, const double* gshift,
+                                                       int nlocal, int nghost, size_t cap,
+                                                       const int* flags, int kstep)
+{
+  if (__atomic_load_n(&flags[F_TRIGGER], __ATOMIC_RELAXED) < kstep) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nghost) return;
+  const int g = nlocal + k;
+  const int src = gsrc[g];
+  if (src < 0) return;  // ghost owned by another GPU: filled by sf_dem_forward_unpack
+  double4 x = xr[src];
+  x.x += gshift[g];
+  x.y += gshift[cap + g];
+  x.z += gshift[2 * cap + g];
+  xr[g] = x;
+  vm[g] = vm[src];
+  om[g] = om[src];
+}
+
+// ------------------------------------------------------------------------------------------------
+// neighbour rebuild
+// ------------------------------------------------------------------------------------------------
+// FixShearHistory::pre_exchange [3P]: remember each touching partner by tag
+__global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const int* numneigh, const int* tag,
+                                                      int* ptag, int nlocal, size_t cap, int M)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int nn = numneigh[i];
+  for (int s = 0; s < M; s++) {
+    int t = -1;
+    if (s < nn) {
+      const int jraw = neigh[(size_t)s * cap + i];
+      if (jraw & kTouchBit) t = tag[jraw & kNeighMask];
+    }
+    ptag[(size_t)s * cap + i] = t;
+  }
+}
+
+struct PbcParams {
+  double lo[3], hi[3];
+  int wrap[3];
+};
+
+__device__ __forceinline__ int bin_coord(double x, double lo, double inv, int n, int& lost)
+{
+  int c = (int)floor((x - lo) * inv);
+  if (c < -1 || c > n) lost = 1;
+  c = c < 0 ? 0 : c;
+  c = c >= n ? n - 1 : c;
+  return c;
+}
+
+__device__ __forceinline__ int bin_of(const double4& x, const BinGrid& g, int& lost)
+{
+  const int cx = bin_coord(x.x, g.lo[0], g.inv[0], g.n[0], lost);
+  const int cy = bin_coord(x.y, g.lo[1], g.inv[1], g.n[1], lost);
+  const int cz = bin_coord(x.z, g.lo[2], g.inv[2], g.n[2], lost);
+  return cx + g.n[0] * (cy + g.n[1] * cz);
+}
+
+// [3P] Domain::pbc for owned atoms + bin key
+__global__ __launch_bounds__(256) void k_pbc_keys(double4* xr, int nlocal, PbcParams pb, BinGrid g,
+                                                  unsigned* keys, int* perm, int* flags)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  double4 x = xr[i];
+  double c[3] = {x.x, x.y, x.z};
+  bool moved = false;
+  for (int k = 0; k < 3; k++) {
+    if (!pb.wrap[k]) continue;
+    const double prd = pb.hi[k] - pb.lo[k];
+    if (c[k] < pb.lo[k]) {
+      c[k] += prd;
+      moved = true;
+    }
+    if (c[k] >= pb.hi[k]) {
+      c[k] -= prd;
+      if (c[k] < pb.lo[k]) c[k] = pb.lo[k];
+      moved = true;
+    }
+  }
+  if (moved) {
+    x.x = c[0];
+    x.y = c[1];
+    x.z = c[2];
+    xr[i] = x;
+  }
+  int lost = 0;
+  keys[i] = (unsigned)bin_of(x, g, lost);
+  perm[i] = i;
+  if (lost) flags[F_LOST] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_gather4(double4* dst, const double4* src, const int* perm, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_rows(T* dst, const T* src, const int* perm, int n, int rows,
+                                                     size_t cap)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = perm[i];
+  for (int r = 0; r < rows; r++) dst[(size_t)r * cap + i] = src[(size_t)r * cap + p];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_copy_rows(T* dst, const T* src, int n, int rows, size_t cap)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int r = 0; r < rows; r++) dst[(size_t)r * cap + i] = src[(size_t)r * cap + i];
+}
+
+// [3P] Comm::borders on one processor, one periodic dimension: atoms (owned or already-ghost)
+// within cutghost of a face get an image on the other side
+struct GhostPtrs {
+  double4 *xr, *vm, *om;
+  int *tag, *type, *mask, *gsrc;
+  double* gshift;
+};
+
+__global__ __launch_bounds__(256) void k_make_ghosts(GhostPtrs G, int nlocal, int nall0, int dim, double lo,
+                                                     double hi, double cut, size_t cap, int* flags)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nall0) return;
+  const double4 x = G.xr[p];
+  const double xp = (dim == 0) ? x.x : (dim == 1) ? x.y : x.z;
+  const double prd = hi - lo;
+  for (int dir = 0; dir < 2; dir++) {
+    const bool take = (dir == 0) ? (xp >= lo && xp <= lo + cut) : (xp >= hi - cut && xp <= hi);
+    if (!take) continue;
+    const int k = atomicAdd(&flags[F_GHOST_COUNT], 1);
+    const size_t g = (size_t)nlocal + k;
+    if (g >= cap) {
+      flags[F_GHOST_OVER] = 1;
+      continue;
+    }
+    const double sh = (dir == 0) ? prd : -prd;
+    double4 xg = x;
+    if (dim == 0) xg.x += sh;
+    else if (dim == 1) xg.y += sh;
+    else xg.z += sh;
+    G.xr[g] = xg;
+    G.vm[g] = G.vm[p];
+    G.om[g] = G.om[p];
+    G.tag[g] = G.tag[p];
+    G.type[g] = G.type[p];
+    G.mask[g] = G.mask[p];
+    // root = an owned atom or a ghost owned by another GPU (gsrc < 0): always current before
+    // k_ghost_forward runs
+    int root = p;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (p >= nlocal && G.gsrc[p] >= 0) {
+      root = G.gsrc[p];
+      s0 = G.gshift[p];
+      s1 = G.gshift[cap + p];
+      s2 = G.gshift[2 * cap + p];
+    }
+    if (dim == 0) s0 += sh;
+    else if (dim == 1) s1 += sh;
+    else s2 += sh;
+    G.gsrc[g] = root;
+    G.gshift[g] = s0;
+    G.gshift[cap + g] = s1;
+    G.gshift[2 * cap + g] = s2;
+  }
+}
+
+// ghosts are not moved: they are index-sorted by (bin, tag) so the list order is deterministic
+__global__ __launch_bounds__(256) void k_ghost_keys(const double4* xr, const int* tag, int nlocal, int nghost,
+                                                    BinGrid g, unsigned long long* keys, int* idx, int* flags)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nghost) return;
+  int lost = 0;
+  const int b = bin_of(xr[nlocal + k], g, lost);
+  keys[k] = ((unsigned long long)(unsigned)b << 32) | (unsigned)tag[nlocal + k];
+  idx[k] = nlocal + k;
+  if (lost) flags[F_LOST] = 1;
+}
+
+// cell_start/cell_end from sorted keys (key >> shift = bin)
+template <class K>
+__global__ __launch_bounds__(256) void k_cell_bounds(const K* keys, int n, int shift, int* cstart, int* cend)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)(keys[i] >> shift);
+  if (i == 0 || (int)(keys[i - 1] >> shift) != b) cstart[b] = i;
+  if (i == n - 1 || (int)(keys[i + 1] >> shift) != b) cend[b] = i + 1;
+}
+
+struct BuildParams {
+  int nlocal, M, Mold;
+  size_t cap;
+  double skin_gran;   // skin (+ smax when cohesion is on) added to ri + rj ; < 0: no granular criterion
+  double cut_lub;     // lubrication cutoff + skin ; 0: off
+  BinGrid g;
+};
+
+// [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
+// history re-injected by partner tag (FixShearHistory)
+__global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double4* xr, const int* tag,
+                                                     const int* cellLS, const int* cellLE,
+                                                     const int* cellGS, const int* cellGE,
+                                                     const int* ghost_order, const int* numneigh_old,
+                                                     const int* ptag_old, const double* shear_old,
+                                                     int* neigh, int* numneigh, double* shear, int* flags)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B.nlocal) return;
+  const double4 xi = xr[i];
+  int lost = 0;
+  const int cx = bin_coord(xi.x, B.g.lo[0], B.g.inv[0], B.g.n[0], lost);
+  const int cy = bin_coord(xi.y, B.g.lo[1], B.g.inv[1], B.g.n[1], lost);
+  const int cz = bin_coord(xi.z, B.g.lo[2], B.g.inv[2], B.g.n[2], lost);
+  const int nold = numneigh_old ? numneigh_old[i] : 0;
+  int n = 0;
+  for (int bz = cz - 1; bz <= cz + 1; bz++) {
+    if (bz < 0 || bz >= B.g.n[2]) continue;
+    for (int by = cy - 1; by <= cy + 1; by++) {
+      if (by < 0 || by >= B.g.n[1]) continue;
+      for (int bx = cx - 1; bx <= cx + 1; bx++) {
+        if (bx < 0 || bx >= B.g.n[0]) continue;
+        const int b = bx + B.g.n[0] * (by + B.g.n[1] * bz);
+        for (int pass = 0; pass < 2; pass++) {
+          const int ks = pass ? cellGS[b] : cellLS[b];
+          const int ke = pass ? cellGE[b] : cellLE[b];
+          for (int k = ks; k < ke; k++) {
+            const int j = pass ? ghost_order[k] : k;
+            if (j == i) continue;
+            const double4 xj = xr[j];
+            const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const double rsq = dx * dx + dy * dy + dz * dz;
+            double cut = B.cut_lub;
+            if (B.skin_gran >= 0.0) {
+              const double cg = xi.w + xj.w + B.skin_gran;
+              cut = cg > cut ? cg : cut;
+            }
+            if (rsq > cut * cut) continue;
+            if (n < B.M) {
+              int entry = j;
+              double sx = 0.0, sy = 0.0, sz = 0.0;
+              const int tj = tag[j];
+              for (int s = 0; s < nold; s++) {
+                if (ptag_old[(size_t)s * B.cap + i] == tj) {
+                  entry |= kTouchBit;
+                  const size_t ob = (size_t)(3 * s) * B.cap + i;
+                  sx = shear_old[ob];
+                  sy = shear_old[ob + B.cap];
+                  sz = shear_old[ob + 2 * B.cap];
+                  break;
+                }
+              }
+              neigh[(size_t)n * B.cap + i] = entry;
+              const size_t nb = (size_t)(3 * n) * B.cap + i;
+              shear[nb] = sx;
+              shear[nb + B.cap] = sy;
+              shear[nb + 2 * B.cap] = sz;
+            }
+            n++;
+          }
+        }
+      }
+    }
+  }
+  if (n > B.M) {
+    atomicMax(&flags[F_NEIGH_OVER], n);
+    n = B.M;
+  }
+  numneigh[i] = n;
+  atomicMax(&flags[F_MAXNEIGH], n);
+}
+
+__global__ __launch_bounds__(256) void k_store_xhold(const double4* xr, double* xhold, int nlocal, size_t cap)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const double4 x = xr[i];
+  xhold[i] = x.x;
+  xhold[cap + i] = x.y;
+  xhold[2 * cap + i] = x.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host <-> device marshalling of the lammps_* surface
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_info(const double4* xr, const double4* vm, const double4* om,
+                                                   const double4* force, const double4* torque, int n,
+                                                   double* x, double* v, double* w, double* f, double* t,
+                                                   double* diam, double* rho)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 a = xr[i], b = vm[i];
+  if (x) { x[3 * i] = a.x; x[3 * i + 1] = a.y; x[3 * i + 2] = a.z; }
+  if (v) { v[3 * i] = b.x; v[3 * i + 1] = b.y; v[3 * i + 2] = b.z; }
+  if (w) { const double4 c = om[i]; w[3 * i] = c.x; w[3 * i + 1] = c.y; w[3 * i + 2] = c.z; }
+  if (f) { const double4 c = force[i]; f[3 * i] = c.x; f[3 * i + 1] = c.y; f[3 * i + 2] = c.z; }
+  if (t) { const double4 c = torque[i]; t[3 * i] = c.x; t[3 * i + 1] = c.y; t[3 * i + 2] = c.z; }
+  if (diam) diam[i] = a.w * 2.0;                                               // library.cpp:196
+  if (rho) rho[i] = 3.0 * b.w / (4.0 * kPiTypo * a.w * a.w * a.w);             // library.cpp:200
+}
+
+__global__ __launch_bounds__(256) void k_tag_map(const int* tag, int n, int* map, int maxtag)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = tag[i];
+  if (t >= 1 && t <= maxtag) map[t - 1] = i;
+}
+
+// library.cpp:344-366: incoming rows are matched to atoms by tag
+__global__ __launch_bounds__(256) void k_put_fdrag(const double* in, const int* tagIn, const int* cpuIn, int n,
+                                                   const int* map, int maxtag, double* fdrag, int* foamCpuId,
+                                                   size_t cap, int* flags)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int t = tagIn[k];
+  const int i = (t >= 1 && t <= maxtag) ? map[t - 1] : -1;
+  if (i < 0) {
+    flags[F_LOST] = 2;
+    return;
+  }
+  fdrag[i] = in[3 * k];
+  fdrag[cap + i] = in[3 * k + 1];
+  fdrag[2 * cap + i] = in[3 * k + 2];
+  if (cpuIn) foamCpuId[i] = cpuIn[k];
+}
+
+__global__ __launch_bounds__(256) void k_set_velocity(double4* vm, int n, double vx, double vy, double vz)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double4 v = vm[i];
+  v.x = vx; v.y = vy; v.z = vz;
+  vm[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_count_pairs(const int* numneigh, int n, unsigned long long* out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long c = (i < n) ? (unsigned long long)numneigh[i] : 0ull;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// touching pairs (i-side copy) -> (tag_i, tag_j, shear) compacted with an atomic cursor
+__global__ __launch_bounds__(256) void k_collect_history(const int* neigh, const int* numneigh, const double* shear,
+                                                         const int* tag, int nlocal, size_t cap,
+                                                         unsigned long long* cursor, long long max, int* ti,
+                                                         int* tj, double* sh)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int nn = numneigh[i];
+  const int tagi = tag[i];
+  for (int s = 0; s < nn; s++) {
+    const int jraw = neigh[(size_t)s * cap + i];
+    if (!(jraw & kTouchBit)) continue;
+    const int tagj = tag[jraw & kNeighMask];
+    if (tagi >= tagj) continue;  // the j side holds the bitwise-negated copy
+    const long long k = (long long)atomicAdd(cursor, 1ull);
+    if (k < max) {
+      ti[k] = tagi;
+      tj[k] = tagj;
+      const size_t b = (size_t)(3 * s) * cap + i;
+      sh[3 * k] = shear[b];
+      sh[3 * k + 1] = shear[b + cap];
+      sh[3 * k + 2] = shear[b + 2 * cap];
+    }
+  }
+}
+
+}  // namespace sf

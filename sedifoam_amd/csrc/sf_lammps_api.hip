@@ -1,0 +1,564 @@
+// sf_lammps_api.hip -- the LAMMPS-shaped plug-in surface of the DEM engine:
+//   * input-script commands for the pair_style / fix lines of the hot path
+//     (style names and argument order as registered in interfaceToLammps/style_user.h:43-50,65-74
+//      and parsed in pair_gran_hertzFix_history.cpp:293-317, fix_fluid_drag.cpp:31-55,
+//      fix_cohesive.cpp:38-57, fix_wall_granFix.cpp:44-141, [3P] pair_lubricate.cpp settings)
+//   * the patched C library interface, interfaceToLammps/library.h:29-63 / library.cpp
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/sedifoam_amd.h"
+#include "sf_handles.h"
+
+using sf::DemEngine;
+using sf::SfLammps;
+
+namespace {
+
+std::vector<std::string> split(const std::string& line)
+{
+  std::string s = line.substr(0, line.find('#'));
+  std::istringstream is(s);
+  std::vector<std::string> w;
+  std::string t;
+  while (is >> t) w.push_back(t);
+  return w;
+}
+
+double num(const std::string& s)
+{
+  char* end = nullptr;
+  const double v = std::strtod(s.c_str(), &end);
+  if (end == s.c_str() || *end != '\0') sf::fail("Expected floating point parameter in input script or data file: %s", s.c_str());
+  return v;
+}
+
+int inum(const std::string& s)
+{
+  char* end = nullptr;
+  const long v = std::strtol(s.c_str(), &end, 10);
+  if (end == s.c_str() || *end != '\0') sf::fail("Expected integer parameter in input script or data file: %s", s.c_str());
+  return (int)v;
+}
+
+void read_data(SfLammps& L, const std::string& path)
+{
+  // [3P] read_data for atom_style sphere: "N atoms", "lo hi xlo xhi" ..., section "Atoms":
+  // id type diameter density x y z   (e.g. cases/auto-testing/test-cases/xiaocase3/IC_uniform.in)
+  std::ifstream f(path);
+  if (!f) sf::fail("Cannot open file %s", path.c_str());
+  std::string line;
+  std::getline(f, line);  // title
+  long natoms = -1;
+  double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+  bool in_atoms = false;
+  std::vector<double> x, diam, dens;
+  std::vector<int> tag, type;
+  while (std::getline(f, line)) {
+    std::vector<std::string> w = split(line);
+    if (w.empty()) continue;
+    if (!in_atoms) {
+      if (w.size() >= 2 && w[1] == "atoms") natoms = std::atol(w[0].c_str());
+      else if (w.size() >= 4 && w[2] == "xlo") { lo[0] = num(w[0]); hi[0] = num(w[1]); }
+      else if (w.size() >= 4 && w[2] == "ylo") { lo[1] = num(w[0]); hi[1] = num(w[1]); }
+      else if (w.size() >= 4 && w[2] == "zlo") { lo[2] = num(w[0]); hi[2] = num(w[1]); }
+      else if (w[0] == "Atoms") in_atoms = true;
+      continue;
+    }
+    if (w[0] == "Velocities") break;
+    if (w.size() < 7) sf::fail("Incorrect atom format in data file");
+    tag.push_back(inum(w[0]));
+    type.push_back(inum(w[1]));
+    diam.push_back(num(w[2]));
+    dens.push_back(num(w[3]));
+    x.push_back(num(w[4]));
+    x.push_back(num(w[5]));
+    x.push_back(num(w[6]));
+  }
+  if (natoms >= 0 && (long)tag.size() != natoms) sf::fail("Did not assign all atoms correctly");
+  L.eng.set_box(lo, hi);
+  L.eng.create_atoms((int)tag.size(), x.data(), nullptr, nullptr, diam.data(), dens.data(), tag.data(),
+                     type.data());
+}
+
+void cmd_pair_style(SfLammps& L, const std::vector<std::string>& w, size_t a)
+{
+  if (a >= w.size()) sf::fail("Illegal pair_style command");
+  const std::string& st = w[a];
+  if (st == "hybrid/overlay" || st == "hybrid") {
+    // sub-styles follow, each with its own arguments
+    size_t k = a + 1;
+    while (k < w.size()) {
+      size_t e = k + 1;
+      while (e < w.size() && w[e] != "gran/hertzFix/history" && w[e] != "gran/hooke/history" &&
+             w[e] != "lubricate/poly")
+        e++;
+      std::vector<std::string> sub(w.begin() + k, w.begin() + e);
+      sub.insert(sub.begin(), "pair_style");
+      cmd_pair_style(L, sub, 1);
+      k = e;
+    }
+    L.pair_hybrid = true;
+    return;
+  }
+  if (st == "gran/hertzFix/history" || st == "gran/hooke/history") {
+    if (w.size() - a - 1 != 6) sf::fail("Illegal pair_style command");  // pair_gran_hertzFix_history.cpp:295
+    const bool ktn = w[a + 2] == "NULL", gtn = w[a + 4] == "NULL";
+    L.eng.set_pair_gran(st == "gran/hertzFix/history" ? 2 : 1, num(w[a + 1]), ktn, ktn ? 0.0 : num(w[a + 2]),
+                        num(w[a + 3]), gtn, gtn ? 0.0 : num(w[a + 4]), num(w[a + 5]), inum(w[a + 6]));
+    return;
+  }
+  if (st == "lubricate/poly") {
+    // [3P] PairLubricate::settings: mu flaglog flagfld cutinner cutoff [flagHI flagVF]
+    const size_t n = w.size() - a - 1;
+    if (n != 5 && n != 7) sf::fail("Illegal pair_style command");
+    int flagHI = 1, flagVF = 1;
+    if (n == 7) {
+      flagHI = inum(w[a + 6]);
+      flagVF = inum(w[a + 7]);
+    }
+    L.eng.set_pair_lubricate(num(w[a + 1]), inum(w[a + 2]), inum(w[a + 3]), num(w[a + 4]), num(w[a + 5]), flagHI,
+                             flagVF);
+    return;
+  }
+  if (st == "none") return;
+  sf::fail("Unknown pair style %s", st.c_str());
+}
+
+void cmd_fix(SfLammps& L, const std::vector<std::string>& w)
+{
+  if (w.size() < 4) sf::fail("Illegal fix command");
+  if (w[2] != "all") sf::fail("fix %s: only group `all` is supported by this engine", w[1].c_str());
+  const std::string& st = w[3];
+  const int narg = (int)w.size() - 1;  // LAMMPS narg counts ID group style ...
+  if (st == "nve/sphere") {
+    L.eng.set_nve_sphere();
+  } else if (st == "gravity") {
+    // fix ID group gravity magnitude vector x y z
+    if (narg < 8 || w[5] != "vector") sf::fail("Illegal fix gravity command (only `vector` style)");
+    L.eng.set_gravity(num(w[4]), num(w[6]), num(w[7]), num(w[8]));
+  } else if (st == "fdrag") {
+    if (narg < 3) sf::fail("Illegal fix fdrag command");  // fix_fluid_drag.cpp:34
+    double carrier = 0.0;
+    if (narg == 4) carrier = (double)std::atoi(w[4].c_str());  // integer parse, fix_fluid_drag.cpp:53
+    L.eng.set_fdrag(carrier);
+  } else if (st == "cohesive") {
+    if (narg != 8) sf::fail("Illegal fix cohesive command");  // fix_cohesive.cpp:41
+    L.eng.set_cohesive(std::atof(w[4].c_str()), std::atof(w[5].c_str()), std::atof(w[6].c_str()),
+                       std::atof(w[7].c_str()), std::atoi(w[8].c_str()));
+  } else if (st == "wall/gran" || st == "wall/granFix") {
+    if (narg < 10) sf::fail("Illegal fix %s command", st.c_str());  // fix_wall_granFix.cpp:47
+    const bool ktn = w[5] == "NULL", gtn = w[7] == "NULL";
+    int dim;
+    if (w[10] == "xplane") dim = 0;
+    else if (w[10] == "yplane") dim = 1;
+    else if (w[10] == "zplane") dim = 2;
+    else sf::fail("fix %s: only xplane/yplane/zplane walls are supported", st.c_str());
+    if (narg < 12) sf::fail("Illegal fix %s command", st.c_str());
+    if (narg > 12) sf::fail("fix %s: wiggle/shear walls are not supported", st.c_str());
+    const bool lon = w[11] == "NULL", hin = w[12] == "NULL";
+    L.eng.add_wall(dim, lon, lon ? 0.0 : num(w[11]), hin, hin ? 0.0 : num(w[12]), num(w[4]), ktn,
+                   ktn ? 0.0 : num(w[5]), num(w[6]), gtn, gtn ? 0.0 : num(w[7]), num(w[8]), inum(w[9]),
+                   st == "wall/granFix");
+  } else
+    sf::fail("Unknown fix style %s", st.c_str());
+}
+
+void command(SfLammps& L, const std::string& line)
+{
+  std::vector<std::string> w = split(line);
+  if (w.empty()) return;
+  const std::string& c = w[0];
+  if (c == "units") {
+    if (w.size() != 2 || (w[1] != "lj" && w[1] != "si")) sf::fail("units %s not supported (lj | si: nktv2p = 1)", w.size() > 1 ? w[1].c_str() : "");
+  } else if (c == "atom_style") {
+    if (w.size() < 2 || w[1] != "sphere") sf::fail("atom_style must be sphere");
+  } else if (c == "newton") {
+    if (w.size() < 2 || w[1] != "off") sf::fail("newton must be off (every reference case; pair lubricate/poly requires it)");
+  } else if (c == "communicate") {
+    // "communicate single vel yes": ghost velocities are always carried here
+  } else if (c == "boundary") {
+    if (w.size() != 4) sf::fail("Illegal boundary command");
+    int p[3];
+    for (int k = 0; k < 3; k++) p[k] = (w[k + 1] == "p" || w[k + 1] == "pp");
+    L.eng.set_periodic(p[0], p[1], p[2]);
+  } else if (c == "read_data") {
+    if (w.size() < 2) sf::fail("Illegal read_data command");
+    read_data(L, w[1]);
+  } else if (c == "neighbor") {
+    if (w.size() < 2) sf::fail("Illegal neighbor command");
+    L.eng.set_skin(num(w[1]));
+  } else if (c == "neigh_modify") {
+    for (size_t k = 1; k + 1 < w.size(); k += 2)
+      if (w[k] == "one") L.eng.set_max_neigh(inum(w[k + 1]));
+  } else if (c == "pair_style") {
+    cmd_pair_style(L, w, 1);
+  } else if (c == "timestep") {
+    if (w.size() != 2) sf::fail("Illegal timestep command");
+    L.eng.set_timestep(num(w[1]));
+  } else if (c == "velocity") {
+    if (w.size() >= 6 && w[1] == "all" && w[2] == "set") L.eng.set_velocity_all(num(w[3]), num(w[4]), num(w[5]));
+    else sf::fail("velocity: only `velocity all set vx vy vz` is supported");
+  } else if (c == "fix") {
+    cmd_fix(L, w);
+  } else if (c == "run") {
+    if (w.size() < 2) sf::fail("Illegal run command");
+    L.eng.run(inum(w[1]));
+  } else if (c == "pair_coeff" || c == "atom_modify" || c == "processors" || c == "thermo" ||
+             c == "thermo_style" || c == "thermo_modify" || c == "dump" || c == "dump_modify" ||
+             c == "restart" || c == "group" || c == "echo" || c == "log" || c == "dimension") {
+    // accepted, nothing to do on this path
+  } else
+    sf::fail("Unknown command: %s", c.c_str());
+}
+
+SfLammps* H(void* p)
+{
+  if (!p) sf::fail("null engine handle");
+  return static_cast<SfLammps*>(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sf_last_error(void) { return sf::last_error().c_str(); }
+const char* sf_version(void) { return "sedifoam_amd 0.1 (gfx950)"; }
+
+int sf_device_check(void)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    sf::set_error("no HIP device: %s", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return -1;
+  }
+  return 0;
+}
+
+int sf_lammps_open(int, char**, intptr_t comm, void** ptr)
+{
+  SF_API_BEGIN
+  SfLammps* L = new SfLammps();
+  L->comm = comm;
+  *ptr = L;
+  SF_API_END(0)
+}
+
+int sf_lammps_close(void* ptr)
+{
+  SF_API_BEGIN
+  delete H(ptr);
+  SF_API_END(0)
+}
+
+const char* sf_lammps_command(void* ptr, const char* line)
+{
+  try {
+    command(*H(ptr), line);
+    return nullptr;
+  } catch (const std::exception& ex) {
+    sf::set_error("%s", ex.what());
+    return sf::last_error().c_str();
+  }
+}
+
+int sf_lammps_file(void* ptr, const char* path)
+{
+  SF_API_BEGIN
+  std::ifstream f(path);
+  if (!f) sf::fail("Cannot open input script %s", path);
+  std::string line;
+  while (std::getline(f, line)) command(*H(ptr), line);
+  SF_API_END(0)
+}
+
+int sf_lammps_sync(void* ptr)
+{
+  SF_API_BEGIN
+  SF_HIP(hipStreamSynchronize(H(ptr)->eng.stream()));
+  SF_API_END(0)
+}
+
+int sf_lammps_get_global_n(void* ptr)
+{
+  SF_API_BEGIN
+  const int n = H(ptr)->eng.nlocal();
+  SF_API_END(n)
+}
+
+int sf_lammps_get_initial_np(void* ptr, int* np_)
+{
+  SF_API_BEGIN
+  DemEngine& e = H(ptr)->eng;
+  for (int r = 0; r < e.nranks(); r++) np_[r] = 0;
+  np_[e.rank()] = e.nlocal();
+  SF_API_END(0)
+}
+
+int sf_lammps_get_initial_info(void* ptr, double* coords, double* velos, double* diam, double* rho_, int* tag_,
+                               int* lmpCpuId_, int* type_)
+{
+  SF_API_BEGIN
+  DemEngine& e = H(ptr)->eng;
+  e.get_initial_info(coords, velos, diam, rho_, tag_, type_);
+  if (lmpCpuId_)
+    for (int i = 0; i < e.nlocal(); i++) lmpCpuId_[i] = e.rank();
+  SF_API_END(0)
+}
+
+int sf_lammps_get_local_n(void* ptr)
+{
+  SF_API_BEGIN
+  const int n = H(ptr)->eng.nlocal();
+  SF_API_END(n)
+}
+
+int sf_lammps_get_local_domain(void* ptr, double* domain_)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.sublo_hi(domain_);
+  SF_API_END(0)
+}
+
+int sf_lammps_get_local_info(void* ptr, double* coords, double* velos_, int* foamCpuId_, int* lmpCpuId_, int* tag_)
+{
+  SF_API_BEGIN
+  DemEngine& e = H(ptr)->eng;
+  e.get_local_info(coords, velos_, foamCpuId_, tag_);
+  if (lmpCpuId_)
+    for (int i = 0; i < e.nlocal(); i++) lmpCpuId_[i] = e.rank();
+  SF_API_END(0)
+}
+
+int sf_lammps_put_local_info(void* ptr, int nLocalIn, const double* fdrag, const double* /*DuDt ignored*/,
+                             const int* foamCpuIdIn, const int* tagIn)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.put_local_info(nLocalIn, fdrag, foamCpuIdIn, tagIn);
+  SF_API_END(0)
+}
+
+int sf_lammps_step(void* ptr, int n)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.run(n);
+  SF_API_END(0)
+}
+
+int sf_lammps_set_timestep(void* ptr, double dt_i)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_timestep(dt_i);
+  SF_API_END(0)
+}
+
+double sf_lammps_get_timestep(void* ptr)
+{
+  try {
+    return H(ptr)->eng.timestep();
+  } catch (const std::exception& ex) {
+    sf::set_error("%s", ex.what());
+    return -1.0;
+  }
+}
+
+int sf_lammps_create_particle(void* ptr, int npAdd, const double* position, const double* tag, double diameter,
+                              double rho, int type, const double* vel)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.create_particles(npAdd, position, tag, diameter, rho, type, vel);
+  SF_API_END(0)
+}
+
+int sf_lammps_delete_particle(void* ptr, const int* deleteList, int nDelete)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.delete_particles(deleteList, nDelete);
+  SF_API_END(0)
+}
+
+int sf_dem_create_atoms(void* ptr, int n, const double* x, const double* v, const double* omega,
+                        const double* diameter, const double* density, const int* tag, const int* type)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.create_atoms(n, x, v, omega, diameter, density, tag, type);
+  SF_API_END(0)
+}
+
+int sf_dem_set_box(void* ptr, const double lo[3], const double hi[3])
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_box(lo, hi);
+  SF_API_END(0)
+}
+
+int sf_dem_get_info(void* ptr, sf_dem_info* out)
+{
+  SF_API_BEGIN
+  DemEngine& e = H(ptr)->eng;
+  out->nlocal = e.nlocal();
+  out->nghost = e.nghost();
+  out->capacity = (int)e.capacity();
+  out->max_neigh_used = e.max_neigh_used();
+  out->max_neigh_cap = e.max_neigh_cap();
+  out->nbuilds = e.nbuilds();
+  out->nsteps = e.nsteps();
+  out->npairs_full = e.npairs_full();
+  SF_API_END(0)
+}
+
+int sf_dem_device_view_get(void* ptr, sf_dem_device_view* out)
+{
+  SF_API_BEGIN
+  DemEngine& e = H(ptr)->eng;
+  out->xr = (void*)e.d_xr();
+  out->vm = (void*)e.d_vm();
+  out->om = (void*)e.d_om();
+  out->force = e.d_force();
+  out->torque = e.d_torque();
+  out->fdrag = e.d_fdrag();
+  out->DuDt = e.d_DuDt();
+  out->vOld = e.d_vOld();
+  out->tag = e.d_tag();
+  out->type = e.d_type();
+  out->foamCpuId = e.d_foamCpuId();
+  out->nlocal = e.nlocal();
+  out->nghost = e.nghost();
+  out->capacity = (int)e.capacity();
+  out->stream = e.stream();
+  SF_API_END(0)
+}
+
+int sf_dem_get_forces(void* ptr, double* f, double* torque, double* omega, int* tag)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.get_forces(f, torque, omega, tag);
+  SF_API_END(0)
+}
+
+long long sf_dem_get_history(void* ptr, long long max, int* tag_i, int* tag_j, double* shear)
+{
+  SF_API_BEGIN
+  const long long n = H(ptr)->eng.get_history(max, tag_i, tag_j, shear);
+  SF_API_END(n)
+}
+
+int sf_dem_get_wall_shear(void* ptr, int w, double* shear)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.get_wall_shear(w, shear);
+  SF_API_END(0)
+}
+
+int sf_dem_set_subdomain(void* ptr, int rank, int nranks, double sublo, double subhi)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_subdomain(rank, nranks, sublo, subhi);
+  SF_API_END(0)
+}
+
+int sf_dem_run_begin(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.run_begin();
+  SF_API_END(0)
+}
+
+int sf_dem_substep(void* ptr, int last)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.substep(last != 0);
+  SF_API_END(0)
+}
+
+int sf_dem_need_rebuild(void* ptr)
+{
+  SF_API_BEGIN
+  const int r = H(ptr)->eng.need_rebuild() ? 1 : 0;
+  SF_API_END(r)
+}
+
+int sf_dem_rebuild_begin(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.rebuild_begin();
+  SF_API_END(0)
+}
+
+int sf_dem_rebuild_sort(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.rebuild_sort();
+  SF_API_END(0)
+}
+
+int sf_dem_rebuild_finish(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.rebuild_finish();
+  SF_API_END(0)
+}
+
+int sf_dem_setup(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.setup();
+  SF_API_END(0)
+}
+
+long long sf_dem_border_pack(void* ptr, int side, double xshift, double* dev_buf, long long max_atoms)
+{
+  SF_API_BEGIN
+  const long long n = H(ptr)->eng.border_pack(side, xshift, dev_buf, max_atoms);
+  SF_API_END(n)
+}
+
+int sf_dem_border_unpack(void* ptr, int side, const double* dev_buf, long long natoms)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.border_unpack(side, dev_buf, natoms);
+  SF_API_END(0)
+}
+
+long long sf_dem_forward_pack(void* ptr, int side, double xshift, double* dev_buf)
+{
+  SF_API_BEGIN
+  const long long n = H(ptr)->eng.forward_pack(side, xshift, dev_buf);
+  SF_API_END(n)
+}
+
+int sf_dem_forward_unpack(void* ptr, int side, const double* dev_buf, long long natoms)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.forward_unpack(side, dev_buf, natoms);
+  SF_API_END(0)
+}
+
+long long sf_dem_migrate_pack(void* ptr, int side, double xshift, double* dev_buf, long long max_doubles)
+{
+  SF_API_BEGIN
+  const long long n = H(ptr)->eng.migrate_pack(side, xshift, dev_buf, max_doubles);
+  SF_API_END(n)
+}
+
+int sf_dem_migrate_unpack(void* ptr, const double* dev_buf, long long ndoubles)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.migrate_unpack(dev_buf, ndoubles);
+  SF_API_END(0)
+}
+
+int sf_dem_migrate_record_doubles(void* ptr)
+{
+  SF_API_BEGIN
+  const int n = H(ptr)->eng.migrate_record_doubles();
+  SF_API_END(n)
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// sf_physics.h -- per-pair / per-particle force laws as __device__ inline functions (gfx950, FP64).
+//
+// One definition of each law, shared by the fused sub-step kernel (sf_dem_kernels.hip) and the
+// stand-alone PairStyle/FixStyle entry points (sf_kernels_api.hip).  Expression order follows the
+// reference so that results agree with its CPU build to rounding (FMA contraction is the only
+// difference):
+//   hertz_history_law  : interfaceToLammps/pair_gran_hertzFix_history.cpp:142-261 (pair),
+//                        interfaceToLammps/fix_wall_granFix.cpp:558-679 (wall twin)
+//   hooke_history_law  : interfaceToLammps/fix_wall_granFix.cpp:441-554 and its pair twin
+//                        (LAMMPS 1Feb14 gran/hooke/history)
+//   cohesive_ccel      : interfaceToLammps/fix_cohesive.cpp:184-196, :236-245
+//   lubricate_poly_pair: interfaceToLammps/pair_lubricate_poly.cpp:241-399
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sf {
+
+constexpr double kPi = 3.14159265358979323846;          // MathConst::MY_PI
+constexpr double kPiTypo = 3.14159265358917323846;      // fix_fluid_drag.cpp:147, library.cpp:200,460
+
+struct GranParams {
+  double kn, kt, gamman, gammat, xmu;
+  double beta;      // Hertz: -ln(e)/sqrt(ln(e)^2+pi^2), evaluated once on the host (pure function of gamman)
+  int dampflag;
+  int style;        // 0 none, 1 hooke/history, 2 hertzFix/history
+};
+
+struct Vec3 {
+  double x, y, z;
+};
+__device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct ContactIn {
+  Vec3 del;        // from partner (or wall) to the particle
+  double rsq;
+  Vec3 vr;         // relative translational velocity
+  Vec3 wsum;       // radi*omega_i + radj*omega_j   (wall: radius*omega)
+  double meff;
+  double overlap;  // radsum - r  |  radius - r
+  double reff;     // overlap*radi*radj/radsum | overlap*radius  (Hertz only)
+  double r, rinv;
+};
+
+struct ContactOut {
+  Vec3 F;          // force on the particle
+  Vec3 tor;        // rinv * (del x fs); caller applies -radius
+};
+
+// Hertzian history contact.  shear is read/updated in place (registers).
+__device__ __forceinline__ void hertz_history_law(const GranParams& p, double dt, bool shearupdate,
+                                                  const ContactIn& c, Vec3& sh, ContactOut& o)
+{
+  const double rsqinv = 1.0 / c.rsq;
+  const double vnnr = dot(c.vr, c.del);
+  const double s = vnnr * rsqinv;
+  const Vec3 vt = {c.vr.x - c.del.x * s, c.vr.y - c.del.y * s, c.vr.z - c.del.z * s};
+  const Vec3 wr = c.rinv * c.wsum;
+
+  const double polyhertz = sqrt(c.reff);
+  const double sn = 2.0 * 1.0 / 1.82 * p.kn * polyhertz;
+  const double st = 8.0 * 1.0 / 8.84 * p.kn * polyhertz;
+  const double c56 = 2.0 * sqrt(5.0 / 6.0);
+  const double damp = c56 * p.beta * vnnr * rsqinv;
+  const double ccel = polyhertz * 4.0 / 5.46 * p.kn * c.overlap * c.rinv - sqrt(sn * c.meff) * damp;
+
+  const Vec3 vtr = {vt.x - (c.del.z * wr.y - c.del.y * wr.z), vt.y - (c.del.x * wr.z - c.del.z * wr.x),
+                    vt.z - (c.del.y * wr.x - c.del.x * wr.y)};
+  if (shearupdate) {
+    sh.x += vtr.x * dt;
+    sh.y += vtr.y * dt;
+    sh.z += vtr.z * dt;
+  }
+  const double shrmag = sqrt(dot(sh, sh));
+  const double rsht = dot(sh, c.del) * rsqinv;
+  if (shearupdate) {
+    sh.x -= rsht * c.del.x;
+    sh.y -= rsht * c.del.y;
+    sh.z -= rsht * c.del.z;
+  }
+  const double kts = polyhertz * 8.0 / 8.84 * p.kt;
+  const double sdamp = sqrt(st * c.meff) * c56 * p.beta;
+  Vec3 fs = {-kts * sh.x - sdamp * vtr.x, -kts * sh.y - sdamp * vtr.y, -kts * sh.z - sdamp * vtr.z};
+  const double fsmag = sqrt(dot(fs, fs));
+  const double fn = p.xmu * fabs(ccel * c.r);
+  if (fsmag > fn) {
+    if (shrmag != 0.0) {
+      const double ratio = fn / fsmag;
+      const double qs = sdamp / 8.84 * 8.0 / p.kt;
+      const Vec3 q = {qs * vtr.x, qs * vtr.y, qs * vtr.z};
+      sh.x = ratio * (sh.x + q.x) - q.x;
+      sh.y = ratio * (sh.y + q.y) - q.y;
+      sh.z = ratio * (sh.z + q.z) - q.z;
+      fs = ratio * fs;
+    } else
+      fs = {0.0, 0.0, 0.0};
+  }
+  o.F = {c.del.x * ccel + fs.x, c.del.y * ccel + fs.y, c.del.z * ccel + fs.z};
+  o.tor = {c.rinv * (c.del.y * fs.z - c.del.z * fs.y), c.rinv * (c.del.z * fs.x - c.del.x * fs.z),
+           c.rinv * (c.del.x * fs.y - c.del.y * fs.x)};
+}
+
+// Hookean history contact.
+__device__ __forceinline__ void hooke_history_law(const GranParams& p, double dt, bool shearupdate,
+                                                  const ContactIn& c, Vec3& sh, ContactOut& o)
+{
+  const double rsqinv = 1.0 / c.rsq;
+  const double vnnr = dot(c.vr, c.del);
+  const double s = vnnr * rsqinv;
+  const Vec3 vt = {c.vr.x - c.del.x * s, c.vr.y - c.del.y * s, c.vr.z - c.del.z * s};
+  const Vec3 wr = c.rinv * c.wsum;
+  const double damp = c.meff * p.gamman * vnnr * rsqinv;
+  const double ccel = p.kn * c.overlap * c.rinv - damp;
+  const Vec3 vtr = {vt.x - (c.del.z * wr.y - c.del.y * wr.z), vt.y - (c.del.x * wr.z - c.del.z * wr.x),
+                    vt.z - (c.del.y * wr.x - c.del.x * wr.y)};
+  if (shearupdate) {
+    sh.x += vtr.x * dt;
+    sh.y += vtr.y * dt;
+    sh.z += vtr.z * dt;
+  }
+  const double shrmag = sqrt(dot(sh, sh));
+  const double rsht = dot(sh, c.del) * rsqinv;
+  if (shearupdate) {
+    sh.x -= rsht * c.del.x;
+    sh.y -= rsht * c.del.y;
+    sh.z -= rsht * c.del.z;
+  }
+  const double mg = c.meff * p.gammat;
+  Vec3 fs = {-(p.kt * sh.x + mg * vtr.x), -(p.kt * sh.y + mg * vtr.y), -(p.kt * sh.z + mg * vtr.z)};
+  const double fsmag = sqrt(dot(fs, fs));
+  const double fn = p.xmu * fabs(ccel * c.r);
+  if (fsmag > fn) {
+    if (shrmag != 0.0) {
+      const double ratio = fn / fsmag;
+      const Vec3 q = {mg * vtr.x / p.kt, mg * vtr.y / p.kt, mg * vtr.z / p.kt};
+      sh.x = ratio * (sh.x + q.x) - q.x;
+      sh.y = ratio * (sh.y + q.y) - q.y;
+      sh.z = ratio * (sh.z + q.z) - q.z;
+      fs = ratio * fs;
+    } else
+      fs = {0.0, 0.0, 0.0};
+  }
+  o.F = {c.del.x * ccel + fs.x, c.del.y * ccel + fs.y, c.del.z * ccel + fs.z};
+  o.tor = {c.rinv * (c.del.y * fs.z - c.del.z * fs.y), c.rinv * (c.del.z * fs.x - c.del.x * fs.z),
+           c.rinv * (c.del.x * fs.y - c.del.y * fs.x)};
+}
+
+template <int STYLE>
+__device__ __forceinline__ void gran_history_law(const GranParams& p, double dt, bool shearupdate,
+                                                 const ContactIn& c, Vec3& sh, ContactOut& o)
+{
+  if (STYLE == 2) hertz_history_law(p, dt, shearupdate, c, sh, o);
+  else hooke_history_law(p, dt, shearupdate, c, sh, o);
+}
+
+struct CoheParams {
+  double ah, lam, smin, smax;
+  int opt;
+  int enabled;
+};
+
+// scalar cohesive coefficient: force on i = del * ccel / r  (fix_cohesive.cpp:187-203, :239-252)
+__device__ __forceinline__ double cohesive_ccel(const CoheParams& p, double r, double radsum)
+{
+  const double del = r - radsum;
+  double ccel;
+  if (p.opt == 0) {
+    const double PInv = 0.25 / atan(1.0);
+    const double lam = p.lam;
+    if (del > lam * PInv)
+      ccel = -p.ah * radsum * lam *
+             (6.4988e-3 - 4.5316e-4 * lam / del + 1.1326e-5 * lam * lam / del / del) / del / del / del;
+    else {
+      const double s = (del > p.smin) ? del : p.smin;
+      ccel = -p.ah * (lam + 22.242 * s) * radsum * lam / 24.0 / (lam + 11.121 * s) / (lam + 11.121 * s) / s / s;
+    }
+  } else {
+    const double r2 = radsum * radsum;
+    const double r6 = r2 * r2 * r2;  // pow(radsum,6)
+    if (del > p.smin)
+      ccel = -p.ah * r6 / 6.0 / del / del / (r + radsum) / (r + radsum) / r / r / r;
+    else
+      ccel = -p.ah * r6 / 6.0 / p.smin / p.smin / (p.smin + 2.0 * radsum) / (p.smin + 2.0 * radsum) /
+             (p.smin + radsum) / (p.smin + radsum) / (p.smin + radsum);
+  }
+  return ccel;
+}
+
+struct LubParams {
+  double mu, cut_inner, cut_global, R0, RT0, RS0, vxmu2f;
+  int flaglog, flagfld, flagHI, flagVF;
+  int enabled;
+};
+
+// lubrication force/torque on i from neighbour j (full list: only i is updated), Ef = 0.
+__device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del, double rsq, double radi,
+                                                    double radj, Vec3 vi0, Vec3 vj0, Vec3 wi, Vec3 wj,
+                                                    Vec3& F, Vec3& T)
+{
+  const double r = sqrt(rsq);
+  const Vec3 n = {del.x / r, del.y / r, del.z / r};
+  const Vec3 xl = {-n.x * radi, -n.y * radi, -n.z * radi};
+  const Vec3 jl = {-n.x * radj, -n.y * radj, -n.z * radj};
+  const Vec3 vi = {vi0.x + (wi.y * xl.z - wi.z * xl.y), vi0.y + (wi.z * xl.x - wi.x * xl.z),
+                   vi0.z + (wi.x * xl.y - wi.y * xl.x)};
+  const Vec3 vj = {vj0.x - (wj.y * jl.z - wj.z * jl.y), vj0.y - (wj.z * jl.x - wj.x * jl.z),
+                   vj0.z - (wj.x * jl.y - wj.y * jl.x)};
+  double h_sep = r - radi - radj;
+  if (r < p.cut_inner) h_sep = 100 * radi + 100 * radj;  // the reference's edit, :294-295
+  h_sep = h_sep / radi;
+  const double beta0 = radj / radi;
+  const double beta1 = 1.0 + beta0;
+  double a_sq, a_sh = 0.0, a_pu = 0.0;
+  if (p.flaglog) {
+    const double b02 = beta0 * beta0, b03 = b02 * beta0, b04 = b02 * b02;
+    const double b13 = beta1 * beta1 * beta1, b14 = b13 * beta1;
+    const double lg = log(1.0 / h_sep);
+    a_sq = beta0 * beta0 / beta1 / beta1 / h_sep + (1.0 + 7.0 * beta0 + beta0 * beta0) / 5.0 / b13 * lg;
+    a_sq += (1.0 + 18.0 * beta0 - 29.0 * beta0 * beta0 + 18.0 * b03 + b04) / 21.0 / b14 * h_sep * lg;
+    a_sq *= 6.0 * kPi * p.mu * radi;
+    a_sh = 4.0 * beta0 * (2.0 + beta0 + 2.0 * beta0 * beta0) / 15.0 / b13 * lg;
+    a_sh += 4.0 * (16.0 - 45.0 * beta0 + 58.0 * beta0 * beta0 - 45.0 * b03 + 16.0 * b04) / 375.0 / b14 * h_sep * lg;
+    a_sh *= 6.0 * kPi * p.mu * radi;
+    a_pu = beta0 * (4.0 + beta0) / 10.0 / beta1 / beta1 * lg;
+    a_pu += (32.0 - 33.0 * beta0 + 83.0 * beta0 * beta0 + 43.0 * b03) / 250.0 / b13 * h_sep * lg;
+    a_pu *= 8.0 * kPi * p.mu * (radi * radi * radi);
+  } else
+    a_sq = 6.0 * kPi * p.mu * radi * (beta0 * beta0 / beta1 / beta1 / h_sep);
+
+  const Vec3 vr = vi - vj;
+  const double vnnr = dot(vr, del) / r;
+  const Vec3 vn = {vnnr * del.x / r, vnnr * del.y / r, vnnr * del.z / r};
+  const Vec3 vt = vr - vn;
+  Vec3 f = a_sq * vn;
+  if (p.flaglog) f = f + a_sh * vt;
+  f = p.vxmu2f * f;
+  F = F - f;
+  if (p.flaglog) {
+    const Vec3 t = {xl.y * f.z - xl.z * f.y, xl.z * f.x - xl.x * f.z, xl.x * f.y - xl.y * f.x};
+    T = T - p.vxmu2f * t;
+    const Vec3 dw = wi - wj;
+    const double wdotn = dot(dw, del) / r;
+    const Vec3 wt = {dw.x - wdotn * del.x / r, dw.y - wdotn * del.y / r, dw.z - wdotn * del.z / r};
+    T = T - p.vxmu2f * (a_pu * wt);
+  }
+}
+
+}  // namespace sf

@@ -1,0 +1,44 @@
+// sf_sort.hip -- key/value radix sorts used only on neighbour rebuilds (rocPRIM device primitives;
+// kept in their own translation unit because the header is heavy to compile).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "sf_dem.h"
+
+namespace sf {
+
+template <class K>
+static void sort_pairs(void*& tmp, size_t& tmp_bytes, K* keys_in, K* keys_out, int* vals_in, int* vals_out, int n,
+                       int end_bit, hipStream_t s)
+{
+  if (n <= 0) return;
+  size_t need = 0;
+  SF_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                   (unsigned)end_bit, s));
+  if (need > tmp_bytes) {
+    if (tmp) {
+      SF_HIP(hipStreamSynchronize(s));
+      SF_HIP(hipFree(tmp));
+    }
+    tmp_bytes = need + need / 4 + 4096;
+    SF_HIP(hipMalloc(&tmp, tmp_bytes));
+  }
+  size_t avail = tmp_bytes;
+  SF_HIP(rocprim::radix_sort_pairs(tmp, avail, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                   (unsigned)end_bit, s));
+}
+
+void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
+                    int* vals_out, int n, int end_bit, hipStream_t s)
+{
+  sort_pairs<unsigned>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, s);
+}
+
+void sort_pairs_u64(void*& tmp, size_t& tmp_bytes, unsigned long long* keys_in, unsigned long long* keys_out,
+                    int* vals_in, int* vals_out, int n, int end_bit, hipStream_t s)
+{
+  sort_pairs<unsigned long long>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, s);
+}
+
+}  // namespace sf
