@@ -416,9 +416,9 @@ static void push_int(int **a, int *cap, int n, int val)
 }
 
 /* ---- [3P] Neighbor::build: granular half list (+history), regular half list, full list ---- */
-static void build_lists(orc_dem *d)
+static void build_lists(orc_dem *d, partners *pps)
 {
-  partners ps;
+  partners ps = *pps;
   bingrid g;
   int n = d->nlocal, i, k, bx, by, bz;
   int need_half = 0, w;
@@ -428,7 +428,6 @@ static void build_lists(orc_dem *d)
   for (w = 0; w < d->nfix; w++)
     if (d->fix[w].kind == FIX_COHESIVE) need_half = 1;
 
-  partners_from_list(d, &ps);
   bin_atoms(d, &g);
 
   d->first = xrealloc(d->first, sizeof(int) * ((size_t)n + 1));
@@ -580,9 +579,11 @@ void orc_dem_setup(orc_dem *d)
                    (d->boxhi[2] - d->boxlo[2]);
     orc_lubricate_init(&d->lub, d->nlocal, d->radius, vol_T);
   }
+  partners ps;
+  partners_from_list(d, &ps); /* empty: no list yet */
   pbc(d);
   make_ghosts(d);
-  build_lists(d);
+  build_lists(d, &ps);
   compute_forces(d, 1);
   d->setup_done = 1;
 }
@@ -595,9 +596,13 @@ void orc_dem_run(orc_dem *d, int nsteps)
     orc_nve_sphere_initial(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius,
                            d->rmass);
     if (check_distance(d)) {
+      /* Verlet::run order [3P]: pre_exchange (FixShearHistory copies the history out of the OLD
+       * list, whose ghost indices are still valid) -> pbc -> borders -> build */
+      partners ps;
+      partners_from_list(d, &ps);
       pbc(d);
       make_ghosts(d);
-      build_lists(d);
+      build_lists(d, &ps);
     } else
       forward_comm(d);
     compute_forces(d, 0);
