@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-DEM-substeps/s of the sediFoam hot path on MI355X.
+
+One "step" = one `lammps_step(S)` call (S = 50 DEM sub-steps, BASELINE.json configs[2..3]) of the fused
+Hertz-history contact / fix fdrag / wall / gravity / nve-sphere kernel over a synthetic 1 M-particle
+monodisperse Hertz packing, particle state resident in HBM before timing starts.
+With --gpus N (launched through torch.distributed.run, one rank per GPU) every rank owns one such slab
+of a periodic channel N times as long, with a ghost-particle halo over RCCL: weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_substep): algorithmic bytes
+per launch (284 + 52*K_half bytes per particle-substep) / its mean duration from HIP
+events on the engine's own stream.  `cpu_baseline` times the CPU oracle (a port of the reference's
+algorithm; the reference itself needs LAMMPS + OpenFOAM, absent here) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def build_engine(bed, script):
+    from sedifoam_amd import Lammps
+    lmp = Lammps()
+    lmp.set_box(bed["boxlo"], bed["boxhi"])
+    lmp.create_atoms(bed["x"], bed["diameter"], bed["density"], v=bed["v"])
+    for line in script:
+        lmp.command(line)
+    return lmp
+
+
+def cpu_baseline(ncells, script_kw, substeps):
+    """Oracle (CPU port of the reference algorithm) on the same kind of bed: particle-substeps/s."""
+    from oracle import binding as ob
+    from sedifoam_amd import synthetic
+    bed = synthetic.fcc_bed(ncells, seed=12345 + 3)
+    r = 0.5 * bed["diameter"]
+    m = 4.0 * np.pi / 3.0 * r ** 3 * bed["density"]
+    dem = ob.OracleDem(bed["x"], r, m, bed["boxlo"], bed["boxhi"], periodic=bed["periodic"], v=bed["v"])
+    dem.pair_gran("hertz", script_kw["kn"], None, script_kw["gamman"], None, script_kw["xmu"], 1)
+    dem.fix_gravity(script_kw["g"], 0.0, -1.0, 0.0)
+    dem.fix_fdrag(0.0)
+    dem.fix_wall(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]), script_kw["kn"], None, script_kw["gamman"],
+                 None, script_kw["xmu"], 1)
+    dem.neighbor(script_kw["skin_d"] * 1.0e-3)
+    dem.timestep(script_kw["dt"])
+    dem.setup()
+    t0 = time.perf_counter()
+    dem.run(substeps)
+    dt = time.perf_counter() - t0
+    return bed["n"] * substeps / dt, bed["n"], dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=1000000, help="particles per GPU")
+    ap.add_argument("--substeps", type=int, default=50, help="DEM sub-steps per step (per CFD step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sedifoam_amd import synthetic
+    kw = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
+    ncells = synthetic.fcc_cells_for(args.particles)
+    bed = synthetic.fcc_bed(ncells, seed=12345 + 3 + rank)
+    script = synthetic.hertz_script(bed, **kw)
+    N = bed["n"]
+
+    if world > 1:
+        from sedifoam_amd.halo import SlabDriver
+        lmp = SlabDriver.from_bed(bed, script, dist, rank, world)
+    else:
+        lmp = build_engine(bed, script)
+    lmp.setup()
+    info = lmp.info()
+    k_half = info.npairs_full / 2.0 / max(info.nlocal, 1)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lmp.step(args.substeps)
+    lmp.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lmp.step(args.substeps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = lmp.get_profile()
+    lmp.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ntot = torch.tensor([float(N)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ntot)
+        n_total = float(ntot.item())
+    else:
+        n_total = float(N)
+
+    value = n_total * args.substeps * args.steps / elapsed
+    b_alg = 284.0 + 52.0 * k_half
+    mean_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+    achieved = b_alg * N / mean_kernel_s / 1e9 if launches else 0.0
+    info2 = lmp.info()
+    out = {
+        "metric": "particle-DEM-substeps/sec",
+        "value": value,
+        "unit": "particle-substeps/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "1M-particle monodisperse Hertz-history packing (FCC bed, d=1mm, 2%% overlap), "
+                        "periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step" % args.substeps,
+            "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
+            "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
+            "decomposition": "x-slabs, ghost halo over RCCL" if world > 1 else "single domain",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_substep<hertz>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_particle_substep": b_alg,
+            "mean_kernel_us": mean_kernel_s * 1e6, "launches_timed": int(launches),
+            "traffic": None,
+        },
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        sample_n = args.cpu_sample or 250000
+        sub = 20
+        v, n_s, secs = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub)
+        out["cpu_baseline"] = {"value": v, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
+                               "sample": "%d-particle bed of the same packing, %d sub-steps, %.1f s, "
+                                         "oracle/ (C, gcc -O2) single thread" % (n_s, sub, secs)}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

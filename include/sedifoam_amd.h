@@ -113,6 +113,10 @@ typedef struct {
   void *stream; /* hipStream_t */
 } sf_dem_device_view;
 int sf_dem_device_view_get(void *ptr, sf_dem_device_view *out);
+/* HIP-event timing of every launch of the fused sub-step kernel since profiling was switched on
+ * (events recorded on the engine's stream): number of launches and their summed duration */
+int sf_dem_set_profiling(void *ptr, int on);
+int sf_dem_get_profile(void *ptr, long long *launches, double *kernel_ms);
 /* forces/torques of owned atoms to host AoS (3n each, engine order) with tags */
 int sf_dem_get_forces(void *ptr, double *f, double *torque, double *omega, int *tag);
 /* touching pairs (tag_i < tag_j, shear oriented i->j) ; returns count or <0 */

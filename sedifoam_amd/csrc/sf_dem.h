@@ -178,6 +178,9 @@ class DemEngine {
   bool is_setup() const { return setup_done_; }
   double cutneighmax() const;
   double last_substep_ms() const { return last_substep_ms_; }
+  // per-launch HIP-event timing of the fused sub-step kernel (bench.py roofline leg)
+  void set_profiling(bool on);
+  void get_profile(long long* launches, double* kernel_ms);
 
  private:
   void ensure_capacity(size_t need);
@@ -252,6 +255,12 @@ class DemEngine {
   long long nsend_[2] = {0, 0};
   int recv_first_[2] = {0, 0}, recv_count_[2] = {0, 0};
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  bool profiling_ = false;
+  std::vector<hipEvent_t> prof_ev_;   // pairs (start, stop) of launches not yet harvested
+  size_t prof_used_ = 0;
+  long long prof_launches_ = 0;
+  double prof_ms_ = 0.0;
+  void harvest_profile();
 };
 
 // sf_sort.hip

@@ -98,6 +98,7 @@ DemEngine::~DemEngine()
   if (h_flags_) (void)hipHostFree(h_flags_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
+  for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -410,12 +411,57 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
   const StepParams S = step_params(mode, kstep);
   const dim3 grid(div_up(nlocal_, 256));
   const bool cohe = cohe_.enabled, lub = lub_.enabled;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (profiling_) {
+    if (prof_used_ + 2 > prof_ev_.size()) {
+      for (int k = 0; k < 2; k++) {
+        hipEvent_t e;
+        SF_HIP(hipEventCreate(&e));
+        prof_ev_.push_back(e);
+      }
+    }
+    e0 = prof_ev_[prof_used_++];
+    e1 = prof_ev_[prof_used_++];
+    SF_HIP(hipEventRecord(e0, stream_));
+  }
   switch (gran_.style) {
     case 2: launch_substep_style<2>(cohe, lub, grid, stream_, P, S); break;
     case 1: launch_substep_style<1>(cohe, lub, grid, stream_, P, S); break;
     default: launch_substep_style<0>(cohe, lub, grid, stream_, P, S); break;
   }
   SF_HIP(hipGetLastError());
+  if (profiling_) SF_HIP(hipEventRecord(e1, stream_));
+}
+
+void DemEngine::set_profiling(bool on)
+{
+  sync();
+  harvest_profile();
+  profiling_ = on;
+  prof_launches_ = 0;
+  prof_ms_ = 0.0;
+}
+
+void DemEngine::harvest_profile()
+{
+  for (size_t k = 0; k + 1 < prof_used_; k += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, prof_ev_[k], prof_ev_[k + 1]) == hipSuccess) {
+      // launches skipped by the stale-list early exit still count as launches: they are part of what
+      // a run costs, and are a handful of microseconds
+      prof_ms_ += ms;
+      prof_launches_++;
+    }
+  }
+  prof_used_ = 0;
+}
+
+void DemEngine::get_profile(long long* launches, double* kernel_ms)
+{
+  sync();
+  harvest_profile();
+  *launches = prof_launches_;
+  *kernel_ms = prof_ms_;
 }
 
 void DemEngine::launch_ghost_forward(int buf, int kstep)
@@ -744,6 +790,7 @@ void DemEngine::run(int nsteps)
   SF_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
   last_substep_ms_ = ms / nsteps;
   nsteps_ += nsteps;
+  if (profiling_) harvest_profile();
 }
 
 // ------------------------------------------------------------------------------------------------

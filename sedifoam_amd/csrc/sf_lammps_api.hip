@@ -435,6 +435,20 @@ int sf_dem_device_view_get(void* ptr, sf_dem_device_view* out)
   SF_API_END(0)
 }
 
+int sf_dem_set_profiling(void* ptr, int on)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_profiling(on != 0);
+  SF_API_END(0)
+}
+
+int sf_dem_get_profile(void* ptr, long long* launches, double* kernel_ms)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.get_profile(launches, kernel_ms);
+  SF_API_END(0)
+}
+
 int sf_dem_get_forces(void* ptr, double* f, double* torque, double* omega, int* tag)
 {
   SF_API_BEGIN

@@ -135,6 +135,15 @@ class Lammps:
         check(self.L.sf_dem_device_view_get(self.ptr, C.byref(out)))
         return out
 
+    def set_profiling(self, on=True):
+        check(self.L.sf_dem_set_profiling(self.ptr, int(on)))
+
+    def get_profile(self):
+        """(launches, summed kernel milliseconds) of the fused sub-step kernel, from HIP events."""
+        n = C.c_longlong(); ms = C.c_double()
+        check(self.L.sf_dem_get_profile(self.ptr, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def get_state(self):
         """x, v, omega, f, torque of the owned atoms sorted by tag."""
         n = self.get_local_n()
