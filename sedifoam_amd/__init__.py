@@ -6,3 +6,4 @@ lammpsFoam/enhancedCloud.H + dragModels).  No CPU fallback exists.
 """
 from ._lib import SfError, lib, exported_symbols  # noqa: F401
 from .lammps import Lammps  # noqa: F401
+from .cloud import enhancedCloud, dragModel, adjustLampTimestep  # noqa: F401

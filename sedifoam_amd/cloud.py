@@ -1,0 +1,158 @@
+"""Host-side mirror of the OpenFOAM plug-in surfaces of the hot path:
+
+  dragModel      lammpsFoam/dragModels/dragModel/dragModel.H:55-138, newDragModel.C:31-64
+                 (run-time selection by the `dragModel` keyword of constant/cloudProperties)
+  enhancedCloud  lammpsFoam/enhancedCloud.H:183-249 (evolve, calcTcFields, Omega, Asrc, ...)
+
+Everything numerical happens in libsedifoam_amd.so on the GPU; this file only marshals."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SfError, check, dp, ip
+
+_DRAG_TABLE = {"ErgunWenYu": 0, "SyamlalOBrien": 1}
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(dp if a.dtype == np.float64 else ip)
+
+
+class dragModel:
+    """dragModel::New(cloudDict, transDict, alpha, pd) + Jd(Ur) on device arrays (torch CUDA tensors)."""
+
+    def __init__(self, name, nub, rhob):
+        if name not in _DRAG_TABLE:
+            # newDragModel.C:45-55: FatalError listing the selection table
+            raise SfError("Unknown dragModel type %s\n\nValid dragModel types are :\n%s"
+                          % (name, sorted(_DRAG_TABLE)))
+        self.name = name
+        self.model = _DRAG_TABLE[name]
+        self.nuf = float(nub)
+        self.rhof = float(rhob)
+
+    @classmethod
+    def New(cls, cloudDict, transDict):
+        return cls(cloudDict["dragModel"], transDict["nub"], transDict["rhob"])
+
+    def Jd(self, Ur, alpha, pd):
+        """Ur, alpha, pd: 1-D float64 CUDA tensors of equal size; returns a new tensor (tmp<scalarField>)."""
+        import torch
+        if not (Ur.numel() == alpha.numel() == pd.numel()):
+            raise SfError("%s::Jd() Inconsistent Ur/Alpha/pd. Ur size: %d Alpha size: %d pd size: %d"
+                          % (self.name, Ur.numel(), alpha.numel(), pd.numel()))
+        out = torch.empty_like(Ur)
+        L = _lib.lib()
+        check(L.sfk_drag_model_jd(self.model, Ur.numel(), Ur.data_ptr(), alpha.data_ptr(), pd.data_ptr(),
+                                  self.nuf, self.rhof, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out
+
+
+class enhancedCloud:
+    """enhancedCloud(U, p, Ue, Uf, DDtUf, nu, alpha, cloudDict, transDict, ...) on a uniform hex block.
+
+    cloudDict keys (constant/cloudProperties): dragModel, subCycles, particleDrag, particlePressureGrad,
+    particleBuoyancy, particleAddedMass, particleLift, lubricationForce, g, maxPossibleAlpha.
+    transDict keys (constant/transportProperties): rhob, nub."""
+
+    def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT):
+        self.L = _lib.lib()
+        self.lmp = lammps
+        name = cloudDict.get("dragModel", "ErgunWenYu")
+        if name not in _DRAG_TABLE:
+            raise SfError("Unknown dragModel type %s\n\nValid dragModel types are :\n%s"
+                          % (name, sorted(_DRAG_TABLE)))
+        pr = _lib.CloudProps()
+        pr.dragModel = _DRAG_TABLE[name]
+        pr.subCycles = int(cloudDict.get("subCycles", 1))
+        pr.particleDrag = int(cloudDict.get("particleDrag", True))                    # enhancedCloud.C:586
+        pr.particlePressureGrad = int(cloudDict.get("particlePressureGrad", True))    # :587
+        pr.particleBuoyancy = int(cloudDict.get("particleBuoyancy", False))           # :589
+        pr.particleAddedMass = int(cloudDict.get("particleAddedMass", False))         # :591
+        pr.particleLift = int(cloudDict.get("particleLift", False))                   # :593
+        pr.lubricationForce = int(cloudDict.get("lubricationForce", False))           # :597
+        g = cloudDict.get("g", (0.0, 0.0, 0.0))
+        pr.gravity = (C.c_double * 3)(*g)
+        pr.rhob = float(transDict["rhob"])
+        pr.nub = float(transDict["nub"])
+        pr.maxPossibleAlpha = float(cloudDict.get("maxPossibleAlpha", 0.0))
+        m = _lib.CloudMesh()
+        m.origin = (C.c_double * 3)(*mesh_origin)
+        m.dx = (C.c_double * 3)(*mesh_dx)
+        m.n = (C.c_int * 3)(*mesh_n)
+        self.ncells = int(np.prod(mesh_n))
+        h = C.c_void_p()
+        check(self.L.sf_cloud_create(lammps.ptr, C.byref(m), C.byref(pr), float(deltaT), C.byref(h)))
+        self.ptr = h
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            check(self.L.sf_cloud_destroy(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setFluid(self, Uf=None, DDtUf=None, gradp=None, curlU=None):
+        arrs = [None if a is None else _f64(a).reshape(self.ncells, 3) for a in (Uf, DDtUf, gradp, curlU)]
+        check(self.L.sf_cloud_set_fluid(self.ptr, *[_p(a) for a in arrs]))
+
+    def evolve(self):
+        check(self.L.sf_cloud_evolve(self.ptr))
+
+    def calcTcFields(self):
+        check(self.L.sf_cloud_calc_tc_fields(self.ptr))
+
+    def _fields(self):
+        g = np.zeros(self.ncells); ue = np.zeros((self.ncells, 3))
+        a = np.zeros((self.ncells, 3)); om = np.zeros(self.ncells)
+        check(self.L.sf_cloud_get_fields(self.ptr, _p(g), _p(ue), _p(a), _p(om)))
+        return g, ue, a, om
+
+    def gamma(self):
+        return self._fields()[0]
+
+    def Ue(self):
+        return self._fields()[1]
+
+    def Asrc(self):
+        return self._fields()[2]
+
+    def Omega(self):
+        return self._fields()[3]
+
+    def particleCount(self):
+        return check(self.L.sf_cloud_particle_count(self.ptr))
+
+    def particles(self):
+        n = self.particleCount()
+        tag = np.zeros(n, np.int32); cell = np.zeros(n, np.int32)
+        pd = np.zeros((n, 3)); jd = np.zeros(n)
+        check(self.L.sf_cloud_get_particles(self.ptr, _p(tag), _p(cell), _p(pd), _p(jd)))
+        return dict(tag=tag, cell=cell, pDrag=pd, Jd=jd)
+
+    def cpuTimeSplit(self):
+        t = _lib.CloudTimers()
+        check(self.L.sf_cloud_get_timers(self.ptr, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+
+def adjustLampTimestep(deltaT, dtLampIn, subCycles):
+    """softParticleCloud::adjustLampTimestep (softParticleCloud.C:209-261)."""
+    L = _lib.lib()
+    dt = C.c_double(); steps = C.c_int(); sc = C.c_int(); ss = C.c_int()
+    rc = L.sf_cloud_adjust_timestep(deltaT, dtLampIn, subCycles, C.byref(dt), C.byref(steps), C.byref(sc),
+                                    C.byref(ss))
+    if rc != 0:
+        raise SfError("softParticleCloud::adjustLampTimestep() Time step adjustment error.")
+    return dict(dtLampAdj=dt.value, solidStepsPerDt=steps.value, subCycles=sc.value, subSteps=ss.value)

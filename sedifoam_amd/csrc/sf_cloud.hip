@@ -95,13 +95,13 @@ struct CloudFlagsDev {
 __global__ __launch_bounds__(256) void k_drag_on_particles(
     int n, size_t cap, const double4* xr, const double4* vm, const int* tag, MeshDev m, CloudFlagsDev fl,
     const double* gamma, const double* UfS, const double* gradp, const double* DDtUf, const double* curlU,
-    double* UOld_bytag, int maxtag, int first_call, int* cell_out, double* Jd_out, double* fdrag, double* DuDt)
+    double* UOld_bytag, int maxtag, int first_call, int* cell_bytag, double* Jd_bytag, double* pDrag_bytag,
+    double* fdrag, double* DuDt)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double4 x = xr[i], v = vm[i];
   const int c = cell_of(m, x.x, x.y, x.z);
-  cell_out[i] = c;
   const int t = tag[i];
   double F[3] = {0.0, 0.0, 0.0};
   double jd = 0.0;
@@ -153,10 +153,15 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
         F[1] += 6 * 3.1416 * fl.nub * fl.rhob * (-U[1]) / distWall * (d * d) / 4.0 * 1.0;
     }
   }
-  Jd_out[i] = jd;
   for (int k = 0; k < 3; k++) {
     fdrag[(size_t)k * cap + i] = F[k];
     DuDt[(size_t)k * cap + i] = dudt[k];
+  }
+  // diagnostics kept by tag (the DEM engine may re-sort its atoms at any neighbour rebuild)
+  if (t >= 1 && t <= maxtag) {
+    cell_bytag[t - 1] = c;
+    Jd_bytag[t - 1] = jd;
+    for (int k = 0; k < 3; k++) pDrag_bytag[(size_t)k * maxtag + (t - 1)] = F[k];
   }
 }
 
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void k_calc_tc(int ncells, const int* cstart, 
                                                  const double4* xr, const double4* vm, const double* V,
                                                  const double* gamma, const double* UfS, int dragModel,
                                                  double nub, double rhob, double* Asrc, double* Omega,
-                                                 double* Jd_out)
+                                                 const int* tag, double* Jd_bytag, int maxtag)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncells) return;
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(256) void k_calc_tc(int ncells, const int* cstart, 
     const double r0 = uf[0] - v.x, r1 = uf[1] - v.y, r2 = uf[2] - v.z;
     const double mag = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
     const double jd = jd_model(dragModel, mag, alpha, d, nub, rhob);
-    Jd_out[i] = jd;
+    const int t = tag[i];
+    if (t >= 1 && t <= maxtag) Jd_bytag[t - 1] = jd;
     const double omg = Vol * jd / V[c];
     a0 += omg * (v.x - uf[0]);
     a1 += omg * (v.y - uf[1]);
@@ -321,7 +327,7 @@ class Cloud {
 
   ~Cloud()
   {
-    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_})
+    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_})
       if (p) (void)hipFree(p);
     for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_})
       if (p) (void)hipFree(p);
@@ -371,7 +377,8 @@ class Cloud {
     sort_by_cell(n);
     k_calc_tc<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_, cstart_ + mesh_.ncells + 1, idx2_,
                                                          e.d_xr(), e.d_vm(), V_, gamma_, Uf_, props_.dragModel,
-                                                         props_.nub, props_.rhob, Asrc_, Omega_, Jd_);
+                                                         props_.nub, props_.rhob, Asrc_, Omega_, e.d_tag(), Jd_,
+                                                         maxtag_);
     t_.calcTc += sync_now() - t0;
   }
 
@@ -392,25 +399,22 @@ class Cloud {
     const int n = e.nlocal();
     if (!n) return;
     ensure_particle_arrays();
-    std::vector<int> ht(n), hc(n);
-    std::vector<double> hj(n), hf(3 * (size_t)n);
+    std::vector<int> ht(n), hc(maxtag_);
+    std::vector<double> hj(maxtag_), hf(3 * (size_t)maxtag_);
     SF_HIP(hipMemcpyAsync(ht.data(), e.d_tag(), sizeof(int) * n, hipMemcpyDeviceToHost, s_));
-    SF_HIP(hipMemcpyAsync(hc.data(), cell_, sizeof(int) * n, hipMemcpyDeviceToHost, s_));
-    SF_HIP(hipMemcpyAsync(hj.data(), Jd_, sizeof(double) * n, hipMemcpyDeviceToHost, s_));
-    for (int k = 0; k < 3; k++)
-      SF_HIP(hipMemcpyAsync(hf.data() + (size_t)k * n, e.d_fdrag() + (size_t)k * e.capacity(), sizeof(double) * n,
-                            hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipMemcpyAsync(hc.data(), cell_, sizeof(int) * maxtag_, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipMemcpyAsync(hj.data(), Jd_, sizeof(double) * maxtag_, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipMemcpyAsync(hf.data(), pDragT_, sizeof(double) * 3 * (size_t)maxtag_, hipMemcpyDeviceToHost, s_));
     SF_HIP(hipStreamSynchronize(s_));
-    std::vector<int> order(n);
-    for (int i = 0; i < n; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return ht[a] < ht[b]; });
+    std::sort(ht.begin(), ht.end());
     for (int r = 0; r < n; r++) {
-      const int i = order[r];
-      if (tag) tag[r] = ht[i];
-      if (cell) cell[r] = hc[i];
-      if (Jd) Jd[r] = hj[i];
+      const int t = ht[r] - 1;
+      if (tag) tag[r] = ht[r];
+      if (t < 0 || t >= maxtag_) continue;
+      if (cell) cell[r] = hc[t];
+      if (Jd) Jd[r] = hj[t];
       if (pDrag)
-        for (int k = 0; k < 3; k++) pDrag[3 * r + k] = hf[(size_t)k * n + i];
+        for (int k = 0; k < 3; k++) pDrag[3 * r + k] = hf[(size_t)k * maxtag_ + t];
     }
   }
 
@@ -438,8 +442,6 @@ class Cloud {
         SF_HIP(hipMalloc(p, bytes));
         SF_HIP(hipMemsetAsync(*p, 0, bytes, s_));
       };
-      re((void**)&Jd_, sizeof(double) * cap);
-      re((void**)&cell_, sizeof(int) * cap);
       re((void**)&keys_, sizeof(unsigned) * cap);
       re((void**)&keys2_, sizeof(unsigned) * cap);
       re((void**)&idx_, sizeof(int) * cap);
@@ -460,6 +462,14 @@ class Cloud {
         SF_HIP(hipFree(UOld_));
       }
       UOld_ = nu;
+      auto re2 = [&](void** p, size_t bytes) {
+        if (*p) SF_HIP(hipFree(*p));
+        SF_HIP(hipMalloc(p, bytes));
+        SF_HIP(hipMemsetAsync(*p, 0, bytes, s_));
+      };
+      re2((void**)&Jd_, sizeof(double) * newmax);
+      re2((void**)&cell_, sizeof(int) * newmax);
+      re2((void**)&pDragT_, sizeof(double) * 3 * (size_t)newmax);
       maxtag_ = newmax;
     }
   }
@@ -489,8 +499,8 @@ class Cloud {
     ensure_particle_arrays();
     k_drag_on_particles<<<div_up(n, 256), 256, 0, s_>>>(n, e.capacity(), e.d_xr(), e.d_vm(), e.d_tag(), mesh_,
                                                         flags(), gamma_, Uf_, gradp_, DDtUf_, curlU_, UOld_,
-                                                        maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, e.d_fdrag(),
-                                                        e.d_DuDt());
+                                                        maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, pDragT_,
+                                                        e.d_fdrag(), e.d_DuDt());
     first_drag_ = false;
   }
 
@@ -526,7 +536,7 @@ class Cloud {
   int subCycles_ = 1, subSteps_ = 1;
   double *V_ = nullptr, *gamma_ = nullptr, *Ue_ = nullptr, *Asrc_ = nullptr, *Omega_ = nullptr;
   double *Uf_ = nullptr, *DDtUf_ = nullptr, *gradp_ = nullptr, *curlU_ = nullptr;
-  double *Jd_ = nullptr, *UOld_ = nullptr;
+  double *Jd_ = nullptr, *UOld_ = nullptr, *pDragT_ = nullptr;   // by tag
   int *cstart_ = nullptr, *cell_ = nullptr, *idx_ = nullptr, *idx2_ = nullptr;
   unsigned *keys_ = nullptr, *keys2_ = nullptr;
   void* sort_tmp_ = nullptr;

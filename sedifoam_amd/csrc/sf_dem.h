@@ -260,7 +260,7 @@ class DemEngine {
   size_t prof_used_ = 0;
   long long prof_launches_ = 0;
   double prof_ms_ = 0.0;
-  void harvest_profile();
+  void harvest_profile(size_t first_pair, size_t valid_pairs);
 };
 
 // sf_sort.hip

@@ -436,30 +436,30 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
 void DemEngine::set_profiling(bool on)
 {
   sync();
-  harvest_profile();
+  prof_used_ = 0;
   profiling_ = on;
   prof_launches_ = 0;
   prof_ms_ = 0.0;
 }
 
-void DemEngine::harvest_profile()
+void DemEngine::harvest_profile(size_t first_pair, size_t valid_pairs)
 {
-  for (size_t k = 0; k + 1 < prof_used_; k += 2) {
+  // event pairs [first_pair, first_pair + valid_pairs) belong to launches that really executed; later
+  // pairs of the batch were early exits on a stale list (a few microseconds each) and are not counted
+  for (size_t q = first_pair; q < first_pair + valid_pairs && 2 * q + 1 < prof_used_; q++) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, prof_ev_[k], prof_ev_[k + 1]) == hipSuccess) {
-      // launches skipped by the stale-list early exit still count as launches: they are part of what
-      // a run costs, and are a handful of microseconds
+    if (hipEventElapsedTime(&ms, prof_ev_[2 * q], prof_ev_[2 * q + 1]) == hipSuccess) {
       prof_ms_ += ms;
       prof_launches_++;
     }
   }
-  prof_used_ = 0;
 }
 
 void DemEngine::get_profile(long long* launches, double* kernel_ms)
 {
   sync();
-  harvest_profile();
+  harvest_profile(0, prof_used_ / 2);
+  prof_used_ = 0;
   *launches = prof_launches_;
   *kernel_ms = prof_ms_;
 }
@@ -766,6 +766,7 @@ void DemEngine::run(int nsteps)
   SF_HIP(hipEventRecord(ev0_, stream_));
   while (k < nsteps) {
     const int base = cur_;
+    prof_used_ = 0;
     for (int s = k; s < nsteps; s++) {
       const int in_buf = (base + (s - k)) & 1;
       launch_substep(in_buf, (s == nsteps - 1) ? 1 : 0, s);
@@ -773,6 +774,10 @@ void DemEngine::run(int nsteps)
     }
     read_flags();
     const int trig = h_flags_[F_TRIGGER];
+    if (profiling_) {
+      harvest_profile(0, trig == INT_MAX ? (size_t)(nsteps - k) : (size_t)std::max(0, trig + 1 - k));
+      prof_used_ = 0;
+    }
     if (trig == INT_MAX) {
       cur_ = (base + (nsteps - k)) & 1;
       k = nsteps;
@@ -790,7 +795,6 @@ void DemEngine::run(int nsteps)
   SF_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
   last_substep_ms_ = ms / nsteps;
   nsteps_ += nsteps;
-  if (profiling_) harvest_profile();
 }
 
 // ------------------------------------------------------------------------------------------------
