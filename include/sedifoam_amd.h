@@ -136,9 +136,11 @@ int sf_dem_rebuild_begin(void *ptr);        /* shear history -> partner tags; fo
 int sf_dem_rebuild_sort(void *ptr);         /* pbc + sort owned atoms by bin (after migration) */
 int sf_dem_rebuild_finish(void *ptr);       /* periodic ghosts (y,z), bins, full list, history */
 /* halo: side 0 = towards -x neighbour, 1 = towards +x.  Buffers are DEVICE doubles.
+ * pack: side = the face the atoms sit at / leave through; unpack: side = the neighbour the data came FROM.
  * border records (on rebuild)  : 13 doubles / atom (x y z r vx vy vz m wx wy wz tag type)
  * forward records (every step) : 9 doubles / atom  (x y z vx vy vz wx wy wz)
- * migrate records (on rebuild) : variable, see DESIGN.md */
+ * migrate records (on rebuild) : sf_dem_migrate_record_doubles() doubles / atom (26 + 3 nwalls + 4 slots:
+ *                                state, fix fdrag arrays, wall shear, partner tags + shear history) */
 long long sf_dem_border_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_atoms);
 int sf_dem_border_unpack(void *ptr, int side, const double *dev_buf, long long natoms);
 long long sf_dem_forward_pack(void *ptr, int side, double xshift, double *dev_buf);
@@ -146,6 +148,13 @@ int sf_dem_forward_unpack(void *ptr, int side, const double *dev_buf, long long 
 long long sf_dem_migrate_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_doubles);
 int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
 int sf_dem_migrate_record_doubles(void *ptr);
+/* history slots carried by a migrating atom: the max over all ranks of sf_dem_info.max_neigh_used */
+int sf_dem_migrate_set_slots(void *ptr, int mrec);
+/* refresh the periodic y/z images (also of ghosts received from other GPUs) after a forward unpack */
+int sf_dem_ghost_forward_local(void *ptr);
+/* issue all engine work on a caller-owned hipStream_t (NULL = the legacy default stream, which is torch's
+ * default; (void*)-1 = back to the engine's own stream) */
+int sf_dem_set_stream(void *ptr, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (2) per-kernel entry points (device pointers; stream = hipStream_t or NULL)

@@ -107,6 +107,9 @@ _SIGS = {
     "sf_dem_migrate_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp, C.c_longlong]),
     "sf_dem_migrate_unpack": (C.c_int, [vp, vp, C.c_longlong]),
     "sf_dem_migrate_record_doubles": (C.c_int, [vp]),
+    "sf_dem_migrate_set_slots": (C.c_int, [vp, C.c_int]),
+    "sf_dem_ghost_forward_local": (C.c_int, [vp]),
+    "sf_dem_set_stream": (C.c_int, [vp, vp]),
     "sfk_gran_settings": (C.c_int, [C.POINTER(GranParams), C.c_double, C.c_int, C.c_double, C.c_double,
                                     C.c_int, C.c_double, C.c_double, C.c_int, C.c_double]),
     "sfk_pair_gran_history_compute": (C.c_int, [C.c_int, C.POINTER(GranParams), C.c_double, C.c_int, C.c_int,

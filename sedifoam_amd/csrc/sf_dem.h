@@ -153,9 +153,14 @@ class DemEngine {
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;
+  void migrate_set_slots(int mrec);
+  void ghost_forward_local();
 
   // device view for the cloud
   hipStream_t stream() const { return stream_; }
+  // run on a caller-owned stream (e.g. torch's current stream, so RCCL traffic orders after the pack
+  // kernels without host synchronisation)
+  void set_stream(hipStream_t s);
   size_t capacity() const { return cap_; }
   const double4* d_xr() const { return xr_[cur_].as<double4>(); }
   const double4* d_vm() const { return vm_[cur_].as<double4>(); }
@@ -191,7 +196,11 @@ class DemEngine {
   void launch_substep(int in_buf, int mode, int kstep);
   void launch_ghost_forward(int buf, int kstep);
   void launch_initial_integrate();
-  void rebuild();          // rebuild_begin + rebuild_finish
+  void rebuild();          // rebuild_begin + rebuild_sort + rebuild_finish
+  void permute_locals(const int* perm, int n_new);
+  void migrate_compact();
+  void compute_partner_tags();
+  int select_locals(int mode, double bound, DevArray& list);
   void make_periodic_ghosts();
   void bin_and_build();
   void read_flags();
@@ -201,6 +210,8 @@ class DemEngine {
   void sync() const { SF_HIP(hipStreamSynchronize(stream_)); }
 
   hipStream_t stream_ = nullptr;
+  hipStream_t own_stream_ = nullptr;
+  bool external_stream_ = false;
   size_t cap_ = 0;
   int nlocal_ = 0, nghost_ = 0, next_ghost_ = 0;   // next_ghost_: external ghosts appended by border_unpack
   int cur_ = 0;
@@ -216,7 +227,10 @@ class DemEngine {
   int periodic_[3] = {0, 0, 0};
   int rank_ = 0, nranks_ = 1;
   double sublo_x_ = 0.0, subhi_x_ = 1.0;
-  bool have_subdomain_ = false;
+  bool have_subdomain_ = false;   // true: the x halo is external (driven through sf_dem_border_* etc.)
+  int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
+  bool migrate_pending_ = false;
+  DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x
   double skin_ = 0.0, dt_ = 0.0;
   double rmax_ = 0.0;
 
@@ -237,7 +251,7 @@ class DemEngine {
   DevArray wshear_, wtouch_;
   DevArray gsrc_, gshift_;
   DevArray neigh_, numneigh_, shear_;
-  DevArray neigh_old_, numneigh_old_, shear_old_, ptag_;
+  DevArray neigh_old_, numneigh_old_, shear_old_, ptag_;   // B-side buffers swapped in by permute/build
   DevArray tmp4_, tmpd_, tmpi_;        // gather scratch
   DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
   int* cell_start_ = nullptr;          // [4][nbins]: local start/end, ghost start/end

@@ -71,7 +71,8 @@ DemEngine::DemEngine()
   if (e != hipSuccess || ndev == 0)
     fail("sedifoam_amd: no HIP device available (%s) -- this library has no CPU path",
          e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-  SF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  SF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  stream_ = own_stream_;
   SF_HIP(hipMalloc(&d_flags_, sizeof(int) * F_NFLAGS));
   SF_HIP(hipHostMalloc(&h_flags_, sizeof(int) * F_NFLAGS));
   SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
@@ -84,7 +85,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1]};
+               &sendlist_[0], &sendlist_[1], &leave_};
 }
 
 DemEngine::~DemEngine()
@@ -99,7 +100,19 @@ DemEngine::~DemEngine()
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
   for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void DemEngine::set_stream(hipStream_t s)
+{
+  sync();
+  if (s == (hipStream_t)-1) {  // sentinel: back to the engine's own stream
+    stream_ = own_stream_;
+    external_stream_ = false;
+  } else {                     // includes the null (legacy default) stream, which is what torch uses by default
+    stream_ = s;
+    external_stream_ = true;
+  }
 }
 
 void DemEngine::alloc_all(size_t cap)
@@ -142,6 +155,7 @@ void DemEngine::alloc_all(size_t cap)
   keys64_alt_.alloc(sizeof(unsigned long long), 1, cap, s);
   sendlist_[0].alloc(sizeof(int), 1, cap, s);
   sendlist_[1].alloc(sizeof(int), 1, cap, s);
+  leave_.alloc(sizeof(int), 1, cap, s);
   cap_ = cap;
 }
 
@@ -492,7 +506,7 @@ void DemEngine::compute_grid()
   double hi[3] = {subhi_x_, boxhi_[1], boxhi_[2]};
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
-    const bool ext = periodic_[k] || (k == 0 && nranks_ > 1);
+    const bool ext = periodic_[k] || (k == 0 && have_subdomain_);
     const double l = ext ? lo[k] - cut : lo[k];
     const double h = ext ? hi[k] + cut : hi[k];
     int n = (int)((h - l) / cut);
@@ -509,51 +523,42 @@ void DemEngine::compute_grid()
   }
 }
 
+void DemEngine::compute_partner_tags()
+{
+  if (have_list_ && nlocal_ && max_neigh_used_ > 0)
+    k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
+                                                              tag_.as<int>(), ptag_.as<int>(), nlocal_, cap_,
+                                                              max_neigh_used_);
+}
+
 void DemEngine::rebuild_begin()
 {
   if (!nlocal_ && !nghost_) return;
   compute_grid();
-  if (have_list_ && nlocal_)
-    k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
-                                                              tag_.as<int>(), ptag_.as<int>(), nlocal_, cap_,
-                                                              max_neigh_used_);
+  compute_partner_tags();
   nghost_ = 0;
   next_ghost_ = 0;
   nsend_[0] = nsend_[1] = 0;
   recv_count_[0] = recv_count_[1] = 0;
 }
 
-void DemEngine::rebuild_sort()
+// Re-order (and possibly shrink to n_new) every per-atom array of the owned atoms: dst[i] = src[perm[i]].
+// The old-list rows (partner tags, slot counts, shear) travel with their atom through the B-side buffers.
+void DemEngine::permute_locals(const int* perm, int n_new)
 {
-  if (!nlocal_) return;
-  PbcParams pb;
-  for (int k = 0; k < 3; k++) {
-    pb.lo[k] = boxlo_[k];
-    pb.hi[k] = boxhi_[k];
-    // x is wrapped here only when this GPU owns the whole periodic length; with several slabs the
-    // wrap is applied by the migration shift
-    pb.wrap[k] = periodic_[k] && !(k == 0 && nranks_ > 1);
-  }
-  const int nb = div_up(nlocal_, 256);
-  k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
-                                      perm_.as<int>(), d_flags_);
-  int bits = 1;
-  while ((1 << bits) < grid_.nbins) bits++;
-  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
-                 perm_alt_.as<int>(), nlocal_, bits, stream_);
-  const int* perm = perm_alt_.as<int>();
-  // physically re-order every per-atom array of the owned atoms
+  if (n_new <= 0) return;
+  const int nb = div_up(n_new, 256);
   auto g4 = [&](DevArray& a) {
-    k_gather4<<<nb, 256, 0, stream_>>>(tmp4_.as<double4>(), a.as<double4>(), perm, nlocal_);
-    SF_HIP(hipMemcpyAsync(a.ptr, tmp4_.ptr, sizeof(double4) * nlocal_, hipMemcpyDeviceToDevice, stream_));
+    k_gather4<<<nb, 256, 0, stream_>>>(tmp4_.as<double4>(), a.as<double4>(), perm, n_new);
+    SF_HIP(hipMemcpyAsync(a.ptr, tmp4_.ptr, sizeof(double4) * n_new, hipMemcpyDeviceToDevice, stream_));
   };
   auto gd = [&](DevArray& a, int rows) {
-    k_gather_rows<double><<<nb, 256, 0, stream_>>>(tmpd_.as<double>(), a.as<double>(), perm, nlocal_, rows, cap_);
-    k_copy_rows<double><<<nb, 256, 0, stream_>>>(a.as<double>(), tmpd_.as<double>(), nlocal_, rows, cap_);
+    k_gather_rows<double><<<nb, 256, 0, stream_>>>(tmpd_.as<double>(), a.as<double>(), perm, n_new, rows, cap_);
+    k_copy_rows<double><<<nb, 256, 0, stream_>>>(a.as<double>(), tmpd_.as<double>(), n_new, rows, cap_);
   };
   auto gi = [&](DevArray& a) {
-    k_gather_rows<int><<<nb, 256, 0, stream_>>>(tmpi_.as<int>(), a.as<int>(), perm, nlocal_, 1, cap_);
-    SF_HIP(hipMemcpyAsync(a.ptr, tmpi_.ptr, sizeof(int) * nlocal_, hipMemcpyDeviceToDevice, stream_));
+    k_gather_rows<int><<<nb, 256, 0, stream_>>>(tmpi_.as<int>(), a.as<int>(), perm, n_new, 1, cap_);
+    SF_HIP(hipMemcpyAsync(a.ptr, tmpi_.ptr, sizeof(int) * n_new, hipMemcpyDeviceToDevice, stream_));
   };
   g4(xr_[cur_]);
   g4(vm_[cur_]);
@@ -572,17 +577,41 @@ void DemEngine::rebuild_sort()
   if (nwalls_) {
     gd(wshear_, 3 * nwalls_);
     k_gather_rows<unsigned char><<<nb, 256, 0, stream_>>>((unsigned char*)tmpi_.ptr, wtouch_.as<unsigned char>(),
-                                                          perm, nlocal_, 1, cap_);
-    SF_HIP(hipMemcpyAsync(wtouch_.ptr, tmpi_.ptr, nlocal_, hipMemcpyDeviceToDevice, stream_));
+                                                          perm, n_new, 1, cap_);
+    SF_HIP(hipMemcpyAsync(wtouch_.ptr, tmpi_.ptr, n_new, hipMemcpyDeviceToDevice, stream_));
   }
-  if (have_list_) {
-    // old list rows travel with their atom: partner tags -> neigh_old_, shear -> shear_old_
-    k_gather_rows<int><<<nb, 256, 0, stream_>>>(numneigh_old_.as<int>(), numneigh_.as<int>(), perm, nlocal_, 1, cap_);
-    k_gather_rows<int><<<nb, 256, 0, stream_>>>(neigh_old_.as<int>(), ptag_.as<int>(), perm, nlocal_,
+  if (have_list_ && max_neigh_used_ > 0) {
+    k_gather_rows<int><<<nb, 256, 0, stream_>>>(numneigh_old_.as<int>(), numneigh_.as<int>(), perm, n_new, 1, cap_);
+    k_gather_rows<int><<<nb, 256, 0, stream_>>>(neigh_old_.as<int>(), ptag_.as<int>(), perm, n_new,
                                                 max_neigh_used_, cap_);
-    k_gather_rows<double><<<nb, 256, 0, stream_>>>(shear_old_.as<double>(), shear_.as<double>(), perm, nlocal_,
+    k_gather_rows<double><<<nb, 256, 0, stream_>>>(shear_old_.as<double>(), shear_.as<double>(), perm, n_new,
                                                    3 * max_neigh_used_, cap_);
+    std::swap(numneigh_, numneigh_old_);
+    std::swap(ptag_, neigh_old_);
+    std::swap(shear_, shear_old_);
   }
+}
+
+void DemEngine::rebuild_sort()
+{
+  if (migrate_pending_) migrate_compact();
+  if (!nlocal_) return;
+  PbcParams pb;
+  for (int k = 0; k < 3; k++) {
+    pb.lo[k] = boxlo_[k];
+    pb.hi[k] = boxhi_[k];
+    // x is wrapped here only when this GPU owns the whole periodic length; with several slabs the
+    // wrap is applied by the migration shift
+    pb.wrap[k] = periodic_[k] && !(k == 0 && have_subdomain_);
+  }
+  const int nb = div_up(nlocal_, 256);
+  k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
+                                      perm_.as<int>(), d_flags_);
+  int bits = 1;
+  while ((1 << bits) < grid_.nbins) bits++;
+  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
+                 perm_alt_.as<int>(), nlocal_, bits, stream_);
+  permute_locals(perm_alt_.as<int>(), nlocal_);
   // sorted bin keys -> cell ranges of owned atoms
   SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
   k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
@@ -601,7 +630,7 @@ void DemEngine::make_periodic_ghosts()
     bool over = false;
     for (int dim = 0; dim < 3; dim++) {
       if (!periodic_[dim]) continue;
-      if (dim == 0 && nranks_ > 1) continue;  // x images come from the neighbour GPUs
+      if (dim == 0 && have_subdomain_) continue;  // x images come from the neighbour GPUs (or the driver's self loop)
       GhostPtrs G{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
                   type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
       if (nall0)
@@ -657,8 +686,8 @@ void DemEngine::bin_and_build()
     B.g = grid_;
     k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
-        have_list_ ? numneigh_old_.as<int>() : nullptr, neigh_old_.as<int>(), shear_old_.as<double>(),
-        neigh_.as<int>(), numneigh_.as<int>(), shear_.as<double>(), d_flags_);
+        have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_.as<double>(), neigh_.as<int>(),
+        numneigh_old_.as<int>(), shear_old_.as<double>(), d_flags_);
     read_flags();
     if (h_flags_[F_NEIGH_OVER] > M_) {
       // more neighbours than slots: widen the slot-major arrays and build again.  The old-history
@@ -673,6 +702,8 @@ void DemEngine::bin_and_build()
     reset_flag(F_LOST, 0);
     fail("Lost atoms: an atom left the (non-periodic) simulation box");  // thermo_modify lost error
   }
+  std::swap(numneigh_, numneigh_old_);
+  std::swap(shear_, shear_old_);
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
                                                            cap_);
@@ -722,8 +753,11 @@ void DemEngine::setup()
       lub_.RS0 = 20.0 / 3.0 * kPi * mu * (1.0 + 3.64 * vol_f - 6.95 * vol_f * vol_f);
     }
   }
-  have_list_ = false;
-  if (nranks_ == 1) rebuild();
+  if (!have_subdomain_) {
+    have_list_ = false;
+    rebuild();
+  } else if (!have_list_)
+    fail("sf_dem_setup on a decomposed domain: run the rebuild protocol (sf_dem_rebuild_*) first");
   // (multi-rank: the driver has already run rebuild_begin / migrate / sort / borders / finish)
   reset_flag(F_TRIGGER, INT_MAX);
   launch_substep(cur_, 2, 0);
@@ -758,7 +792,7 @@ void DemEngine::run(int nsteps)
 {
   if (!setup_done_) setup();
   if (nsteps <= 0) return;
-  if (nranks_ > 1) fail("sf_lammps_step on a decomposed domain: drive the sub-steps through sf_dem_*");
+  if (have_subdomain_) fail("sf_lammps_step on a decomposed domain: drive the sub-steps through sf_dem_*");
   reset_flag(F_TRIGGER, INT_MAX);
   launch_initial_integrate();
   launch_ghost_forward(cur_, 0);

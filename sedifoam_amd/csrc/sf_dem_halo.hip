@@ -1,4 +1,15 @@
-// sf_dem_halo.hip -- ghost-particle halo of the 1-D slab decomposition and particle injection/removal.
+// sf_dem_halo.hip -- ghost-particle halo of the 1-D slab decomposition (one GPU per slab along x) and
+// particle injection/removal.
+//
+// This is the device half of what LAMMPS' Comm class does for the reference ([3P] comm.cpp, configured by
+// `communicate single vel yes`, `newton off` in every in.lammps): exchange() = atoms that left the slab
+// migrate with all their per-atom data (incl. fix fdrag's arrays, fix_fluid_drag.cpp:211-243, the wall shear
+// history, fix_wall_granFix.cpp:726-744, and the pair shear history by partner tag, FixShearHistory);
+// borders() = atoms within the ghost cutoff of a slab face become ghost atoms of the neighbour slab;
+// forward_comm() = ghost x, v, omega refreshed every sub-step (72 B per ghost).  With `newton off` there is
+// no reverse (force) communication: both owners evaluate a cross-boundary contact.
+// Packing/unpacking run as HIP kernels on device buffers; the transport between GPUs (RCCL send/recv over
+// xGMI) is done by the host driver, sedifoam_amd/halo.py.
 #include <algorithm>
 #include <vector>
 
@@ -6,17 +17,398 @@
 
 namespace sf {
 
-long long DemEngine::border_pack(int, double, double*, long long) { fail("border_pack: not implemented yet"); }
-void DemEngine::border_unpack(int, const double*, long long) { fail("border_unpack: not implemented yet"); }
-long long DemEngine::forward_pack(int, double, double*) { fail("forward_pack: not implemented yet"); }
-void DemEngine::forward_unpack(int, const double*, long long) { fail("forward_unpack: not implemented yet"); }
-long long DemEngine::migrate_pack(int, double, double*, long long) { fail("migrate_pack: not implemented yet"); }
-void DemEngine::migrate_unpack(const double*, long long) { fail("migrate_unpack: not implemented yet"); }
-int DemEngine::migrate_record_doubles() const { return 0; }
-void DemEngine::create_particles(int, const double*, const double*, double, double, int, const double*)
+constexpr int kBorderDoubles = 13;
+constexpr int kForwardDoubles = 9;
+constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec
+
+// key 0 = selected, 1 = not (a stable 1-bit sort then lists the selected atoms first, ascending)
+// mode 0: x < bound ; mode 1: x >= bound
+__global__ __launch_bounds__(256) void k_select_keys(const double4* xr, int n, int mode, double bound,
+                                                     unsigned* keys, int* idx, int* counter)
 {
-  fail("lammps_create_particle: not implemented yet");
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = xr[i].x;
+  const bool sel = mode == 0 ? (x < bound) : (x >= bound);
+  keys[i] = sel ? 0u : 1u;
+  idx[i] = i;
+  if (sel) atomicAdd(counter, 1);
 }
-void DemEngine::delete_particles(const int*, int) { fail("lammps_delete_particle: not implemented yet"); }
+
+__global__ __launch_bounds__(256) void k_border_pack(const int* list, int n, double xshift, const double4* xr,
+                                                     const double4* vm, const double4* om, const int* tag,
+                                                     const int* type, double* buf)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double* b = buf + (size_t)k * kBorderDoubles;
+  b[0] = x.x + xshift; b[1] = x.y; b[2] = x.z; b[3] = x.w;
+  b[4] = v.x; b[5] = v.y; b[6] = v.z; b[7] = v.w;
+  b[8] = w.x; b[9] = w.y; b[10] = w.z;
+  b[11] = (double)tag[i];
+  b[12] = (double)type[i];
+}
+
+__global__ __launch_bounds__(256) void k_border_unpack(const double* buf, int n, int first, double4* xr, double4* vm,
+                                                       double4* om, double4* xr_b, double4* vm_b, int* tag,
+                                                       int* type, int* mask, int* gsrc)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double* b = buf + (size_t)k * kBorderDoubles;
+  const int g = first + k;
+  xr[g] = {b[0], b[1], b[2], b[3]};
+  vm[g] = {b[4], b[5], b[6], b[7]};
+  om[g] = {b[8], b[9], b[10], 0.0};
+  // radius and mass (.w) must also be valid in the other ping-pong buffer: the forward halo only
+  // carries x, v, omega
+  xr_b[g] = {b[0], b[1], b[2], b[3]};
+  vm_b[g] = {b[4], b[5], b[6], b[7]};
+  tag[g] = (int)b[11];
+  type[g] = (int)b[12];
+  mask[g] = 1;
+  gsrc[g] = -1;  // owned by another GPU
+}
+
+__global__ __launch_bounds__(256) void k_forward_pack(const int* list, int n, double xshift, const double4* xr,
+                                                      const double4* vm, const double4* om, double* buf)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double* b = buf + (size_t)k * kForwardDoubles;
+  b[0] = x.x + xshift; b[1] = x.y; b[2] = x.z;
+  b[3] = v.x; b[4] = v.y; b[5] = v.z;
+  b[6] = w.x; b[7] = w.y; b[8] = w.z;
+}
+
+__global__ __launch_bounds__(256) void k_forward_unpack(const double* buf, int n, int first, double4* xr, double4* vm,
+                                                        double4* om)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double* b = buf + (size_t)k * kForwardDoubles;
+  const int g = first + k;
+  double4 x = xr[g], v = vm[g];
+  x.x = b[0]; x.y = b[1]; x.z = b[2];
+  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  xr[g] = x;   // radius / mass (.w) were set by the border exchange
+  vm[g] = v;
+  om[g] = {b[6], b[7], b[8], 0.0};
+}
+
+struct MigratePtrs {
+  double4 *xr, *vm, *om;
+  int *tag, *type, *mask, *foamCpuId, *numneigh, *ptag;
+  double *fdrag, *DuDt, *vOld, *wshear, *shear;
+  unsigned char* wtouch;
+};
+
+__global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, double xshift, MigratePtrs P, size_t cap,
+                                                      int nwalls, int mrec, int have_list, int rec, double* buf,
+                                                      int* leave, int code)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = list[k];
+  leave[i] = code;
+  double* b = buf + (size_t)k * rec;
+  const double4 x = P.xr[i], v = P.vm[i], w = P.om[i];
+  b[0] = x.x + xshift; b[1] = x.y; b[2] = x.z; b[3] = x.w;
+  b[4] = v.x; b[5] = v.y; b[6] = v.z; b[7] = v.w;
+  b[8] = w.x; b[9] = w.y; b[10] = w.z;
+  b[11] = P.tag[i]; b[12] = P.type[i]; b[13] = P.mask[i]; b[14] = P.foamCpuId[i];
+  for (int c = 0; c < 3; c++) {
+    b[15 + c] = P.fdrag[(size_t)c * cap + i];
+    b[18 + c] = P.DuDt[(size_t)c * cap + i];
+    b[21 + c] = P.vOld[(size_t)c * cap + i];
+  }
+  b[24] = P.wtouch[i];
+  for (int c = 0; c < 3 * nwalls; c++) b[25 + c] = P.wshear[(size_t)c * cap + i];
+  double* h = b + 25 + 3 * nwalls;
+  const int nn = have_list ? min(P.numneigh[i], mrec) : 0;
+  h[0] = nn;
+  for (int s = 0; s < mrec; s++) {
+    const bool ok = s < nn;
+    h[1 + 4 * s] = ok ? (double)P.ptag[(size_t)s * cap + i] : -1.0;
+    for (int c = 0; c < 3; c++) h[2 + 4 * s + c] = ok ? P.shear[(size_t)(3 * s + c) * cap + i] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(128) void k_migrate_unpack(const double* buf, int n, int first, MigratePtrs P, size_t cap,
+                                                        int nwalls, int mrec, int rec)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double* b = buf + (size_t)k * rec;
+  const int i = first + k;
+  P.xr[i] = {b[0], b[1], b[2], b[3]};
+  P.vm[i] = {b[4], b[5], b[6], b[7]};
+  P.om[i] = {b[8], b[9], b[10], 0.0};
+  P.tag[i] = (int)b[11]; P.type[i] = (int)b[12]; P.mask[i] = (int)b[13]; P.foamCpuId[i] = (int)b[14];
+  for (int c = 0; c < 3; c++) {
+    P.fdrag[(size_t)c * cap + i] = b[15 + c];
+    P.DuDt[(size_t)c * cap + i] = b[18 + c];
+    P.vOld[(size_t)c * cap + i] = b[21 + c];
+  }
+  P.wtouch[i] = (unsigned char)b[24];
+  for (int c = 0; c < 3 * nwalls; c++) P.wshear[(size_t)c * cap + i] = b[25 + c];
+  const double* h = b + 25 + 3 * nwalls;
+  P.numneigh[i] = (int)h[0];
+  for (int s = 0; s < mrec; s++) {
+    P.ptag[(size_t)s * cap + i] = (int)h[1 + 4 * s];
+    for (int c = 0; c < 3; c++) P.shear[(size_t)(3 * s + c) * cap + i] = h[2 + 4 * s + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stay_keys(const int* leave, int n, unsigned* keys, int* idx)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = leave[i] ? 1u : 0u;
+  idx[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+int DemEngine::select_locals(int mode, double bound, DevArray& list)
+{
+  if (!nlocal_) return 0;
+  reset_flag(F_SEND_COUNT, 0);
+  k_select_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, mode, bound,
+                                                           keys_.as<unsigned>(), perm_.as<int>(),
+                                                           d_flags_ + F_SEND_COUNT);
+  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
+                 list.as<int>(), nlocal_, 1, stream_);
+  read_flags();
+  return h_flags_[F_SEND_COUNT];
+}
+
+long long DemEngine::border_pack(int side, double xshift, double* buf, long long max_atoms)
+{
+  if (side < 0 || side > 1) fail("border_pack: side must be 0 or 1");
+  const double cut = cutneighmax();
+  const int n = select_locals(side == 0 ? 0 : 1, side == 0 ? sublo_x_ + cut : subhi_x_ - cut, sendlist_[side]);
+  if (n > max_atoms) fail("border_pack: %d atoms do not fit the %lld-atom buffer", n, max_atoms);
+  nsend_[side] = n;
+  if (n)
+    k_border_pack<<<div_up(n, 256), 256, 0, stream_>>>(sendlist_[side].as<int>(), n, xshift, xr_[cur_].as<double4>(),
+                                                       vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
+                                                       tag_.as<int>(), type_.as<int>(), buf);
+  if (!external_stream_) sync();
+  return n;
+}
+
+void DemEngine::border_unpack(int side, const double* buf, long long natoms)
+{
+  if (side < 0 || side > 1) fail("border_unpack: side must be 0 or 1");
+  const int n = (int)natoms;
+  ensure_capacity((size_t)nlocal_ + next_ghost_ + n + 1024);
+  const int first = nlocal_ + next_ghost_;
+  recv_first_[side] = first;
+  recv_count_[side] = n;
+  if (n)
+    k_border_unpack<<<div_up(n, 256), 256, 0, stream_>>>(buf, n, first, xr_[cur_].as<double4>(),
+                                                         vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
+                                                         xr_[cur_ ^ 1].as<double4>(), vm_[cur_ ^ 1].as<double4>(),
+                                                         tag_.as<int>(), type_.as<int>(), mask_.as<int>(),
+                                                         gsrc_.as<int>());
+  next_ghost_ += n;
+  if (!external_stream_) sync();
+}
+
+long long DemEngine::forward_pack(int side, double xshift, double* buf)
+{
+  const int n = (int)nsend_[side];
+  if (n)
+    k_forward_pack<<<div_up(n, 256), 256, 0, stream_>>>(sendlist_[side].as<int>(), n, xshift,
+                                                        xr_[cur_].as<double4>(), vm_[cur_].as<double4>(),
+                                                        om_[cur_].as<double4>(), buf);
+  if (!external_stream_) sync();
+  return n;
+}
+
+void DemEngine::forward_unpack(int side, const double* buf, long long natoms)
+{
+  if (natoms != recv_count_[side])
+    fail("forward_unpack: got %lld ghosts from side %d, the border exchange set up %d", natoms, side,
+         recv_count_[side]);
+  const int n = (int)natoms;
+  if (n)
+    k_forward_unpack<<<div_up(n, 256), 256, 0, stream_>>>(buf, n, recv_first_[side], xr_[cur_].as<double4>(),
+                                                          vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+}
+
+void DemEngine::ghost_forward_local() { launch_ghost_forward(cur_, 0); }
+
+void DemEngine::migrate_set_slots(int mrec)
+{
+  mrec_ = std::max(mrec, 0);
+  if (mrec_ > M_) grow_neigh(mrec_ + 4);
+  max_neigh_used_ = std::max(max_neigh_used_, mrec_);
+}
+
+int DemEngine::migrate_record_doubles() const { return kMigrateFixed + 3 * nwalls_ + 4 * mrec_; }
+
+static MigratePtrs mig_ptrs(DevArray& xr, DevArray& vm, DevArray& om, DevArray& tag, DevArray& type, DevArray& mask,
+                            DevArray& foam, DevArray& numneigh, DevArray& ptag, DevArray& fdrag, DevArray& DuDt,
+                            DevArray& vOld, DevArray& wshear, DevArray& shear, DevArray& wtouch)
+{
+  MigratePtrs P;
+  P.xr = xr.as<double4>(); P.vm = vm.as<double4>(); P.om = om.as<double4>();
+  P.tag = tag.as<int>(); P.type = type.as<int>(); P.mask = mask.as<int>(); P.foamCpuId = foam.as<int>();
+  P.numneigh = numneigh.as<int>(); P.ptag = ptag.as<int>();
+  P.fdrag = fdrag.as<double>(); P.DuDt = DuDt.as<double>(); P.vOld = vOld.as<double>();
+  P.wshear = wshear.as<double>(); P.shear = shear.as<double>();
+  P.wtouch = wtouch.as<unsigned char>();
+  return P;
+}
+
+long long DemEngine::migrate_pack(int side, double xshift, double* buf, long long max_doubles)
+{
+  if (side < 0 || side > 1) fail("migrate_pack: side must be 0 or 1");
+  if (!migrate_pending_ && nlocal_) {
+    SF_HIP(hipMemsetAsync(leave_.ptr, 0, sizeof(int) * nlocal_, stream_));
+    migrate_pending_ = true;
+  }
+  DevArray& list = sendlist_[side];  // reused: the border exchange refills it afterwards
+  const int n = select_locals(side == 0 ? 0 : 1, side == 0 ? sublo_x_ : subhi_x_, list);
+  const int rec = migrate_record_doubles();
+  if ((long long)n * rec > max_doubles)
+    fail("migrate_pack: %d atoms x %d doubles do not fit the %lld-double buffer", n, rec, max_doubles);
+  if (n) {
+    MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_,
+                             fdrag_, DuDt_, vOld_, wshear_, shear_, wtouch_);
+    k_migrate_pack<<<div_up(n, 128), 128, 0, stream_>>>(list.as<int>(), n, xshift, P, cap_, nwalls_, mrec_,
+                                                        have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1);
+  }
+  sync();
+  return (long long)n * rec;
+}
+
+void DemEngine::migrate_compact()
+{
+  migrate_pending_ = false;
+  if (!nlocal_) return;
+  k_stay_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(leave_.as<int>(), nlocal_, keys_.as<unsigned>(),
+                                                         perm_.as<int>());
+  // count leavers: select on the key itself
+  reset_flag(F_SEND_COUNT2, 0);
+  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
+                 perm_alt_.as<int>(), nlocal_, 1, stream_);
+  // number staying = first index with key 1
+  std::vector<unsigned> hk(nlocal_);
+  SF_HIP(hipMemcpyAsync(hk.data(), keys_alt_.ptr, sizeof(unsigned) * nlocal_, hipMemcpyDeviceToHost, stream_));
+  sync();
+  const int nstay = (int)(std::lower_bound(hk.begin(), hk.end(), 1u) - hk.begin());
+  if (nstay == nlocal_) return;
+  permute_locals(perm_alt_.as<int>(), nstay);
+  nlocal_ = nstay;
+}
+
+void DemEngine::migrate_unpack(const double* buf, long long ndoubles)
+{
+  if (migrate_pending_) migrate_compact();
+  const int rec = migrate_record_doubles();
+  if (ndoubles % rec) fail("migrate_unpack: %lld doubles is not a multiple of the %d-double record", ndoubles, rec);
+  const int n = (int)(ndoubles / rec);
+  if (!n) return;
+  ensure_capacity((size_t)nlocal_ + n + 1024);
+  MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_, fdrag_,
+                           DuDt_, vOld_, wshear_, shear_, wtouch_);
+  k_migrate_unpack<<<div_up(n, 128), 128, 0, stream_>>>(buf, n, nlocal_, P, cap_, nwalls_, mrec_, rec);
+  nlocal_ += n;
+  // tags of immigrants may exceed what this rank has seen
+  std::vector<double> hb((size_t)n * rec);
+  SF_HIP(hipMemcpyAsync(hb.data(), buf, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, stream_));
+  sync();
+  for (int k = 0; k < n; k++) {
+    max_tag_ = std::max(max_tag_, (int)hb[(size_t)k * rec + 11]);
+    rmax_ = std::max(rmax_, hb[(size_t)k * rec + 3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lammps_create_particle / lammps_delete_particle (library.cpp:406-621)
+// ------------------------------------------------------------------------------------------------
+void DemEngine::create_particles(int np, const double* pos, const double* tag, double diameter, double rho, int type,
+                                 const double* vel)
+{
+  if (np <= 0) return;
+  ensure_capacity((size_t)nlocal_ + nghost_ + np + 1024);
+  const double r = 0.5 * diameter;
+  // library.cpp:460 -- the reference's mistyped pi literal is kept
+  const double m = 4.0 * kPiTypo / 3.0 * r * r * r * rho;
+  std::vector<double4> hx(np), hv(np), hw(np, double4{0, 0, 0, 0}), hz(np, double4{0, 0, 0, 0});
+  std::vector<int> ht(np), hty(np, type), hm(np, 1), h0(np, 0);
+  for (int k = 0; k < np; k++) {
+    hx[k] = {pos[3 * k], pos[3 * k + 1], pos[3 * k + 2], r};
+    hv[k] = {vel[0], vel[1], vel[2], m};
+    ht[k] = (int)tag[k];  // library.cpp:437
+    max_tag_ = std::max(max_tag_, ht[k]);
+  }
+  rmax_ = std::max(rmax_, r);
+  // ghosts are dropped (library.cpp:476-480 resets nghost) and re-created by the forced rebuild below
+  const size_t o4 = sizeof(double4) * nlocal_, oi = sizeof(int) * nlocal_;
+  auto up = [&](DevArray& a, const void* src, size_t bytes, size_t off) {
+    SF_HIP(hipMemcpyAsync((char*)a.ptr + off, src, bytes, hipMemcpyHostToDevice, stream_));
+  };
+  up(xr_[cur_], hx.data(), sizeof(double4) * np, o4);
+  up(vm_[cur_], hv.data(), sizeof(double4) * np, o4);
+  up(om_[cur_], hw.data(), sizeof(double4) * np, o4);
+  up(force_, hz.data(), sizeof(double4) * np, o4);
+  up(torque_, hz.data(), sizeof(double4) * np, o4);
+  up(tag_, ht.data(), sizeof(int) * np, oi);
+  up(type_, hty.data(), sizeof(int) * np, oi);
+  up(mask_, hm.data(), sizeof(int) * np, oi);
+  up(foamCpuId_, h0.data(), sizeof(int) * np, oi);
+  up(numneigh_, h0.data(), sizeof(int) * np, oi);
+  std::vector<double> z(np, 0.0);
+  for (int c = 0; c < 3; c++) {
+    up(fdrag_, z.data(), sizeof(double) * np, sizeof(double) * ((size_t)c * cap_ + nlocal_));
+    up(DuDt_, z.data(), sizeof(double) * np, sizeof(double) * ((size_t)c * cap_ + nlocal_));
+    up(vOld_, z.data(), sizeof(double) * np, sizeof(double) * ((size_t)c * cap_ + nlocal_));
+  }
+  std::vector<unsigned char> zb(np, 0);
+  up(wtouch_, zb.data(), np, nlocal_);
+  sync();
+  nlocal_ += np;
+  nghost_ = 0;
+  // next_reneighbor = ntimestep + 1 for every fix (library.cpp:482-486): rebuild before the next force
+  if (setup_done_ && !have_subdomain_) rebuild();
+}
+
+void DemEngine::delete_particles(const int* tags, int n)
+{
+  if (n <= 0 || !nlocal_) return;
+  std::vector<int> ht(nlocal_), leave(nlocal_, 0);
+  SF_HIP(hipMemcpyAsync(ht.data(), tag_.ptr, sizeof(int) * nlocal_, hipMemcpyDeviceToHost, stream_));
+  sync();
+  std::vector<int> del(tags, tags + n);
+  std::sort(del.begin(), del.end());
+  int ndel = 0;
+  for (int i = 0; i < nlocal_; i++)
+    if (std::binary_search(del.begin(), del.end(), ht[i])) {
+      leave[i] = 1;
+      ndel++;
+    }
+  if (!ndel) return;
+  if (have_list_) {
+    // the history of the surviving atoms must outlive the compaction
+    compute_partner_tags();
+  }
+  SF_HIP(hipMemcpyAsync(leave_.ptr, leave.data(), sizeof(int) * nlocal_, hipMemcpyHostToDevice, stream_));
+  migrate_compact();
+  nghost_ = 0;
+  if (setup_done_ && !have_subdomain_) {
+    // list rows are already partner tags: rebuild without recomputing them
+    compute_grid();
+    next_ghost_ = 0;
+    rebuild_sort();
+    rebuild_finish();
+  }
+}
 
 }  // namespace sf

@@ -568,6 +568,27 @@ int sf_dem_migrate_unpack(void* ptr, const double* dev_buf, long long ndoubles)
   SF_API_END(0)
 }
 
+int sf_dem_migrate_set_slots(void* ptr, int mrec)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.migrate_set_slots(mrec);
+  SF_API_END(0)
+}
+
+int sf_dem_ghost_forward_local(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.ghost_forward_local();
+  SF_API_END(0)
+}
+
+int sf_dem_set_stream(void* ptr, void* stream)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_stream((hipStream_t)stream);
+  SF_API_END(0)
+}
+
 int sf_dem_migrate_record_doubles(void* ptr)
 {
   SF_API_BEGIN

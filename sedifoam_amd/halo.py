@@ -1,0 +1,276 @@
+"""One-process-per-GPU driver of the DEM engine on a 1-D slab decomposition along x.
+
+What LAMMPS' Comm class does for the reference under `mpirun -np N` ([3P] comm.cpp: exchange / borders /
+forward_comm), re-designed for MI355X: the pack / unpack halves are HIP kernels on device
+buffers inside libsedifoam_amd.so (csrc/sf_dem_halo.hip), the transport is torch.distributed point-to-point
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  A slab has two face neighbours,
+so each GPU talks to two peers over two xGMI links; with `newton off` there is no reverse (force) message.
+
+Per DEM sub-step: one fused force/integrate kernel, one 1-int all-reduce (did any atom move > skin/2?),
+one forward halo (72 B per ghost).  On a rebuild: migration of atoms that left the slab (with fix fdrag
+arrays, wall and pair shear history), border exchange of ghost atoms, device neighbour build.
+
+The driver only talks to an "engine adaptor" (HipSlabEngine below; the CPU tests plug the oracle in through
+the same interface), so the protocol is exercised without a GPU by tests/test_halo_gloo.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+BORDER_DOUBLES = 13
+FORWARD_DOUBLES = 9
+
+
+class HipSlabEngine:
+    """Adaptor: sedifoam_amd.Lammps + torch CUDA buffers -> the calls SlabDriver makes."""
+
+    def __init__(self, lmp):
+        import torch
+        from . import _lib
+        self.torch = torch
+        self.lmp = lmp
+        self.L = lmp.L
+        self.check = _lib.check
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        # run the engine on torch's current stream: RCCL traffic then orders after the pack kernels and the
+        # unpack kernels after the receives without host synchronisation
+        self.check(self.L.sf_dem_set_stream(lmp.ptr, torch.cuda.current_stream().cuda_stream))
+
+    def alloc(self, ndoubles):
+        return self.torch.empty(max(int(ndoubles), 1), dtype=self.torch.float64, device=self.device)
+
+    def info(self):
+        return self.lmp.info()
+
+    def set_subdomain(self, rank, world, lo, hi):
+        self.check(self.L.sf_dem_set_subdomain(self.lmp.ptr, rank, world, lo, hi))
+
+    def setup(self):
+        self.check(self.L.sf_dem_setup(self.lmp.ptr))
+
+    def run_begin(self):
+        self.check(self.L.sf_dem_run_begin(self.lmp.ptr))
+
+    def substep(self, last):
+        self.check(self.L.sf_dem_substep(self.lmp.ptr, int(last)))
+
+    def need_rebuild(self):
+        return self.check(self.L.sf_dem_need_rebuild(self.lmp.ptr))
+
+    def rebuild_begin(self):
+        self.check(self.L.sf_dem_rebuild_begin(self.lmp.ptr))
+
+    def rebuild_sort(self):
+        self.check(self.L.sf_dem_rebuild_sort(self.lmp.ptr))
+
+    def rebuild_finish(self):
+        self.check(self.L.sf_dem_rebuild_finish(self.lmp.ptr))
+
+    def migrate_set_slots(self, m):
+        self.check(self.L.sf_dem_migrate_set_slots(self.lmp.ptr, int(m)))
+
+    def migrate_record_doubles(self):
+        return self.check(self.L.sf_dem_migrate_record_doubles(self.lmp.ptr))
+
+    def migrate_pack(self, side, xshift, buf):
+        return self.check(self.L.sf_dem_migrate_pack(self.lmp.ptr, side, xshift, buf.data_ptr(), buf.numel()))
+
+    def migrate_unpack(self, buf, ndoubles):
+        self.check(self.L.sf_dem_migrate_unpack(self.lmp.ptr, buf.data_ptr(), int(ndoubles)))
+
+    def border_pack(self, side, xshift, buf):
+        return self.check(self.L.sf_dem_border_pack(self.lmp.ptr, side, xshift, buf.data_ptr(),
+                                                    buf.numel() // BORDER_DOUBLES))
+
+    def border_unpack(self, side, buf, natoms):
+        self.check(self.L.sf_dem_border_unpack(self.lmp.ptr, side, buf.data_ptr(), int(natoms)))
+
+    def forward_pack(self, side, xshift, buf):
+        return self.check(self.L.sf_dem_forward_pack(self.lmp.ptr, side, xshift, buf.data_ptr()))
+
+    def forward_unpack(self, side, buf, natoms):
+        self.check(self.L.sf_dem_forward_unpack(self.lmp.ptr, side, buf.data_ptr(), int(natoms)))
+
+    def ghost_forward_local(self):
+        self.check(self.L.sf_dem_ghost_forward_local(self.lmp.ptr))
+
+
+class SlabDriver:
+    """lammps_step() for one slab of an x-decomposed domain.  All methods are collective over the ranks."""
+
+    def __init__(self, eng, dist, rank, world, xlo, xhi, periodic_x=True, halo_atoms=None):
+        import torch
+        self.torch = torch
+        self.e = eng
+        self.dist = dist
+        self.rank, self.world = rank, world
+        self.L = float(xhi - xlo)
+        self.periodic_x = bool(periodic_x)
+        self.left = rank - 1 if rank > 0 else (world - 1 if periodic_x else None)
+        self.right = rank + 1 if rank < world - 1 else (0 if periodic_x else None)
+        # shift applied to what goes out through the global box faces
+        self.shift_left = self.L if (rank == 0 and periodic_x) else 0.0
+        self.shift_right = -self.L if (rank == world - 1 and periodic_x) else 0.0
+        w = self.L / world
+        self.sublo, self.subhi = xlo + rank * w, xlo + (rank + 1) * w
+        if rank == world - 1:
+            self.subhi = float(xhi)
+        eng.set_subdomain(rank, world, self.sublo, self.subhi)
+        self._cap_atoms = int(halo_atoms) if halo_atoms else max(eng.info().nlocal, 4096)
+        self._bufs = {}
+        self._nrecv = [0, 0]
+        self.n_rebuilds = 0
+        self.is_setup = False
+
+    # ---- plumbing ----
+    def _buf(self, name, ndoubles):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < ndoubles:
+            b = self.e.alloc(int(ndoubles * 1.25) + 64)
+            self._bufs[name] = b
+        return b
+
+    def _allreduce_max(self, v):
+        if self.world == 1:
+            return int(v)
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.e.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def _exchange(self, send_l, n_l, send_r, n_r, known=None):
+        """send_l[:n_l] goes to the left neighbour, send_r[:n_r] to the right one.
+        Returns (from_left, n_from_left, from_right, n_from_right) in doubles.  `known` = receive sizes
+        when both sides already know them (forward halo), else they are exchanged first."""
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            # one slab: my own images.  What leaves through the left face arrives from the right.
+            if self.periodic_x:
+                return send_r, n_r, send_l, n_l
+            return send_l, 0, send_r, 0
+        if self.left is None:
+            n_l = 0
+        if self.right is None:
+            n_r = 0
+        if known is None:
+            cs_l = torch.tensor([n_l], dtype=torch.int64, device=self.e.device)
+            cs_r = torch.tensor([n_r], dtype=torch.int64, device=self.e.device)
+            cr_l = torch.zeros(1, dtype=torch.int64, device=self.e.device)
+            cr_r = torch.zeros(1, dtype=torch.int64, device=self.e.device)
+            ops = []
+            if self.left is not None:
+                ops.append(dist.P2POp(dist.isend, cs_l, self.left, tag=10))
+            if self.right is not None:
+                ops.append(dist.P2POp(dist.isend, cs_r, self.right, tag=11))
+            if self.right is not None:
+                ops.append(dist.P2POp(dist.irecv, cr_r, self.right, tag=10))   # leftward traffic comes from my right
+            if self.left is not None:
+                ops.append(dist.P2POp(dist.irecv, cr_l, self.left, tag=11))
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            m_l, m_r = int(cr_l.item()), int(cr_r.item())
+        else:
+            m_l, m_r = known
+        recv_l = self._buf("recv_l", m_l)
+        recv_r = self._buf("recv_r", m_r)
+        ops = []
+        if self.left is not None and n_l:
+            ops.append(dist.P2POp(dist.isend, send_l[:n_l], self.left, tag=20))
+        if self.right is not None and n_r:
+            ops.append(dist.P2POp(dist.isend, send_r[:n_r], self.right, tag=21))
+        if self.right is not None and m_r:
+            ops.append(dist.P2POp(dist.irecv, recv_r[:m_r], self.right, tag=20))
+        if self.left is not None and m_l:
+            ops.append(dist.P2POp(dist.irecv, recv_l[:m_l], self.left, tag=21))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        return recv_l, m_l, recv_r, m_r
+
+    # ---- the three halo operations ----
+    def rebuild(self):
+        e = self.e
+        e.rebuild_begin()
+        e.migrate_set_slots(self._allreduce_max(e.info().max_neigh_used))
+        rec = e.migrate_record_doubles()
+        nmax = max(self._cap_atoms // 8, 1024)
+        b0 = self._buf("mig_l", nmax * rec)
+        b1 = self._buf("mig_r", nmax * rec)
+        n0 = e.migrate_pack(0, self.shift_left, b0)
+        n1 = e.migrate_pack(1, self.shift_right, b1)
+        rl, ml, rr, mr = self._exchange(b0, n0, b1, n1)
+        if self.world == 1 and not self.periodic_x and (n0 or n1):
+            raise RuntimeError("Lost atoms: an atom left the non-periodic box in x")
+        e.migrate_unpack(rl, ml)
+        e.migrate_unpack(rr, mr)
+        e.rebuild_sort()
+        cap = max(self._cap_atoms, e.info().nlocal)
+        s0 = self._buf("bor_l", cap * BORDER_DOUBLES)
+        s1 = self._buf("bor_r", cap * BORDER_DOUBLES)
+        a0 = e.border_pack(0, self.shift_left, s0)
+        a1 = e.border_pack(1, self.shift_right, s1)
+        self._nsend = [a0, a1]
+        rl, ml, rr, mr = self._exchange(s0, a0 * BORDER_DOUBLES, s1, a1 * BORDER_DOUBLES)
+        self._nrecv = [ml // BORDER_DOUBLES, mr // BORDER_DOUBLES]
+        e.border_unpack(0, rl, self._nrecv[0])
+        e.border_unpack(1, rr, self._nrecv[1])
+        e.rebuild_finish()
+        self.n_rebuilds += 1
+
+    def forward(self):
+        e = self.e
+        f0 = self._buf("fwd_l", self._nsend[0] * FORWARD_DOUBLES)
+        f1 = self._buf("fwd_r", self._nsend[1] * FORWARD_DOUBLES)
+        a0 = e.forward_pack(0, self.shift_left, f0)
+        a1 = e.forward_pack(1, self.shift_right, f1)
+        rl, ml, rr, mr = self._exchange(f0, a0 * FORWARD_DOUBLES, f1, a1 * FORWARD_DOUBLES,
+                                        known=(self._nrecv[0] * FORWARD_DOUBLES, self._nrecv[1] * FORWARD_DOUBLES))
+        e.forward_unpack(0, rl, ml // FORWARD_DOUBLES)
+        e.forward_unpack(1, rr, mr // FORWARD_DOUBLES)
+        e.ghost_forward_local()
+
+    # ---- lammps_* surface ----
+    def setup(self):
+        self.rebuild()
+        self.e.setup()
+        self.is_setup = True
+
+    def step(self, n):
+        """lammps_step(n) = "run n pre no post no" (library.cpp:372-386) on the decomposed domain."""
+        if not self.is_setup:
+            self.setup()
+        e = self.e
+        e.run_begin()
+        for s in range(int(n)):
+            if self._allreduce_max(e.need_rebuild()):
+                self.rebuild()
+            else:
+                self.forward()
+            e.substep(s == n - 1)
+
+    def info(self):
+        return self.e.info()
+
+    def set_profiling(self, on=True):
+        self.e.lmp.set_profiling(on)
+
+    def get_profile(self):
+        return self.e.lmp.get_profile()
+
+    @classmethod
+    def from_bed(cls, bed, script, dist, rank, world):
+        """bench.py: every rank owns one copy of `bed` (its own seed), laid side by side along x."""
+        from . import Lammps
+        lx = float(bed["boxhi"][0] - bed["boxlo"][0])
+        x = np.array(bed["x"], copy=True)
+        x[:, 0] += rank * lx
+        lo = np.array(bed["boxlo"], dtype=np.float64)
+        hi = np.array(bed["boxhi"], dtype=np.float64)
+        hi[0] = lo[0] + world * lx
+        lmp = Lammps()
+        lmp.set_box(lo, hi)
+        n = x.shape[0]
+        lmp.create_atoms(x, bed["diameter"], bed["density"], v=bed["v"],
+                         tag=np.arange(1, n + 1, dtype=np.int64) + rank * n)
+        for line in script:
+            lmp.command(line)
+        return cls(HipSlabEngine(lmp), dist, rank, world, lo[0], hi[0], periodic_x=bool(bed["periodic"][0]))
