@@ -92,6 +92,27 @@ def _declare(L):
     L.orc_dem_get_history.argtypes = [C.c_void_p, C.c_int, ip, ip, dp]
     L.orc_dem_get_history.restype = C.c_int
     L.orc_dem_get_wall_shear.argtypes = [C.c_void_p, C.c_int, dp]
+    vp = C.c_void_p
+    L.orc_dem_set_subdomain.argtypes = [vp, C.c_double, C.c_double]
+    for name in ("orc_dem_run_begin", "orc_dem_ext_setup", "orc_dem_rebuild_begin", "orc_dem_rebuild_sort",
+                 "orc_dem_rebuild_finish", "orc_dem_ghost_forward_local"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = None
+    L.orc_dem_substep.argtypes = [vp, C.c_int]
+    for name in ("orc_dem_need_rebuild", "orc_dem_max_partners", "orc_dem_migrate_record_doubles"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_int
+    L.orc_dem_migrate_set_slots.argtypes = [vp, C.c_int]
+    L.orc_dem_migrate_pack.argtypes = [vp, C.c_int, C.c_double, vp, C.c_long]
+    L.orc_dem_migrate_pack.restype = C.c_long
+    L.orc_dem_migrate_unpack.argtypes = [vp, vp, C.c_long]
+    L.orc_dem_border_pack.argtypes = [vp, C.c_int, C.c_double, vp, C.c_long]
+    L.orc_dem_border_pack.restype = C.c_long
+    L.orc_dem_border_unpack.argtypes = [vp, C.c_int, vp, C.c_long]
+    L.orc_dem_forward_pack.argtypes = [vp, C.c_int, C.c_double, vp]
+    L.orc_dem_forward_pack.restype = C.c_long
+    L.orc_dem_forward_unpack.argtypes = [vp, C.c_int, vp, C.c_long]
+    L.orc_dem_forward_unpack.restype = C.c_int
     L.orc_gran_settings.argtypes = [C.POINTER(GranParams), C.c_double, C.c_int, C.c_double,
                                     C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                     C.c_double]
@@ -256,3 +277,87 @@ class OracleDem:
         self.L.orc_dem_get_wall_shear(self.h, w, P(sh))
         self.L.orc_dem_get(self.h, None, None, None, None, None, P(tag))
         return sh[np.argsort(tag, kind="stable")]
+
+
+class OracleSlabEngine:
+    """Adaptor with the interface sedifoam_amd.halo.SlabDriver expects, backed by the CPU oracle and torch CPU
+    tensors -- the stand-in for HipSlabEngine in the gloo (no-GPU) tests of the multi-rank protocol."""
+
+    class _Info:
+        pass
+
+    def __init__(self, dem):
+        import torch
+        self.torch = torch
+        self.dem = dem
+        self.L = dem.L
+        self.h = dem.h
+        self.device = torch.device("cpu")
+
+    def alloc(self, ndoubles):
+        return self.torch.zeros(max(int(ndoubles), 1), dtype=self.torch.float64)
+
+    def info(self):
+        i = self._Info()
+        i.nlocal = self.dem.nlocal
+        i.nghost = self.dem.nghost
+        i.max_neigh_used = self.L.orc_dem_max_partners(self.h)
+        return i
+
+    def set_subdomain(self, rank, world, lo, hi):
+        self.L.orc_dem_set_subdomain(self.h, lo, hi)
+
+    def setup(self):
+        self.L.orc_dem_ext_setup(self.h)
+
+    def run_begin(self):
+        self.L.orc_dem_run_begin(self.h)
+
+    def substep(self, last):
+        self.L.orc_dem_substep(self.h, int(last))
+
+    def need_rebuild(self):
+        return self.L.orc_dem_need_rebuild(self.h)
+
+    def rebuild_begin(self):
+        self.L.orc_dem_rebuild_begin(self.h)
+
+    def rebuild_sort(self):
+        self.L.orc_dem_rebuild_sort(self.h)
+
+    def rebuild_finish(self):
+        self.L.orc_dem_rebuild_finish(self.h)
+
+    def migrate_set_slots(self, m):
+        self.L.orc_dem_migrate_set_slots(self.h, int(m))
+
+    def migrate_record_doubles(self):
+        return self.L.orc_dem_migrate_record_doubles(self.h)
+
+    def migrate_pack(self, side, xshift, buf):
+        n = self.L.orc_dem_migrate_pack(self.h, side, xshift, buf.data_ptr(), buf.numel())
+        if n < 0:
+            raise RuntimeError("migrate buffer too small")
+        return n
+
+    def migrate_unpack(self, buf, ndoubles):
+        self.L.orc_dem_migrate_unpack(self.h, buf.data_ptr(), int(ndoubles))
+
+    def border_pack(self, side, xshift, buf):
+        n = self.L.orc_dem_border_pack(self.h, side, xshift, buf.data_ptr(), buf.numel() // 13)
+        if n < 0:
+            raise RuntimeError("border buffer too small")
+        return n
+
+    def border_unpack(self, side, buf, natoms):
+        self.L.orc_dem_border_unpack(self.h, side, buf.data_ptr(), int(natoms))
+
+    def forward_pack(self, side, xshift, buf):
+        return self.L.orc_dem_forward_pack(self.h, side, xshift, buf.data_ptr())
+
+    def forward_unpack(self, side, buf, natoms):
+        if self.L.orc_dem_forward_unpack(self.h, side, buf.data_ptr(), int(natoms)) != 0:
+            raise RuntimeError("forward_unpack: ghost count mismatch")
+
+    def ghost_forward_local(self):
+        self.L.orc_dem_ghost_forward_local(self.h)

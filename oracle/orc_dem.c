@@ -18,65 +18,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "sedifoam_oracle.h"
+#include "orc_dem_priv.h"
 
-enum { FIX_GRAVITY = 1, FIX_FDRAG, FIX_WALL, FIX_COHESIVE };
-
-typedef struct {
-  int kind;
-  /* gravity */
-  double gmag, gdir[3];
-  /* fdrag */
-  double carrier_rho;
-  /* wall */
-  int wallstyle;
-  double lo, hi;
-  orc_gran_params wp;
-  double *wshear; /* 3*nmax */
-  /* cohesive */
-  double ah, lam, smin, smax;
-  int opt;
-} orc_fix;
-
-#define MAXFIX 16
-
-struct orc_dem {
-  int nlocal, nghost, nmax;
-  double *x, *v, *omega, *f, *torque, *radius, *rmass;
-  int *tag, *mask;
-  int *gsrc;           /* ghost -> index it copies (may itself be a ghost of an earlier dim) */
-  double *gshift;      /* 3 per ghost */
-  double *xhold;       /* 3*nlocal at last build */
-  double boxlo[3], boxhi[3];
-  int periodic[3];
-  double skin, dt;
-  int pair_style;      /* 0 none 1 hooke 2 hertz */
-  orc_gran_params gp;
-  int have_lub;
-  orc_lub_params lub;
-  int nfix;
-  orc_fix fix[MAXFIX];
-  /* fix fdrag per-atom arrays (fix_fluid_drag.cpp:181-187) */
-  double *ffluiddrag, *DuDt, *vOld;
-  /* granular half list + history */
-  int *first, *jlist, *touch;
-  double *shear;
-  int listcap;
-  /* regular half list (fix cohesive) and full list (lubricate/poly) */
-  int *hfirst, *hjlist;
-  int hcap;
-  int *ffirst, *fjlist;
-  int fcap;
-  int *ilist;
-  /* bins */
-  int *binhead, *binnext;
-  int nbins_alloc;
-  int nbuilds;
-  int setup_done;
-  int nthreads;
-};
-
-static void *xrealloc(void *p, size_t n)
+void *orc__xrealloc(void *p, size_t n)
 {
   void *q = realloc(p, n ? n : 1);
   if (!q) {
@@ -86,27 +30,27 @@ static void *xrealloc(void *p, size_t n)
   return q;
 }
 
-static void grow_atoms(orc_dem *d, int nmax)
+void orc__grow_atoms(orc_dem *d, int nmax)
 {
   int w;
   if (nmax <= d->nmax) return;
   nmax = nmax + nmax / 4 + 64;
-  d->x = xrealloc(d->x, sizeof(double) * 3 * nmax);
-  d->v = xrealloc(d->v, sizeof(double) * 3 * nmax);
-  d->omega = xrealloc(d->omega, sizeof(double) * 3 * nmax);
-  d->f = xrealloc(d->f, sizeof(double) * 3 * nmax);
-  d->torque = xrealloc(d->torque, sizeof(double) * 3 * nmax);
-  d->radius = xrealloc(d->radius, sizeof(double) * nmax);
-  d->rmass = xrealloc(d->rmass, sizeof(double) * nmax);
-  d->tag = xrealloc(d->tag, sizeof(int) * nmax);
-  d->mask = xrealloc(d->mask, sizeof(int) * nmax);
-  d->gsrc = xrealloc(d->gsrc, sizeof(int) * nmax);
-  d->gshift = xrealloc(d->gshift, sizeof(double) * 3 * nmax);
-  d->binnext = xrealloc(d->binnext, sizeof(int) * nmax);
+  d->x = orc__xrealloc(d->x, sizeof(double) * 3 * nmax);
+  d->v = orc__xrealloc(d->v, sizeof(double) * 3 * nmax);
+  d->omega = orc__xrealloc(d->omega, sizeof(double) * 3 * nmax);
+  d->f = orc__xrealloc(d->f, sizeof(double) * 3 * nmax);
+  d->torque = orc__xrealloc(d->torque, sizeof(double) * 3 * nmax);
+  d->radius = orc__xrealloc(d->radius, sizeof(double) * nmax);
+  d->rmass = orc__xrealloc(d->rmass, sizeof(double) * nmax);
+  d->tag = orc__xrealloc(d->tag, sizeof(int) * nmax);
+  d->mask = orc__xrealloc(d->mask, sizeof(int) * nmax);
+  d->gsrc = orc__xrealloc(d->gsrc, sizeof(int) * nmax);
+  d->gshift = orc__xrealloc(d->gshift, sizeof(double) * 3 * nmax);
+  d->binnext = orc__xrealloc(d->binnext, sizeof(int) * nmax);
   for (w = 0; w < d->nfix; w++)
     if (d->fix[w].kind == FIX_WALL) {
       int old = d->nmax, i;
-      d->fix[w].wshear = xrealloc(d->fix[w].wshear, sizeof(double) * 3 * nmax);
+      d->fix[w].wshear = orc__xrealloc(d->fix[w].wshear, sizeof(double) * 3 * nmax);
       for (i = 3 * old; i < 3 * nmax; i++) d->fix[w].wshear[i] = 0.0;
     }
   d->nmax = nmax;
@@ -118,7 +62,7 @@ orc_dem *orc_dem_create(int n, const double *x, const double *v, const double *o
 {
   orc_dem *d = calloc(1, sizeof(orc_dem));
   int i, k;
-  grow_atoms(d, n);
+  orc__grow_atoms(d, n);
   d->nlocal = n;
   for (i = 0; i < n; i++) {
     for (k = 0; k < 3; k++) {
@@ -141,6 +85,7 @@ orc_dem *orc_dem_create(int n, const double *x, const double *v, const double *o
   d->ffluiddrag = calloc(3 * (size_t)(n ? n : 1), sizeof(double));
   d->DuDt = calloc(3 * (size_t)(n ? n : 1), sizeof(double));
   d->vOld = calloc(3 * (size_t)(n ? n : 1), sizeof(double));
+  d->localcap = n ? n : 1;
   d->ilist = malloc(sizeof(int) * (n ? n : 1));
   for (i = 0; i < n; i++) d->ilist[i] = i;
   d->skin = 0.0;
@@ -238,7 +183,7 @@ static double max_radius(const orc_dem *d)
   return m;
 }
 
-static double cutneighmax(const orc_dem *d)
+double orc__cutneighmax(const orc_dem *d)
 {
   double c = 0.0;
   if (d->pair_style) c = 2.0 * max_radius(d);
@@ -247,11 +192,12 @@ static double cutneighmax(const orc_dem *d)
 }
 
 /* ---- [3P] Domain::pbc for owned atoms ---- */
-static void pbc(orc_dem *d)
+void orc__pbc(orc_dem *d)
 {
   int i, k;
   for (k = 0; k < 3; k++) {
     if (!d->periodic[k]) continue;
+    if (k == 0 && d->external_x) continue; /* wrapped by the migration shift */
     double lo = d->boxlo[k], hi = d->boxhi[k], prd = hi - lo;
     for (i = 0; i < d->nlocal; i++) {
       double *xi = &d->x[3 * i + k];
@@ -265,13 +211,14 @@ static void pbc(orc_dem *d)
 }
 
 /* ---- [3P] Comm::borders on one processor: periodic images as ghost atoms ---- */
-static void make_ghosts(orc_dem *d)
+void orc__make_ghosts(orc_dem *d)
 {
-  double cutghost = cutneighmax(d);
+  double cutghost = orc__cutneighmax(d);
   int dim, dir, p, k;
-  d->nghost = 0;
+  d->nghost = d->external_x ? d->next_ghost : 0;
   for (dim = 0; dim < 3; dim++) {
     if (!d->periodic[dim]) continue;
+    if (dim == 0 && d->external_x) continue; /* x images come from the neighbour slabs */
     double lo = d->boxlo[dim], hi = d->boxhi[dim], prd = hi - lo;
     int nall0 = d->nlocal + d->nghost;
     for (dir = 0; dir < 2; dir++) {
@@ -281,7 +228,7 @@ static void make_ghosts(orc_dem *d)
                               : (xp >= hi - cutghost && xp <= hi);
         if (!take) continue;
         int g = d->nlocal + d->nghost;
-        grow_atoms(d, g + 1);
+        orc__grow_atoms(d, g + 1);
         for (k = 0; k < 3; k++) {
           d->gshift[3 * g + k] = 0.0;
           d->x[3 * g + k] = d->x[3 * p + k];
@@ -302,12 +249,13 @@ static void make_ghosts(orc_dem *d)
 }
 
 /* ---- [3P] Comm::forward_comm: ghosts follow their source (x with shift, v, omega) ---- */
-static void forward_comm(orc_dem *d)
+void orc__forward_comm(orc_dem *d)
 {
   int g, k;
   int nall = d->nlocal + d->nghost;
   for (g = d->nlocal; g < nall; g++) { /* sources always precede their ghosts */
     int p = d->gsrc[g];
+    if (p < 0) continue; /* owned by another slab: refreshed by orc_dem_forward_unpack */
     for (k = 0; k < 3; k++) {
       d->x[3 * g + k] = d->x[3 * p + k] + d->gshift[3 * g + k];
       d->v[3 * g + k] = d->v[3 * p + k];
@@ -324,11 +272,12 @@ typedef struct {
 
 static void bin_atoms(orc_dem *d, bingrid *g)
 {
-  double cut = cutneighmax(d);
+  double cut = orc__cutneighmax(d);
   int k, i, nall = d->nlocal + d->nghost, nb;
   for (k = 0; k < 3; k++) {
     double lo = d->boxlo[k], hi = d->boxhi[k];
-    if (d->periodic[k]) { lo -= cut; hi += cut; }
+    if (k == 0 && d->external_x) { lo = d->sublo - cut; hi = d->subhi + cut; }
+    else if (d->periodic[k]) { lo -= cut; hi += cut; }
     else {
       /* non-periodic: cover whatever the atoms span (walls keep them near the box) */
       for (i = 0; i < nall; i++) {
@@ -346,7 +295,7 @@ static void bin_atoms(orc_dem *d, bingrid *g)
   }
   nb = g->n[0] * g->n[1] * g->n[2];
   if (nb > d->nbins_alloc) {
-    d->binhead = xrealloc(d->binhead, sizeof(int) * nb);
+    d->binhead = orc__xrealloc(d->binhead, sizeof(int) * nb);
     d->nbins_alloc = nb;
   }
   for (i = 0; i < nb; i++) d->binhead[i] = -1;
@@ -364,13 +313,8 @@ static void bin_atoms(orc_dem *d, bingrid *g)
 }
 
 /* partner store built from the old list (FixShearHistory::pre_exchange [3P]) */
-typedef struct {
-  int *pfirst;   /* nlocal+1 */
-  int *ptag;
-  double *pshear;
-} partners;
 
-static void partners_from_list(const orc_dem *d, partners *ps)
+void orc__partners_from_list(const orc_dem *d, orc_partners *ps)
 {
   int n = d->nlocal, i, jj, k;
   int *cnt = calloc((size_t)n + 1, sizeof(int));
@@ -410,19 +354,19 @@ static void push_int(int **a, int *cap, int n, int val)
 {
   if (n >= *cap) {
     *cap = *cap * 2 + 1024;
-    *a = xrealloc(*a, sizeof(int) * (size_t)*cap);
+    *a = orc__xrealloc(*a, sizeof(int) * (size_t)*cap);
   }
   (*a)[n] = val;
 }
 
 /* ---- [3P] Neighbor::build: granular half list (+history), regular half list, full list ---- */
-static void build_lists(orc_dem *d, partners *pps)
+void orc__build_lists(orc_dem *d, orc_partners *pps)
 {
-  partners ps = *pps;
+  orc_partners ps = *pps;
   bingrid g;
   int n = d->nlocal, i, k, bx, by, bz;
   int need_half = 0, w;
-  double cutmax = cutneighmax(d);
+  double cutmax = orc__cutneighmax(d);
   double cutmaxsq = cutmax * cutmax;
   double lubcut = d->have_lub ? d->lub.cut_global + d->skin : 0.0;
   for (w = 0; w < d->nfix; w++)
@@ -430,9 +374,9 @@ static void build_lists(orc_dem *d, partners *pps)
 
   bin_atoms(d, &g);
 
-  d->first = xrealloc(d->first, sizeof(int) * ((size_t)n + 1));
-  d->hfirst = xrealloc(d->hfirst, sizeof(int) * ((size_t)n + 1));
-  d->ffirst = xrealloc(d->ffirst, sizeof(int) * ((size_t)n + 1));
+  d->first = orc__xrealloc(d->first, sizeof(int) * ((size_t)n + 1));
+  d->hfirst = orc__xrealloc(d->hfirst, sizeof(int) * ((size_t)n + 1));
+  d->ffirst = orc__xrealloc(d->ffirst, sizeof(int) * ((size_t)n + 1));
   int ng = 0, nh = 0, nf = 0;
   int shearcap = d->listcap;
   for (i = 0; i < n; i++) {
@@ -474,8 +418,8 @@ static void build_lists(orc_dem *d, partners *pps)
               if (rsq <= cut * cut) {
                 push_int(&d->jlist, &d->listcap, ng, j);
                 if (d->listcap != shearcap) {
-                  d->touch = xrealloc(d->touch, sizeof(int) * (size_t)d->listcap);
-                  d->shear = xrealloc(d->shear, sizeof(double) * 3 * (size_t)d->listcap);
+                  d->touch = orc__xrealloc(d->touch, sizeof(int) * (size_t)d->listcap);
+                  d->shear = orc__xrealloc(d->shear, sizeof(double) * 3 * (size_t)d->listcap);
                   shearcap = d->listcap;
                 }
                 /* history re-injection by partner tag */
@@ -506,7 +450,7 @@ static void build_lists(orc_dem *d, partners *pps)
 }
 
 /* [3P] Neighbor::check_distance */
-static int check_distance(const orc_dem *d)
+int orc__check_distance(const orc_dem *d)
 {
   double delta = 0.5 * d->skin, deltasq = delta * delta;
   int i;
@@ -519,7 +463,7 @@ static int check_distance(const orc_dem *d)
   return 0;
 }
 
-static void compute_forces(orc_dem *d, int setupflag)
+void orc__compute_forces(orc_dem *d, int setupflag)
 {
   int nall = d->nlocal + d->nghost, i, w;
   int shearupdate = setupflag ? 0 : 1; /* pair_gran_hertzFix_history.cpp:65-66 */
@@ -579,12 +523,12 @@ void orc_dem_setup(orc_dem *d)
                    (d->boxhi[2] - d->boxlo[2]);
     orc_lubricate_init(&d->lub, d->nlocal, d->radius, vol_T);
   }
-  partners ps;
-  partners_from_list(d, &ps); /* empty: no list yet */
-  pbc(d);
-  make_ghosts(d);
-  build_lists(d, &ps);
-  compute_forces(d, 1);
+  orc_partners ps;
+  orc__partners_from_list(d, &ps); /* empty: no list yet */
+  orc__pbc(d);
+  orc__make_ghosts(d);
+  orc__build_lists(d, &ps);
+  orc__compute_forces(d, 1);
   d->setup_done = 1;
 }
 
@@ -595,17 +539,17 @@ void orc_dem_run(orc_dem *d, int nsteps)
   for (s = 0; s < nsteps; s++) {
     orc_nve_sphere_initial(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius,
                            d->rmass);
-    if (check_distance(d)) {
+    if (orc__check_distance(d)) {
       /* Verlet::run order [3P]: pre_exchange (FixShearHistory copies the history out of the OLD
        * list, whose ghost indices are still valid) -> pbc -> borders -> build */
-      partners ps;
-      partners_from_list(d, &ps);
-      pbc(d);
-      make_ghosts(d);
-      build_lists(d, &ps);
+      orc_partners ps;
+      orc__partners_from_list(d, &ps);
+      orc__pbc(d);
+      orc__make_ghosts(d);
+      orc__build_lists(d, &ps);
     } else
-      forward_comm(d);
-    compute_forces(d, 0);
+      orc__forward_comm(d);
+    orc__compute_forces(d, 0);
     orc_nve_sphere_final(d->nlocal, d->dt, d->v, d->omega, d->f, d->torque, d->radius, d->rmass);
   }
 }

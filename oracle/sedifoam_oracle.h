@@ -155,6 +155,27 @@ int orc_dem_get_history(const orc_dem *d, int max, int *tag_i, int *tag_j, doubl
 /* per-atom wall shear of wall w (AoS 3*nlocal, driver order) */
 void orc_dem_get_wall_shear(const orc_dem *d, int w, double *shear);
 
+/* ---- one slab of an x-decomposed domain (orc_halo.c): same calls and record layouts as the product's
+ * sf_dem_* halo entry points, so sedifoam_amd/halo.py can be driven on CPUs (gloo) ---- */
+void orc_dem_set_subdomain(orc_dem *d, double sublo, double subhi);
+int orc_dem_max_partners(const orc_dem *d);
+void orc_dem_run_begin(orc_dem *d);
+void orc_dem_substep(orc_dem *d, int last);
+int orc_dem_need_rebuild(const orc_dem *d);
+void orc_dem_ext_setup(orc_dem *d);
+void orc_dem_rebuild_begin(orc_dem *d);
+void orc_dem_rebuild_sort(orc_dem *d);
+void orc_dem_rebuild_finish(orc_dem *d);
+void orc_dem_migrate_set_slots(orc_dem *d, int mrec);
+int orc_dem_migrate_record_doubles(const orc_dem *d);
+long orc_dem_migrate_pack(orc_dem *d, int side, double xshift, double *buf, long max_doubles);
+void orc_dem_migrate_unpack(orc_dem *d, const double *buf, long ndoubles);
+long orc_dem_border_pack(orc_dem *d, int side, double xshift, double *buf, long max_atoms);
+void orc_dem_border_unpack(orc_dem *d, int side, const double *buf, long natoms);
+long orc_dem_forward_pack(orc_dem *d, int side, double xshift, double *buf);
+int orc_dem_forward_unpack(orc_dem *d, int side, const double *buf, long natoms);
+void orc_dem_ghost_forward_local(orc_dem *d);
+
 /* ---- OpenFOAM side (enhancedCloud / dragModels) ---- */
 /* A5: ErgunWenYu::Jd  lammpsFoam/dragModels/ErgunWenYu/ErgunWenYu.C:86-145 */
 void orc_ergun_wenyu_jd(int n, const double *Ur, const double *alpha, const double *pd,
