@@ -1,0 +1,104 @@
+"""CPU-side checks (no GPU, no compute): the C-ABI library loads and exports every symbol that
+include/sedifoam_amd.h declares, host-only entry points behave like the reference, and the product refuses to
+run without a HIP device instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sedifoam_amd.h")
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = txt.split("#ifdef SEDIFOAM_AMD_LAMMPS_NAMES")[0]          # the inline aliases are not exports
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfk?_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import sedifoam_amd
+    L = C.CDLL(sedifoam_amd._lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 60
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # and the python binding table covers the same set
+    assert set(sedifoam_amd.exported_symbols()) == set(names)
+    sedifoam_amd.lib()
+
+
+def test_header_cites_reference_interface():
+    txt = open(HEADER).read()
+    for needle in ("library.h:29", "library.h:58", "library.cpp:344-366", "pair_gran_hertzFix_history.cpp:45-287",
+                   "fix_cohesive.cpp:138-263", "pair_lubricate_poly.cpp:65-444", "fix_fluid_drag.cpp:114-164",
+                   "ErgunWenYu.C:86-145", "enhancedCloud.C:669-787", "enhancedCloud.C:316-441",
+                   "softParticleCloud.C:209-261"):
+        assert needle in txt, needle
+
+
+def _gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu(), reason="checks the no-device behaviour")
+def test_no_device_means_loud_failure_not_fallback():
+    import sedifoam_amd
+    L = sedifoam_amd.lib()
+    assert L.sf_device_check() != 0
+    with pytest.raises(sedifoam_amd.SfError, match="no HIP device"):
+        sedifoam_amd.Lammps()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sedifoam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in src and "import oracle" not in src and "sedifoam_oracle" not in src, f
+
+
+def test_adjust_lamp_timestep_host_logic():
+    # softParticleCloud.C:209-261 : xiaocase3 (2e-5 / 2e-7, 1 sub-cycle), multiParticles (1e-3 / 1e-5, 2)
+    from sedifoam_amd import adjustLampTimestep, SfError
+    r = adjustLampTimestep(2e-5, 2e-7, 1)
+    assert r == dict(dtLampAdj=pytest.approx(2e-7), solidStepsPerDt=100, subCycles=1, subSteps=100)
+    r = adjustLampTimestep(1e-3, 1e-5, 2)
+    assert (r["solidStepsPerDt"], r["subCycles"], r["subSteps"]) == (100, 2, 50)
+    r = adjustLampTimestep(1e-3, 3e-5, 4)          # round(33.3) = 33 -> (33/4)*4 = 32 steps, dt = 1e-3/33
+    assert r["solidStepsPerDt"] == 32 and r["subSteps"] == 8 and r["dtLampAdj"] == pytest.approx(1e-3 / 33)
+    r = adjustLampTimestep(1e-6, 1e-5, 3)          # dnSub = round(0.1) = 0 -> 1 ; subCycles clipped to 0 steps
+    assert r["subSteps"] == 1
+    # and it agrees with the oracle's restatement
+    from oracle import binding as ob
+    dt = C.c_double(); st = C.c_int(); sc = C.c_int(); ss = C.c_int()
+    for args in ((2e-5, 2e-7, 1), (1e-3, 1e-5, 2), (1e-3, 3e-5, 4), (5e-4, 7e-6, 5)):
+        rc = ob.lib().orc_adjust_timestep(*args, C.byref(dt), C.byref(st), C.byref(sc), C.byref(ss))
+        if rc == 0:
+            r = adjustLampTimestep(*args)
+            assert (r["dtLampAdj"], r["solidStepsPerDt"], r["subCycles"], r["subSteps"]) == (
+                dt.value, st.value, sc.value, ss.value)
+        else:
+            with pytest.raises(SfError):
+                adjustLampTimestep(*args)
+
+
+def test_gran_settings_like_pair_style_parser():
+    # pair_gran_hertzFix_history.cpp:293-317
+    import sedifoam_amd
+    from sedifoam_amd._lib import GranParams
+    L = sedifoam_amd.lib()
+    p = GranParams()
+    assert L.sfk_gran_settings(C.byref(p), 1e7, 1, 0.0, 0.5, 1, 0.0, 0.4, 1, 1.0) == 0
+    assert p.kt == pytest.approx(1e7 * 2.0 / 7.0) and p.gammat == 0.25
+    assert L.sfk_gran_settings(C.byref(p), 1e7, 1, 0.0, 0.5, 1, 0.0, 0.4, 0, 1.0) == 0 and p.gammat == 0.0
+    assert L.sfk_gran_settings(C.byref(p), -1.0, 1, 0.0, 0.5, 1, 0.0, 0.4, 1, 1.0) == -1
+    assert b"Illegal pair_style" in L.sf_last_error()
+    assert L.sfk_gran_settings(C.byref(p), 1.0, 1, 0.0, 0.5, 1, 0.0, 0.4, 2, 1.0) == -1

@@ -1,0 +1,195 @@
+"""Known-answer tests for the parts of the oracle that NO reference golden vector reaches
+("parity unpinned" in oracle/sedifoam_oracle.h): gran/hertzFix/history, fix cohesive, pair lubricate/poly,
+ErgunWenYu, fix fdrag's added-mass term.  Expected values are derived by hand from the formulas in the cited
+reference lines (closed forms for special configurations), not from running the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+L = ob.lib()
+
+
+def _pair(x, v, w, r, m, p, dt=1e-6, shear0=None, hertz=True, shearupdate=1):
+    x = ob.f64(x); v = ob.f64(v); w = ob.f64(w); r = ob.f64(r); m = ob.f64(m)
+    mask = ob.i32([1, 1])
+    ilist = ob.i32([0, 1]); first = ob.i32([0, 1, 1]); jlist = ob.i32([1])
+    touch = ob.i32([1 if shear0 is not None else 0])
+    shear = ob.f64(shear0 if shear0 is not None else [0, 0, 0])
+    nl = ob.NeighList(2, ob.P(ilist), ob.P(first), ob.P(jlist), ob.P(touch), ob.P(shear))
+    f = np.zeros((2, 3)); t = np.zeros((2, 3))
+    fn = L.orc_pair_gran_hertzfix_history if hertz else L.orc_pair_gran_hooke_history
+    fn(C.byref(p), dt, shearupdate, 2, ob.P(x), ob.P(v), ob.P(w), ob.P(r), ob.P(m), ob.P(mask), 0,
+       C.byref(nl), ob.P(f), ob.P(t))
+    return f, t, shear, touch
+
+
+def _params(kn=1e7, gamman=0.5, xmu=0.4):
+    p = ob.GranParams()
+    assert L.orc_gran_settings(C.byref(p), kn, 1, 0.0, gamman, 1, 0.0, xmu, 1, 1.0) == 0
+    return p
+
+
+def test_hertz_static_normal_force_closed_form():
+    # two equal spheres at rest, overlap delta: only the Hertz spring acts
+    # F = polyhertz * (4/5.46) kn * delta, polyhertz = sqrt(delta * R/2)   (pair_gran_hertzFix_history.cpp:199-200)
+    R, delta, kn = 0.5e-3, 2.0e-5, 1e7
+    p = _params(kn)
+    x = [[0, 0, 0], [2 * R - delta, 0, 0]]
+    f, t, sh, touch = _pair(x, np.zeros((2, 3)), np.zeros((2, 3)), [R, R], [1e-6, 1e-6], p)
+    F = np.sqrt(delta * R * R / (2 * R)) * 4.0 / 5.46 * kn * delta
+    assert f[0, 0] == pytest.approx(-F, rel=1e-14) and f[1, 0] == pytest.approx(F, rel=1e-14)
+    assert np.all(f[:, 1:] == 0) and np.all(t == 0) and touch[0] == 1 and np.all(sh == 0)
+
+
+def test_hertz_normal_damping_uses_gamman_as_restitution():
+    # approaching at speed u along the line of centres: extra repulsion sqrt(sn meff) * 2 sqrt(5/6) beta u
+    # with beta = -ln(e)/sqrt(ln(e)^2 + pi^2), sn = (2/1.82) kn polyhertz   (:192-200)
+    R, delta, kn, e, m, u = 0.5e-3, 2.0e-5, 1e7, 0.5, 2e-6, 0.1
+    p = _params(kn, gamman=e)
+    x = [[0, 0, 0], [2 * R - delta, 0, 0]]
+    v = [[u / 2, 0, 0], [-u / 2, 0, 0]]
+    f, _, _, _ = _pair(x, v, np.zeros((2, 3)), [R, R], [m, m], p)
+    poly = np.sqrt(delta * R / 2)
+    beta = -np.log(e) / np.sqrt(np.log(e) ** 2 + np.pi ** 2)
+    spring = poly * 4.0 / 5.46 * kn * delta
+    damping = np.sqrt(2.0 / 1.82 * kn * poly * (m / 2)) * 2 * np.sqrt(5.0 / 6.0) * beta * u
+    assert f[1, 0] == pytest.approx(spring + damping, rel=1e-13)
+    assert f[0, 0] == -f[1, 0]
+
+
+def test_hertz_tangential_spring_and_coulomb_cap():
+    # pure sliding in y with an existing shear displacement s: fs = -polyhertz (8/8.84) kt s  (:234) unless
+    # |fs| > xmu |Fn| where it is capped and the stored shear rescaled (:243-253)
+    R, delta, kn, xmu = 0.5e-3, 2.0e-5, 1e7, 0.4
+    p = _params(kn, xmu=xmu)
+    kt = kn * 2.0 / 7.0
+    x = [[0, 0, 0], [2 * R - delta, 0, 0]]
+    poly = np.sqrt(delta * R / 2)
+    Fn = poly * 4.0 / 5.46 * kn * delta
+    s_small = 1e-8
+    f, t, sh, _ = _pair(x, np.zeros((2, 3)), np.zeros((2, 3)), [R, R], [1e-6] * 2, p, shear0=[0, s_small, 0],
+                        shearupdate=1)
+    fs = -poly * 8.0 / 8.84 * kt * s_small
+    assert abs(fs) < xmu * Fn
+    assert f[0, 1] == pytest.approx(fs, rel=1e-13) and f[1, 1] == pytest.approx(-fs, rel=1e-13)
+    # torque = -R * (del x fs)/r on both : del = (-(2R-delta),0,0), fs along y -> z torque
+    r = 2 * R - delta
+    assert t[0, 2] == pytest.approx(-R * (-(r) * fs) / r, rel=1e-13) and t[1, 2] == pytest.approx(t[0, 2], rel=1e-13)
+    s_big = 1e-4
+    f, t, sh, _ = _pair(x, np.zeros((2, 3)), np.zeros((2, 3)), [R, R], [1e-6] * 2, p, shear0=[0, s_big, 0])
+    assert abs(f[0, 1]) == pytest.approx(xmu * Fn, rel=1e-13)
+    assert sh[1] == pytest.approx(xmu * Fn / (poly * 8.0 / 8.84 * kt), rel=1e-13)   # rescaled displacement
+
+
+def test_non_touching_pair_resets_history():
+    p = _params()
+    f, t, sh, touch = _pair([[0, 0, 0], [1.01e-3, 0, 0]], np.zeros((2, 3)), np.zeros((2, 3)), [0.5e-3] * 2,
+                            [1e-6] * 2, p, shear0=[1e-6, 2e-6, 3e-6])
+    assert touch[0] == 0 and np.all(sh == 0) and np.all(f == 0)
+
+
+def _half_list():
+    ilist = ob.i32([0, 1]); first = ob.i32([0, 1, 1]); jlist = ob.i32([1])
+    return ilist, first, jlist, ob.NeighList(2, ob.P(ilist), ob.P(first), ob.P(jlist), None, None)
+
+
+def test_cohesive_opt1_hamaker_sphere_sphere():
+    # ccel = -ah R^6 / (6 del^2 (r+R)^2 r^3), R = ri+rj, del = r-R  (fix_cohesive.cpp:239-241)
+    ah, ri, rj, gap, smin, smax = 1e-19, 0.4e-3, 0.6e-3, 5e-6, 1e-9, 1e-4
+    keep = _half_list()
+    x = ob.f64([[0, 0, 0], [0, ri + rj + gap, 0]]); rad = ob.f64([ri, rj]); mask = ob.i32([1, 1])
+    f = np.zeros((2, 3))
+    assert L.orc_fix_cohesive(ah, 1e-7, smin, smax, 1, 2, 0, ob.P(x), ob.P(rad), ob.P(mask), 1, C.byref(keep[3]),
+                              ob.P(f)) == 0
+    R = ri + rj; r = R + gap
+    ccel = -ah * R ** 6 / 6.0 / gap ** 2 / (r + R) ** 2 / r ** 3
+    # force on i = del_vec * ccel / r with del_vec = xi - xj = (0,-r,0): attraction pulls i towards +y
+    assert f[0, 1] == pytest.approx(-ccel, rel=1e-12) and f[0, 1] > 0 and f[1, 1] == -f[0, 1]
+    # below smin the gap is clamped (:242-244)
+    x2 = ob.f64([[0, 0, 0], [0, R + 0.5e-9, 0]]); f2 = np.zeros((2, 3))
+    L.orc_fix_cohesive(ah, 1e-7, smin, smax, 1, 2, 0, ob.P(x2), ob.P(rad), ob.P(mask), 1, C.byref(keep[3]), ob.P(f2))
+    cc = -ah * R ** 6 / 6.0 / smin ** 2 / (smin + 2 * R) ** 2 / (smin + R) ** 3
+    assert f2[0, 1] == pytest.approx(-cc, rel=1e-12)
+    # beyond smax nothing; invalid option is an error (:262)
+    x3 = ob.f64([[0, 0, 0], [0, R + 2e-4, 0]]); f3 = np.zeros((2, 3))
+    L.orc_fix_cohesive(ah, 1e-7, smin, smax, 1, 2, 0, ob.P(x3), ob.P(rad), ob.P(mask), 1, C.byref(keep[3]), ob.P(f3))
+    assert np.all(f3 == 0)
+    assert L.orc_fix_cohesive(ah, 1e-7, smin, smax, 2, 2, 0, ob.P(x), ob.P(rad), ob.P(mask), 1, C.byref(keep[3]),
+                              ob.P(f)) == -1
+
+
+def test_cohesive_opt0_three_branches():
+    ah, lam, smin, smax, R = 1e-19, 1e-7, 1e-9, 1e-4, 1e-3
+    keep = _half_list()
+    rad = ob.f64([R / 2, R / 2]); mask = ob.i32([1, 1])
+    for gap in (5e-8, 2e-8, 5e-10):      # > lam/pi ; (smin, lam/pi] ; < smin
+        x = ob.f64([[0, 0, 0], [R + gap, 0, 0]]); f = np.zeros((2, 3))
+        L.orc_fix_cohesive(ah, lam, smin, smax, 0, 2, 0, ob.P(x), ob.P(rad), ob.P(mask), 1, C.byref(keep[3]), ob.P(f))
+        if gap > lam / np.pi:
+            cc = -ah * R * lam * (6.4988e-3 - 4.5316e-4 * lam / gap + 1.1326e-5 * lam ** 2 / gap ** 2) / gap ** 3
+        else:
+            s = max(gap, smin)
+            cc = -ah * (lam + 22.242 * s) * R * lam / 24.0 / (lam + 11.121 * s) ** 2 / s ** 2
+        assert f[0, 0] == pytest.approx(-cc, rel=1e-12) and f[1, 0] == -f[0, 0]
+
+
+def test_lubricate_squeeze_equal_spheres_and_inner_cutoff_edit():
+    # flaglog = 0: F = 6 pi mu ri (beta0^2/beta1^2/h) vn with h = gap/ri, beta0 = 1 -> 6 pi mu ri /(4 h) * vn
+    mu, ri, gap, u = 1e-3, 0.5e-3, 2e-5, 0.05
+    lp = ob.LubParams(); lp.mu = mu; lp.flaglog = 0; lp.flagfld = 0; lp.flagHI = 1; lp.flagVF = 0
+    lp.cut_inner = 1.001e-3; lp.cut_global = 1.2e-3; lp.vxmu2f = 1.0
+    ilist = ob.i32([0, 1]); first = ob.i32([0, 1, 2]); jlist = ob.i32([1, 0])
+    nl = ob.NeighList(2, ob.P(ilist), ob.P(first), ob.P(jlist), None, None)
+    rad = ob.f64([ri, ri])
+    x = ob.f64([[0, 0, 0], [2 * ri + gap, 0, 0]]); v = ob.f64([[u, 0, 0], [0, 0, 0]]); w = np.zeros((2, 3))
+    f = np.zeros((2, 3)); t = np.zeros((2, 3))
+    L.orc_pair_lubricate_poly(C.byref(lp), 2, ob.P(x), ob.P(v), ob.P(w), ob.P(rad), C.byref(nl), ob.P(f), ob.P(t))
+    a_sq = 6 * np.pi * mu * ri * (1.0 / 4.0 / (gap / ri))
+    assert f[0, 0] == pytest.approx(-a_sq * u, rel=1e-12)      # resists the approach
+    assert f[1, 0] == pytest.approx(+a_sq * u, rel=1e-12)      # full list: j computes its own (opposite) force
+    # closer than cut_inner: the reference's edit sets h_sep = 100 (ri + rj) (pair_lubricate_poly.cpp:294-295)
+    x2 = ob.f64([[0, 0, 0], [2 * ri + 0.5e-6, 0, 0]]); f2 = np.zeros((2, 3)); t2 = np.zeros((2, 3))
+    L.orc_pair_lubricate_poly(C.byref(lp), 2, ob.P(x2), ob.P(v), ob.P(w), ob.P(rad), C.byref(nl), ob.P(f2), ob.P(t2))
+    a2 = 6 * np.pi * mu * ri * (1.0 / 4.0 / (100 * 2 * ri / ri))
+    assert f2[0, 0] == pytest.approx(-a2 * u, rel=1e-12)
+    # isotropic FLD terms and the volume-fraction constants (:213-220, :551-559)
+    lp.flagfld = 1; lp.flagHI = 0; lp.flagVF = 1
+    L.orc_lubricate_init(C.byref(lp), 2, ob.P(rad), 1e-6)
+    vol_f = 2 * 4.0 / 3.0 * np.pi * ri ** 3 / 1e-6
+    assert lp.R0 == pytest.approx(6 * np.pi * mu * (1 + 2.16 * vol_f), rel=1e-14)
+    assert lp.RT0 == pytest.approx(8 * np.pi * mu, rel=1e-14)
+    f3 = np.zeros((2, 3)); t3 = np.zeros((2, 3)); w3 = ob.f64([[0, 0, 2.0], [0, 0, 0]])
+    L.orc_pair_lubricate_poly(C.byref(lp), 2, ob.P(x), ob.P(v), ob.P(w3), ob.P(rad), C.byref(nl), ob.P(f3), ob.P(t3))
+    assert f3[0, 0] == pytest.approx(-lp.R0 * ri * u, rel=1e-14)
+    assert t3[0, 2] == pytest.approx(-lp.RT0 * ri ** 3 * 2.0, rel=1e-14)
+
+
+def test_ergun_wenyu_branches():
+    nu, rho = 1e-6, 1000.0
+    Ur = ob.f64([0.1, 0.1, 5.0]); alpha = ob.f64([0.1, 0.5, 0.1]); d = ob.f64([1e-3, 1e-3, 1e-3]); out = np.zeros(3)
+    L.orc_ergun_wenyu_jd(3, ob.P(Ur), ob.P(alpha), ob.P(d), nu, rho, ob.P(out))
+    # Wen-Yu, beta = 0.9 > 0.8, Re = 90 (ErgunWenYu.C:104-118)
+    beta = 0.9; Re = beta * 0.1 * 1e-3 / nu
+    Cd = 24 * (1 + 0.15 * Re ** 0.687) / Re
+    assert out[0] == pytest.approx(0.75 * Cd * rho * 0.1 * beta ** -2.65 / 1e-3, rel=1e-13)
+    # Ergun, beta = 0.5 <= 0.8 (:124-131)
+    assert out[1] == pytest.approx(150 * 0.5 * nu * rho / (0.5e-3) ** 2 + 1.75 * rho * 0.1 / 0.5e-3, rel=1e-13)
+    # Re = 4500 > 1000 -> Cd = 0.44 (:111-114)
+    assert out[2] == pytest.approx(0.75 * 0.44 * rho * 5.0 * 0.9 ** -2.65 / 1e-3, rel=1e-13)
+
+
+def test_fix_fdrag_added_mass_and_mistyped_pi():
+    # f += ffluiddrag + carrier_rho/rho * 0.5 m (DuDt - (v - vOld)/dt), rho from the mistyped pi (:147-157)
+    n = 1; dt = 1e-6; r = 0.5e-3; m = 1.4e-6
+    v = ob.f64([[0.2, 0, 0]]); vOld = ob.f64([[0.1, 0, 0]]); fd = ob.f64([[1e-6, 2e-6, 3e-6]]); du = ob.f64([[5.0, 0, 0]])
+    f = np.zeros((1, 3)); mask = ob.i32([1])
+    L.orc_fix_fluid_drag(n, dt, 1000.0, ob.P(v), ob.P(ob.f64([m])), ob.P(ob.f64([r])), ob.P(mask), 1, ob.P(fd), ob.P(du),
+                         ob.P(vOld), ob.P(f))
+    rho_p = 3.0 * m / (4.0 * 3.14159265358917323846 * r ** 3)
+    acc = (0.2 - 0.1) / dt
+    assert f[0, 0] == pytest.approx(1e-6 + 1000.0 / rho_p * 0.5 * m * (5.0 - acc), rel=1e-14)
+    assert f[0, 1] == pytest.approx(2e-6, rel=1e-14) and vOld[0, 0] == 0.2
+    assert rho_p != 3.0 * m / (4.0 * np.pi * r ** 3)        # the typo is preserved (2e-13 relative)
