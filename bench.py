@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--particles", type=int, default=1000000, help="particles per GPU")
     ap.add_argument("--substeps", type=int, default=50, help="DEM sub-steps per step (per CFD step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab-driver", action="store_true",
+                    help="drive the sub-steps through the multi-rank SlabDriver even at N=1 (self halo)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
     args = ap.parse_args()
 
@@ -94,7 +96,7 @@ def main():
     script = synthetic.hertz_script(bed, **kw)
     N = bed["n"]
 
-    if world > 1:
+    if world > 1 or args.slab_driver:
         from sedifoam_amd.halo import SlabDriver
         lmp = SlabDriver.from_bed(bed, script, dist, rank, world)
     else:
@@ -152,7 +154,8 @@ def main():
                         "periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step" % args.substeps,
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
-            "decomposition": "x-slabs, ghost halo over RCCL" if world > 1 else "single domain",
+            "decomposition": "x-slabs, ghost halo over RCCL" if world > 1 else
+                             ("single slab through the halo driver" if args.slab_driver else "single domain"),
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_substep<hertz>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -163,8 +166,8 @@ def main():
         },
     }
     if rank == 0 and not args.no_cpu_baseline:
-        sample_n = args.cpu_sample or 250000
-        sub = 20
+        sample_n = args.cpu_sample or 1000000
+        sub = 50
         v, n_s, secs = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub)
         out["cpu_baseline"] = {"value": v, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
                                "sample": "%d-particle bed of the same packing, %d sub-steps, %.1f s, "
