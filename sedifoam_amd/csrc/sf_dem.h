@@ -37,6 +37,7 @@ enum Flag {
   F_LOST,           // atoms outside a non-periodic box (bins clamp them; reported)
   F_SEND_COUNT,     // scratch counter for halo packing
   F_SEND_COUNT2,
+  F_STAGE_MAX,      // largest number of atoms any tile stages in LDS
   F_NFLAGS = 16
 };
 
@@ -66,6 +67,12 @@ struct DemPtrs {
   const double* xhold;     // [3][cap]
   const int* mask;
   int* flags;
+  // LDS-staged tiles (k_substep_lds)
+  const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
+  const int* tile_first;        // [ntiles] owned-atom range of a tile
+  const int* tile_last;
+  const int* stage_start;       // [ntiles+1] range of the tile in stage_idx
+  const int* stage_idx;         // atom indices (owned or ghost) to stage, bin by bin
 };
 
 struct StepParams {
@@ -76,6 +83,8 @@ struct StepParams {
   CoheParams cohe;
   LubParams lub;
   int nwalls;
+  int stage_cap;   // LDS slots per workgroup in k_substep_lds
+  int xcd_remap;   // blockIdx -> contiguous chunk per XCD (8 XCDs, block b runs on XCD b % 8)
   WallParams wall[kMaxWalls];
   int have_gravity;
   double gacc[3];
@@ -88,8 +97,20 @@ struct StepParams {
 struct BinGrid {
   double lo[3], inv[3];
   int n[3];
-  int nbins;
+  int nbins;       // key space: tiles * tile^3 (>= n[0]*n[1]*n[2])
+  int tile;        // bins are numbered tile by tile (tile x tile x tile bins) so that particles that are
+  int nt[3];       // close in space are close in memory in all three directions; tile <= 1: plain x-fastest
 };
+
+// bin coordinates -> sort key / cell index
+__host__ __device__ __forceinline__ int bin_key(const BinGrid& g, int cx, int cy, int cz)
+{
+  if (g.tile <= 1) return cx + g.n[0] * (cy + g.n[1] * cz);
+  const int T = g.tile;
+  const int tx = cx / T, ty = cy / T, tz = cz / T;
+  const int lx = cx - tx * T, ly = cy - ty * T, lz = cz - tz * T;
+  return ((tx + g.nt[0] * (ty + g.nt[1] * tz)) * T + lz) * T * T + ly * T + lx;
+}
 
 class DemEngine {
  public:
@@ -228,6 +249,7 @@ class DemEngine {
   int rank_ = 0, nranks_ = 1;
   double sublo_x_ = 0.0, subhi_x_ = 1.0;
   bool have_subdomain_ = false;   // true: the x halo is external (driven through sf_dem_border_* etc.)
+  int opt_tile_ = 4, opt_xcd_remap_ = 1, opt_lds_ = 0;   // SF_TILE / SF_XCD_REMAP / SF_LDS overrides (LDS staging: see DESIGN.md, measured slower so far)   // SF_TILE / SF_XCD_REMAP environment overrides
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;
   DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x
@@ -252,6 +274,16 @@ class DemEngine {
   DevArray gsrc_, gshift_;
   DevArray neigh_, numneigh_, shear_;
   DevArray neigh_old_, numneigh_old_, shear_old_, ptag_;   // B-side buffers swapped in by permute/build
+  DevArray nloc_;                      // [M][cap] uint16 (see DemPtrs::nloc)
+  int* tile_tab_ = nullptr;            // [2][ntiles] tile_first / tile_last, then [ntiles+1] counts, starts
+  size_t tile_alloc_ = 0;
+  int* stage_idx_ = nullptr;
+  size_t stage_alloc_ = 0;
+  int* eoff_ = nullptr;                // [ntiles][(T+2)^3] offset of an extended bin in the tile's staged copy
+  size_t eoff_alloc_ = 0;
+  int ntiles_ = 0, stage_cap_ = 0;
+  bool lds_active_ = false;
+  void build_stage_tables();
   DevArray tmp4_, tmpd_, tmpi_;        // gather scratch
   DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
   int* cell_start_ = nullptr;          // [4][nbins]: local start/end, ghost start/end
@@ -280,6 +312,7 @@ class DemEngine {
 // sf_sort.hip
 void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
                     int* vals_out, int n, int end_bit, hipStream_t s);
+void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s);
 void sort_pairs_u64(void*& tmp, size_t& tmp_bytes, unsigned long long* keys_in,
                     unsigned long long* keys_out, int* vals_in, int* vals_out, int n, int end_bit,
                     hipStream_t s);

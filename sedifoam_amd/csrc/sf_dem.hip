@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "sf_dem_kernels.h"
@@ -45,6 +46,17 @@ static double hertz_beta(double gamman)
   return -(lg) / std::sqrt(lg * lg + kPi * kPi);
 }
 
+void fold_hertz_constants(GranParams& p)
+{
+  const double c56 = 2.0 * std::sqrt(5.0 / 6.0);
+  p.h_sn = 2.0 * 1.0 / 1.82 * p.kn;
+  p.h_cn = 4.0 / 5.46 * p.kn;
+  p.h_ct = 8.0 / 8.84 * p.kt;
+  p.h_inv_ct = p.kt > 0.0 ? 8.0 / 8.84 / p.kt : 0.0;
+  p.h_c56beta = c56 * p.beta;
+  p.h_stsn_c56beta = std::sqrt((8.0 * 1.0 / 8.84) / (2.0 * 1.0 / 1.82)) * c56 * p.beta;
+}
+
 static void gran_settings(GranParams& p, int style, double kn, bool kt_null, double kt, double gamman,
                           bool gammat_null, double gammat, double xmu, int dampflag, double nktv2p)
 {
@@ -62,6 +74,7 @@ static void gran_settings(GranParams& p, int style, double kn, bool kt_null, dou
   p.kn /= nktv2p;
   p.kt /= nktv2p;
   p.beta = (style == 2 && gamman > 0.0) ? hertz_beta(gamman) : 0.0;
+  fold_hertz_constants(p);
 }
 
 DemEngine::DemEngine()
@@ -78,6 +91,9 @@ DemEngine::DemEngine()
   SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
   SF_HIP(hipEventCreate(&ev0_));
   SF_HIP(hipEventCreate(&ev1_));
+  if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
+  if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
+  if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -85,7 +101,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_};
 }
 
 DemEngine::~DemEngine()
@@ -93,6 +109,9 @@ DemEngine::~DemEngine()
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevArray* a : per_atom_) a->release();
   if (cell_start_) (void)hipFree(cell_start_);
+  if (tile_tab_) (void)hipFree(tile_tab_);
+  if (stage_idx_) (void)hipFree(stage_idx_);
+  if (eoff_) (void)hipFree(eoff_);
   if (tagmap_) (void)hipFree(tagmap_);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (d_flags_) (void)hipFree(d_flags_);
@@ -156,6 +175,7 @@ void DemEngine::alloc_all(size_t cap)
   sendlist_[0].alloc(sizeof(int), 1, cap, s);
   sendlist_[1].alloc(sizeof(int), 1, cap, s);
   leave_.alloc(sizeof(int), 1, cap, s);
+  nloc_.alloc(sizeof(unsigned short), M_, cap, s);
   cap_ = cap;
 }
 
@@ -187,6 +207,7 @@ void DemEngine::grow_neigh(int newM)
   regrow(neigh_old_, 1);
   regrow(shear_old_, 3);
   regrow(ptag_, 1);
+  regrow(nloc_, 1);
   M_ = newM;
 }
 
@@ -276,6 +297,7 @@ void DemEngine::set_pair_gran(int style, double kn, bool kt_null, double kt, dou
   for (int w = 0; w < nwalls_; w++) {
     walls_[w].gp.style = style;
     walls_[w].gp.beta = (style == 2 && walls_[w].gp.gamman > 0.0) ? hertz_beta(walls_[w].gp.gamman) : 0.0;
+    fold_hertz_constants(walls_[w].gp);
   }
 }
 
@@ -381,6 +403,11 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.xhold = xhold_.as<double>();
   P.mask = mask_.as<int>();
   P.flags = d_flags_;
+  P.nloc = nloc_.as<unsigned short>();
+  P.tile_first = tile_tab_;
+  P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
+  P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
+  P.stage_idx = stage_idx_;
   return P;
 }
 
@@ -398,6 +425,8 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.cohe = cohe_;
   S.lub = lub_;
   S.nwalls = nwalls_;
+  S.xcd_remap = opt_xcd_remap_;
+  S.stage_cap = stage_cap_;
   for (int w = 0; w < nwalls_; w++) S.wall[w] = walls_[w];
   S.have_gravity = have_gravity_;
   for (int k = 0; k < 3; k++) S.gacc[k] = gacc_[k];
@@ -418,12 +447,33 @@ static void launch_substep_style(bool cohe, bool lub, dim3 grid, hipStream_t s, 
   else k_substep<STYLE, false, false><<<grid, 256, 0, s>>>(P, S);
 }
 
+template <int STYLE, bool COHE, bool LUB>
+static void launch_lds_one(dim3 grid, size_t lds, hipStream_t s, const DemPtrs& P, const StepParams& S)
+{
+  static size_t granted = 0;   // dynamic LDS above the 64 KiB default has to be requested per kernel
+  if (lds > 65536 && lds > granted) {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_substep_lds<STYLE, COHE, LUB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    granted = 160 * 1024;
+  }
+  k_substep_lds<STYLE, COHE, LUB><<<grid, 256, lds, s>>>(P, S);
+}
+
+template <int STYLE>
+static void launch_lds_style(bool cohe, bool lub, dim3 grid, size_t lds, hipStream_t s, const DemPtrs& P,
+                             const StepParams& S)
+{
+  if (cohe && lub) launch_lds_one<STYLE, true, true>(grid, lds, s, P, S);
+  else if (cohe) launch_lds_one<STYLE, true, false>(grid, lds, s, P, S);
+  else if (lub) launch_lds_one<STYLE, false, true>(grid, lds, s, P, S);
+  else launch_lds_one<STYLE, false, false>(grid, lds, s, P, S);
+}
+
 void DemEngine::launch_substep(int in_buf, int mode, int kstep)
 {
   if (!nlocal_) return;
   const DemPtrs P = ptrs(in_buf);
   const StepParams S = step_params(mode, kstep);
-  const dim3 grid(div_up(nlocal_, 256));
   const bool cohe = cohe_.enabled, lub = lub_.enabled;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (profiling_) {
@@ -438,10 +488,22 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
     e1 = prof_ev_[prof_used_++];
     SF_HIP(hipEventRecord(e0, stream_));
   }
-  switch (gran_.style) {
-    case 2: launch_substep_style<2>(cohe, lub, grid, stream_, P, S); break;
-    case 1: launch_substep_style<1>(cohe, lub, grid, stream_, P, S); break;
-    default: launch_substep_style<0>(cohe, lub, grid, stream_, P, S); break;
+  if (lds_active_) {
+    // one workgroup per tile; LDS = staged x (32 B) + v (32 B) + omega (24 B) per atom of the extended tile
+    const dim3 grid(ntiles_);
+    const size_t lds = (size_t)stage_cap_ * 88;
+    switch (gran_.style) {
+      case 2: launch_lds_style<2>(cohe, lub, grid, lds, stream_, P, S); break;
+      case 1: launch_lds_style<1>(cohe, lub, grid, lds, stream_, P, S); break;
+      default: launch_lds_style<0>(cohe, lub, grid, lds, stream_, P, S); break;
+    }
+  } else {
+    const dim3 grid(div_up(nlocal_, 256));
+    switch (gran_.style) {
+      case 2: launch_substep_style<2>(cohe, lub, grid, stream_, P, S); break;
+      case 1: launch_substep_style<1>(cohe, lub, grid, stream_, P, S); break;
+      default: launch_substep_style<0>(cohe, lub, grid, stream_, P, S); break;
+    }
   }
   SF_HIP(hipGetLastError());
   if (profiling_) SF_HIP(hipEventRecord(e1, stream_));
@@ -514,7 +576,12 @@ void DemEngine::compute_grid()
     grid_.lo[k] = l;
     grid_.n[k] = n;
     grid_.inv[k] = n / (h - l);
-    grid_.nbins *= n;
+  }
+  grid_.tile = opt_tile_ > 1 ? opt_tile_ : 1;
+  grid_.nbins = 1;
+  for (int k = 0; k < 3; k++) {
+    grid_.nt[k] = (grid_.n[k] + grid_.tile - 1) / grid_.tile;
+    grid_.nbins *= grid_.nt[k] * grid_.tile;
   }
   if ((size_t)grid_.nbins > cell_alloc_) {
     if (cell_start_) SF_HIP(hipFree(cell_start_));
@@ -616,6 +683,21 @@ void DemEngine::rebuild_sort()
   SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
   k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
                                                    cell_start_ + cell_alloc_);
+  // owned range of every tile (bin keys are tile-major: key >> log2(T^3) is the tile id)
+  const int T = grid_.tile;
+  ntiles_ = grid_.nt[0] * grid_.nt[1] * grid_.nt[2];
+  if (T >= 2 && !(T & (T - 1))) {
+    if ((size_t)ntiles_ + 1 > tile_alloc_) {
+      if (tile_tab_) SF_HIP(hipFree(tile_tab_));
+      tile_alloc_ = (size_t)ntiles_ + ntiles_ / 8 + 16;
+      SF_HIP(hipMalloc(&tile_tab_, sizeof(int) * 4 * tile_alloc_));
+    }
+    int shift = 0;
+    while ((1 << shift) < T * T * T) shift++;
+    SF_HIP(hipMemsetAsync(tile_tab_, 0, sizeof(int) * 4 * tile_alloc_, stream_));
+    k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, shift, tile_tab_,
+                                                     tile_tab_ + tile_alloc_);
+  }
 }
 
 void DemEngine::make_periodic_ghosts()
@@ -653,6 +735,47 @@ void DemEngine::make_periodic_ghosts()
   fail("ghost creation: capacity could not be grown");
 }
 
+// Tables of the LDS-staged kernel: per tile the list of atoms (owned and ghost) in its (T+2)^3 extended bins and
+// the offset of every extended bin in that list.  Falls back to the gathering kernel when tiles are off, T is
+// not a power of two, or a tile would not fit the 160 KiB of LDS.
+void DemEngine::build_stage_tables()
+{
+  lds_active_ = false;
+  const int T = grid_.tile;
+  if (!opt_lds_ || T < 2 || (T & (T - 1)) || !nlocal_) return;
+  if (!tile_tab_) return;
+  const int E = T + 2, EB = E * E * E;
+  if ((size_t)ntiles_ * EB > eoff_alloc_) {
+    if (eoff_) SF_HIP(hipFree(eoff_));
+    eoff_alloc_ = (size_t)ntiles_ * EB + 1024;
+    SF_HIP(hipMalloc(&eoff_, sizeof(int) * eoff_alloc_));
+  }
+  int* tcount = tile_tab_ + 2 * tile_alloc_;
+  int* tstart = tile_tab_ + 3 * tile_alloc_;
+  int* cellLS = cell_start_;
+  int* cellLE = cell_start_ + cell_alloc_;
+  int* cellGS = cell_start_ + 2 * cell_alloc_;
+  int* cellGE = cell_start_ + 3 * cell_alloc_;
+  reset_flag(F_STAGE_MAX, 0);
+  k_tile_stage_count<<<div_up(ntiles_, 128), 128, 0, stream_>>>(grid_, cellLS, cellLE, cellGS, cellGE, ntiles_,
+                                                               tcount, d_flags_);
+  exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, tcount, tstart, ntiles_ + 1, stream_);
+  int total = 0;
+  SF_HIP(hipMemcpyAsync(&total, tstart + ntiles_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  read_flags();
+  stage_cap_ = h_flags_[F_STAGE_MAX];
+  if ((size_t)stage_cap_ * 88 > 150 * 1024 || stage_cap_ > 65535) return;   // does not fit: gather kernel
+  if ((size_t)total > stage_alloc_) {
+    if (stage_idx_) SF_HIP(hipFree(stage_idx_));
+    stage_alloc_ = (size_t)total + total / 8 + 1024;
+    SF_HIP(hipMalloc(&stage_idx_, sizeof(int) * stage_alloc_));
+  }
+  k_tile_stage_fill<<<div_up(ntiles_, 128), 128, 0, stream_>>>(grid_, cellLS, cellLE, cellGS, cellGE,
+                                                              perm_alt_.as<int>(), ntiles_, tstart, eoff_,
+                                                              stage_idx_);
+  lds_active_ = true;
+}
+
 void DemEngine::bin_and_build()
 {
   if (!nlocal_) {
@@ -673,6 +796,7 @@ void DemEngine::bin_and_build()
     k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
         keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE);
   }
+  build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {
     reset_flag(F_NEIGH_OVER, 0);
     reset_flag(F_MAXNEIGH, 0);
@@ -684,6 +808,8 @@ void DemEngine::bin_and_build()
     B.skin_gran = gran_.style ? skin_ + (cohe_.enabled ? cohe_.smax : 0.0) : -1.0;
     B.cut_lub = lub_.enabled ? lub_.cut_global + skin_ : 0.0;
     B.g = grid_;
+    B.eoff = lds_active_ ? eoff_ : nullptr;
+    B.nloc = nloc_.as<unsigned short>();
     k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
         have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_.as<double>(), neigh_.as<int>(),

@@ -17,14 +17,12 @@ __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 // ------------------------------------------------------------------------------------------------
 // fused DEM sub-step
 // ------------------------------------------------------------------------------------------------
-template <int STYLE, bool COHE, bool LUB>
-__global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
+// One owned atom: neighbour loop + post_force fixes + integration.  LDS = false: the neighbour's records are
+// gathered from HBM/L2 by global index; LDS = true: from the tile's staged copy in LDS (k_substep_lds).
+template <int STYLE, bool COHE, bool LUB, bool LDS>
+__device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i,
+                                                 const double4* lx, const double4* lv, const double* lw)
 {
-  // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
-  // (the host rebuilds and relaunches from that sub-step)
-  if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= S.nlocal) return;
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
 
@@ -38,26 +36,48 @@ __global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
   const int nn = P.numneigh[i];
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
+  // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
+  // The next slot's index is fetched one iteration ahead and x, v, omega of the neighbour (plus the
+  // slot's shear history, whose address does not depend on j) are requested together, so a slot costs
+  // one memory round trip instead of three dependent ones.
+  int jraw_next = nn > 0 ? P.neigh[i] : 0;
   for (int s = 0; s < nn; s++) {
     const size_t slot = (size_t)s * cap + i;
-    const int jraw = P.neigh[slot];
+    const int jraw = jraw_next;
+    if (s + 1 < nn) jraw_next = P.neigh[slot + cap];
     const int j = jraw & kNeighMask;
-    const double4 xj4 = P.xr_in[j];
+    int jl = 0;   // index of the neighbour's records: LDS slot (staged tile) or global atom index
+    if (LDS) jl = P.nloc[slot];
+    const double4 xj4 = LDS ? lx[jl] : P.xr_in[j];
+    double4 vj4 = {0, 0, 0, 0}, wj4 = {0, 0, 0, 0};
+    bool have_vw = false;
+    Vec3 sh = {0.0, 0.0, 0.0};
+    const size_t sbase = (size_t)(3 * s) * cap + i;
+    if (STYLE != 0) {
+      if (LDS) {
+        vj4 = lv[jl];
+        wj4 = {lw[3 * jl], lw[3 * jl + 1], lw[3 * jl + 2], 0.0};
+      } else {
+        vj4 = P.vm_in[j];
+        wj4 = P.om_in[j];
+      }
+      have_vw = true;
+      if (jraw & kTouchBit) {
+        sh.x = P.shear[sbase];
+        sh.y = P.shear[sbase + cap];
+        sh.z = P.shear[sbase + 2 * cap];
+      }
+    }
     const Vec3 del = xi - v3(xj4);
     const double rsq = dot(del, del);
     const double radj = xj4.w;
     const double radsum = radi + radj;
-    bool have_vw = false;
-    double4 vj4 = {0, 0, 0, 0}, wj4 = {0, 0, 0, 0};
 
     if (STYLE != 0) {
       if (rsq >= radsum * radsum) {
         // unset non-touching neighbours (:131-139); the stale shear is ignored once the bit is clear
         if (jraw & kTouchBit) P.neigh[slot] = j;
       } else {
-        vj4 = P.vm_in[j];
-        wj4 = P.om_in[j];
-        have_vw = true;
         ContactIn c;
         c.del = del;
         c.rsq = rsq;
@@ -69,13 +89,6 @@ __global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
         c.meff = mi * mj / (mi + mj);
         c.overlap = radsum - c.r;
         c.reff = (radsum - c.r) * radi * radj / radsum;
-        Vec3 sh = {0.0, 0.0, 0.0};
-        const size_t sbase = (size_t)(3 * s) * cap + i;
-        if (jraw & kTouchBit) {
-          sh.x = P.shear[sbase];
-          sh.y = P.shear[sbase + cap];
-          sh.z = P.shear[sbase + 2 * cap];
-        }
         ContactOut o;
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
         P.shear[sbase] = sh.x;
@@ -98,8 +111,13 @@ __global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
     if (LUB) {
       if (S.lub.flagHI && rsq < lub_cutsq) {
         if (!have_vw) {
-          vj4 = P.vm_in[j];
-          wj4 = P.om_in[j];
+          if (LDS) {
+            vj4 = lv[jl];
+            wj4 = {lw[3 * jl], lw[3 * jl + 1], lw[3 * jl + 2], 0.0};
+          } else {
+            vj4 = P.vm_in[j];
+            wj4 = P.om_in[j];
+          }
         }
         lubricate_poly_pair(S.lub, del, rsq, radi, radj, vi, v3(vj4), wi, v3(wj4), F, T);
       }
@@ -196,6 +214,61 @@ __global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
   }
 }
 
+template <int STYLE, bool COHE, bool LUB>
+__global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
+{
+  // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
+  // (the host rebuilds and relaunches from that sub-step)
+  if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;
+  // The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by
+  // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
+  // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
+  int bid = blockIdx.x;
+  if (S.xcd_remap) {
+    const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int i = bid * blockDim.x + threadIdx.x;
+  if (i >= S.nlocal) return;
+  substep_particle<STYLE, COHE, LUB, false>(P, S, i, nullptr, nullptr, nullptr);
+}
+
+// LDS-staged cell bins: one workgroup per tile of T x T x T bins.  The x/v/omega records of every atom in
+// the tile and in the one-bin shell around it (owned and ghost) are copied ONCE into LDS with mostly
+// sequential loads (atoms are sorted tile by tile, bin by bin); the 12-odd neighbour look-ups per atom then
+// hit LDS (ds_read_b128) instead of issuing 6 scattered 16-byte global loads each, which is what saturates
+// the vector-memory address pipe of a CU in k_substep.  nloc[slot][i] is the neighbour's position in that
+// staged copy, written when the list is built.
+template <int STYLE, bool COHE, bool LUB>
+__global__ __launch_bounds__(256) void k_substep_lds(DemPtrs P, StepParams S)
+{
+  extern __shared__ double4 lds4[];
+  if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;
+  int tile = blockIdx.x;
+  if (S.xcd_remap) {
+    const int nb = gridDim.x, xcd = tile & 7, q = nb >> 3, r = nb & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+  }
+  const int first = P.tile_first[tile], last = P.tile_last[tile];
+  if (first >= last) return;
+  const int s0 = P.stage_start[tile], ns = P.stage_start[tile + 1] - s0;
+  double4* lx = lds4;
+  double4* lv = lds4 + S.stage_cap;
+  double* lw = reinterpret_cast<double*>(lds4 + 2 * (size_t)S.stage_cap);
+  for (int k = threadIdx.x; k < ns; k += blockDim.x) {
+    const int g = P.stage_idx[s0 + k];
+    lx[k] = P.xr_in[g];
+    lv[k] = P.vm_in[g];
+    const double4 w = P.om_in[g];
+    lw[3 * k] = w.x;
+    lw[3 * k + 1] = w.y;
+    lw[3 * k + 2] = w.z;
+  }
+  __syncthreads();
+  for (int i = first + threadIdx.x; i < last; i += blockDim.x)
+    substep_particle<STYLE, COHE, LUB, true>(P, S, i, lx, lv, lw);
+}
+
 // first half-kick of a run with the forces stored by the previous run's last sub-step
 __global__ __launch_bounds__(256) void k_initial_integrate(double4* xr, double4* vm, double4* om,
                                                            const double4* force, const double4* torque,
@@ -285,7 +358,7 @@ __device__ __forceinline__ int bin_of(const double4& x, const BinGrid& g, int& l
   const int cx = bin_coord(x.x, g.lo[0], g.inv[0], g.n[0], lost);
   const int cy = bin_coord(x.y, g.lo[1], g.inv[1], g.n[1], lost);
   const int cz = bin_coord(x.z, g.lo[2], g.inv[2], g.n[2], lost);
-  return cx + g.n[0] * (cy + g.n[1] * cz);
+  return bin_key(g, cx, cy, cz);
 }
 
 // [3P] Domain::pbc for owned atoms + bin key
@@ -432,6 +505,8 @@ struct BuildParams {
   double skin_gran;   // skin (+ smax when cohesion is on) added to ri + rj ; < 0: no granular criterion
   double cut_lub;     // lubrication cutoff + skin ; 0: off
   BinGrid g;
+  const int* eoff;    // LDS staging: [tile][(T+2)^3] offsets (nullptr: no staging tables)
+  unsigned short* nloc;
 };
 
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
@@ -452,13 +527,18 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   const int cz = bin_coord(xi.z, B.g.lo[2], B.g.inv[2], B.g.n[2], lost);
   const int nold = numneigh_old ? numneigh_old[i] : 0;
   int n = 0;
+  const int T = B.g.tile, E = T + 2;
+  const int tx = cx / T, ty = cy / T, tz = cz / T;
+  const int* eo = B.eoff ? B.eoff + (size_t)(tx + B.g.nt[0] * (ty + B.g.nt[1] * tz)) * (E * E * E) : nullptr;
   for (int bz = cz - 1; bz <= cz + 1; bz++) {
     if (bz < 0 || bz >= B.g.n[2]) continue;
     for (int by = cy - 1; by <= cy + 1; by++) {
       if (by < 0 || by >= B.g.n[1]) continue;
       for (int bx = cx - 1; bx <= cx + 1; bx++) {
         if (bx < 0 || bx >= B.g.n[0]) continue;
-        const int b = bx + B.g.n[0] * (by + B.g.n[1] * bz);
+        const int b = bin_key(B.g, bx, by, bz);
+        const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;
+        const int nloc_b = cellLE[b] - cellLS[b];
         for (int pass = 0; pass < 2; pass++) {
           const int ks = pass ? cellGS[b] : cellLS[b];
           const int ke = pass ? cellGE[b] : cellLE[b];
@@ -489,6 +569,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
                 }
               }
               neigh[(size_t)n * B.cap + i] = entry;
+              if (eo) B.nloc[(size_t)n * B.cap + i] = (unsigned short)(ebase + (pass ? nloc_b + (k - ks) : (k - ks)));
               const size_t nb = (size_t)(3 * n) * B.cap + i;
               shear[nb] = sx;
               shear[nb + B.cap] = sy;
@@ -506,6 +587,61 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   }
   numneigh[i] = n;
   atomicMax(&flags[F_MAXNEIGH], n);
+}
+
+// ---- LDS staging tables: which atoms a tile's workgroup copies into LDS, bin by bin ----
+__global__ __launch_bounds__(128) void k_tile_stage_count(BinGrid g, const int* cellLS, const int* cellLE,
+                                                          const int* cellGS, const int* cellGE, int ntiles,
+                                                          int* count, int* flags)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const int T = g.tile, E = T + 2;
+  const int tx = t % g.nt[0], ty = (t / g.nt[0]) % g.nt[1], tz = t / (g.nt[0] * g.nt[1]);
+  int total = 0;
+  for (int ez = 0; ez < E; ez++) {
+    const int bz = tz * T - 1 + ez;
+    if (bz < 0 || bz >= g.n[2]) continue;
+    for (int ey = 0; ey < E; ey++) {
+      const int by = ty * T - 1 + ey;
+      if (by < 0 || by >= g.n[1]) continue;
+      for (int ex = 0; ex < E; ex++) {
+        const int bx = tx * T - 1 + ex;
+        if (bx < 0 || bx >= g.n[0]) continue;
+        const int b = bin_key(g, bx, by, bz);
+        total += (cellLE[b] - cellLS[b]) + (cellGE[b] - cellGS[b]);
+      }
+    }
+  }
+  count[t] = total;
+  atomicMax(&flags[F_STAGE_MAX], total);
+}
+
+__global__ __launch_bounds__(128) void k_tile_stage_fill(BinGrid g, const int* cellLS, const int* cellLE,
+                                                         const int* cellGS, const int* cellGE,
+                                                         const int* ghost_order, int ntiles, const int* start,
+                                                         int* eoff, int* stage_idx)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const int T = g.tile, E = T + 2;
+  const int tx = t % g.nt[0], ty = (t / g.nt[0]) % g.nt[1], tz = t / (g.nt[0] * g.nt[1]);
+  int run = 0;
+  int* out = stage_idx + start[t];
+  for (int ez = 0; ez < E; ez++) {
+    const int bz = tz * T - 1 + ez;
+    for (int ey = 0; ey < E; ey++) {
+      const int by = ty * T - 1 + ey;
+      for (int ex = 0; ex < E; ex++) {
+        const int bx = tx * T - 1 + ex;
+        eoff[(size_t)t * (E * E * E) + (ez * E + ey) * E + ex] = run;
+        if (bz < 0 || bz >= g.n[2] || by < 0 || by >= g.n[1] || bx < 0 || bx >= g.n[0]) continue;
+        const int b = bin_key(g, bx, by, bz);
+        for (int k = cellLS[b]; k < cellLE[b]; k++) out[run++] = k;
+        for (int k = cellGS[b]; k < cellGE[b]; k++) out[run++] = ghost_order[k];
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_store_xhold(const double4* xr, double* xhold, int nlocal, size_t cap)

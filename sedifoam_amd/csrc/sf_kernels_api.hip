@@ -199,6 +199,7 @@ int sfk_pair_gran_history_compute(int hertz, const sfk_gran_params* p, double dt
   g.dampflag = p->dampflag;
   g.style = hertz ? 2 : 1;
   g.beta = (hertz && p->gamman > 0.0) ? sf::beta_of(p->gamman) : 0.0;
+  sf::fold_hertz_constants(g);
   if (inum > 0) {
     const dim3 grid(sf::div_up(inum, 256));
     hipStream_t s = (hipStream_t)stream;

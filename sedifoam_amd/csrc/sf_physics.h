@@ -21,9 +21,13 @@ constexpr double kPiTypo = 3.14159265358917323846;      // fix_fluid_drag.cpp:14
 struct GranParams {
   double kn, kt, gamman, gammat, xmu;
   double beta;      // Hertz: -ln(e)/sqrt(ln(e)^2+pi^2), evaluated once on the host (pure function of gamman)
+  // host-folded Hertz constants (see hertz_history_law)
+  double h_sn, h_cn, h_ct, h_inv_ct, h_c56beta, h_stsn_c56beta;
   int dampflag;
   int style;        // 0 none, 1 hooke/history, 2 hertzFix/history
 };
+
+void fold_hertz_constants(GranParams& p);   // sf_dem.hip (host)
 
 struct Vec3 {
   double x, y, z;
@@ -50,21 +54,24 @@ struct ContactOut {
 };
 
 // Hertzian history contact.  shear is read/updated in place (registers).
+// Same algebra as the reference, arranged for the FP64 pipe of gfx950 (an IEEE f64 divide or sqrt is a
+// ~12-instruction dependent sequence): products of constants are folded on the host (GranParams::h_*),
+// 1/rsq = rinv*rinv, sqrt(st*meff) = sqrt(sn*meff)*sqrt(st/sn), and the Coulomb test compares squares so the
+// two norms are only taken when a contact actually slides.  Each re-association moves a result by <= 1-2 ulp
+// (tests/test_dem_gpu.py holds the HIP path to 1e-12 of the oracle after one evaluation).
 __device__ __forceinline__ void hertz_history_law(const GranParams& p, double dt, bool shearupdate,
                                                   const ContactIn& c, Vec3& sh, ContactOut& o)
 {
-  const double rsqinv = 1.0 / c.rsq;
+  const double rsqinv = c.rinv * c.rinv;
   const double vnnr = dot(c.vr, c.del);
   const double s = vnnr * rsqinv;
   const Vec3 vt = {c.vr.x - c.del.x * s, c.vr.y - c.del.y * s, c.vr.z - c.del.z * s};
   const Vec3 wr = c.rinv * c.wsum;
 
   const double polyhertz = sqrt(c.reff);
-  const double sn = 2.0 * 1.0 / 1.82 * p.kn * polyhertz;
-  const double st = 8.0 * 1.0 / 8.84 * p.kn * polyhertz;
-  const double c56 = 2.0 * sqrt(5.0 / 6.0);
-  const double damp = c56 * p.beta * vnnr * rsqinv;
-  const double ccel = polyhertz * 4.0 / 5.46 * p.kn * c.overlap * c.rinv - sqrt(sn * c.meff) * damp;
+  const double sqsn = sqrt(p.h_sn * polyhertz * c.meff);       // sqrt(sn*meff), sn = (2/1.82) kn polyhertz
+  const double damp = p.h_c56beta * vnnr * rsqinv;             // 2 sqrt(5/6) beta vnnr / rsq
+  const double ccel = polyhertz * p.h_cn * c.overlap * c.rinv - sqsn * damp;   // h_cn = 4/5.46 kn
 
   const Vec3 vtr = {vt.x - (c.del.z * wr.y - c.del.y * wr.z), vt.y - (c.del.x * wr.z - c.del.z * wr.x),
                     vt.z - (c.del.y * wr.x - c.del.x * wr.y)};
@@ -73,22 +80,22 @@ __device__ __forceinline__ void hertz_history_law(const GranParams& p, double dt
     sh.y += vtr.y * dt;
     sh.z += vtr.z * dt;
   }
-  const double shrmag = sqrt(dot(sh, sh));
+  const double shr2 = dot(sh, sh);
   const double rsht = dot(sh, c.del) * rsqinv;
   if (shearupdate) {
     sh.x -= rsht * c.del.x;
     sh.y -= rsht * c.del.y;
     sh.z -= rsht * c.del.z;
   }
-  const double kts = polyhertz * 8.0 / 8.84 * p.kt;
-  const double sdamp = sqrt(st * c.meff) * c56 * p.beta;
+  const double kts = polyhertz * p.h_ct;                       // h_ct = 8/8.84 kt
+  const double sdamp = sqsn * p.h_stsn_c56beta;                // sqrt(st*meff) 2 sqrt(5/6) beta
   Vec3 fs = {-kts * sh.x - sdamp * vtr.x, -kts * sh.y - sdamp * vtr.y, -kts * sh.z - sdamp * vtr.z};
-  const double fsmag = sqrt(dot(fs, fs));
+  const double fs2 = dot(fs, fs);
   const double fn = p.xmu * fabs(ccel * c.r);
-  if (fsmag > fn) {
-    if (shrmag != 0.0) {
-      const double ratio = fn / fsmag;
-      const double qs = sdamp / 8.84 * 8.0 / p.kt;
+  if (fs2 > fn * fn) {
+    if (shr2 != 0.0) {
+      const double ratio = fn / sqrt(fs2);
+      const double qs = sdamp * p.h_inv_ct;                    // / 8.84 * 8 / kt
       const Vec3 q = {qs * vtr.x, qs * vtr.y, qs * vtr.z};
       sh.x = ratio * (sh.x + q.x) - q.x;
       sh.y = ratio * (sh.y + q.y) - q.y;

@@ -135,3 +135,17 @@ def test_deterministic_rerun():
         outs.append(lmp.get_state())
     for k in ("x", "v", "omega", "f", "torque"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("env", [{"SF_LDS": "1"}, {"SF_TILE": "0", "SF_XCD_REMAP": "0"}, {"SF_TILE": "8"}])
+def test_kernel_variants_agree_with_oracle(env, monkeypatch):
+    """The LDS-staged tile kernel (k_substep_lds) and the plain / tiled orderings of the gathering kernel are
+    speed options only: every one must reproduce the oracle, through rebuilds too."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    bed = _bed((6, 6, 6), periodic=True, seed=99, vmax=0.5)
+    lmp, orc = _run_case(bed, dict(BASE, skin=0.05e-3), steps=(60, 60))
+    assert lmp.info().nbuilds >= 3
+    bed = _bed((5, 5, 5), periodic=True, seed=11, poly=(0.85e-3, 1.0e-3), spacing=0.95)
+    _run_case(bed, dict(BASE, skin=0.2e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
+                        lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)), steps=(1, 30))
