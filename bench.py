@@ -165,6 +165,15 @@ def main():
             "traffic": None,
         },
     }
+    # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes
+    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_b_pmc_summary.json for the calibration note)
+    pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")
+    if os.path.exists(pmc) and args.particles == 1000000:
+        try:
+            out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]["total_raw"]
+            out["roofline"]["traffic_source"] = "profiles/r01_b_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+        except Exception:
+            pass
     if rank == 0 and not args.no_cpu_baseline:
         sample_n = args.cpu_sample or 1000000
         sub = 50
