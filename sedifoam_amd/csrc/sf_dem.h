@@ -84,6 +84,7 @@ struct StepParams {
   LubParams lub;
   int nwalls;
   int stage_cap;   // LDS slots per workgroup in k_substep_lds
+  int occ;         // register-budget variant of k_substep (waves per SIMD the compiler must allow)
   int xcd_remap;   // blockIdx -> contiguous chunk per XCD (8 XCDs, block b runs on XCD b % 8)
   WallParams wall[kMaxWalls];
   int have_gravity;
@@ -97,6 +98,7 @@ struct StepParams {
 struct BinGrid {
   double lo[3], inv[3];
   int n[3];
+  int stencil;     // neighbour search radius in cells (cells may be finer than the cutoff: cell = cut / stencil)
   int nbins;       // key space: tiles * tile^3 (>= n[0]*n[1]*n[2])
   int tile;        // bins are numbered tile by tile (tile x tile x tile bins) so that particles that are
   int nt[3];       // close in space are close in memory in all three directions; tile <= 1: plain x-fastest
@@ -249,7 +251,7 @@ class DemEngine {
   int rank_ = 0, nranks_ = 1;
   double sublo_x_ = 0.0, subhi_x_ = 1.0;
   bool have_subdomain_ = false;   // true: the x halo is external (driven through sf_dem_border_* etc.)
-  int opt_tile_ = 4, opt_xcd_remap_ = 1, opt_lds_ = 0;   // SF_TILE / SF_XCD_REMAP / SF_LDS overrides (LDS staging: see DESIGN.md, measured slower so far)   // SF_TILE / SF_XCD_REMAP environment overrides
+  int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_occ_ = 0, opt_sub_ = 2;   // SF_SUB: cells per cutoff length; SF_TILE / SF_XCD_REMAP / SF_LDS overrides (LDS staging: see DESIGN.md, measured slower so far)   // SF_TILE / SF_XCD_REMAP environment overrides
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;
   DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x

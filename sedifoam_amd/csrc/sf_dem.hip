@@ -94,6 +94,8 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
+  if (const char* e = getenv("SF_OCC")) opt_occ_ = atoi(e);
+  if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -427,6 +429,7 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.nwalls = nwalls_;
   S.xcd_remap = opt_xcd_remap_;
   S.stage_cap = stage_cap_;
+  S.occ = opt_occ_;
   for (int w = 0; w < nwalls_; w++) S.wall[w] = walls_[w];
   S.have_gravity = have_gravity_;
   for (int k = 0; k < 3; k++) S.gacc[k] = gacc_[k];
@@ -444,6 +447,9 @@ static void launch_substep_style(bool cohe, bool lub, dim3 grid, hipStream_t s, 
   if (cohe && lub) k_substep<STYLE, true, true><<<grid, 256, 0, s>>>(P, S);
   else if (cohe) k_substep<STYLE, true, false><<<grid, 256, 0, s>>>(P, S);
   else if (lub) k_substep<STYLE, false, true><<<grid, 256, 0, s>>>(P, S);
+  else if (STYLE == 2 && S.occ == 4) k_substep<2, false, false, 4><<<grid, 256, 0, s>>>(P, S);
+  else if (STYLE == 2 && S.occ == 5) k_substep<2, false, false, 5><<<grid, 256, 0, s>>>(P, S);
+  else if (STYLE == 2 && S.occ == 6) k_substep<2, false, false, 6><<<grid, 256, 0, s>>>(P, S);
   else k_substep<STYLE, false, false><<<grid, 256, 0, s>>>(P, S);
 }
 
@@ -572,12 +578,13 @@ void DemEngine::compute_grid()
     const double l = ext ? lo[k] - cut : lo[k];
     const double h = ext ? hi[k] + cut : hi[k];
     int n = (int)((h - l) / cut);
-    n = std::max(1, std::min(n, 1 << 9));
+    n = std::max(1, std::min(n, 1 << 9)) * opt_sub_;   // cells of size >= cut / sub, searched +-sub cells
     grid_.lo[k] = l;
     grid_.n[k] = n;
     grid_.inv[k] = n / (h - l);
   }
-  grid_.tile = opt_tile_ > 1 ? opt_tile_ : 1;
+  grid_.stencil = opt_sub_;
+  grid_.tile = opt_tile_ > 1 ? opt_tile_ * opt_sub_ : 1;   // tiles keep their physical size
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
     grid_.nt[k] = (grid_.n[k] + grid_.tile - 1) / grid_.tile;
@@ -742,7 +749,7 @@ void DemEngine::build_stage_tables()
 {
   lds_active_ = false;
   const int T = grid_.tile;
-  if (!opt_lds_ || T < 2 || (T & (T - 1)) || !nlocal_) return;
+  if (!opt_lds_ || T < 2 || (T & (T - 1)) || !nlocal_ || grid_.stencil != 1) return;
   if (!tile_tab_) return;
   const int E = T + 2, EB = E * E * E;
   if ((size_t)ntiles_ * EB > eoff_alloc_) {

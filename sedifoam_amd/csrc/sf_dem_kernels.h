@@ -37,35 +37,60 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
-  // The next slot's index is fetched one iteration ahead and x, v, omega of the neighbour (plus the
-  // slot's shear history, whose address does not depend on j) are requested together, so a slot costs
-  // one memory round trip instead of three dependent ones.
-  int jraw_next = nn > 0 ? P.neigh[i] : 0;
+  // Software pipeline: the index of slot s+2 and the x, v, omega records of slot s+1 are requested before the
+  // contact of slot s is evaluated, so the next neighbour's gather latency hides behind ~230 FP64 instructions
+  // (4 waves per SIMD cannot hide it alone).  The shear loads of slot s are issued BEFORE that prefetch: vmcnt
+  // retires in order, so the contact law only waits for them and the prefetch stays in flight.  Measured at 1 M
+  // atoms: 249 -> 224 us.  Prefetching the shear history as well costs 10 VGPRs (3 waves/SIMD) and loses 10 %.
+  constexpr bool NEED_VW = (STYLE != 0) || LUB;
+  int jraw_n1 = nn > 0 ? P.neigh[i] : 0;
+  int jraw_n2 = nn > 1 ? P.neigh[cap + i] : 0;
+  double4 xn4 = {0, 0, 0, 0}, vn4 = {0, 0, 0, 0}, wn4 = {0, 0, 0, 0};
+  int ln1 = 0;
+  if (nn > 0) {
+    if (LDS) {
+      ln1 = P.nloc[i];
+    } else {
+      const int j0 = jraw_n1 & kNeighMask;
+      xn4 = P.xr_in[j0];
+      if (NEED_VW) {
+        vn4 = P.vm_in[j0];
+        wn4 = P.om_in[j0];
+      }
+    }
+  }
   for (int s = 0; s < nn; s++) {
     const size_t slot = (size_t)s * cap + i;
-    const int jraw = jraw_next;
-    if (s + 1 < nn) jraw_next = P.neigh[slot + cap];
-    const int j = jraw & kNeighMask;
-    int jl = 0;   // index of the neighbour's records: LDS slot (staged tile) or global atom index
-    if (LDS) jl = P.nloc[slot];
-    const double4 xj4 = LDS ? lx[jl] : P.xr_in[j];
-    double4 vj4 = {0, 0, 0, 0}, wj4 = {0, 0, 0, 0};
-    bool have_vw = false;
-    Vec3 sh = {0.0, 0.0, 0.0};
     const size_t sbase = (size_t)(3 * s) * cap + i;
-    if (STYLE != 0) {
+    const int jraw = jraw_n1;
+    const int j = jraw & kNeighMask;
+    double4 xj4 = xn4, vj4 = vn4, wj4 = wn4;
+    const int jl = ln1;   // LDS slot of the neighbour (staged tile)
+    Vec3 sh = {0.0, 0.0, 0.0};
+    if (STYLE != 0 && (jraw & kTouchBit)) {
+      sh.x = P.shear[sbase];
+      sh.y = P.shear[sbase + cap];
+      sh.z = P.shear[sbase + 2 * cap];
+    }
+    jraw_n1 = jraw_n2;
+    if (s + 2 < nn) jraw_n2 = P.neigh[slot + 2 * cap];
+    if (s + 1 < nn) {
       if (LDS) {
+        ln1 = P.nloc[slot + cap];
+      } else {
+        const int j1 = jraw_n1 & kNeighMask;
+        xn4 = P.xr_in[j1];
+        if (NEED_VW) {
+          vn4 = P.vm_in[j1];
+          wn4 = P.om_in[j1];
+        }
+      }
+    }
+    if (LDS) {
+      xj4 = lx[jl];
+      if (NEED_VW) {
         vj4 = lv[jl];
         wj4 = {lw[3 * jl], lw[3 * jl + 1], lw[3 * jl + 2], 0.0};
-      } else {
-        vj4 = P.vm_in[j];
-        wj4 = P.om_in[j];
-      }
-      have_vw = true;
-      if (jraw & kTouchBit) {
-        sh.x = P.shear[sbase];
-        sh.y = P.shear[sbase + cap];
-        sh.z = P.shear[sbase + 2 * cap];
       }
     }
     const Vec3 del = xi - v3(xj4);
@@ -110,15 +135,6 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     }
     if (LUB) {
       if (S.lub.flagHI && rsq < lub_cutsq) {
-        if (!have_vw) {
-          if (LDS) {
-            vj4 = lv[jl];
-            wj4 = {lw[3 * jl], lw[3 * jl + 1], lw[3 * jl + 2], 0.0};
-          } else {
-            vj4 = P.vm_in[j];
-            wj4 = P.om_in[j];
-          }
-        }
         lubricate_poly_pair(S.lub, del, rsq, radi, radj, vi, v3(vj4), wi, v3(wj4), F, T);
       }
     }
@@ -214,8 +230,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
 }
 
-template <int STYLE, bool COHE, bool LUB>
-__global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
+template <int STYLE, bool COHE, bool LUB, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
@@ -530,14 +546,15 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   const int T = B.g.tile, E = T + 2;
   const int tx = cx / T, ty = cy / T, tz = cz / T;
   const int* eo = B.eoff ? B.eoff + (size_t)(tx + B.g.nt[0] * (ty + B.g.nt[1] * tz)) * (E * E * E) : nullptr;
-  for (int bz = cz - 1; bz <= cz + 1; bz++) {
+  const int R = B.g.stencil;
+  for (int bz = cz - R; bz <= cz + R; bz++) {
     if (bz < 0 || bz >= B.g.n[2]) continue;
-    for (int by = cy - 1; by <= cy + 1; by++) {
+    for (int by = cy - R; by <= cy + R; by++) {
       if (by < 0 || by >= B.g.n[1]) continue;
-      for (int bx = cx - 1; bx <= cx + 1; bx++) {
+      for (int bx = cx - R; bx <= cx + R; bx++) {
         if (bx < 0 || bx >= B.g.n[0]) continue;
         const int b = bin_key(B.g, bx, by, bz);
-        const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;
+        const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;   // stencil 1 only
         const int nloc_b = cellLE[b] - cellLS[b];
         for (int pass = 0; pass < 2; pass++) {
           const int ks = pass ? cellGS[b] : cellLS[b];

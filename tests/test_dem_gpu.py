@@ -137,7 +137,9 @@ def test_deterministic_rerun():
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-@pytest.mark.parametrize("env", [{"SF_LDS": "1"}, {"SF_TILE": "0", "SF_XCD_REMAP": "0"}, {"SF_TILE": "8"}])
+@pytest.mark.parametrize("env", [{"SF_LDS": "1", "SF_TILE": "4", "SF_SUB": "1"},
+                                 {"SF_TILE": "0", "SF_XCD_REMAP": "0", "SF_SUB": "1"},
+                                 {"SF_TILE": "8", "SF_SUB": "2"}, {"SF_TILE": "4", "SF_SUB": "3"}])
 def test_kernel_variants_agree_with_oracle(env, monkeypatch):
     """The LDS-staged tile kernel (k_substep_lds) and the plain / tiled orderings of the gathering kernel are
     speed options only: every one must reproduce the oracle, through rebuilds too."""
