@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--particles", type=int, default=1000000, help="particles per GPU")
     ap.add_argument("--substeps", type=int, default=50, help="DEM sub-steps per step (per CFD step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-coupled", action="store_true")
     ap.add_argument("--slab-driver", action="store_true",
                     help="drive the sub-steps through the multi-rank SlabDriver even at N=1 (self halo)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
@@ -166,14 +167,35 @@ def main():
         },
     }
     # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes
-    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_b_pmc_summary.json for the calibration note)
-    pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")
+    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_c_pmc_summary.json for the calibration note)
+    pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_summary.json")
     if os.path.exists(pmc) and args.particles == 1000000:
         try:
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]["total_raw"]
-            out["roofline"]["traffic_source"] = "profiles/r01_b_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+            out["roofline"]["traffic_source"] = "profiles/r01_c_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
         except Exception:
             pass
+    # secondary metric of BASELINE.json: coupled CFD-DEM steps/s (drag closure + drag assembly + S sub-steps +
+    # cell owner + void-fraction / Ue scatter + Asrc) through the device-resident enhancedCloud, frozen fluid
+    if world == 1 and not args.slab_driver and not args.no_coupled:
+        from sedifoam_amd import enhancedCloud
+        mesh_n = np.array([32, 32, 32])
+        dx = (bed["boxhi"] - bed["boxlo"]) / mesh_n
+        cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n,
+                              dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65),
+                              dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"])
+        nc = int(np.prod(mesh_n))
+        cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)))
+        for _ in range(2):
+            cloud.evolve(); cloud.calcTcFields()
+        barrier()
+        t1 = time.perf_counter()
+        ncpl = max(3, args.steps // 2)
+        for _ in range(ncpl):
+            cloud.evolve(); cloud.calcTcFields()
+        barrier()
+        out["config"]["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
+        out["config"]["coupled_step"] = "ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc, 32^3 mesh" % args.substeps
     if rank == 0 and not args.no_cpu_baseline:
         sample_n = args.cpu_sample or 1000000
         sub = 50
