@@ -179,13 +179,15 @@ def main():
     # cell owner + void-fraction / Ue scatter + Asrc) through the device-resident enhancedCloud, frozen fluid
     if world == 1 and not args.slab_driver and not args.no_coupled:
         from sedifoam_amd import enhancedCloud
-        mesh_n = np.array([32, 32, 32])
+        # cells at least 3 d wide (a centre-counted void fraction above 1 makes every closure return inf)
+        mesh_n = np.clip(((bed["boxhi"] - bed["boxlo"]) / 3.0e-3).astype(int), 1, 32)
         dx = (bed["boxhi"] - bed["boxlo"]) / mesh_n
         cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n,
                               dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65),
                               dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"])
         nc = int(np.prod(mesh_n))
         cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)))
+        cloud.calcTcFields()   # lammpsFoam.C includes liftDragCoeffs.H (alpha cap + calcTcFields) before the time loop
         for _ in range(2):
             cloud.evolve(); cloud.calcTcFields()
         barrier()
@@ -195,7 +197,8 @@ def main():
             cloud.evolve(); cloud.calcTcFields()
         barrier()
         out["config"]["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
-        out["config"]["coupled_step"] = "ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc, 32^3 mesh" % args.substeps
+        out["config"]["coupled_step"] = "ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc, %dx%dx%d mesh" % (
+            args.substeps, mesh_n[0], mesh_n[1], mesh_n[2])
     if rank == 0 and not args.no_cpu_baseline:
         sample_n = args.cpu_sample or 1000000
         sub = 50

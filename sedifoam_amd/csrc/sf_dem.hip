@@ -441,16 +441,13 @@ StepParams DemEngine::step_params(int mode, int kstep) const
 }
 
 template <int STYLE>
-static void launch_substep_style(bool cohe, bool lub, dim3 grid, hipStream_t s, const DemPtrs& P,
+static void launch_substep_style(bool cohe, bool lub, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
                                  const StepParams& S)
 {
-  if (cohe && lub) k_substep<STYLE, true, true><<<grid, 256, 0, s>>>(P, S);
-  else if (cohe) k_substep<STYLE, true, false><<<grid, 256, 0, s>>>(P, S);
-  else if (lub) k_substep<STYLE, false, true><<<grid, 256, 0, s>>>(P, S);
-  else if (STYLE == 2 && S.occ == 4) k_substep<2, false, false, 4><<<grid, 256, 0, s>>>(P, S);
-  else if (STYLE == 2 && S.occ == 5) k_substep<2, false, false, 5><<<grid, 256, 0, s>>>(P, S);
-  else if (STYLE == 2 && S.occ == 6) k_substep<2, false, false, 6><<<grid, 256, 0, s>>>(P, S);
-  else k_substep<STYLE, false, false><<<grid, 256, 0, s>>>(P, S);
+  if (cohe && lub) k_substep<STYLE, true, true><<<grid, block, 0, s>>>(P, S);
+  else if (cohe) k_substep<STYLE, true, false><<<grid, block, 0, s>>>(P, S);
+  else if (lub) k_substep<STYLE, false, true><<<grid, block, 0, s>>>(P, S);
+  else k_substep<STYLE, false, false><<<grid, block, 0, s>>>(P, S);
 }
 
 template <int STYLE, bool COHE, bool LUB>
@@ -504,11 +501,13 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
       default: launch_lds_style<0>(cohe, lub, grid, lds, stream_, P, S); break;
     }
   } else {
-    const dim3 grid(div_up(nlocal_, 256));
+    // enough workgroups to cover the 256 CUs even for small beds (one atom per lane either way)
+    const int block = nlocal_ >= 512 * 1024 ? 256 : (nlocal_ >= 128 * 1024 ? 128 : 64);
+    const dim3 grid(div_up(nlocal_, block));
     switch (gran_.style) {
-      case 2: launch_substep_style<2>(cohe, lub, grid, stream_, P, S); break;
-      case 1: launch_substep_style<1>(cohe, lub, grid, stream_, P, S); break;
-      default: launch_substep_style<0>(cohe, lub, grid, stream_, P, S); break;
+      case 2: launch_substep_style<2>(cohe, lub, grid, block, stream_, P, S); break;
+      case 1: launch_substep_style<1>(cohe, lub, grid, block, stream_, P, S); break;
+      default: launch_substep_style<0>(cohe, lub, grid, block, stream_, P, S); break;
     }
   }
   SF_HIP(hipGetLastError());

@@ -230,8 +230,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
 }
 
-template <int STYLE, bool COHE, bool LUB, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void k_substep(DemPtrs P, StepParams S)
+template <int STYLE, bool COHE, bool LUB>
+__global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)

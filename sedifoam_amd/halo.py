@@ -98,8 +98,11 @@ class HipSlabEngine:
 class SlabDriver:
     """lammps_step() for one slab of an x-decomposed domain.  All methods are collective over the ranks."""
 
-    def __init__(self, eng, dist, rank, world, xlo, xhi, periodic_x=True, halo_atoms=None):
+    def __init__(self, eng, dist, rank, world, xlo, xhi, periodic_x=True, halo_atoms=None, transport="direct"):
         import torch
+        # "direct": P2P on the engine's own (device) buffers = RCCL over xGMI.  "host": stage through CPU tensors
+        # (lets a gloo process group carry the halo of GPU engines, e.g. two ranks sharing one GPU in a test).
+        self.transport = transport
         self.torch = torch
         self.e = eng
         self.dist = dist
@@ -133,7 +136,8 @@ class SlabDriver:
     def _allreduce_max(self, v):
         if self.world == 1:
             return int(v)
-        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.e.device)
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64,
+                              device=self.e.device if self.transport == "direct" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
@@ -151,11 +155,12 @@ class SlabDriver:
             n_l = 0
         if self.right is None:
             n_r = 0
+        tdev = self.e.device if self.transport == "direct" else torch.device("cpu")
         if known is None:
-            cs_l = torch.tensor([n_l], dtype=torch.int64, device=self.e.device)
-            cs_r = torch.tensor([n_r], dtype=torch.int64, device=self.e.device)
-            cr_l = torch.zeros(1, dtype=torch.int64, device=self.e.device)
-            cr_r = torch.zeros(1, dtype=torch.int64, device=self.e.device)
+            cs_l = torch.tensor([n_l], dtype=torch.int64, device=tdev)
+            cs_r = torch.tensor([n_r], dtype=torch.int64, device=tdev)
+            cr_l = torch.zeros(1, dtype=torch.int64, device=tdev)
+            cr_r = torch.zeros(1, dtype=torch.int64, device=tdev)
             ops = []
             if self.left is not None:
                 ops.append(dist.P2POp(dist.isend, cs_l, self.left, tag=10))
@@ -172,18 +177,29 @@ class SlabDriver:
             m_l, m_r = known
         recv_l = self._buf("recv_l", m_l)
         recv_r = self._buf("recv_r", m_r)
+        if self.transport == "direct":
+            tx_l, tx_r, rx_l, rx_r = send_l, send_r, recv_l, recv_r
+        else:
+            if self.e.device.type == "cuda":
+                torch.cuda.synchronize()
+            tx_l, tx_r = send_l[:n_l].cpu(), send_r[:n_r].cpu()
+            rx_l = torch.empty(max(m_l, 1), dtype=torch.float64)
+            rx_r = torch.empty(max(m_r, 1), dtype=torch.float64)
         ops = []
         if self.left is not None and n_l:
-            ops.append(dist.P2POp(dist.isend, send_l[:n_l], self.left, tag=20))
+            ops.append(dist.P2POp(dist.isend, tx_l[:n_l], self.left, tag=20))
         if self.right is not None and n_r:
-            ops.append(dist.P2POp(dist.isend, send_r[:n_r], self.right, tag=21))
+            ops.append(dist.P2POp(dist.isend, tx_r[:n_r], self.right, tag=21))
         if self.right is not None and m_r:
-            ops.append(dist.P2POp(dist.irecv, recv_r[:m_r], self.right, tag=20))
+            ops.append(dist.P2POp(dist.irecv, rx_r[:m_r], self.right, tag=20))
         if self.left is not None and m_l:
-            ops.append(dist.P2POp(dist.irecv, recv_l[:m_l], self.left, tag=21))
+            ops.append(dist.P2POp(dist.irecv, rx_l[:m_l], self.left, tag=21))
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
+        if self.transport != "direct":
+            recv_l[:m_l].copy_(rx_l[:m_l])
+            recv_r[:m_r].copy_(rx_r[:m_r])
         return recv_l, m_l, recv_r, m_r
 
     # ---- the three halo operations ----
@@ -257,7 +273,7 @@ class SlabDriver:
         return self.e.lmp.get_profile()
 
     @classmethod
-    def from_bed(cls, bed, script, dist, rank, world):
+    def from_bed(cls, bed, script, dist, rank, world, transport="direct"):
         """bench.py: every rank owns one copy of `bed` (its own seed), laid side by side along x."""
         from . import Lammps
         lx = float(bed["boxhi"][0] - bed["boxlo"][0])
@@ -273,4 +289,5 @@ class SlabDriver:
                          tag=np.arange(1, n + 1, dtype=np.int64) + rank * n)
         for line in script:
             lmp.command(line)
-        return cls(HipSlabEngine(lmp), dist, rank, world, lo[0], hi[0], periodic_x=bool(bed["periodic"][0]))
+        return cls(HipSlabEngine(lmp), dist, rank, world, lo[0], hi[0], periodic_x=bool(bed["periodic"][0]),
+                   transport=transport)

@@ -42,3 +42,79 @@ def test_self_halo_matches_internal_periodic_and_oracle(vmax, skin, steps):
         assert set(ha) == set(hb)
     if vmax > 0.1:
         assert drv.n_rebuilds >= 3      # migration across the periodic face + history carry-over exercised
+
+
+def _two_rank_worker(rank, world, port, outdir, steps):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sedifoam_amd import Lammps
+    from sedifoam_amd.halo import SlabDriver, HipSlabEngine
+    from tests import dem_cases as dc
+    import tests.test_dem_gpu as T
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.5)
+    cfg = dict(T.BASE, skin=0.05e-3)
+    cfg["walls"] = T._walls(bed)
+    lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
+    w = (hi - lo) / world
+    mine = (bed["x"][:, 0] >= lo + rank * w) & ((bed["x"][:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
+    lmp = Lammps()
+    lmp.set_box(bed["boxlo"], bed["boxhi"])
+    lmp.create_atoms(bed["x"][mine], bed["diameter"][mine], bed["density"][mine], v=bed["v"][mine],
+                     tag=(np.nonzero(mine)[0] + 1))
+    for line in dc.script_lines(bed, cfg):
+        lmp.command(line)
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
+    drv.setup()
+    for n in steps:
+        drv.step(n)
+    st = lmp.get_state()
+    h = lmp.history()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), rebuilds=drv.n_rebuilds,
+             hk=np.array(sorted(h), dtype=np.int64).reshape(-1, 2), hv=np.array([h[k] for k in sorted(h)]).reshape(-1, 3),
+             **st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_one_gpu_match_single_domain():
+    """Two HIP engines (two processes on the same GPU) exchanging their halo through the driver -- the
+    decomposed N > 1 path with the real kernels; only the wire is gloo-through-host instead of RCCL."""
+    import os, socket, tempfile
+    import torch.multiprocessing as mp
+    steps = (50, 50)
+    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.5)
+    cfg = dict(T.BASE, skin=0.05e-3)
+    cfg["walls"] = T._walls(bed)
+    ref = dc.make_hip(bed, cfg)
+    ref.setup()
+    for n in steps:
+        ref.step(n)
+    a = ref.get_state(); ha = ref.history()
+    assert ref.info().nbuilds >= 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_two_rank_worker, args=(2, port, out, steps), nprocs=2, join=True)
+        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    tag = np.concatenate([p["tag"] for p in parts])
+    assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
+    order = np.argsort(tag)
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    for k in ("x", "v", "omega", "f", "torque"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        want = a[k].copy()
+        if k == "x":
+            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            assert np.max(np.abs(got - want)) <= 1e-12
+        else:
+            assert dc.rel_err(got, want) <= 1e-9, k
+    assert all(int(p["rebuilds"]) >= 3 for p in parts)
+    hb = {}
+    for p in parts:
+        for (i, j), sv in zip(p["hk"], p["hv"]):
+            hb.setdefault((int(i), int(j)), sv)
+    assert set(hb) == set(ha)
