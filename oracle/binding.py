@@ -293,6 +293,7 @@ class OracleSlabEngine:
         self.L = dem.L
         self.h = dem.h
         self.device = torch.device("cpu")
+        self._trigger = torch.full((1,), 2 ** 31 - 1, dtype=torch.int32)
 
     def alloc(self, ndoubles):
         return self.torch.zeros(max(int(ndoubles), 1), dtype=self.torch.float64)
@@ -311,13 +312,32 @@ class OracleSlabEngine:
         self.L.orc_dem_ext_setup(self.h)
 
     def run_begin(self):
+        self._trigger[0] = 2 ** 31 - 1
         self.L.orc_dem_run_begin(self.h)
+        if self.L.orc_dem_need_rebuild(self.h):
+            self._trigger[0] = -1
 
     def substep(self, last):
         self.L.orc_dem_substep(self.h, int(last))
 
     def need_rebuild(self):
         return self.L.orc_dem_need_rebuild(self.h)
+
+    # batch mode of the driver: the oracle emulates the device-resident trigger word with a CPU tensor
+    @property
+    def trigger(self):
+        return self._trigger
+
+    def substep_k(self, last, kstep):
+        # a sub-step behind the (all-reduced) trigger exits early, like the HIP kernel
+        if int(self._trigger[0]) < kstep:
+            return
+        self.L.orc_dem_substep(self.h, int(last))
+        if not last and self.L.orc_dem_need_rebuild(self.h):
+            self._trigger[0] = min(int(self._trigger[0]), kstep)
+
+    def batch_end(self, first_k, launched):
+        return int(self._trigger[0])
 
     def rebuild_begin(self):
         self.L.orc_dem_rebuild_begin(self.h)
@@ -327,6 +347,7 @@ class OracleSlabEngine:
 
     def rebuild_finish(self):
         self.L.orc_dem_rebuild_finish(self.h)
+        self._trigger[0] = 2 ** 31 - 1
 
     def migrate_set_slots(self, m):
         self.L.orc_dem_migrate_set_slots(self.h, int(m))

@@ -97,6 +97,9 @@ _SIGS = {
     "sf_dem_run_begin": (C.c_int, [vp]),
     "sf_dem_substep": (C.c_int, [vp, C.c_int]),
     "sf_dem_need_rebuild": (C.c_int, [vp]),
+    "sf_dem_substep_k": (C.c_int, [vp, C.c_int, C.c_int]),
+    "sf_dem_batch_end": (C.c_int, [vp, C.c_int, C.c_int, ip]),
+    "sf_dem_set_flag_buffer": (C.c_int, [vp, vp]),
     "sf_dem_rebuild_begin": (C.c_int, [vp]),
     "sf_dem_rebuild_sort": (C.c_int, [vp]),
     "sf_dem_rebuild_finish": (C.c_int, [vp]),

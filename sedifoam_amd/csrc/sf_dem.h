@@ -147,6 +147,11 @@ class DemEngine {
   void run(int nsteps);    // "run n pre no post no"
   void run_begin();
   void substep(bool last);
+  // batch mode of the multi-rank driver: sub-step with an explicit index for the stale-list early exit, and the
+  // end-of-batch bookkeeping (returns the trigger index, INT_MAX if none; fixes the ping-pong parity)
+  void substep_k(bool last, int kstep);
+  int batch_end(int first_k, int launched);
+  void set_flag_buffer(int* dev);
   bool need_rebuild();
   void rebuild_begin();
   void rebuild_sort();
@@ -295,6 +300,7 @@ class DemEngine {
   void* sort_tmp_ = nullptr;
   size_t sort_tmp_bytes_ = 0;
   int* d_flags_ = nullptr;
+  int* own_flags_ = nullptr;
   int* h_flags_ = nullptr;             // pinned
   std::vector<DevArray*> per_atom_;    // registry for capacity growth
   BinGrid grid_{};

@@ -86,7 +86,8 @@ DemEngine::DemEngine()
          e == hipSuccess ? "device count 0" : hipGetErrorString(e));
   SF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-  SF_HIP(hipMalloc(&d_flags_, sizeof(int) * F_NFLAGS));
+  SF_HIP(hipMalloc(&own_flags_, sizeof(int) * F_NFLAGS));
+  d_flags_ = own_flags_;
   SF_HIP(hipHostMalloc(&h_flags_, sizeof(int) * F_NFLAGS));
   SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
   SF_HIP(hipEventCreate(&ev0_));
@@ -116,7 +117,7 @@ DemEngine::~DemEngine()
   if (eoff_) (void)hipFree(eoff_);
   if (tagmap_) (void)hipFree(tagmap_);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
-  if (d_flags_) (void)hipFree(d_flags_);
+  if (own_flags_) (void)hipFree(own_flags_);
   if (h_flags_) (void)hipHostFree(h_flags_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -912,6 +913,35 @@ void DemEngine::substep(bool last)
   launch_ghost_forward(cur_ ^ 1, 0);
   cur_ ^= 1;
   nsteps_++;
+}
+
+void DemEngine::substep_k(bool last, int kstep)
+{
+  launch_substep(cur_, last ? 1 : 0, kstep);
+  launch_ghost_forward(cur_ ^ 1, kstep);
+  cur_ ^= 1;
+}
+
+int DemEngine::batch_end(int first_k, int launched)
+{
+  read_flags();
+  const int trig = h_flags_[F_TRIGGER];
+  const int executed = trig == INT_MAX ? launched : std::max(0, trig + 1 - first_k);
+  // every substep_k flipped the buffer parity; the early-exited ones must not count
+  if ((launched - executed) & 1) cur_ ^= 1;
+  nsteps_ += executed;
+  return trig;
+}
+
+void DemEngine::set_flag_buffer(int* dev)
+{
+  sync();
+  if (!dev) dev = own_flags_;
+  if (dev != d_flags_) {
+    SF_HIP(hipMemcpyAsync(dev, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToDevice, stream_));
+    sync();
+    d_flags_ = dev;
+  }
 }
 
 bool DemEngine::need_rebuild()

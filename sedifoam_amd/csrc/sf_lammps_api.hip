@@ -491,6 +491,27 @@ int sf_dem_substep(void* ptr, int last)
   SF_API_END(0)
 }
 
+int sf_dem_substep_k(void* ptr, int last, int kstep)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.substep_k(last != 0, kstep);
+  SF_API_END(0)
+}
+
+int sf_dem_batch_end(void* ptr, int first_k, int launched, int* trigger)
+{
+  SF_API_BEGIN
+  *trigger = H(ptr)->eng.batch_end(first_k, launched);
+  SF_API_END(0)
+}
+
+int sf_dem_set_flag_buffer(void* ptr, void* dev_ints)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_flag_buffer((int*)dev_ints);
+  SF_API_END(0)
+}
+
 int sf_dem_need_rebuild(void* ptr)
 {
   SF_API_BEGIN

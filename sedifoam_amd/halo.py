@@ -35,6 +35,11 @@ class HipSlabEngine:
         # run the engine on torch's current stream: RCCL traffic then orders after the pack kernels and the
         # unpack kernels after the receives without host synchronisation
         self.check(self.L.sf_dem_set_stream(lmp.ptr, torch.cuda.current_stream().cuda_stream))
+        # the engine's flag block lives in a torch tensor so that word 0 (the rebuild trigger) can be
+        # all-reduced over the ranks on the stream, between two sub-steps, without the host looking at it
+        self.flags = torch.zeros(16, dtype=torch.int32, device=self.device)
+        self.check(self.L.sf_dem_set_flag_buffer(lmp.ptr, self.flags.data_ptr()))
+        self.trigger = self.flags[0:1]
 
     def alloc(self, ndoubles):
         return self.torch.empty(max(int(ndoubles), 1), dtype=self.torch.float64, device=self.device)
@@ -56,6 +61,14 @@ class HipSlabEngine:
 
     def need_rebuild(self):
         return self.check(self.L.sf_dem_need_rebuild(self.lmp.ptr))
+
+    def substep_k(self, last, kstep):
+        self.check(self.L.sf_dem_substep_k(self.lmp.ptr, int(last), int(kstep)))
+
+    def batch_end(self, first_k, launched):
+        t = C.c_int()
+        self.check(self.L.sf_dem_batch_end(self.lmp.ptr, int(first_k), int(launched), C.byref(t)))
+        return t.value
 
     def rebuild_begin(self):
         self.check(self.L.sf_dem_rebuild_begin(self.lmp.ptr))
@@ -250,18 +263,40 @@ class SlabDriver:
         self.e.setup()
         self.is_setup = True
 
+    def _reduce_trigger(self):
+        """global rebuild vote: MIN over the ranks of the device-resident trigger word, on the stream."""
+        if self.world == 1:
+            return
+        trig = self.e.trigger
+        if self.transport == "direct":
+            self.dist.all_reduce(trig, op=self.dist.ReduceOp.MIN)
+        else:
+            h = trig.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN)
+            trig.copy_(h)
+
     def step(self, n):
-        """lammps_step(n) = "run n pre no post no" (library.cpp:372-386) on the decomposed domain."""
+        """lammps_step(n) = "run n pre no post no" (library.cpp:372-386) on the decomposed domain.
+
+        All n sub-steps (kernel + rebuild vote + forward halo each) are queued without the host waiting for any
+        of them: a sub-step whose index lies behind the all-reduced trigger exits early on every rank, the host
+        synchronises once per batch, rebuilds if the trigger fired and queues the rest."""
         if not self.is_setup:
             self.setup()
+        n = int(n)
         e = self.e
         e.run_begin()
-        for s in range(int(n)):
-            if self._allreduce_max(e.need_rebuild()):
-                self.rebuild()
-            else:
+        k = 0
+        while k < n:
+            for s in range(k, n):
+                self._reduce_trigger()
                 self.forward()
-            e.substep(s == n - 1)
+                e.substep_k(s == n - 1, s)
+            trig = e.batch_end(k, n - k)
+            if trig >= n:
+                break
+            k = trig + 1          # sub-steps k..trig ran (trig = -1: the list was stale for sub-step 0)
+            self.rebuild()
 
     def info(self):
         return self.e.info()
