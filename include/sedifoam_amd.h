@@ -154,6 +154,10 @@ long long sf_dem_border_pack(void *ptr, int side, double xshift, double *dev_buf
 int sf_dem_border_unpack(void *ptr, int side, const double *dev_buf, long long natoms);
 long long sf_dem_forward_pack(void *ptr, int side, double xshift, double *dev_buf);
 int sf_dem_forward_unpack(void *ptr, int side, const double *dev_buf, long long natoms);
+/* both faces in one launch each (per-sub-step path); unpack2 also refreshes the local y/z images */
+int sf_dem_forward_pack2(void *ptr, double shift0, double *buf0, double shift1, double *buf1, long long *n0,
+                         long long *n1);
+int sf_dem_forward_unpack2(void *ptr, const double *buf0, long long n0, const double *buf1, long long n1);
 long long sf_dem_migrate_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_doubles);
 int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
 int sf_dem_migrate_record_doubles(void *ptr);

@@ -107,6 +107,8 @@ _SIGS = {
     "sf_dem_border_unpack": (C.c_int, [vp, C.c_int, vp, C.c_longlong]),
     "sf_dem_forward_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp]),
     "sf_dem_forward_unpack": (C.c_int, [vp, C.c_int, vp, C.c_longlong]),
+    "sf_dem_forward_pack2": (C.c_int, [vp, C.c_double, vp, C.c_double, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "sf_dem_forward_unpack2": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_longlong]),
     "sf_dem_migrate_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp, C.c_longlong]),
     "sf_dem_migrate_unpack": (C.c_int, [vp, vp, C.c_longlong]),
     "sf_dem_migrate_record_doubles": (C.c_int, [vp]),

@@ -178,6 +178,8 @@ class DemEngine {
   void border_unpack(int side, const double* buf, long long natoms);
   long long forward_pack(int side, double xshift, double* buf);
   void forward_unpack(int side, const double* buf, long long natoms);
+  void forward_pack2(double shift0, double* buf0, double shift1, double* buf1, long long* n0, long long* n1);
+  void forward_unpack2(const double* buf0, long long n0, const double* buf1, long long n1);
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;
@@ -222,7 +224,9 @@ class DemEngine {
   DemPtrs ptrs(int in_buf) const;
   StepParams step_params(int mode, int kstep) const;
   void launch_substep(int in_buf, int mode, int kstep);
+public:
   void launch_ghost_forward(int buf, int kstep);
+private:
   void launch_initial_integrate();
   void rebuild();          // rebuild_begin + rebuild_sort + rebuild_finish
   void permute_locals(const int* perm, int n_new);

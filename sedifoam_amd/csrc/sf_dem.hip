@@ -918,7 +918,8 @@ void DemEngine::substep(bool last)
 void DemEngine::substep_k(bool last, int kstep)
 {
   launch_substep(cur_, last ? 1 : 0, kstep);
-  launch_ghost_forward(cur_ ^ 1, kstep);
+  // decomposed domain: the driver refreshes every ghost (received ones, then their local images) right after
+  if (!have_subdomain_) launch_ghost_forward(cur_ ^ 1, kstep);
   cur_ ^= 1;
 }
 

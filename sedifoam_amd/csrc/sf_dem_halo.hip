@@ -11,6 +11,7 @@
 // Packing/unpacking run as HIP kernels on device buffers; the transport between GPUs (RCCL send/recv over
 // xGMI) is done by the host driver, sedifoam_amd/halo.py.
 #include <algorithm>
+#include <climits>
 #include <vector>
 
 #include "sf_dem.h"
@@ -241,7 +242,79 @@ void DemEngine::forward_unpack(int side, const double* buf, long long natoms)
                                                           vm_[cur_].as<double4>(), om_[cur_].as<double4>());
 }
 
-void DemEngine::ghost_forward_local() { launch_ghost_forward(cur_, 0); }
+void DemEngine::ghost_forward_local() { launch_ghost_forward(cur_, INT_MIN); }
+
+// both faces in one launch each (the per-sub-step path of the multi-rank driver)
+__global__ __launch_bounds__(256) void k_forward_pack2(const int* list0, int n0, double shift0, double* buf0,
+                                                       const int* list1, int n1, double shift1, double* buf1,
+                                                       const double4* xr, const double4* vm, const double4* om)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int* list = list0;
+  double shift = shift0;
+  double* buf = buf0;
+  if (k >= n0) {
+    k -= n0;
+    if (k >= n1) return;
+    list = list1;
+    shift = shift1;
+    buf = buf1;
+  }
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double* b = buf + (size_t)k * kForwardDoubles;
+  b[0] = x.x + shift; b[1] = x.y; b[2] = x.z;
+  b[3] = v.x; b[4] = v.y; b[5] = v.z;
+  b[6] = w.x; b[7] = w.y; b[8] = w.z;
+}
+
+__global__ __launch_bounds__(256) void k_forward_unpack2(const double* buf0, int n0, int first0, const double* buf1,
+                                                         int n1, int first1, double4* xr, double4* vm, double4* om)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* buf = buf0;
+  int first = first0;
+  if (k >= n0) {
+    k -= n0;
+    if (k >= n1) return;
+    buf = buf1;
+    first = first1;
+  }
+  const double* b = buf + (size_t)k * kForwardDoubles;
+  const int g = first + k;
+  double4 x = xr[g], v = vm[g];
+  x.x = b[0]; x.y = b[1]; x.z = b[2];
+  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  xr[g] = x;
+  vm[g] = v;
+  om[g] = {b[6], b[7], b[8], 0.0};
+}
+
+void DemEngine::forward_pack2(double shift0, double* buf0, double shift1, double* buf1, long long* n0, long long* n1)
+{
+  *n0 = nsend_[0];
+  *n1 = nsend_[1];
+  const int tot = (int)(nsend_[0] + nsend_[1]);
+  if (tot)
+    k_forward_pack2<<<div_up(tot, 256), 256, 0, stream_>>>(sendlist_[0].as<int>(), (int)nsend_[0], shift0, buf0,
+                                                           sendlist_[1].as<int>(), (int)nsend_[1], shift1, buf1,
+                                                           xr_[cur_].as<double4>(), vm_[cur_].as<double4>(),
+                                                           om_[cur_].as<double4>());
+  if (!external_stream_) sync();
+}
+
+void DemEngine::forward_unpack2(const double* buf0, long long n0, const double* buf1, long long n1)
+{
+  if (n0 != recv_count_[0] || n1 != recv_count_[1])
+    fail("forward_unpack: got %lld/%lld ghosts, the border exchange set up %d/%d", n0, n1, recv_count_[0],
+         recv_count_[1]);
+  const int tot = (int)(n0 + n1);
+  if (tot)
+    k_forward_unpack2<<<div_up(tot, 256), 256, 0, stream_>>>(buf0, (int)n0, recv_first_[0], buf1, (int)n1,
+                                                             recv_first_[1], xr_[cur_].as<double4>(),
+                                                             vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+  launch_ghost_forward(cur_, INT_MIN);   // local y/z images of everything, received ghosts included
+}
 
 void DemEngine::migrate_set_slots(int mrec)
 {

@@ -575,6 +575,21 @@ int sf_dem_forward_unpack(void* ptr, int side, const double* dev_buf, long long 
   SF_API_END(0)
 }
 
+int sf_dem_forward_pack2(void* ptr, double shift0, double* buf0, double shift1, double* buf1, long long* n0,
+                         long long* n1)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.forward_pack2(shift0, buf0, shift1, buf1, n0, n1);
+  SF_API_END(0)
+}
+
+int sf_dem_forward_unpack2(void* ptr, const double* buf0, long long n0, const double* buf1, long long n1)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.forward_unpack2(buf0, n0, buf1, n1);
+  SF_API_END(0)
+}
+
 long long sf_dem_migrate_pack(void* ptr, int side, double xshift, double* dev_buf, long long max_doubles)
 {
   SF_API_BEGIN

@@ -107,6 +107,15 @@ class HipSlabEngine:
     def ghost_forward_local(self):
         self.check(self.L.sf_dem_ghost_forward_local(self.lmp.ptr))
 
+    def forward_pack2(self, shift0, buf0, shift1, buf1):
+        n0 = C.c_longlong(); n1 = C.c_longlong()
+        self.check(self.L.sf_dem_forward_pack2(self.lmp.ptr, shift0, buf0.data_ptr(), shift1, buf1.data_ptr(),
+                                               C.byref(n0), C.byref(n1)))
+        return n0.value, n1.value
+
+    def forward_unpack2(self, buf0, n0, buf1, n1):
+        self.check(self.L.sf_dem_forward_unpack2(self.lmp.ptr, buf0.data_ptr(), int(n0), buf1.data_ptr(), int(n1)))
+
 
 class SlabDriver:
     """lammps_step() for one slab of an x-decomposed domain.  All methods are collective over the ranks."""
@@ -249,13 +258,19 @@ class SlabDriver:
         e = self.e
         f0 = self._buf("fwd_l", self._nsend[0] * FORWARD_DOUBLES)
         f1 = self._buf("fwd_r", self._nsend[1] * FORWARD_DOUBLES)
-        a0 = e.forward_pack(0, self.shift_left, f0)
-        a1 = e.forward_pack(1, self.shift_right, f1)
+        if hasattr(e, "forward_pack2"):
+            a0, a1 = e.forward_pack2(self.shift_left, f0, self.shift_right, f1)
+        else:
+            a0 = e.forward_pack(0, self.shift_left, f0)
+            a1 = e.forward_pack(1, self.shift_right, f1)
         rl, ml, rr, mr = self._exchange(f0, a0 * FORWARD_DOUBLES, f1, a1 * FORWARD_DOUBLES,
                                         known=(self._nrecv[0] * FORWARD_DOUBLES, self._nrecv[1] * FORWARD_DOUBLES))
-        e.forward_unpack(0, rl, ml // FORWARD_DOUBLES)
-        e.forward_unpack(1, rr, mr // FORWARD_DOUBLES)
-        e.ghost_forward_local()
+        if hasattr(e, "forward_unpack2"):
+            e.forward_unpack2(rl, ml // FORWARD_DOUBLES, rr, mr // FORWARD_DOUBLES)
+        else:
+            e.forward_unpack(0, rl, ml // FORWARD_DOUBLES)
+            e.forward_unpack(1, rr, mr // FORWARD_DOUBLES)
+            e.ghost_forward_local()
 
     # ---- lammps_* surface ----
     def setup(self):
