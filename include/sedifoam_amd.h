@@ -231,6 +231,13 @@ typedef struct {
   double gravity[3];      /* cloudProperties: g */
   double rhob, nub;       /* transportProperties */
   double maxPossibleAlpha;
+  /* diffusion-based coarse graining (enhancedCloud::smoothField, enhancedCloud.C:790-907; keys read at
+   * :564-583 and createFields.H:126-149): band width b (tau = b^2/4), implicit steps, which fields, and the
+   * diagonal of smoothDirection.  diffusionBandWidth <= 0 or diffusionSteps <= 0: no smoothing. */
+  double diffusionBandWidth;
+  int diffusionSteps;
+  int UfSmooth, UpSmooth, dragSmooth, alphaSmooth;
+  double smoothDirection[3];
 } sf_cloud_props;
 /* uniform hex block mesh (blockMeshDict: hex (...) (nx ny nz) simpleGrading (1 1 1)) */
 typedef struct {
@@ -249,6 +256,8 @@ int sf_cloud_set_fluid(void *cloud, const double *Uf, const double *DDtUf, const
 int sf_cloud_evolve(void *cloud);
 /* enhancedCloud::calcTcFields()  enhancedCloud.C:316-441 */
 int sf_cloud_calc_tc_fields(void *cloud);
+/* stand-alone smoothField on a host field [ncells][ncomp] (ncomp 1 or 3), in place */
+int sf_cloud_smooth_field(void *cloud, double *field, int ncomp);
 /* accessors: gamma (alpha) [ncells], Ue [ncells][3], Asrc [ncells][3], Omega [ncells] to host */
 int sf_cloud_get_fields(void *cloud, double *gamma, double *Ue, double *Asrc, double *Omega);
 /* per-particle results of the last evolve sub-cycle in tag order (n = particle count):

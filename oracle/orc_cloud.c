@@ -15,6 +15,8 @@
  */
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
 #include "sedifoam_oracle.h"
 
 #define ROOTVSMALL 1.0e-150
@@ -214,4 +216,141 @@ int orc_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double
   *solidStepsPerDt = steps;
   *subCycles = sc;
   return 0;
+}
+
+/* ---- N1: enhancedCloud::smoothField  lammpsFoam/enhancedCloud.C:790-907 (setup :564-583) --------------------
+ * `diffusionSteps` implicit-Euler steps of d(phi)/dt = div(D grad phi) up to tau = b^2/4, zero-gradient
+ * boundaries, on one uniform hex block: each step solves (I - dtau L) phi_new = phi_old with the 7-point
+ * Laplacian ([3P]: what fvm::ddt - fvm::laplacian(DT, .) with "Gauss linear corrected" assembles on an orthogonal
+ * uniform mesh).  The reference uses PCG/DIC to 1e-10; here plain CG to 1e-15 (a different solver than the
+ * product's, same linear system). */
+typedef struct {
+  int n[3];
+  double c[3];
+} orc_stencil;
+
+static void apply_A(const orc_stencil *st, const double *v, double *out)
+{
+  int i, j, k;
+  const int sx = 1, sy = st->n[0], sz = st->n[0] * st->n[1];
+  for (k = 0; k < st->n[2]; k++)
+    for (j = 0; j < st->n[1]; j++)
+      for (i = 0; i < st->n[0]; i++) {
+        int c = i + st->n[0] * (j + st->n[1] * k);
+        double vc = v[c], acc = vc;
+        if (i > 0) acc += st->c[0] * (vc - v[c - sx]);
+        if (i < st->n[0] - 1) acc += st->c[0] * (vc - v[c + sx]);
+        if (j > 0) acc += st->c[1] * (vc - v[c - sy]);
+        if (j < st->n[1] - 1) acc += st->c[1] * (vc - v[c + sy]);
+        if (k > 0) acc += st->c[2] * (vc - v[c - sz]);
+        if (k < st->n[2] - 1) acc += st->c[2] * (vc - v[c + sz]);
+        out[c] = acc;
+      }
+}
+
+void orc_smooth_field(const int n[3], const double dx[3], const double D[3], double band, int steps, int ncomp,
+                      double *field)
+{
+  int nc = n[0] * n[1] * n[2], s, comp, c, it;
+  orc_stencil st;
+  if (!(band > 0.0) || steps <= 0) return;
+  double dtau = (band * band / 4.0) / (steps + 1.0e-150);         /* :564-565 */
+  for (c = 0; c < 3; c++) {
+    st.n[c] = n[c];
+    st.c[c] = dtau * D[c] / (dx[c] * dx[c]);
+  }
+  double *x = malloc(sizeof(double) * nc), *r = malloc(sizeof(double) * nc), *p = malloc(sizeof(double) * nc),
+         *ap = malloc(sizeof(double) * nc);
+  for (s = 0; s < steps; s++)
+    for (comp = 0; comp < ncomp; comp++) {
+      double rr = 0.0, bb = 0.0;
+      for (c = 0; c < nc; c++) x[c] = field[(size_t)c * ncomp + comp];
+      apply_A(&st, x, ap);
+      for (c = 0; c < nc; c++) {
+        r[c] = x[c] - ap[c];
+        p[c] = r[c];
+        rr += r[c] * r[c];
+        bb += x[c] * x[c];
+      }
+      for (it = 0; it < 5000 && rr > 1e-30 * bb; it++) {
+        double pap = 0.0, rrn = 0.0;
+        apply_A(&st, p, ap);
+        for (c = 0; c < nc; c++) pap += p[c] * ap[c];
+        double alpha = rr / pap;
+        for (c = 0; c < nc; c++) {
+          x[c] += alpha * p[c];
+          r[c] -= alpha * ap[c];
+          rrn += r[c] * r[c];
+        }
+        double beta = rrn / rr;
+        for (c = 0; c < nc; c++) p[c] = r[c] + beta * p[c];
+        rr = rrn;
+      }
+      for (c = 0; c < nc; c++) field[(size_t)c * ncomp + comp] = x[c];
+    }
+  free(x); free(r); free(p); free(ap);
+}
+
+/* particleToEulerianField with the smoothing branches (:944-962) */
+void orc_particle_to_eulerian_smooth(int n, const int *cell, const double *d, const double *U, int ncells,
+                                     const double *V, const orc_smooth *sm, double *gamma, double *Ue)
+{
+  int i, c, k;
+  for (c = 0; c < ncells; c++) {
+    gamma[c] = 0.0;
+    Ue[3 * c] = Ue[3 * c + 1] = Ue[3 * c + 2] = 0.0;
+  }
+  for (i = 0; i < n; i++) {
+    double Vol = FOAM_PI * d[i] * d[i] * d[i] / 6.0;
+    c = cell[i];
+    if (c < 0) continue;
+    gamma[c] += Vol;
+    for (k = 0; k < 3; k++) Ue[3 * c + k] += Vol * U[3 * i + k];
+  }
+  for (c = 0; c < ncells; c++) {
+    gamma[c] /= V[c];
+    for (k = 0; k < 3; k++) Ue[3 * c + k] /= V[c];
+  }
+  if (sm && sm->alphaSmooth) orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 1, gamma);
+  if (sm && sm->UpSmooth) orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 3, Ue);
+  for (c = 0; c < ncells; c++)
+    if (gamma[c] > ROOTVSMALL)
+      for (k = 0; k < 3; k++) Ue[3 * c + k] /= gamma[c];
+}
+
+/* UfSmoothed (:675-690) */
+void orc_uf_smoothed(int ncells, const double *Uf, const double *gamma, const orc_smooth *sm, double *UfS)
+{
+  int c, k;
+  memcpy(UfS, Uf, sizeof(double) * 3 * (size_t)ncells);
+  if (!sm || !sm->UfSmooth || !(sm->band > 0.0) || sm->steps <= 0) return;
+  for (c = 0; c < ncells; c++)
+    for (k = 0; k < 3; k++) UfS[3 * c + k] *= (1 - gamma[c]);
+  orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 3, UfS);
+  for (c = 0; c < ncells; c++)
+    for (k = 0; k < 3; k++) UfS[3 * c + k] /= (1 - gamma[c]);
+}
+
+/* calcTcFields with the smoothing branch (:407-416) */
+void orc_calc_tc_fields_smooth(int n, const int *cell, const double *d, const double *U, const double *Jd,
+                               int ncells, const double *V, const double *gamma, const double *UfSmoothed,
+                               const orc_smooth *sm, double *Asrc, double *Omega)
+{
+  int i, c, k;
+  for (c = 0; c < ncells; c++) {
+    Omega[c] = 0.0;
+    Asrc[3 * c] = Asrc[3 * c + 1] = Asrc[3 * c + 2] = 0.0;
+  }
+  for (i = 0; i < n; i++) {
+    c = cell[i];
+    if (c < 0) continue;
+    double Vol = FOAM_PI * d[i] * d[i] * d[i] / 6.0;
+    double omg = Vol * Jd[i] / V[c];
+    for (k = 0; k < 3; k++) Asrc[3 * c + k] += omg * (U[3 * i + k] - UfSmoothed[3 * c + k]);
+  }
+  for (c = 0; c < ncells; c++)
+    for (k = 0; k < 3; k++) Asrc[3 * c + k] = Asrc[3 * c + k] * (1 - gamma[c]);
+  if (sm && sm->dragSmooth) orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 3, Asrc);
+  for (c = 0; c < ncells; c++)
+    for (k = 0; k < 3; k++) Asrc[3 * c + k] /= (1 - gamma[c]);
 }

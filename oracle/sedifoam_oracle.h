@@ -213,6 +213,24 @@ void orc_calc_tc_fields(int n, const int *cell, const double *d, const double *U
                         const double *Jd, int ncells, const double *V, const double *gamma,
                         const double *UfSmoothed, double *Asrc, double *Omega);
 
+/* N1: enhancedCloud::smoothField  enhancedCloud.C:790-907 on a uniform hex block, and the three places the
+ * reference applies it (:675-690 UfSmoothed, :944-962 gamma / Ue, :407-416 Asrc) */
+typedef struct {
+  int n[3];
+  double dx[3], D[3];
+  double band;
+  int steps;
+  int UfSmooth, UpSmooth, dragSmooth, alphaSmooth;
+} orc_smooth;
+void orc_smooth_field(const int n[3], const double dx[3], const double D[3], double band, int steps, int ncomp,
+                      double *field);
+void orc_particle_to_eulerian_smooth(int n, const int *cell, const double *d, const double *U, int ncells,
+                                     const double *V, const orc_smooth *sm, double *gamma, double *Ue);
+void orc_uf_smoothed(int ncells, const double *Uf, const double *gamma, const orc_smooth *sm, double *UfS);
+void orc_calc_tc_fields_smooth(int n, const int *cell, const double *d, const double *U, const double *Jd,
+                               int ncells, const double *V, const double *gamma, const double *UfSmoothed,
+                               const orc_smooth *sm, double *Asrc, double *Omega);
+
 /* A10: adjustLampTimestep  softParticleCloud.C:209-261.  returns 0, or -1 (FatalError case) */
 int orc_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double *dtLampAdj,
                         int *solidStepsPerDt, int *subCycles, int *subSteps);

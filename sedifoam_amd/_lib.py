@@ -50,7 +50,10 @@ class CloudProps(C.Structure):
                 ("particlePressureGrad", C.c_int), ("particleBuoyancy", C.c_int),
                 ("particleAddedMass", C.c_int), ("particleLift", C.c_int),
                 ("lubricationForce", C.c_int), ("gravity", C.c_double * 3),
-                ("rhob", C.c_double), ("nub", C.c_double), ("maxPossibleAlpha", C.c_double)]
+                ("rhob", C.c_double), ("nub", C.c_double), ("maxPossibleAlpha", C.c_double),
+                ("diffusionBandWidth", C.c_double), ("diffusionSteps", C.c_int), ("UfSmooth", C.c_int),
+                ("UpSmooth", C.c_int), ("dragSmooth", C.c_int), ("alphaSmooth", C.c_int),
+                ("smoothDirection", C.c_double * 3)]
 
 
 class CloudMesh(C.Structure):
@@ -131,6 +134,7 @@ _SIGS = {
     "sf_cloud_set_fluid": (C.c_int, [vp, dp, dp, dp, dp]),
     "sf_cloud_evolve": (C.c_int, [vp]),
     "sf_cloud_calc_tc_fields": (C.c_int, [vp]),
+    "sf_cloud_smooth_field": (C.c_int, [vp, dp, C.c_int]),
     "sf_cloud_get_fields": (C.c_int, [vp, dp, dp, dp, dp]),
     "sf_cloud_get_particles": (C.c_int, [vp, ip, ip, dp, dp]),
     "sf_cloud_particle_count": (C.c_int, [vp]),

@@ -59,7 +59,8 @@ class enhancedCloud:
     """enhancedCloud(U, p, Ue, Uf, DDtUf, nu, alpha, cloudDict, transDict, ...) on a uniform hex block.
 
     cloudDict keys (constant/cloudProperties): dragModel, subCycles, particleDrag, particlePressureGrad,
-    particleBuoyancy, particleAddedMass, particleLift, lubricationForce, g, maxPossibleAlpha.
+    particleBuoyancy, particleAddedMass, particleLift, lubricationForce, g, maxPossibleAlpha, diffusionBandWidth,
+    diffusionSteps, UfSmooth, UpSmooth, dragSmooth, alphaSmooth, smoothDirection.
     transDict keys (constant/transportProperties): rhob, nub."""
 
     def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT):
@@ -83,6 +84,18 @@ class enhancedCloud:
         pr.rhob = float(transDict["rhob"])
         pr.nub = float(transDict["nub"])
         pr.maxPossibleAlpha = float(cloudDict.get("maxPossibleAlpha", 0.0))
+        pr.diffusionBandWidth = float(cloudDict.get("diffusionBandWidth", 0.0))
+        pr.diffusionSteps = int(cloudDict.get("diffusionSteps", 0))
+        pr.UfSmooth = int(cloudDict.get("UfSmooth", True))          # enhancedCloud.C:573-576
+        pr.UpSmooth = int(cloudDict.get("UpSmooth", True))
+        pr.dragSmooth = int(cloudDict.get("dragSmooth", True))
+        pr.alphaSmooth = int(cloudDict.get("alphaSmooth", True))
+        sd = cloudDict.get("smoothDirection", (1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0))   # :578-583 (tensor)
+        if len(sd) == 9:
+            if any(abs(sd[k]) > 0 for k in (1, 2, 3, 5, 6, 7)):
+                raise SfError("smoothDirection: only diagonal tensors are supported")
+            sd = (sd[0], sd[4], sd[8])
+        pr.smoothDirection = (C.c_double * 3)(*sd)
         m = _lib.CloudMesh()
         m.origin = (C.c_double * 3)(*mesh_origin)
         m.dx = (C.c_double * 3)(*mesh_dx)
@@ -106,6 +119,13 @@ class enhancedCloud:
     def setFluid(self, Uf=None, DDtUf=None, gradp=None, curlU=None):
         arrs = [None if a is None else _f64(a).reshape(self.ncells, 3) for a in (Uf, DDtUf, gradp, curlU)]
         check(self.L.sf_cloud_set_fluid(self.ptr, *[_p(a) for a in arrs]))
+
+    def smoothField(self, field):
+        """enhancedCloud::smoothField on a host array [ncells] or [ncells][3]; returns the smoothed copy."""
+        f = np.array(field, dtype=np.float64, order="C", copy=True)
+        ncomp = 1 if f.ndim == 1 else f.shape[1]
+        check(self.L.sf_cloud_smooth_field(self.ptr, _p(f.reshape(-1)), ncomp))
+        return f
 
     def evolve(self):
         check(self.L.sf_cloud_evolve(self.ptr))

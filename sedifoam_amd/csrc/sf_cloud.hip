@@ -17,6 +17,7 @@
 
 #include "../../include/sedifoam_amd.h"
 #include "sf_handles.h"
+#include "sf_smooth.h"
 
 namespace sf {
 
@@ -210,12 +211,7 @@ __global__ __launch_bounds__(256) void k_particle_to_eulerian(int ncells, const 
   u0 /= Vc;
   u1 /= Vc;
   u2 /= Vc;
-  if (g > kRootVSmall) {
-    u0 /= g;
-    u1 /= g;
-    u2 /= g;
-  }
-  gamma[c] = g;
+  gamma[c] = g;   // Ue /= gamma happens after the (optional) smoothing of both fields (:944-962)
   Ue[3 * c] = u0;
   Ue[3 * c + 1] = u1;
   Ue[3 * c + 2] = u2;
@@ -248,11 +244,35 @@ __global__ __launch_bounds__(256) void k_calc_tc(int ncells, const int* cstart, 
     a1 += omg * (v.y - uf[1]);
     a2 += omg * (v.z - uf[2]);
   }
+  // weighted by (1 - gamma) for the smoothing step (:407-408); k_unweight divides again (:415-416)
   const double w = 1 - alpha;
-  Asrc[3 * c] = a0 * w / w;
-  Asrc[3 * c + 1] = a1 * w / w;
-  Asrc[3 * c + 2] = a2 * w / w;
+  Asrc[3 * c] = a0 * w;
+  Asrc[3 * c + 1] = a1 * w;
+  Asrc[3 * c + 2] = a2 * w;
   Omega[c] = 0.0;
+}
+
+// Ue /= gamma where gamma > ROOTVSMALL (:955-962)
+__global__ __launch_bounds__(256) void k_divide_ue(int ncells, const double* gamma, double* Ue)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  const double g = gamma[c];
+  if (g > kRootVSmall)
+    for (int k = 0; k < 3; k++) Ue[3 * c + k] /= g;
+}
+
+// f *= (1 - gamma) (mode 0) or f /= (1 - gamma) (mode 1) on a vector field; mode 2: dst = src
+__global__ __launch_bounds__(256) void k_weight(int ncells, int mode, const double* gamma, double* f, const double* src)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  if (mode == 2) {
+    for (int k = 0; k < 3; k++) f[3 * c + k] = src[3 * c + k];
+    return;
+  }
+  const double w = 1 - gamma[c];
+  for (int k = 0; k < 3; k++) f[3 * c + k] = mode == 0 ? f[3 * c + k] * w : f[3 * c + k] / w;
 }
 
 __global__ __launch_bounds__(256) void k_cap_alpha(int ncells, double* gamma, double maxAlpha)
@@ -316,18 +336,21 @@ class Cloud {
     alloc(DDtUf_, 3 * nc);
     alloc(gradp_, 3 * nc);
     alloc(curlU_, 3 * nc);
+    alloc(UfS_, 3 * nc);
+    smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_);
     SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
     std::vector<double> hV(nc, mesh.dx[0] * mesh.dx[1] * mesh.dx[2]);
     SF_HIP(hipMemcpyAsync(V_, hV.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s_));
     SF_HIP(hipStreamSynchronize(s_));
     if (!e.is_setup()) e.setup();  // lammps_step(0) at construction, softParticleCloud.C:189
     particle_to_eulerian();        // enhancedCloud.C:635
+    update_uf_smoothed();          // :641-655
     SF_HIP(hipStreamSynchronize(s_));
   }
 
   ~Cloud()
   {
-    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_})
+    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_, UfS_})
       if (p) (void)hipFree(p);
     for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_})
       if (p) (void)hipFree(p);
@@ -347,7 +370,7 @@ class Cloud {
   {
     const double t0 = now();
     DemEngine& e = lmp_->eng;
-    // UfSmoothed_ = Uf_ (diffusion smoothing is the "next" row N1)
+    update_uf_smoothed();   // :675-690
     for (int k = 0; k < subCycles_; k++) {
       double t1 = now();
       drag_on_particles();
@@ -376,9 +399,11 @@ class Cloud {
       k_cap_alpha<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, gamma_, props_.maxPossibleAlpha);
     sort_by_cell(n);
     k_calc_tc<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_, cstart_ + mesh_.ncells + 1, idx2_,
-                                                         e.d_xr(), e.d_vm(), V_, gamma_, Uf_, props_.dragModel,
+                                                         e.d_xr(), e.d_vm(), V_, gamma_, UfS_, props_.dragModel,
                                                          props_.nub, props_.rhob, Asrc_, Omega_, e.d_tag(), Jd_,
                                                          maxtag_);
+    if (props_.dragSmooth) smoother_.smooth(Asrc_, 3);                                         // :410-413
+    k_weight<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, 1, gamma_, Asrc_, nullptr);   // :415-416
     t_.calcTc += sync_now() - t0;
   }
 
@@ -498,7 +523,7 @@ class Cloud {
     if (!n) return;
     ensure_particle_arrays();
     k_drag_on_particles<<<div_up(n, 256), 256, 0, s_>>>(n, e.capacity(), e.d_xr(), e.d_vm(), e.d_tag(), mesh_,
-                                                        flags(), gamma_, Uf_, gradp_, DDtUf_, curlU_, UOld_,
+                                                        flags(), gamma_, UfS_, gradp_, DDtUf_, curlU_, UOld_,
                                                         maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, pDragT_,
                                                         e.d_fdrag(), e.d_DuDt());
     first_drag_ = false;
@@ -526,7 +551,38 @@ class Cloud {
     k_particle_to_eulerian<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_,
                                                                       cstart_ + mesh_.ncells + 1, idx2_, e.d_xr(),
                                                                       e.d_vm(), V_, gamma_, Ue_);
+    if (props_.alphaSmooth) smoother_.smooth(gamma_, 1);   // :944-948
+    if (props_.UpSmooth) smoother_.smooth(Ue_, 3);         // :950-953
+    k_divide_ue<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, gamma_, Ue_);
   }
+
+  // UfSmoothed_ = Uf_ [ * (1 - gamma), smoothed, / (1 - gamma) ]   enhancedCloud.C:675-690
+  void update_uf_smoothed()
+  {
+    const int nb = div_up(mesh_.ncells, 256);
+    k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 2, gamma_, UfS_, Uf_);
+    if (props_.UfSmooth && smoother_.enabled()) {
+      k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 0, gamma_, UfS_, nullptr);
+      smoother_.smooth(UfS_, 3);
+      k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 1, gamma_, UfS_, nullptr);
+    }
+  }
+
+public:
+  void smooth_host_field(double* field, int ncomp)
+  {
+    if (ncomp != 1 && ncomp != 3) fail("smoothField: ncomp must be 1 or 3");
+    const size_t nb = sizeof(double) * (size_t)mesh_.ncells * ncomp;
+    double* d = nullptr;
+    SF_HIP(hipMalloc(&d, nb));
+    SF_HIP(hipMemcpyAsync(d, field, nb, hipMemcpyHostToDevice, s_));
+    smoother_.smooth(d, ncomp);
+    SF_HIP(hipMemcpyAsync(field, d, nb, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+    (void)hipFree(d);
+  }
+
+ private:
 
   SfLammps* lmp_;
   sf_cloud_props props_;
@@ -535,7 +591,8 @@ class Cloud {
   hipStream_t s_ = nullptr;
   int subCycles_ = 1, subSteps_ = 1;
   double *V_ = nullptr, *gamma_ = nullptr, *Ue_ = nullptr, *Asrc_ = nullptr, *Omega_ = nullptr;
-  double *Uf_ = nullptr, *DDtUf_ = nullptr, *gradp_ = nullptr, *curlU_ = nullptr;
+  double *Uf_ = nullptr, *DDtUf_ = nullptr, *gradp_ = nullptr, *curlU_ = nullptr, *UfS_ = nullptr;
+  DiffusionSmoother smoother_;
   double *Jd_ = nullptr, *UOld_ = nullptr, *pDragT_ = nullptr;   // by tag
   int *cstart_ = nullptr, *cell_ = nullptr, *idx_ = nullptr, *idx2_ = nullptr;
   unsigned *keys_ = nullptr, *keys2_ = nullptr;
@@ -585,6 +642,13 @@ int sf_cloud_calc_tc_fields(void* cloud)
 {
   SF_API_BEGIN
   static_cast<Cloud*>(cloud)->calc_tc_fields();
+  SF_API_END(0)
+}
+
+int sf_cloud_smooth_field(void* cloud, double* field, int ncomp)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->smooth_host_field(field, ncomp);
   SF_API_END(0)
 }
 

@@ -1,0 +1,37 @@
+// sf_smooth.h -- diffusion-based coarse graining of cell fields (SURVEY "next" row N1):
+//   enhancedCloud::smoothField  lammpsFoam/enhancedCloud.C:790-907, set up at :564-583
+// The reference integrates d(phi)/dt = div(D grad phi) from 0 to b^2/4 (b = diffusionBandWidth) in
+// `diffusionSteps` implicit-Euler steps with zero-gradient boundaries, each step one
+// `solve(fvm::ddt(phi) - fvm::laplacian(DT, phi))` by PCG (tolerance 1e-10, system/fvSolution: tempDiffScalar).
+// On the uniform hex block that is (I - dtau*L) phi_new = phi_old with the 7-point Laplacian; here it is solved
+// matrix-free by conjugate gradients on the GPU (HBM-bound stencil + deterministic two-stage reductions, all
+// scalars device-resident; the host looks at the residual every 8 iterations).
+#pragma once
+#include "sf_common.h"
+
+namespace sf {
+
+class DiffusionSmoother {
+ public:
+  DiffusionSmoother() = default;
+  ~DiffusionSmoother();
+  // n, dx: the hex block; D: diagonal of smoothDirection; band: diffusionBandWidth; steps: diffusionSteps
+  void configure(const int n[3], const double dx[3], const double D[3], double band, int steps, hipStream_t s);
+  bool enabled() const { return enabled_; }
+  // field: ncells*ncomp doubles, component-interleaved (AoS); smoothed in place
+  void smooth(double* field, int ncomp);
+  long long iterations() const { return iters_; }
+
+ private:
+  void solve_component(double* x, int stride);
+  bool enabled_ = false;
+  int n_[3] = {0, 0, 0};
+  int ncells_ = 0, steps_ = 0, nblocks_ = 0;
+  double c_[3] = {0, 0, 0};   // dtau * D_d / dx_d^2
+  hipStream_t s_ = nullptr;
+  double *r_ = nullptr, *p_ = nullptr, *ap_ = nullptr, *partial_ = nullptr, *scal_ = nullptr;
+  double* h_scal_ = nullptr;  // pinned
+  long long iters_ = 0;
+};
+
+}  // namespace sf

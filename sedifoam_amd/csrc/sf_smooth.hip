@@ -1,0 +1,197 @@
+// sf_smooth.hip -- see sf_smooth.h (enhancedCloud::smoothField, lammpsFoam/enhancedCloud.C:790-907).
+#include "sf_smooth.h"
+
+#include <cmath>
+
+namespace sf {
+
+struct Stencil {
+  int n[3];
+  double c[3];
+  int ncells;
+};
+
+// scalars on the device: [0] rr, [1] pAp, [2] alpha, [3] beta, [4] bb (rhs norm^2), [5] rr_new
+enum { S_RR = 0, S_PAP, S_ALPHA, S_BETA, S_BB, S_RRNEW, S_N = 8 };
+
+// (A v)_c with A = I - dtau*L, zero-gradient boundaries (a missing neighbour contributes nothing)
+__device__ __forceinline__ double apply_A(const Stencil& st, const double* v, int stride, int c)
+{
+  const int i = c % st.n[0], j = (c / st.n[0]) % st.n[1], k = c / (st.n[0] * st.n[1]);
+  const double vc = v[(size_t)c * stride];
+  double acc = vc;
+  const int sx = 1, sy = st.n[0], sz = st.n[0] * st.n[1];
+  if (i > 0) acc += st.c[0] * (vc - v[(size_t)(c - sx) * stride]);
+  if (i < st.n[0] - 1) acc += st.c[0] * (vc - v[(size_t)(c + sx) * stride]);
+  if (j > 0) acc += st.c[1] * (vc - v[(size_t)(c - sy) * stride]);
+  if (j < st.n[1] - 1) acc += st.c[1] * (vc - v[(size_t)(c + sy) * stride]);
+  if (k > 0) acc += st.c[2] * (vc - v[(size_t)(c - sz) * stride]);
+  if (k < st.n[2] - 1) acc += st.c[2] * (vc - v[(size_t)(c + sz) * stride]);
+  return acc;
+}
+
+// deterministic block sum: wave shuffles, then the first wave adds the per-wave results
+__device__ __forceinline__ double block_sum(double v)
+{
+  __shared__ double ws[4];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) ws[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = ws[0] + ws[1] + ws[2] + ws[3];
+  __syncthreads();
+  return t;
+}
+
+// x (the field, stride) holds the right-hand side b and is the initial guess: r = b - A b, p = r
+__global__ __launch_bounds__(256) void k_cg_init(Stencil st, const double* x, int stride, double* r, double* p,
+                                                 double* partial)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  double rr = 0.0, bb = 0.0;
+  if (c < st.ncells) {
+    const double b = x[(size_t)c * stride];
+    const double res = b - apply_A(st, x, stride, c);
+    r[c] = res;
+    p[c] = res;
+    rr = res * res;
+    bb = b * b;
+  }
+  const double s1 = block_sum(rr);
+  const double s2 = block_sum(bb);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s1;
+    partial[gridDim.x + blockIdx.x] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cg_ap(Stencil st, const double* p, double* ap, double* partial)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  double v = 0.0;
+  if (c < st.ncells) {
+    const double a = apply_A(st, p, 1, c);
+    ap[c] = a;
+    v = p[c] * a;
+  }
+  const double s = block_sum(v);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_cg_update(int ncells, const double* scal, double* x, int stride, double* r,
+                                                   const double* p, const double* ap, double* partial)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const double alpha = scal[S_ALPHA];
+  double v = 0.0;
+  if (c < ncells) {
+    x[(size_t)c * stride] += alpha * p[c];
+    const double res = r[c] - alpha * ap[c];
+    r[c] = res;
+    v = res * res;
+  }
+  const double s = block_sum(v);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_cg_p(int ncells, const double* scal, const double* r, double* p)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncells) p[c] = r[c] + scal[S_BETA] * p[c];
+}
+
+// one workgroup adds the per-block partial sums in a fixed order and derives the CG scalars
+// mode 0: init (rr, bb) ; 1: pAp -> alpha ; 2: rr_new -> beta, rr = rr_new
+__global__ __launch_bounds__(256) void k_cg_scalars(int mode, int nblocks, const double* partial, double* scal)
+{
+  double v = 0.0, v2 = 0.0;
+  for (int k = threadIdx.x; k < nblocks; k += blockDim.x) {
+    v += partial[k];
+    if (mode == 0) v2 += partial[nblocks + k];
+  }
+  const double s = block_sum(v);
+  const double s2 = (mode == 0) ? block_sum(v2) : 0.0;
+  if (threadIdx.x == 0) {
+    if (mode == 0) {
+      scal[S_RR] = s;
+      scal[S_BB] = s2;
+      scal[S_RRNEW] = s;
+    } else if (mode == 1) {
+      scal[S_PAP] = s;
+      scal[S_ALPHA] = (s != 0.0) ? scal[S_RR] / s : 0.0;
+    } else {
+      scal[S_RRNEW] = s;
+      scal[S_BETA] = (scal[S_RR] != 0.0) ? s / scal[S_RR] : 0.0;
+      scal[S_RR] = s;
+    }
+  }
+}
+
+DiffusionSmoother::~DiffusionSmoother()
+{
+  for (double* q : {r_, p_, ap_, partial_, scal_})
+    if (q) (void)hipFree(q);
+  if (h_scal_) (void)hipHostFree(h_scal_);
+}
+
+void DiffusionSmoother::configure(const int n[3], const double dx[3], const double D[3], double band, int steps,
+                                  hipStream_t s)
+{
+  s_ = s;
+  enabled_ = band > 0.0 && steps > 0;
+  if (!enabled_) return;
+  ncells_ = n[0] * n[1] * n[2];
+  steps_ = steps;
+  const double tau = band * band / 4.0;            // enhancedCloud.C:564
+  const double dtau = tau / (steps + 1.0e-150);    // :565 (diffusionSteps + ROOTVSMALL)
+  for (int k = 0; k < 3; k++) {
+    n_[k] = n[k];
+    c_[k] = dtau * D[k] / (dx[k] * dx[k]);
+  }
+  nblocks_ = div_up(ncells_, 256);
+  SF_HIP(hipMalloc(&r_, sizeof(double) * ncells_));
+  SF_HIP(hipMalloc(&p_, sizeof(double) * ncells_));
+  SF_HIP(hipMalloc(&ap_, sizeof(double) * ncells_));
+  SF_HIP(hipMalloc(&partial_, sizeof(double) * 2 * nblocks_));
+  SF_HIP(hipMalloc(&scal_, sizeof(double) * S_N));
+  SF_HIP(hipHostMalloc(&h_scal_, sizeof(double) * S_N));
+}
+
+void DiffusionSmoother::solve_component(double* x, int stride)
+{
+  Stencil st;
+  for (int k = 0; k < 3; k++) {
+    st.n[k] = n_[k];
+    st.c[k] = c_[k];
+  }
+  st.ncells = ncells_;
+  const dim3 grid(nblocks_);
+  k_cg_init<<<grid, 256, 0, s_>>>(st, x, stride, r_, p_, partial_);
+  k_cg_scalars<<<1, 256, 0, s_>>>(0, nblocks_, partial_, scal_);
+  const double tol2 = 1.0e-26;   // ||r||^2 <= 1e-26 ||b||^2 : far below the reference's PCG tolerance of 1e-10
+  for (int it = 0; it < 2000; it++) {
+    if ((it & 7) == 0) {
+      SF_HIP(hipMemcpyAsync(h_scal_, scal_, sizeof(double) * S_N, hipMemcpyDeviceToHost, s_));
+      SF_HIP(hipStreamSynchronize(s_));
+      if (!(h_scal_[S_RRNEW] > tol2 * h_scal_[S_BB])) return;   // also leaves on an all-zero field
+    }
+    k_cg_ap<<<grid, 256, 0, s_>>>(st, p_, ap_, partial_);
+    k_cg_scalars<<<1, 256, 0, s_>>>(1, nblocks_, partial_, scal_);
+    k_cg_update<<<grid, 256, 0, s_>>>(ncells_, scal_, x, stride, r_, p_, ap_, partial_);
+    k_cg_scalars<<<1, 256, 0, s_>>>(2, nblocks_, partial_, scal_);
+    k_cg_p<<<grid, 256, 0, s_>>>(ncells_, scal_, r_, p_);
+    iters_++;
+  }
+  fail("smoothField: conjugate gradients did not converge in 2000 iterations");
+}
+
+void DiffusionSmoother::smooth(double* field, int ncomp)
+{
+  if (!enabled_) return;
+  for (int step = 0; step < steps_; step++)       // while (diffusionRunTime_.loop()) :825-838
+    for (int k = 0; k < ncomp; k++) solve_component(field + k, ncomp);
+  SF_HIP(hipGetLastError());
+}
+
+}  // namespace sf

@@ -193,3 +193,24 @@ def test_fix_fdrag_added_mass_and_mistyped_pi():
     assert f[0, 0] == pytest.approx(1e-6 + 1000.0 / rho_p * 0.5 * m * (5.0 - acc), rel=1e-14)
     assert f[0, 1] == pytest.approx(2e-6, rel=1e-14) and vOld[0, 0] == 0.2
     assert rho_p != 3.0 * m / (4.0 * np.pi * r ** 3)        # the typo is preserved (2e-13 relative)
+
+
+def test_smooth_field_neumann_eigenmode():
+    """orc_smooth_field (enhancedCloud.C:790-907): cos(pi*m*(i+1/2)/n) is an eigenvector of the zero-gradient
+    7-point Laplacian, so `steps` implicit-Euler steps to tau = b^2/4 scale it by (1 - dtau*lambda)^-steps."""
+    n = np.array([16, 5, 3], np.int32); dx = np.array([1e-3, 2e-3, 3e-3]); D = np.array([1.0, 0.5, 2.0])
+    band, steps, m = 4e-3, 3, 2
+    i = np.arange(n[0])
+    mode = np.cos(np.pi * m * (i + 0.5) / n[0])
+    f = np.tile(mode, n[1] * n[2]) + 0.75                 # x fastest; the constant is the lambda = 0 mode
+    f0 = f.copy()
+    L = ob.lib()
+    L.orc_smooth_field(ob.P(n), ob.P(dx), ob.P(D), band, steps, 1, ob.P(f))
+    dtau = band ** 2 / 4.0 / steps
+    lam = -(2.0 - 2.0 * np.cos(np.pi * m / n[0])) * D[0] / dx[0] ** 2
+    want = 0.75 + (f0 - 0.75) * (1.0 - dtau * lam) ** (-steps)
+    assert np.max(np.abs(f - want)) < 1e-13
+    # band width 0 / zero steps: untouched (diffusionRunTime_ never loops)
+    g = f0.copy()
+    L.orc_smooth_field(ob.P(n), ob.P(dx), ob.P(D), 0.0, steps, 1, ob.P(g))
+    assert np.array_equal(g, f0)
