@@ -158,6 +158,15 @@ int sf_dem_forward_unpack(void *ptr, int side, const double *dev_buf, long long 
 int sf_dem_forward_pack2(void *ptr, double shift0, double *buf0, double shift1, double *buf1, long long *n0,
                          long long *n1);
 int sf_dem_forward_unpack2(void *ptr, const double *buf0, long long n0, const double *buf1, long long n1);
+/* One all-to-all per sub-step instead of a P2P halo plus an all-reduce: the send buffer holds, per peer rank, one
+ * header double (this rank's rebuild trigger) at dev_hdr_off[peer] followed by the forward records for that peer
+ * (left-going records at off0, right-going ones at off1, offsets in doubles).  The unpack side takes the MIN of the
+ * nhdr received headers into the device trigger word and refreshes the ghosts that came from the left / right. */
+int sf_dem_forward_pack_fused(void *ptr, double shift0, long long off0, double shift1, long long off1,
+                              const int *dev_hdr_off, int nhdr, double *dev_sendbuf);
+int sf_dem_forward_unpack_fused(void *ptr, const double *dev_recvbuf, long long off_from_left,
+                                long long n_from_left, long long off_from_right, long long n_from_right,
+                                const int *dev_hdr_off, int nhdr);
 long long sf_dem_migrate_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_doubles);
 int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
 int sf_dem_migrate_record_doubles(void *ptr);

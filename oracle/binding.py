@@ -392,3 +392,18 @@ class OracleSlabEngine:
 
     def ghost_forward_local(self):
         self.L.orc_dem_ghost_forward_local(self.h)
+
+    # the one-collective forward halo of the driver (header = rebuild trigger, then the records), on CPU tensors
+    def index_table(self, values):
+        return self.torch.tensor(list(values), dtype=self.torch.int32)
+
+    def forward_pack_fused(self, shift0, off0, shift1, off1, hdr_off, sendbuf):
+        sendbuf[hdr_off.long()] = float(int(self._trigger[0]))
+        self.forward_pack(0, shift0, sendbuf[int(off0):])
+        self.forward_pack(1, shift1, sendbuf[int(off1):])
+
+    def forward_unpack_fused(self, recvbuf, off_l, n_l, off_r, n_r, hdr_off):
+        self._trigger[0] = min(int(self._trigger[0]), int(recvbuf[hdr_off.long()].min().item()))
+        self.forward_unpack(0, recvbuf[int(off_l):], n_l)
+        self.forward_unpack(1, recvbuf[int(off_r):], n_r)
+        self.ghost_forward_local()

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsedifoam_amd.so")
+# SF_LIB_PATH: development knob to A/B a differently compiled build of the same library (tests/build_variant.sh)
+LIB_PATH = os.environ.get("SF_LIB_PATH") or os.path.join(HERE, "libsedifoam_amd.so")
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
@@ -112,6 +113,9 @@ _SIGS = {
     "sf_dem_forward_unpack": (C.c_int, [vp, C.c_int, vp, C.c_longlong]),
     "sf_dem_forward_pack2": (C.c_int, [vp, C.c_double, vp, C.c_double, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sf_dem_forward_unpack2": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_longlong]),
+    "sf_dem_forward_pack_fused": (C.c_int, [vp, C.c_double, C.c_longlong, C.c_double, C.c_longlong, vp, C.c_int, vp]),
+    "sf_dem_forward_unpack_fused": (C.c_int, [vp, vp, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, vp,
+                                              C.c_int]),
     "sf_dem_migrate_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp, C.c_longlong]),
     "sf_dem_migrate_unpack": (C.c_int, [vp, vp, C.c_longlong]),
     "sf_dem_migrate_record_doubles": (C.c_int, [vp]),

@@ -102,11 +102,18 @@ struct BinGrid {
   int nbins;       // key space: tiles * tile^3 (>= n[0]*n[1]*n[2])
   int tile;        // bins are numbered tile by tile (tile x tile x tile bins) so that particles that are
   int nt[3];       // close in space are close in memory in all three directions; tile <= 1: plain x-fastest
+  int rowtile;     // > 1: whole x-rows of cells, bundled rowtile x rowtile in (y, z): consecutive rows in memory
+                   // are neighbours in y AND z (lane-contiguous gathers stay contiguous along x)
 };
 
 // bin coordinates -> sort key / cell index
 __host__ __device__ __forceinline__ int bin_key(const BinGrid& g, int cx, int cy, int cz)
 {
+  if (g.rowtile > 1) {
+    const int R = g.rowtile;
+    const int ty = cy / R, tz = cz / R;
+    return cx + g.n[0] * ((cy - ty * R) + R * ((cz - tz * R) + R * (ty + g.nt[1] * tz)));
+  }
   if (g.tile <= 1) return cx + g.n[0] * (cy + g.n[1] * cz);
   const int T = g.tile;
   const int tx = cx / T, ty = cy / T, tz = cz / T;
@@ -180,6 +187,10 @@ class DemEngine {
   void forward_unpack(int side, const double* buf, long long natoms);
   void forward_pack2(double shift0, double* buf0, double shift1, double* buf1, long long* n0, long long* n1);
   void forward_unpack2(const double* buf0, long long n0, const double* buf1, long long n1);
+  void forward_pack_fused(double shift0, long long off0, double shift1, long long off1, const int* hdr_off, int nhdr,
+                          double* sendbuf);
+  void forward_unpack_fused(const double* recvbuf, long long off0, long long n0, long long off1, long long n1,
+                            const int* hdr_off, int nhdr);
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;
@@ -260,7 +271,7 @@ private:
   int rank_ = 0, nranks_ = 1;
   double sublo_x_ = 0.0, subhi_x_ = 1.0;
   bool have_subdomain_ = false;   // true: the x halo is external (driven through sf_dem_border_* etc.)
-  int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_occ_ = 0, opt_sub_ = 2;   // SF_SUB: cells per cutoff length; SF_TILE / SF_XCD_REMAP / SF_LDS overrides (LDS staging: see DESIGN.md, measured slower so far)   // SF_TILE / SF_XCD_REMAP environment overrides
+  int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_occ_ = 0, opt_sub_ = 2, opt_rowtile_ = 0;   // SF_SUB: cells per cutoff length; SF_TILE / SF_XCD_REMAP / SF_LDS overrides (LDS staging: see DESIGN.md, measured slower so far)   // SF_TILE / SF_XCD_REMAP environment overrides
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;
   DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x

@@ -95,6 +95,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
+  if (const char* e = getenv("SF_ROWTILE")) opt_rowtile_ = atoi(e);
   if (const char* e = getenv("SF_OCC")) opt_occ_ = atoi(e);
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   memset(&gran_, 0, sizeof(gran_));
@@ -460,7 +461,8 @@ static void launch_lds_one(dim3 grid, size_t lds, hipStream_t s, const DemPtrs& 
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     granted = 160 * 1024;
   }
-  k_substep_lds<STYLE, COHE, LUB><<<grid, 256, lds, s>>>(P, S);
+  static const int threads = getenv("SF_LDS_THREADS") ? atoi(getenv("SF_LDS_THREADS")) : 256;
+  k_substep_lds<STYLE, COHE, LUB><<<grid, threads, lds, s>>>(P, S);
 }
 
 template <int STYLE>
@@ -585,10 +587,18 @@ void DemEngine::compute_grid()
   }
   grid_.stencil = opt_sub_;
   grid_.tile = opt_tile_ > 1 ? opt_tile_ * opt_sub_ : 1;   // tiles keep their physical size
+  grid_.rowtile = (grid_.tile <= 1 && opt_rowtile_ > 1) ? opt_rowtile_ * opt_sub_ : 0;
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
     grid_.nt[k] = (grid_.n[k] + grid_.tile - 1) / grid_.tile;
     grid_.nbins *= grid_.nt[k] * grid_.tile;
+  }
+  if (grid_.rowtile > 1) {
+    const int R = grid_.rowtile;
+    grid_.nt[0] = 1;
+    grid_.nt[1] = (grid_.n[1] + R - 1) / R;
+    grid_.nt[2] = (grid_.n[2] + R - 1) / R;
+    grid_.nbins = grid_.n[0] * grid_.nt[1] * R * grid_.nt[2] * R;
   }
   if ((size_t)grid_.nbins > cell_alloc_) {
     if (cell_start_) SF_HIP(hipFree(cell_start_));

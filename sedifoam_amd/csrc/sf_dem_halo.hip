@@ -290,6 +290,92 @@ __global__ __launch_bounds__(256) void k_forward_unpack2(const double* buf0, int
   om[g] = {b[6], b[7], b[8], 0.0};
 }
 
+// Fused forward halo for ONE all-to-all per sub-step: the send buffer holds, for every peer rank, a header word
+// (this rank's rebuild trigger, as a double) followed by the halo records meant for that peer, so the same
+// exchange carries the ghosts and the global rebuild vote (MIN over the headers on the receiving side).
+__global__ __launch_bounds__(256) void k_forward_pack_fused(const int* list0, int n0, double shift0, double* buf0,
+                                                            const int* list1, int n1, double shift1, double* buf1,
+                                                            const int* hdr_off, int nhdr, double* sendbuf,
+                                                            const int* flags, const double4* xr, const double4* vm,
+                                                            const double4* om)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int* list = list0;
+  double shift = shift0;
+  double* buf = buf0;
+  if (k >= n0) {
+    k -= n0;
+    if (k >= n1) {
+      k -= n1;
+      if (k < nhdr) sendbuf[hdr_off[k]] = (double)flags[F_TRIGGER];
+      return;
+    }
+    list = list1;
+    shift = shift1;
+    buf = buf1;
+  }
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double* b = buf + (size_t)k * kForwardDoubles;
+  b[0] = x.x + shift; b[1] = x.y; b[2] = x.z;
+  b[3] = v.x; b[4] = v.y; b[5] = v.z;
+  b[6] = w.x; b[7] = w.y; b[8] = w.z;
+}
+
+__global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0, int n0, int first0,
+                                                              const double* buf1, int n1, int first1,
+                                                              const int* hdr_off, int nhdr, const double* recvbuf,
+                                                              int* flags, double4* xr, double4* vm, double4* om)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* buf = buf0;
+  int first = first0;
+  if (k >= n0) {
+    k -= n0;
+    if (k >= n1) {
+      k -= n1;
+      if (k < nhdr) atomicMin(&flags[F_TRIGGER], (int)recvbuf[hdr_off[k]]);
+      return;
+    }
+    buf = buf1;
+    first = first1;
+  }
+  const double* b = buf + (size_t)k * kForwardDoubles;
+  const int g = first + k;
+  double4 x = xr[g], v = vm[g];
+  x.x = b[0]; x.y = b[1]; x.z = b[2];
+  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  xr[g] = x;
+  vm[g] = v;
+  om[g] = {b[6], b[7], b[8], 0.0};
+}
+
+void DemEngine::forward_pack_fused(double shift0, long long off0, double shift1, long long off1, const int* hdr_off,
+                                   int nhdr, double* sendbuf)
+{
+  const int tot = (int)(nsend_[0] + nsend_[1]) + nhdr;
+  if (tot)
+    k_forward_pack_fused<<<div_up(tot, 256), 256, 0, stream_>>>(
+        sendlist_[0].as<int>(), (int)nsend_[0], shift0, sendbuf + off0, sendlist_[1].as<int>(), (int)nsend_[1],
+        shift1, sendbuf + off1, hdr_off, nhdr, sendbuf, d_flags_, xr_[cur_].as<double4>(),
+        vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+  if (!external_stream_) sync();
+}
+
+void DemEngine::forward_unpack_fused(const double* recvbuf, long long off0, long long n0, long long off1,
+                                     long long n1, const int* hdr_off, int nhdr)
+{
+  if (n0 != recv_count_[0] || n1 != recv_count_[1])
+    fail("forward_unpack: got %lld/%lld ghosts, the border exchange set up %d/%d", n0, n1, recv_count_[0],
+         recv_count_[1]);
+  const int tot = (int)(n0 + n1) + nhdr;
+  if (tot)
+    k_forward_unpack_fused<<<div_up(tot, 256), 256, 0, stream_>>>(
+        recvbuf + off0, (int)n0, recv_first_[0], recvbuf + off1, (int)n1, recv_first_[1], hdr_off, nhdr, recvbuf,
+        d_flags_, xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+  launch_ghost_forward(cur_, INT_MIN);   // local y/z images of everything, received ghosts included
+}
+
 void DemEngine::forward_pack2(double shift0, double* buf0, double shift1, double* buf1, long long* n0, long long* n1)
 {
   *n0 = nsend_[0];

@@ -10,9 +10,58 @@
 
 #include "sf_dem.h"
 
+#ifndef SF_UNROLL2
+#define SF_UNROLL2 1
+#endif
+
 namespace sf {
 
 __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
+
+// Streamed (read-once / write-once per sub-step) rows.  SF_NT=1 marks them non-temporal so that they do not
+// evict the neighbour records the gathers want to find again in the 32 KB vector L1.
+#ifndef SF_NT
+#define SF_NT 1
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p)
+{
+#if SF_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, T v)
+{
+#if SF_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ double4 ld_stream4(const double4* p)
+{
+#if SF_NT
+  const double* q = reinterpret_cast<const double*>(p);
+  typedef double d4v __attribute__((ext_vector_type(4)));
+  const d4v v = __builtin_nontemporal_load(reinterpret_cast<const d4v*>(q));
+  return {v.x, v.y, v.z, v.w};
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream4(double4* p, double4 v)
+{
+#if SF_NT
+  typedef double d4v __attribute__((ext_vector_type(4)));
+  d4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<d4v*>(p));
+#else
+  *p = v;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // fused DEM sub-step
@@ -26,14 +75,14 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
 
-  const double4 xi4 = P.xr_in[i];
+  const double4 xi4 = P.xr_in[i];   // also a gather target of the neighbours: keep it cached
   const double4 vi4 = P.vm_in[i];
   const double4 wi4 = P.om_in[i];
   const Vec3 xi = v3(xi4), vi = v3(vi4), wi = v3(wi4);
   const double radi = xi4.w, mi = vi4.w;
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
-  const int nn = P.numneigh[i];
+  const int nn = ld_stream(&P.numneigh[i]);
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
@@ -43,54 +92,51 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // retires in order, so the contact law only waits for them and the prefetch stays in flight.  Measured at 1 M
   // atoms: 249 -> 224 us.  Prefetching the shear history as well costs 10 VGPRs (3 waves/SIMD) and loses 10 %.
   constexpr bool NEED_VW = (STYLE != 0) || LUB;
-  int jraw_n1 = nn > 0 ? P.neigh[i] : 0;
-  int jraw_n2 = nn > 1 ? P.neigh[cap + i] : 0;
-  double4 xn4 = {0, 0, 0, 0}, vn4 = {0, 0, 0, 0}, wn4 = {0, 0, 0, 0};
-  int ln1 = 0;
-  if (nn > 0) {
+  struct Rec {
+    double4 x, v, w;
+    int l;   // LDS: position of the neighbour in the staged tile
+  };
+  // request the records of the neighbour in `slot` (global gather), or its LDS position
+  auto fetch = [&](int jraw, size_t slot, Rec& R) {
     if (LDS) {
-      ln1 = P.nloc[i];
+      R.l = P.nloc[slot];
     } else {
-      const int j0 = jraw_n1 & kNeighMask;
-      xn4 = P.xr_in[j0];
+      const int j = jraw & kNeighMask;
+      R.x = P.xr_in[j];
       if (NEED_VW) {
-        vn4 = P.vm_in[j0];
-        wn4 = P.om_in[j0];
+        R.v = P.vm_in[j];
+        R.w = P.om_in[j];
       }
     }
-  }
-  for (int s = 0; s < nn; s++) {
+  };
+  int jraw_n1 = nn > 0 ? ld_stream(&P.neigh[i]) : 0;
+  int jraw_n2 = nn > 1 ? ld_stream(&P.neigh[cap + i]) : 0;
+  Rec RA, RB;
+  RA.x = RA.v = RA.w = RB.x = RB.v = RB.w = double4{0, 0, 0, 0};
+  RA.l = RB.l = 0;
+  if (nn > 0) fetch(jraw_n1, (size_t)i, RA);
+
+  // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
+  auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more) {
     const size_t slot = (size_t)s * cap + i;
     const size_t sbase = (size_t)(3 * s) * cap + i;
     const int jraw = jraw_n1;
     const int j = jraw & kNeighMask;
-    double4 xj4 = xn4, vj4 = vn4, wj4 = wn4;
-    const int jl = ln1;   // LDS slot of the neighbour (staged tile)
     Vec3 sh = {0.0, 0.0, 0.0};
     if (STYLE != 0 && (jraw & kTouchBit)) {
-      sh.x = P.shear[sbase];
-      sh.y = P.shear[sbase + cap];
-      sh.z = P.shear[sbase + 2 * cap];
+      sh.x = ld_stream(&P.shear[sbase]);
+      sh.y = ld_stream(&P.shear[sbase + cap]);
+      sh.z = ld_stream(&P.shear[sbase + 2 * cap]);
     }
     jraw_n1 = jraw_n2;
-    if (s + 2 < nn) jraw_n2 = P.neigh[slot + 2 * cap];
-    if (s + 1 < nn) {
-      if (LDS) {
-        ln1 = P.nloc[slot + cap];
-      } else {
-        const int j1 = jraw_n1 & kNeighMask;
-        xn4 = P.xr_in[j1];
-        if (NEED_VW) {
-          vn4 = P.vm_in[j1];
-          wn4 = P.om_in[j1];
-        }
-      }
-    }
+    if (s + 2 < nn) jraw_n2 = ld_stream(&P.neigh[slot + 2 * cap]);
+    if (more) fetch(jraw_n1, slot + cap, nxt);
+    double4 xj4 = cur.x, vj4 = cur.v, wj4 = cur.w;
     if (LDS) {
-      xj4 = lx[jl];
+      xj4 = lx[cur.l];
       if (NEED_VW) {
-        vj4 = lv[jl];
-        wj4 = {lw[3 * jl], lw[3 * jl + 1], lw[3 * jl + 2], 0.0};
+        vj4 = lv[cur.l];
+        wj4 = {lw[3 * cur.l], lw[3 * cur.l + 1], lw[3 * cur.l + 2], 0.0};
       }
     }
     const Vec3 del = xi - v3(xj4);
@@ -106,19 +152,26 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         ContactIn c;
         c.del = del;
         c.rsq = rsq;
-        c.r = sqrt(rsq);
-        c.rinv = 1.0 / c.r;
+        sf_sqrt_rsqrt(rsq, c.r, c.rinv);
         c.vr = vi - v3(vj4);
         c.wsum = {radi * wi.x + radj * wj4.x, radi * wi.y + radj * wj4.y, radi * wi.z + radj * wj4.z};
         const double mj = vj4.w;
-        c.meff = mi * mj / (mi + mj);
         c.overlap = radsum - c.r;
+#if SF_FAST_MATH
+        // meff = mi mj/(mi+mj) and reff = overlap radi radj/radsum share one reciprocal
+        const double msum = mi + mj;
+        const double inv = sf_rcp(msum * radsum);
+        c.meff = (mi * mj) * (radsum * inv);
+        c.reff = c.overlap * ((radi * radj) * (msum * inv));
+#else
+        c.meff = mi * mj / (mi + mj);
         c.reff = (radsum - c.r) * radi * radj / radsum;
+#endif
         ContactOut o;
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
-        P.shear[sbase] = sh.x;
-        P.shear[sbase + cap] = sh.y;
-        P.shear[sbase + 2 * cap] = sh.z;
+        st_stream(&P.shear[sbase], sh.x);
+        st_stream(&P.shear[sbase + cap], sh.y);
+        st_stream(&P.shear[sbase + 2 * cap], sh.z);
         if (!(jraw & kTouchBit)) P.neigh[slot] = j | kTouchBit;
         F = F + o.F;
         T = T - radi * o.tor;
@@ -138,7 +191,21 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         lubricate_poly_pair(S.lub, del, rsq, radi, radj, vi, v3(vj4), wi, v3(wj4), F, T);
       }
     }
+  };
+  // unrolled by two so that the prefetch ping-pongs between RA and RB without register copies
+  int s = 0;
+#if SF_UNROLL2
+  for (; s + 1 < nn; s += 2) {
+    slot_body(s, RA, RB, true);
+    slot_body(s + 1, RB, RA, s + 2 < nn);
   }
+  if (s < nn) slot_body(s, RA, RB, false);
+#else
+  for (; s < nn; s++) {
+    slot_body(s, RA, RB, s + 1 < nn);
+    RA = RB;
+  }
+#endif
   if (LUB) {
     if (S.lub.flagfld) {  // isotropic FLD terms, pair_lubricate_poly.cpp:213-220
       const double a = S.lub.vxmu2f * S.lub.R0 * radi;
@@ -217,7 +284,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       vn = vn + dtfm * F;
       xn = xn + S.dt * vn;
       wn = wn + dtirot * T;
-      const double dx = xn.x - P.xhold[i], dy = xn.y - P.xhold[cap + i], dz = xn.z - P.xhold[2 * cap + i];
+      const double dx = xn.x - ld_stream(&P.xhold[i]), dy = xn.y - ld_stream(&P.xhold[cap + i]),
+                   dz = xn.z - ld_stream(&P.xhold[2 * cap + i]);
       if (dx * dx + dy * dy + dz * dz > S.trigger_sq) atomicMin(&P.flags[F_TRIGGER], S.kstep);
     }
   }
@@ -230,8 +298,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
 }
 
+#ifdef SF_WAVES_PER_EU
+#define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu(SF_WAVES_PER_EU, SF_WAVES_PER_EU)))
+#else
+#define SF_SUBSTEP_ATTR
+#endif
 template <int STYLE, bool COHE, bool LUB>
-__global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
+__global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
@@ -256,7 +329,7 @@ __global__ __launch_bounds__(256) void k_substep(DemPtrs P, StepParams S)
 // the vector-memory address pipe of a CU in k_substep.  nloc[slot][i] is the neighbour's position in that
 // staged copy, written when the list is built.
 template <int STYLE, bool COHE, bool LUB>
-__global__ __launch_bounds__(256) void k_substep_lds(DemPtrs P, StepParams S)
+__global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
 {
   extern __shared__ double4 lds4[];
   if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;

@@ -590,6 +590,23 @@ int sf_dem_forward_unpack2(void* ptr, const double* buf0, long long n0, const do
   SF_API_END(0)
 }
 
+int sf_dem_forward_pack_fused(void* ptr, double shift0, long long off0, double shift1, long long off1,
+                              const int* dev_hdr_off, int nhdr, double* dev_sendbuf)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.forward_pack_fused(shift0, off0, shift1, off1, dev_hdr_off, nhdr, dev_sendbuf);
+  SF_API_END(0)
+}
+
+int sf_dem_forward_unpack_fused(void* ptr, const double* dev_recvbuf, long long off_from_left, long long n_from_left,
+                                long long off_from_right, long long n_from_right, const int* dev_hdr_off, int nhdr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.forward_unpack_fused(dev_recvbuf, off_from_left, n_from_left, off_from_right, n_from_right,
+                                   dev_hdr_off, nhdr);
+  SF_API_END(0)
+}
+
 long long sf_dem_migrate_pack(void* ptr, int side, double xshift, double* dev_buf, long long max_doubles)
 {
   SF_API_BEGIN

@@ -37,6 +37,62 @@ __device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a
 __device__ __forceinline__ Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
+// ---- FP64 reciprocal / square root without the IEEE corner-case scaffolding -------------------------------
+// hipcc expands an f64 divide to ~11 and an f64 sqrt to ~19 instructions (v_div_scale/v_div_fixup, ldexp
+// rescaling and class tests for denormals/inf/nan).  The contact laws only ever see finite, normal, positive
+// arguments (squared distances, masses, radii, overlaps), so these use the hardware seed (v_rcp_f64 / v_rsq_f64,
+// ~2^-24 relative) and Newton / Goldschmidt steps: results are within 1-2 ulp of the IEEE ones.
+#ifndef SF_FAST_MATH
+#define SF_FAST_MATH 1
+#endif
+__device__ __forceinline__ double sf_rcp(double x)
+{
+#if SF_FAST_MATH
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+// g = sqrt(x), rinv = 1/sqrt(x) for x > 0 (normal range)
+__device__ __forceinline__ void sf_sqrt_rsqrt(double x, double& g, double& rinv)
+{
+#if SF_FAST_MATH
+  const double y = __builtin_amdgcn_rsq(x);
+  double gg = x * y, h = 0.5 * y;
+  double r = fma(-h, gg, 0.5);
+  gg = fma(gg, r, gg);
+  h = fma(h, r, h);
+  r = fma(-h, gg, 0.5);
+  gg = fma(gg, r, gg);
+  h = fma(h, r, h);
+  gg = fma(fma(-gg, gg, x), h, gg);
+  g = gg;
+  rinv = h + h;
+#else
+  g = sqrt(x);
+  rinv = 1.0 / g;
+#endif
+}
+// sqrt(x) for x >= 0 (0 stays 0)
+__device__ __forceinline__ double sf_sqrt(double x)
+{
+#if SF_FAST_MATH
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  g = fma(fma(-g, g, x), h, g);
+  return x > 0.0 ? g : 0.0;
+#else
+  return sqrt(x);
+#endif
+}
+
 struct ContactIn {
   Vec3 del;        // from partner (or wall) to the particle
   double rsq;
@@ -68,8 +124,8 @@ __device__ __forceinline__ void hertz_history_law(const GranParams& p, double dt
   const Vec3 vt = {c.vr.x - c.del.x * s, c.vr.y - c.del.y * s, c.vr.z - c.del.z * s};
   const Vec3 wr = c.rinv * c.wsum;
 
-  const double polyhertz = sqrt(c.reff);
-  const double sqsn = sqrt(p.h_sn * polyhertz * c.meff);       // sqrt(sn*meff), sn = (2/1.82) kn polyhertz
+  const double polyhertz = sf_sqrt(c.reff);
+  const double sqsn = sf_sqrt(p.h_sn * polyhertz * c.meff);    // sqrt(sn*meff), sn = (2/1.82) kn polyhertz
   const double damp = p.h_c56beta * vnnr * rsqinv;             // 2 sqrt(5/6) beta vnnr / rsq
   const double ccel = polyhertz * p.h_cn * c.overlap * c.rinv - sqsn * damp;   // h_cn = 4/5.46 kn
 
@@ -94,7 +150,9 @@ __device__ __forceinline__ void hertz_history_law(const GranParams& p, double dt
   const double fn = p.xmu * fabs(ccel * c.r);
   if (fs2 > fn * fn) {
     if (shr2 != 0.0) {
-      const double ratio = fn / sqrt(fs2);
+      double fsmag, fsinv;
+      sf_sqrt_rsqrt(fs2, fsmag, fsinv);
+      const double ratio = fn * fsinv;
       const double qs = sdamp * p.h_inv_ct;                    // / 8.84 * 8 / kt
       const Vec3 q = {qs * vtr.x, qs * vtr.y, qs * vtr.z};
       sh.x = ratio * (sh.x + q.x) - q.x;

@@ -14,6 +14,7 @@ The driver only talks to an "engine adaptor" (HipSlabEngine below; the CPU tests
 the same interface), so the protocol is exercised without a GPU by tests/test_halo_gloo.py.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -116,6 +117,17 @@ class HipSlabEngine:
     def forward_unpack2(self, buf0, n0, buf1, n1):
         self.check(self.L.sf_dem_forward_unpack2(self.lmp.ptr, buf0.data_ptr(), int(n0), buf1.data_ptr(), int(n1)))
 
+    def index_table(self, values):
+        return self.torch.tensor(list(values), dtype=self.torch.int32, device=self.device)
+
+    def forward_pack_fused(self, shift0, off0, shift1, off1, hdr_off, sendbuf):
+        self.check(self.L.sf_dem_forward_pack_fused(self.lmp.ptr, shift0, int(off0), shift1, int(off1),
+                                                    hdr_off.data_ptr(), hdr_off.numel(), sendbuf.data_ptr()))
+
+    def forward_unpack_fused(self, recvbuf, off_l, n_l, off_r, n_r, hdr_off):
+        self.check(self.L.sf_dem_forward_unpack_fused(self.lmp.ptr, recvbuf.data_ptr(), int(off_l), int(n_l),
+                                                      int(off_r), int(n_r), hdr_off.data_ptr(), hdr_off.numel()))
+
 
 class SlabDriver:
     """lammps_step() for one slab of an x-decomposed domain.  All methods are collective over the ranks."""
@@ -141,6 +153,12 @@ class SlabDriver:
         if rank == world - 1:
             self.subhi = float(xhi)
         eng.set_subdomain(rank, world, self.sublo, self.subhi)
+        # SF_HALO_SELF_COMM=1: a single rank sends its periodic images to itself through the process group instead
+        # of handing the buffers over locally (exercises the RCCL path on a 1-GPU box)
+        self.self_comm = (world == 1 and periodic_x and dist is not None
+                          and os.environ.get("SF_HALO_SELF_COMM", "0") == "1")
+        # one all-to-all per sub-step (halo + rebuild vote) instead of an all-reduce and a P2P group
+        self.fused = hasattr(eng, "forward_pack_fused") and os.environ.get("SF_HALO_FUSED", "1") != "0"
         self._cap_atoms = int(halo_atoms) if halo_atoms else max(eng.info().nlocal, 4096)
         self._bufs = {}
         self._nrecv = [0, 0]
@@ -156,7 +174,7 @@ class SlabDriver:
         return b
 
     def _allreduce_max(self, v):
-        if self.world == 1:
+        if self.world == 1 and not self.self_comm:
             return int(v)
         t = self.torch.tensor([int(v)], dtype=self.torch.int64,
                               device=self.e.device if self.transport == "direct" else "cpu")
@@ -168,7 +186,7 @@ class SlabDriver:
         Returns (from_left, n_from_left, from_right, n_from_right) in doubles.  `known` = receive sizes
         when both sides already know them (forward halo), else they are exchanged first."""
         torch, dist = self.torch, self.dist
-        if self.world == 1:
+        if self.world == 1 and not self.self_comm:
             # one slab: my own images.  What leaves through the left face arrives from the right.
             if self.periodic_x:
                 return send_r, n_r, send_l, n_l
@@ -254,6 +272,85 @@ class SlabDriver:
         e.rebuild_finish()
         self.n_rebuilds += 1
 
+    def _fused_layout(self):
+        """Send / receive layout of the one-collective forward halo (valid until the next rebuild): per peer rank one
+        header double (rebuild trigger) + the forward records for / from that peer."""
+        F = FORWARD_DOUBLES
+        ns, nr = self._nsend, self._nrecv          # [to left, to right], [from left, from right]
+        W = self.world
+        in_split = [1] * W
+        out_split = [1] * W
+        if self.left is not None:
+            in_split[self.left] += ns[0] * F
+            out_split[self.left] += nr[0] * F
+        if self.right is not None:
+            in_split[self.right] += ns[1] * F
+            out_split[self.right] += nr[1] * F
+        sbase = [0] * W
+        rbase = [0] * W
+        for p in range(1, W):
+            sbase[p] = sbase[p - 1] + in_split[p - 1]
+            rbase[p] = rbase[p - 1] + out_split[p - 1]
+        same = self.left is not None and self.left == self.right
+        lay = dict(in_split=in_split, out_split=out_split, ntx=sum(in_split), nrx=sum(out_split))
+        # left-going records first, then right-going ones, inside the chunk for a peer that is both neighbours;
+        # what a peer sent leftwards reaches me from my right, so its chunk holds [from-right part, from-left part]
+        # records selected at a face without a neighbour (non-periodic box end) go to scratch behind the chunks
+        ntx = lay["ntx"]
+        scratch = 0
+        if self.left is not None:
+            lay["soff_l"] = sbase[self.left] + 1
+        else:
+            lay["soff_l"] = ntx + scratch
+            scratch += ns[0] * F
+        if self.right is not None:
+            lay["soff_r"] = sbase[self.right] + 1 + (ns[0] * F if same else 0)
+        else:
+            lay["soff_r"] = ntx + scratch
+            scratch += ns[1] * F
+        lay["roff_r"] = rbase[self.right] + 1 if self.right is not None else 0
+        lay["roff_l"] = (rbase[self.left] + 1 + (nr[1] * F if same else 0)) if self.left is not None else 0
+        lay["shdr"] = self.e.index_table(sbase)
+        lay["rhdr"] = self.e.index_table(rbase)
+        lay["tx"] = self._buf("a2a_tx", lay["ntx"] + scratch)
+        lay["rx"] = self._buf("a2a_rx", lay["nrx"])
+        return lay
+
+    def _all_to_all(self, lay):
+        """rx[chunk p] <- what rank p put into its chunk for me."""
+        torch, dist = self.torch, self.dist
+        tx, rx = lay["tx"][:lay["ntx"]], lay["rx"][:lay["nrx"]]
+        if self.transport == "direct":
+            dist.all_to_all_single(rx, tx, lay["out_split"], lay["in_split"])
+            return
+        # gloo has no all-to-all: the same chunks as point-to-point messages through host memory
+        if self.e.device.type == "cuda":
+            torch.cuda.synchronize()
+        htx = tx.cpu()
+        hrx = torch.empty(lay["nrx"], dtype=torch.float64)
+        so = ro = 0
+        ops = []
+        for p in range(self.world):
+            a, b = lay["in_split"][p], lay["out_split"][p]
+            if p == self.rank:
+                hrx[ro:ro + b] = htx[so:so + a]
+            else:
+                ops.append(dist.P2POp(dist.isend, htx[so:so + a], p))
+                ops.append(dist.P2POp(dist.irecv, hrx[ro:ro + b], p))
+            so += a
+            ro += b
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        rx.copy_(hrx)
+
+    def forward_fused(self, lay):
+        """rebuild vote + forward halo of one sub-step: pack kernel, ONE collective, unpack kernel."""
+        e = self.e
+        e.forward_pack_fused(self.shift_left, lay["soff_l"], self.shift_right, lay["soff_r"], lay["shdr"], lay["tx"])
+        self._all_to_all(lay)
+        e.forward_unpack_fused(lay["rx"], lay["roff_l"], self._nrecv[0], lay["roff_r"], self._nrecv[1], lay["rhdr"])
+
     def forward(self):
         e = self.e
         f0 = self._buf("fwd_l", self._nsend[0] * FORWARD_DOUBLES)
@@ -280,7 +377,7 @@ class SlabDriver:
 
     def _reduce_trigger(self):
         """global rebuild vote: MIN over the ranks of the device-resident trigger word, on the stream."""
-        if self.world == 1:
+        if self.world == 1 and not self.self_comm:
             return
         trig = self.e.trigger
         if self.transport == "direct":
@@ -302,11 +399,18 @@ class SlabDriver:
         e = self.e
         e.run_begin()
         k = 0
+        fused = self.fused and (self.world > 1 or self.self_comm)
         while k < n:
-            for s in range(k, n):
-                self._reduce_trigger()
-                self.forward()
-                e.substep_k(s == n - 1, s)
+            if fused:
+                lay = self._fused_layout()
+                for s in range(k, n):
+                    self.forward_fused(lay)
+                    e.substep_k(s == n - 1, s)
+            else:
+                for s in range(k, n):
+                    self._reduce_trigger()
+                    self.forward()
+                    e.substep_k(s == n - 1, s)
             trig = e.batch_end(k, n - k)
             if trig >= n:
                 break

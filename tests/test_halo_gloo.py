@@ -36,8 +36,9 @@ def _case(periodic_x=True, vmax=0.5, skin=0.05e-3, seed=31):
     return bed, cfg
 
 
-def _worker(rank, world, port, outdir, periodic_x, steps):
+def _worker(rank, world, port, outdir, periodic_x, steps, mode):
     sys.path.insert(0, ROOT)
+    os.environ["SF_HALO_FUSED"] = "0" if mode == "p2p+allreduce" else "1"
     import torch.distributed as dist
     from oracle import binding as ob
     from sedifoam_amd.halo import SlabDriver
@@ -61,7 +62,9 @@ def _worker(rank, world, port, outdir, periodic_x, steps):
         dem.fix_wall(dim, wlo, whi, cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], 1)
     dem.neighbor(cfg["skin"])
     dem.timestep(cfg["dt"])
-    drv = SlabDriver(ob.OracleSlabEngine(dem), dist, rank, world, lo, hi, periodic_x=periodic_x)
+    drv = SlabDriver(ob.OracleSlabEngine(dem), dist, rank, world, lo, hi, periodic_x=periodic_x,
+                     transport="host" if mode == "fused-p2p" else "direct")
+    assert drv.fused == (mode != "p2p+allreduce")
     drv.setup()
     for n in steps:
         drv.step(n)
@@ -75,8 +78,11 @@ def _worker(rank, world, port, outdir, periodic_x, steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,periodic_x", [(2, True), (3, True), (2, False)])
-def test_decomposed_run_matches_single_domain(world, periodic_x):
+# mode: "fused" = one all_to_all_single per sub-step (halo + rebuild vote; what RCCL runs), "fused-p2p" = the same
+# chunks as point-to-point messages (transport="host"), "p2p+allreduce" = the older two-collective protocol
+@pytest.mark.parametrize("world,periodic_x,mode", [(2, True, "fused"), (3, True, "fused"), (2, False, "fused"),
+                                                   (3, False, "fused-p2p"), (3, True, "p2p+allreduce")])
+def test_decomposed_run_matches_single_domain(world, periodic_x, mode):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     from tests import dem_cases as dc
@@ -90,7 +96,7 @@ def test_decomposed_run_matches_single_domain(world, periodic_x):
     ha = ref.history()
     assert ref.nbuilds >= 3      # the run crosses several rebuilds (migration + history carry-over)
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_worker, args=(world, _free_port(), out, periodic_x, steps), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, periodic_x, steps, mode), nprocs=world, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
     tag = np.concatenate([p["tag"] for p in parts])
     assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]      # nobody lost or duplicated

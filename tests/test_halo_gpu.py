@@ -118,3 +118,58 @@ def test_two_ranks_sharing_one_gpu_match_single_domain():
         for (i, j), sv in zip(p["hk"], p["hv"]):
             hb.setdefault((int(i), int(j)), sv)
     assert set(hb) == set(ha)
+
+
+def _rccl_self_worker(port, outdir):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["SF_HALO_SELF_COMM"] = "1"
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sedifoam_amd.halo import SlabDriver, HipSlabEngine
+    from tests import dem_cases as dc
+    import tests.test_dem_gpu as T
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    bed = T._bed((6, 6, 6), periodic=True, seed=77, vmax=0.5)
+    cfg = dict(T.BASE, skin=0.05e-3)
+    cfg["walls"] = T._walls(bed)
+    lmp = dc.make_hip(bed, cfg)
+    drv = SlabDriver(HipSlabEngine(lmp), dist, 0, 1, float(bed["boxlo"][0]), float(bed["boxhi"][0]),
+                     periodic_x=True, transport="direct")
+    assert drv.self_comm
+    drv.setup()
+    for n in (70, 70):
+        drv.step(n)
+    np.savez(os.path.join(outdir, "self.npz"), rebuilds=drv.n_rebuilds, **lmp.get_state())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_transport_self_images(tmp_path):
+    """transport="direct" (torch.distributed nccl = RCCL, P2P + all-reduce on the engine's device buffers and
+    stream) with one rank sending its periodic images to itself: same protocol and code path as N > 1."""
+    import torch.multiprocessing as mp
+    port = 29600 + (hash(str(tmp_path)) % 300)
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_self_worker, args=(port, str(tmp_path)))
+    p.start()
+    p.join(300)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL self-image halo timed out")
+    assert p.exitcode == 0
+    bed = T._bed((6, 6, 6), periodic=True, seed=77, vmax=0.5)
+    cfg = dict(T.BASE, skin=0.05e-3)
+    cfg["walls"] = T._walls(bed)
+    ref = dc.make_hip(bed, cfg)
+    ref.setup()
+    ref.step(70); ref.step(70)
+    b = ref.get_state()
+    a = np.load(tmp_path / "self.npz")
+    assert int(a["rebuilds"]) >= 3
+    assert (a["tag"] == b["tag"]).all()
+    for k in ("x", "v", "omega", "f", "torque"):
+        assert dc.rel_err(a[k], b[k]) <= 1e-11, k
