@@ -171,12 +171,12 @@ def main():
         },
     }
     # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes
-    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_c_pmc_summary.json for the calibration note)
-    pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_summary.json")
+    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_d_pmc_summary.json for the calibration note)
+    pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_summary.json")
     if os.path.exists(pmc) and args.particles == 1000000:
         try:
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]["total_raw"]
-            out["roofline"]["traffic_source"] = "profiles/r01_c_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+            out["roofline"]["traffic_source"] = "profiles/r01_d_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
         except Exception:
             pass
     # secondary metric of BASELINE.json: coupled CFD-DEM steps/s (drag closure + drag assembly + S sub-steps +
@@ -203,6 +203,25 @@ def main():
         out["config"]["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
         out["config"]["coupled_step"] = "ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc, %dx%dx%d mesh" % (
             args.substeps, mesh_n[0], mesh_n[1], mesh_n[2])
+        # the library.h drop-in boundary (softParticleCloud.C:838-922): per CFD step the caller hands over HOST
+        # arrays (lammps_put_local_info), runs the sub-steps and reads HOST arrays back (lammps_get_local_info);
+        # this rate includes the PCIe copies and the by-tag scatter, it is reported next to `value`, never as it
+        n_loc = lmp.get_local_n()
+        st = lmp.get_local_info()
+        fd = np.zeros((n_loc, 3)); tags = np.ascontiguousarray(st["tag"])
+        lmp.put_local_info(fd, tags, DuDt=np.zeros((n_loc, 3)), foamCpuId=np.zeros(n_loc, np.int32))
+        lmp.step(args.substeps); lmp.get_local_info()
+        barrier()
+        t2 = time.perf_counter()
+        nlib = max(3, args.steps // 2)
+        for _ in range(nlib):
+            lmp.put_local_info(fd, tags, DuDt=np.zeros((n_loc, 3)), foamCpuId=np.zeros(n_loc, np.int32))
+            lmp.step(args.substeps)
+            st = lmp.get_local_info()
+        barrier()
+        out["config"]["host_boundary_substeps_per_s"] = n_loc * args.substeps * nlib / (time.perf_counter() - t2)
+        out["config"]["host_boundary"] = ("lammps_put_local_info + lammps_step(%d) + lammps_get_local_info on host "
+                                          "arrays (PCIe-inclusive)" % args.substeps)
     if rank == 0 and not args.no_cpu_baseline:
         sample_n = args.cpu_sample or 1000000
         sub = 50

@@ -505,7 +505,8 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
     }
   } else {
     // enough workgroups to cover the 256 CUs even for small beds (one atom per lane either way)
-    const int block = nlocal_ >= 512 * 1024 ? 256 : (nlocal_ >= 128 * 1024 ? 128 : 64);
+    static const int block_env = getenv("SF_BLOCK") ? atoi(getenv("SF_BLOCK")) : 0;
+    const int block = block_env ? block_env : (nlocal_ >= 512 * 1024 ? 256 : (nlocal_ >= 128 * 1024 ? 128 : 64));
     const dim3 grid(div_up(nlocal_, block));
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, grid, block, stream_, P, S); break;

@@ -23,6 +23,9 @@ __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 #ifndef SF_NT
 #define SF_NT 1
 #endif
+#ifndef SF_NT_OUT
+#define SF_NT_OUT 0
+#endif
 template <class T>
 __device__ __forceinline__ T ld_stream(const T* p)
 {
@@ -289,9 +292,15 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       if (dx * dx + dy * dy + dz * dz > S.trigger_sq) atomicMin(&P.flags[F_TRIGGER], S.kstep);
     }
   }
+#if SF_NT_OUT
+  st_stream4(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
+  st_stream4(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
+  st_stream4(&P.om_out[i], double4{wn.x, wn.y, wn.z, 0.0});
+#else
   P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
   P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
   P.om_out[i] = {wn.x, wn.y, wn.z, 0.0};
+#endif
   if (S.mode != 0) {
     P.force[i] = {F.x, F.y, F.z, 0.0};
     P.torque[i] = {T.x, T.y, T.z, 0.0};
@@ -313,7 +322,10 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
   int bid = blockIdx.x;
-  if (S.xcd_remap) {
+  // xcd_remap & 2: odd sub-steps sweep the atoms in descending order, so the rows written last by the previous
+  // sub-step (still in L2 / the 256 MB memory-side cache) are the first ones read by this one
+  if ((S.xcd_remap & 2) && (S.kstep & 1)) bid = gridDim.x - 1 - bid;
+  if (S.xcd_remap & 1) {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
