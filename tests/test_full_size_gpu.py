@@ -1,0 +1,118 @@
+"""BASELINE.json's full size (1 M-particle Hertz packing) through size-independent properties -- the oracle takes
+minutes at this size, so these check what must hold for ANY correct implementation of the reference's path:
+Newton's third law of the pair styles (pair_gran_hertzFix_history.cpp:262-283: f[i] += , f[j] -= the same
+numbers), momentum conservation of nve/sphere without external forces, exact additivity of fix fdrag
+(fix_fluid_drag.cpp:150-156), independence of the input order, run-to-run determinism."""
+import numpy as np
+import pytest
+
+from sedifoam_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+N_TARGET = 1000000
+
+
+def _periodic_bed(seed=5):
+    """fully periodic FCC packing (no walls, no gravity): every particle has its 12 overlapping neighbours"""
+    nc = synthetic.fcc_cells_for(N_TARGET)
+    bed = synthetic.fcc_bed(nc, seed=seed, vmax=0.05)
+    bed["boxhi"][1] = nc[1] * bed["edge"]
+    bed["x"][:, 1] -= 0.25 * 0.98e-3       # keep the jittered bottom layer inside [0, Ly)
+    bed["x"][:, 1] %= bed["boxhi"][1]
+    bed["periodic"] = (1, 1, 1)
+    return bed
+
+
+def _engine(bed, order=None, fdrag=None, extra=()):
+    from sedifoam_amd import Lammps
+    lmp = Lammps()
+    lmp.set_box(bed["boxlo"], bed["boxhi"])
+    n = bed["n"]
+    o = np.arange(n) if order is None else order
+    lmp.create_atoms(bed["x"][o], bed["diameter"][o], bed["density"][o], v=bed["v"][o],
+                     tag=(o + 1).astype(np.int64))
+    for line in ["atom_style sphere", "boundary p p p", "newton off", "communicate single vel yes",
+                 "neighbor 0.25e-3 bin", "neigh_modify delay 0",
+                 "pair_style gran/hertzFix/history 1e7 NULL 0.5 NULL 0.4 1", "pair_coeff * *", "timestep 1e-6",
+                 "fix 1 all nve/sphere", "fix 3 all fdrag"] + list(extra):
+        lmp.command(line)
+    if fdrag is not None:
+        lmp.put_local_info(fdrag[o], (o + 1).astype(np.int32))
+    lmp.setup()
+    return lmp
+
+
+@pytest.fixture(scope="module")
+def bed():
+    return _periodic_bed()
+
+
+@pytest.fixture(scope="module")
+def base(bed):
+    lmp = _engine(bed)
+    st0 = lmp.get_state()
+    lmp.step(50)
+    return lmp, st0, lmp.get_state()
+
+
+def test_full_size_newton_third_law_and_momentum(bed, base):
+    lmp, st0, st1 = base
+    assert lmp.info().nlocal == bed["n"] >= N_TARGET
+    assert lmp.info().npairs_full == 12 * bed["n"]                 # every one of the 12 FCC neighbours is listed
+    m = (np.pi / 6.0) * bed["diameter"] ** 3 * bed["density"]
+    for st in (st0, st1):
+        F = st["f"]
+        assert np.isfinite(F).all() and np.isfinite(st["torque"]).all()
+        # sum of all pair forces vanishes: each contact is evaluated from both sides with bitwise opposite results
+        assert np.abs(F.sum(axis=0)).max() <= 1e-11 * np.abs(F).sum()
+    p0 = (m[:, None] * st0["v"]).sum(axis=0)
+    p1 = (m[:, None] * st1["v"]).sum(axis=0)
+    assert np.abs(p1 - p0).max() <= 1e-11 * (m[:, None] * np.abs(st0["v"])).sum()
+    # the packing really interacts: velocities changed, nothing blew up
+    assert np.abs(st1["v"] - st0["v"]).max() > 1e-4 and np.abs(st1["v"]).max() < 1.0
+
+
+def test_full_size_history_is_antisymmetric_and_complete(bed, base):
+    lmp = base[0]
+    cap = int(lmp.info().npairs_full)
+    from sedifoam_amd.lammps import _p
+    ti = np.zeros(cap, np.int32); tj = np.zeros(cap, np.int32); sh = np.zeros((cap, 3))
+    n = lmp.L.sf_dem_get_history(lmp.ptr, cap, _p(ti), _p(tj), _p(sh))
+    # get_history reports each touching pair once (tag_i < tag_j); in the 2 %-overlap packing all 6 N touch
+    assert n == 6 * bed["n"]
+    assert (ti[:n] < tj[:n]).all()
+    key = ti[:n].astype(np.int64) * (bed["n"] + 1) + tj[:n]
+    assert len(np.unique(key)) == n
+    assert np.isfinite(sh[:n]).all() and np.abs(sh[:n]).max() > 0.0
+    # tangential history is perpendicular to the contact normal after the rotation step (:215-224)
+    st = base[2]
+    xi = st["x"][ti[:n] - 1]; xj = st["x"][tj[:n] - 1]
+    L = bed["boxhi"] - bed["boxlo"]
+    d = xi - xj
+    d -= L * np.round(d / L)
+    cosang = np.abs((d * sh[:n]).sum(axis=1)) / (np.linalg.norm(d, axis=1) * np.linalg.norm(sh[:n], axis=1) + 1e-300)
+    assert cosang.max() <= 1e-6
+
+
+def test_full_size_fdrag_is_additive(bed, base):
+    rng = np.random.default_rng(11)
+    fd = rng.normal(scale=1e-6, size=(bed["n"], 3))
+    lmp = _engine(bed, fdrag=fd)
+    a = lmp.get_state()["f"]
+    b = base[1]["f"]
+    # f += fdrag (fix_fluid_drag.cpp:150-156): exactly the pair force plus the per-atom drag, matched by tag
+    assert np.abs(a - (b + fd)).max() <= 1e-14 * np.abs(b).max()
+
+
+def test_full_size_input_order_does_not_matter_and_reruns_are_bitwise(bed, base):
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(bed["n"])
+    lmp = _engine(bed, order=perm)
+    st0 = lmp.get_state()
+    for k in ("x", "v", "f", "torque"):
+        assert np.array_equal(st0[k], base[1][k]), k       # atoms are sorted by (cell, tag): same sums, same bits
+    lmp.step(50)
+    st1 = lmp.get_state()
+    for k in ("x", "v", "omega", "f", "torque"):
+        assert np.array_equal(st1[k], base[2][k]), k
