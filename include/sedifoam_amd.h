@@ -166,7 +166,43 @@ int sf_dem_forward_pack_fused(void *ptr, double shift0, long long off0, double s
                               const int *dev_hdr_off, int nhdr, double *dev_sendbuf);
 int sf_dem_forward_unpack_fused(void *ptr, const double *dev_recvbuf, long long off_from_left,
                                 long long n_from_left, long long off_from_right, long long n_from_right,
-                                const int *dev_hdr_off, int nhdr);
+                                const int *dev_hdr_off, int nhdr, int kstep);
+/* Overlapped halo (opt-in per engine, before the first rebuild): a sub-step is split into the BOUNDARY atoms (those
+ * the forward halo sends or whose list holds an atom of another GPU) and the INTERIOR atoms.  Per sub-step k:
+ *   main stream:  substep_part(2,k) -> [event A] -> substep_part(1,k) -> substep_flip(k)
+ *   comm stream:  wait A -> forward_pack_fused -> all-to-all -> forward_unpack_fused(.., k) -> [event B]
+ *   main stream:  wait B -> substep_part(2,k+1) ...
+ * so the exchange runs under the interior kernel.  The rebuild vote of exchange k (MIN over all ranks) decides
+ * whether sub-step k+1 runs; an interior atom that crosses skin/2 in sub-step k is voted one exchange later, i.e.
+ * sub-step k+1 still runs on every rank and the rebuild follows it.  The neighbour list is built with a 10 % larger
+ * skin in this mode so that it stays a superset of the interacting pairs for that extra sub-step (checked:
+ * sf_dem_overlap_batch_end fails if any atom moved more than 5 % of the skin in one sub-step). */
+int sf_dem_set_overlap(void *ptr, int on, void *comm_stream);
+int sf_dem_overlap_begin(void *ptr);
+int sf_dem_substep_part(void *ptr, int part, int last, int kstep);
+int sf_dem_substep_flip(void *ptr, int kstep);
+int sf_dem_overlap_batch_end(void *ptr, int first_k, int launched, int last_kstep, int *trigger);
+int sf_dem_boundary_count(void *ptr);
+
+/* The per-sub-step loop of a decomposed domain queued from C++ over RCCL (replaces LAMMPS' Comm::forward_comm +
+ * the MPI_Allreduce of Neighbor::decide inside Verlet::run).  sf_dem_comm_unique_id on one rank, the 128 bytes to
+ * every rank by any means (MPI_Bcast, torch.distributed), sf_dem_comm_init collectively.  sf_dem_halo_run(first_k, n)
+ * queues sub-steps first_k .. n-1 (fused pack, one grouped ncclSend/ncclRecv, fused unpack, kernels; overlapped if
+ * sf_dem_set_overlap is on), synchronises once and returns the voted rebuild trigger like sf_dem_batch_end. */
+typedef struct {
+  int world;
+  double shift_left, shift_right;            /* periodic shift applied to what leaves through the box faces */
+  long long soff_l, soff_r;                  /* send buffer: where the left- / right-going records start (doubles) */
+  long long roff_l, n_from_left;             /* receive buffer: records that came from the left neighbour */
+  long long roff_r, n_from_right;
+  const long long *send_off, *send_cnt;      /* per peer rank, in doubles; header word first in every chunk */
+  const long long *recv_off, *recv_cnt;
+  const int *dev_shdr, *dev_rhdr;            /* device tables [world]: header offsets in the send / receive buffer */
+  double *dev_tx, *dev_rx;
+} sf_halo_layout;
+int sf_dem_comm_unique_id(char *id128);
+int sf_dem_comm_init(void *ptr, const char *id128, int rank, int world);
+int sf_dem_halo_run(void *ptr, int first_k, int n, const sf_halo_layout *lay, int *trigger);
 long long sf_dem_migrate_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_doubles);
 int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
 int sf_dem_migrate_record_doubles(void *ptr);

@@ -393,6 +393,24 @@ class OracleSlabEngine:
     def ghost_forward_local(self):
         self.L.orc_dem_ghost_forward_local(self.h)
 
+    # overlapped schedule of the driver, without streams: the boundary part is empty, the interior part is the
+    # whole sub-step (the CPU engine has no reason to split), the vote is the one the fused exchange carries
+    def enable_overlap(self):
+        self.comm_stream = None
+
+    def overlap_begin(self):
+        self._trigger[0] = 2 ** 31 - 1
+
+    def substep_part(self, part, last, kstep):
+        if part == 1:
+            self.substep_k(last, kstep)
+
+    def substep_flip(self, kstep):
+        pass
+
+    def overlap_batch_end(self, first_k, launched, last_kstep):
+        return int(self._trigger[0])
+
     # the one-collective forward halo of the driver (header = rebuild trigger, then the records), on CPU tensors
     def index_table(self, values):
         return self.torch.tensor(list(values), dtype=self.torch.int32)
@@ -402,7 +420,7 @@ class OracleSlabEngine:
         self.forward_pack(0, shift0, sendbuf[int(off0):])
         self.forward_pack(1, shift1, sendbuf[int(off1):])
 
-    def forward_unpack_fused(self, recvbuf, off_l, n_l, off_r, n_r, hdr_off):
+    def forward_unpack_fused(self, recvbuf, off_l, n_l, off_r, n_r, hdr_off, kstep=-1):
         self._trigger[0] = min(int(self._trigger[0]), int(recvbuf[hdr_off.long()].min().item()))
         self.forward_unpack(0, recvbuf[int(off_l):], n_l)
         self.forward_unpack(1, recvbuf[int(off_r):], n_r)

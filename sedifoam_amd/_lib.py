@@ -20,6 +20,16 @@ class SfError(RuntimeError):
     pass
 
 
+class HaloLayout(C.Structure):
+    _fields_ = [("world", C.c_int), ("shift_left", C.c_double), ("shift_right", C.c_double),
+                ("soff_l", C.c_longlong), ("soff_r", C.c_longlong),
+                ("roff_l", C.c_longlong), ("n_from_left", C.c_longlong),
+                ("roff_r", C.c_longlong), ("n_from_right", C.c_longlong),
+                ("send_off", C.POINTER(C.c_longlong)), ("send_cnt", C.POINTER(C.c_longlong)),
+                ("recv_off", C.POINTER(C.c_longlong)), ("recv_cnt", C.POINTER(C.c_longlong)),
+                ("dev_shdr", vp), ("dev_rhdr", vp), ("dev_tx", vp), ("dev_rx", vp)]
+
+
 class DemInfo(C.Structure):
     _fields_ = [("nlocal", C.c_int), ("nghost", C.c_int), ("capacity", C.c_int),
                 ("max_neigh_used", C.c_int), ("max_neigh_cap", C.c_int),
@@ -115,7 +125,16 @@ _SIGS = {
     "sf_dem_forward_unpack2": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_longlong]),
     "sf_dem_forward_pack_fused": (C.c_int, [vp, C.c_double, C.c_longlong, C.c_double, C.c_longlong, vp, C.c_int, vp]),
     "sf_dem_forward_unpack_fused": (C.c_int, [vp, vp, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, vp,
-                                              C.c_int]),
+                                              C.c_int, C.c_int]),
+    "sf_dem_set_overlap": (C.c_int, [vp, C.c_int, vp]),
+    "sf_dem_overlap_begin": (C.c_int, [vp]),
+    "sf_dem_substep_part": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "sf_dem_substep_flip": (C.c_int, [vp, C.c_int]),
+    "sf_dem_overlap_batch_end": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, ip]),
+    "sf_dem_boundary_count": (C.c_int, [vp]),
+    "sf_dem_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "sf_dem_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
+    "sf_dem_halo_run": (C.c_int, [vp, C.c_int, C.c_int, vp, ip]),
     "sf_dem_migrate_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp, C.c_longlong]),
     "sf_dem_migrate_unpack": (C.c_int, [vp, vp, C.c_longlong]),
     "sf_dem_migrate_record_doubles": (C.c_int, [vp]),

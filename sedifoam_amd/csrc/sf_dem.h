@@ -38,6 +38,12 @@ enum Flag {
   F_SEND_COUNT,     // scratch counter for halo packing
   F_SEND_COUNT2,
   F_STAGE_MAX,      // largest number of atoms any tile stages in LDS
+  // overlapped halo (decomposed domain): kernels add their trigger to F_TRIG_LOCAL, the exchange of sub-step s
+  // publishes the MIN over all ranks in F_VOTE0 + (s & 1); the kernels of sub-step s+1 test that word
+  F_TRIG_LOCAL,
+  F_VOTE0,
+  F_VOTE1,
+  F_MARGIN_FAIL,    // an atom moved more than half the list margin in one sub-step (overlap mode)
   F_NFLAGS = 16
 };
 
@@ -67,6 +73,9 @@ struct DemPtrs {
   const double* xhold;     // [3][cap]
   const int* mask;
   int* flags;
+  // boundary / interior split of the overlapped halo
+  const unsigned char* isb;     // [cap] 1 = boundary atom (is sent, or has a neighbour owned by another GPU)
+  const int* blist;             // boundary atoms, ascending
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -78,6 +87,12 @@ struct DemPtrs {
 struct StepParams {
   int nlocal, cap, mode;   // mode 0: force + final + next initial ; 1: last (force + final, store f) ; 2: setup
   int kstep;
+  int part, nb;      // 0: every owned atom ; 1: interior atoms [n_lo, n_hi) ; 2: boundary atoms [0, n_lo) + [n_hi, nlocal)
+  int n_lo, n_hi;
+  int trig_test;     // flag word whose value < kstep means "list stale, do nothing"
+  int trig_set;      // flag word that receives atomicMin(kstep + trig_add) when an atom exceeds skin/2
+  int trig_add;
+  double margin_sq;  // > 0: flag F_MARGIN_FAIL when one sub-step moves an atom by more than sqrt(margin_sq)
   double dt, trigger_sq;
   GranParams gran;
   CoheParams cohe;
@@ -102,6 +117,8 @@ struct BinGrid {
   int nbins;       // key space: tiles * tile^3 (>= n[0]*n[1]*n[2])
   int tile;        // bins are numbered tile by tile (tile x tile x tile bins) so that particles that are
   int nt[3];       // close in space are close in memory in all three directions; tile <= 1: plain x-fastest
+  int xslow;       // 1: z fastest, x slowest (decomposed domain: the atoms next to the two x faces of the slab are
+                   // then a prefix and a suffix of the sorted array = the boundary part of the overlapped halo)
   int rowtile;     // > 1: whole x-rows of cells, bundled rowtile x rowtile in (y, z): consecutive rows in memory
                    // are neighbours in y AND z (lane-contiguous gathers stay contiguous along x)
 };
@@ -109,6 +126,7 @@ struct BinGrid {
 // bin coordinates -> sort key / cell index
 __host__ __device__ __forceinline__ int bin_key(const BinGrid& g, int cx, int cy, int cz)
 {
+  if (g.xslow) return cz + g.n[2] * (cy + g.n[1] * cx);
   if (g.rowtile > 1) {
     const int R = g.rowtile;
     const int ty = cy / R, tz = cz / R;
@@ -158,6 +176,16 @@ class DemEngine {
   // end-of-batch bookkeeping (returns the trigger index, INT_MAX if none; fixes the ping-pong parity)
   void substep_k(bool last, int kstep);
   int batch_end(int first_k, int launched);
+  // overlapped halo (decomposed domain, see sf_dem_halo.hip): boundary atoms first, the exchange of their new
+  // records runs on comm_stream while the interior atoms are advanced on the main stream
+  void set_overlap(bool on, hipStream_t comm_stream);
+  void overlap_begin();                         // after run_begin: reset the local / voted trigger words
+  void substep_part(int part, bool last, int kstep);   // part 2 = boundary, 1 = interior; same buffers for both
+  void substep_flip(int kstep);                 // images of owned atoms + buffer parity, after both parts
+  int overlap_batch_end(int first_k, int launched, int last_kstep);
+  int boundary_count() const { return nb_; }
+  bool overlap() const { return overlap_; }
+  hipStream_t comm_stream() const { return comm_stream_; }
   void set_flag_buffer(int* dev);
   bool need_rebuild();
   void rebuild_begin();
@@ -190,7 +218,7 @@ class DemEngine {
   void forward_pack_fused(double shift0, long long off0, double shift1, long long off1, const int* hdr_off, int nhdr,
                           double* sendbuf);
   void forward_unpack_fused(const double* recvbuf, long long off0, long long n0, long long off1, long long n1,
-                            const int* hdr_off, int nhdr);
+                            const int* hdr_off, int nhdr, int kstep);
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;
@@ -234,9 +262,9 @@ class DemEngine {
   void grow_neigh(int newM);
   DemPtrs ptrs(int in_buf) const;
   StepParams step_params(int mode, int kstep) const;
-  void launch_substep(int in_buf, int mode, int kstep);
+  void launch_substep(int in_buf, int mode, int kstep, int part = 0);
 public:
-  void launch_ghost_forward(int buf, int kstep);
+  void launch_ghost_forward(int buf, int kstep, int phase = 0, int trig_word = F_TRIGGER, hipStream_t s = nullptr);
 private:
   void launch_initial_integrate();
   void rebuild();          // rebuild_begin + rebuild_sort + rebuild_finish
@@ -321,12 +349,20 @@ private:
   BinGrid grid_{};
   // halo bookkeeping: send lists for forward comm [side] (device index arrays) and ghost slot ranges
   DevArray sendlist_[2];
+  DevArray isb_, blist_;               // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
+  int nb_ = 0;                         // boundary atoms = [0, n_lo_) and [n_hi_, nlocal_) of the x-slowest order
+  int n_lo_ = 0, n_hi_ = 0;
+  bool overlap_ = false;
+  hipStream_t comm_stream_ = nullptr;
+  void mark_boundary();
+  double lskin() const { return overlap_ ? 1.1 * skin_ : skin_; }   // list skin: +10 % margin in overlap mode
   long long nsend_[2] = {0, 0};
   int recv_first_[2] = {0, 0}, recv_count_[2] = {0, 0};
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool profiling_ = false;
   std::vector<hipEvent_t> prof_ev_;   // pairs (start, stop) of launches not yet harvested
   size_t prof_used_ = 0;
+  bool prof_open_ = false;             // a boundary part recorded its start event, the interior part closes it
   long long prof_launches_ = 0;
   double prof_ms_ = 0.0;
   void harvest_profile(size_t first_pair, size_t valid_pairs);

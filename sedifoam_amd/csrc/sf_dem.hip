@@ -105,7 +105,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_, &nloc_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &blist_};
 }
 
 DemEngine::~DemEngine()
@@ -180,6 +180,8 @@ void DemEngine::alloc_all(size_t cap)
   sendlist_[1].alloc(sizeof(int), 1, cap, s);
   leave_.alloc(sizeof(int), 1, cap, s);
   nloc_.alloc(sizeof(unsigned short), M_, cap, s);
+  isb_.alloc(sizeof(unsigned char), 1, cap, s);
+  blist_.alloc(sizeof(int), 1, cap, s);
   cap_ = cap;
 }
 
@@ -369,7 +371,7 @@ double DemEngine::cutneighmax() const
   double c = 0.0;
   if (gran_.style) c = 2.0 * rmax_ + (cohe_.enabled ? cohe_.smax : 0.0);
   if (lub_.enabled && lub_.cut_global > c) c = lub_.cut_global;
-  return c + skin_;
+  return c + lskin();
 }
 
 void DemEngine::reset_flag(int idx, int value)
@@ -407,6 +409,8 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.xhold = xhold_.as<double>();
   P.mask = mask_.as<int>();
   P.flags = d_flags_;
+  P.isb = isb_.as<unsigned char>();
+  P.blist = blist_.as<int>();
   P.nloc = nloc_.as<unsigned short>();
   P.tile_first = tile_tab_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
@@ -425,6 +429,12 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.kstep = kstep;
   S.dt = dt_;
   S.trigger_sq = (0.5 * skin_) * (0.5 * skin_);
+  S.part = 0;
+  S.nb = 0;
+  S.trig_test = F_TRIGGER;
+  S.trig_set = F_TRIGGER;
+  S.trig_add = 0;
+  S.margin_sq = 0.0;
   S.gran = gran_;
   S.cohe = cohe_;
   S.lub = lub_;
@@ -475,25 +485,48 @@ static void launch_lds_style(bool cohe, bool lub, dim3 grid, size_t lds, hipStre
   else launch_lds_one<STYLE, false, false>(grid, lds, s, P, S);
 }
 
-void DemEngine::launch_substep(int in_buf, int mode, int kstep)
+void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
 {
   if (!nlocal_) return;
+  if (part == 2 && !nb_) return;   // (no event pair opened: the interior part then times itself)
   const DemPtrs P = ptrs(in_buf);
-  const StepParams S = step_params(mode, kstep);
+  StepParams S = step_params(mode, kstep);
+  if (part) {
+    // overlapped halo: both parts of sub-step k test the vote published by the exchange of sub-step k-1; an
+    // interior trigger can only be voted one exchange later, hence "+1" (sub-step k+1 still runs everywhere)
+    S.part = part;
+    S.nb = nb_;
+    S.n_lo = n_lo_;
+    S.n_hi = n_hi_;
+    S.trig_test = F_VOTE0 + ((kstep + 1) & 1);
+    S.trig_set = F_TRIG_LOCAL;
+    S.trig_add = part == 1 ? 1 : 0;
+    const double half_margin = 0.5 * (lskin() - skin_);
+    S.margin_sq = half_margin * half_margin;
+  }
   const bool cohe = cohe_.enabled, lub = lub_.enabled;
+  // one event pair per sub-step: around the single kernel, or from the boundary part to the interior part
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (profiling_) {
-    if (prof_used_ + 2 > prof_ev_.size()) {
-      for (int k = 0; k < 2; k++) {
-        hipEvent_t e;
-        SF_HIP(hipEventCreate(&e));
-        prof_ev_.push_back(e);
+    if (part != 1 || !prof_open_) {
+      if (prof_used_ + 2 > prof_ev_.size()) {
+        for (int k = 0; k < 2; k++) {
+          hipEvent_t e;
+          SF_HIP(hipEventCreate(&e));
+          prof_ev_.push_back(e);
+        }
       }
+      e0 = prof_ev_[prof_used_++];
+      e1 = prof_ev_[prof_used_++];
+      SF_HIP(hipEventRecord(e0, stream_));
+      prof_open_ = (part == 2);
+      if (part == 2) e1 = nullptr;
+    } else {
+      e1 = prof_ev_[prof_used_ - 1];
+      prof_open_ = false;
     }
-    e0 = prof_ev_[prof_used_++];
-    e1 = prof_ev_[prof_used_++];
-    SF_HIP(hipEventRecord(e0, stream_));
   }
+  if (lds_active_ && part) fail("the LDS-staged kernel has no boundary/interior split (SF_LDS with the overlapped halo)");
   if (lds_active_) {
     // one workgroup per tile; LDS = staged x (32 B) + v (32 B) + omega (24 B) per atom of the extended tile
     const dim3 grid(ntiles_);
@@ -506,8 +539,10 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
   } else {
     // enough workgroups to cover the 256 CUs even for small beds (one atom per lane either way)
     static const int block_env = getenv("SF_BLOCK") ? atoi(getenv("SF_BLOCK")) : 0;
-    const int block = block_env ? block_env : (nlocal_ >= 512 * 1024 ? 256 : (nlocal_ >= 128 * 1024 ? 128 : 64));
-    const dim3 grid(div_up(nlocal_, block));
+    const int nwork = part == 2 ? nb_ : (part == 1 ? n_hi_ - n_lo_ : nlocal_);
+    if (nwork <= 0) return;
+    const int block = block_env ? block_env : (nwork >= 512 * 1024 ? 256 : (nwork >= 128 * 1024 ? 128 : 64));
+    const dim3 grid(div_up(nwork, block));
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, grid, block, stream_, P, S); break;
       case 1: launch_substep_style<1>(cohe, lub, grid, block, stream_, P, S); break;
@@ -515,7 +550,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep)
     }
   }
   SF_HIP(hipGetLastError());
-  if (profiling_) SF_HIP(hipEventRecord(e1, stream_));
+  if (profiling_ && e1) SF_HIP(hipEventRecord(e1, stream_));
 }
 
 void DemEngine::set_profiling(bool on)
@@ -549,12 +584,12 @@ void DemEngine::get_profile(long long* launches, double* kernel_ms)
   *kernel_ms = prof_ms_;
 }
 
-void DemEngine::launch_ghost_forward(int buf, int kstep)
+void DemEngine::launch_ghost_forward(int buf, int kstep, int phase, int trig_word, hipStream_t s)
 {
   if (!nghost_) return;
-  k_ghost_forward<<<div_up(nghost_, 256), 256, 0, stream_>>>(
+  k_ghost_forward<<<div_up(nghost_, 256), 256, 0, s ? s : stream_>>>(
       xr_[buf].as<double4>(), vm_[buf].as<double4>(), om_[buf].as<double4>(), gsrc_.as<int>(),
-      gshift_.as<double>(), nlocal_, nghost_, cap_, d_flags_, kstep);
+      gshift_.as<double>(), nlocal_, nghost_, cap_, d_flags_, kstep, trig_word, phase);
 }
 
 void DemEngine::launch_initial_integrate()
@@ -562,8 +597,8 @@ void DemEngine::launch_initial_integrate()
   if (!nlocal_ || !have_nve_) return;
   k_initial_integrate<<<div_up(nlocal_, 256), 256, 0, stream_>>>(
       xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), force_.as<double4>(),
-      torque_.as<double4>(), xhold_.as<double>(), d_flags_, nlocal_, cap_, dt_,
-      (0.5 * skin_) * (0.5 * skin_));
+      torque_.as<double4>(), xhold_.as<double>(), d_flags_ + (overlap_ ? F_TRIG_LOCAL : F_TRIGGER), nlocal_, cap_,
+      dt_, (0.5 * skin_) * (0.5 * skin_));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -589,6 +624,7 @@ void DemEngine::compute_grid()
   grid_.stencil = opt_sub_;
   grid_.tile = opt_tile_ > 1 ? opt_tile_ * opt_sub_ : 1;   // tiles keep their physical size
   grid_.rowtile = (grid_.tile <= 1 && opt_rowtile_ > 1) ? opt_rowtile_ * opt_sub_ : 0;
+  grid_.xslow = (have_subdomain_ && grid_.tile <= 1 && grid_.rowtile <= 1) ? 1 : 0;
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
     grid_.nt[k] = (grid_.n[k] + grid_.tile - 1) / grid_.tile;
@@ -823,8 +859,8 @@ void DemEngine::bin_and_build()
     B.M = M_;
     B.Mold = max_neigh_used_;
     B.cap = cap_;
-    B.skin_gran = gran_.style ? skin_ + (cohe_.enabled ? cohe_.smax : 0.0) : -1.0;
-    B.cut_lub = lub_.enabled ? lub_.cut_global + skin_ : 0.0;
+    B.skin_gran = gran_.style ? lskin() + (cohe_.enabled ? cohe_.smax : 0.0) : -1.0;
+    B.cut_lub = lub_.enabled ? lub_.cut_global + lskin() : 0.0;
     B.g = grid_;
     B.eoff = lds_active_ ? eoff_ : nullptr;
     B.nloc = nloc_.as<unsigned short>();
@@ -859,6 +895,7 @@ void DemEngine::rebuild_finish()
 {
   make_periodic_ghosts();
   bin_and_build();
+  if (overlap_) mark_boundary();
   reset_flag(F_TRIGGER, INT_MAX);
 }
 
@@ -913,6 +950,7 @@ void DemEngine::setup()
 
 void DemEngine::run_begin()
 {
+  if (overlap_) overlap_begin();
   reset_flag(F_TRIGGER, INT_MAX);
   launch_initial_integrate();
   launch_ghost_forward(cur_, 0);
@@ -940,6 +978,91 @@ int DemEngine::batch_end(int first_k, int launched)
   const int trig = h_flags_[F_TRIGGER];
   const int executed = trig == INT_MAX ? launched : std::max(0, trig + 1 - first_k);
   // every substep_k flipped the buffer parity; the early-exited ones must not count
+  if ((launched - executed) & 1) cur_ ^= 1;
+  nsteps_ += executed;
+  return trig;
+}
+
+void DemEngine::set_overlap(bool on, hipStream_t comm_stream)
+{
+  sync();
+  overlap_ = on;   // (set before the first rebuild: the list skin carries a 10 % margin in this mode)
+  comm_stream_ = on ? comm_stream : nullptr;
+}
+
+void DemEngine::mark_boundary()
+{
+  // Boundary atoms = owned atoms within the list cutoff of one of the slab's two x faces, rounded up to whole cell
+  // layers: they contain every atom the forward halo sends and every atom whose list holds an atom of another GPU
+  // (that atom lies beyond the face and closer than the list cutoff).  In the x-slowest order they are a prefix and
+  // a suffix of the owned atoms.
+  nb_ = n_lo_ = 0;
+  n_hi_ = nlocal_;
+  if (!nlocal_) return;
+  if (!grid_.xslow) fail("overlapped halo: needs the x-slowest atom order (no SF_TILE / SF_ROWTILE)");
+  const double cut = cutneighmax();
+  const double cell = 1.0 / grid_.inv[0];
+  int cx_lo = (int)std::ceil((sublo_x_ + cut - grid_.lo[0]) / cell - 1e-9);
+  int cx_hi = (int)std::floor((subhi_x_ - cut - grid_.lo[0]) / cell + 1e-9);
+  cx_lo = std::max(0, std::min(cx_lo, grid_.n[0]));
+  cx_hi = std::max(cx_lo, std::min(cx_hi, grid_.n[0]));
+  reset_flag(F_SEND_COUNT, 0);
+  reset_flag(F_SEND_COUNT2, 0);
+  static_assert(F_SEND_COUNT2 == F_SEND_COUNT + 1, "adjacent counters");
+  k_count_layers<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, grid_, cx_lo, cx_hi,
+                                                            d_flags_ + F_SEND_COUNT);
+  read_flags();
+  n_lo_ = h_flags_[F_SEND_COUNT];
+  n_hi_ = h_flags_[F_SEND_COUNT2];
+  nb_ = n_lo_ + (nlocal_ - n_hi_);
+  static const bool check = getenv("SF_CHECK_BOUNDARY") && atoi(getenv("SF_CHECK_BOUNDARY"));
+  if (check) {
+    // list-derived classification (sent, or has a neighbour rooted on another GPU) must be inside the two ranges
+    k_mark_boundary<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
+                                                               gsrc_.as<int>(), nullptr, 0, nullptr, 0, nlocal_, cap_,
+                                                               isb_.as<unsigned char>(), 0);
+    const int ns = (int)(nsend_[0] + nsend_[1]);
+    if (ns)
+      k_mark_boundary<<<div_up(ns, 256), 256, 0, stream_>>>(nullptr, nullptr, nullptr, sendlist_[0].as<int>(),
+                                                            (int)nsend_[0], sendlist_[1].as<int>(), (int)nsend_[1],
+                                                            nlocal_, cap_, isb_.as<unsigned char>(), 1);
+    std::vector<unsigned char> h(nlocal_);
+    SF_HIP(hipMemcpyAsync(h.data(), isb_.ptr, nlocal_, hipMemcpyDeviceToHost, stream_));
+    sync();
+    for (int i = n_lo_; i < n_hi_; i++)
+      if (h[i]) fail("overlapped halo: atom %d talks to another GPU but lies in the interior range [%d, %d)", i, n_lo_, n_hi_);
+  }
+}
+
+void DemEngine::overlap_begin()
+{
+  reset_flag(F_TRIG_LOCAL, INT_MAX);
+  reset_flag(F_VOTE0, INT_MAX);
+  reset_flag(F_VOTE1, INT_MAX);
+  reset_flag(F_MARGIN_FAIL, 0);
+}
+
+void DemEngine::substep_part(int part, bool last, int kstep)
+{
+  if (part != 1 && part != 2) fail("substep_part: part must be 1 (interior) or 2 (boundary)");
+  launch_substep(cur_, last ? 1 : 0, kstep, part);
+}
+
+void DemEngine::substep_flip(int kstep)
+{
+  // images of owned atoms (the images of received ghosts follow the unpack on the communication stream)
+  launch_ghost_forward(cur_ ^ 1, kstep, 1, F_VOTE0 + ((kstep + 1) & 1));
+  cur_ ^= 1;
+}
+
+int DemEngine::overlap_batch_end(int first_k, int launched, int last_kstep)
+{
+  read_flags();
+  if (h_flags_[F_MARGIN_FAIL])
+    fail("overlapped halo: an atom moved more than %.3g (5 %% of the skin) in one sub-step; the one-step-late "
+         "rebuild vote of interior atoms is not safe at this speed -- run with SF_HALO_OVERLAP=0", 0.05 * skin_);
+  const int trig = h_flags_[F_VOTE0 + (last_kstep & 1)];
+  const int executed = trig >= first_k + launched ? launched : std::max(0, trig + 1 - first_k);
   if ((launched - executed) & 1) cur_ ^= 1;
   nsteps_ += executed;
   return trig;

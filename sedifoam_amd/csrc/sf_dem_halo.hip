@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void k_forward_unpack2(const double* buf0, int
 __global__ __launch_bounds__(256) void k_forward_pack_fused(const int* list0, int n0, double shift0, double* buf0,
                                                             const int* list1, int n1, double shift1, double* buf1,
                                                             const int* hdr_off, int nhdr, double* sendbuf,
-                                                            const int* flags, const double4* xr, const double4* vm,
-                                                            const double4* om)
+                                                            const int* trig_word, const double4* xr,
+                                                            const double4* vm, const double4* om)
 {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int* list = list0;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_forward_pack_fused(const int* list0, in
     k -= n0;
     if (k >= n1) {
       k -= n1;
-      if (k < nhdr) sendbuf[hdr_off[k]] = (double)flags[F_TRIGGER];
+      if (k < nhdr) sendbuf[hdr_off[k]] = (double)__atomic_load_n(trig_word, __ATOMIC_RELAXED);
       return;
     }
     list = list1;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_forward_pack_fused(const int* list0, in
 __global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0, int n0, int first0,
                                                               const double* buf1, int n1, int first1,
                                                               const int* hdr_off, int nhdr, const double* recvbuf,
-                                                              int* flags, double4* xr, double4* vm, double4* om)
+                                                              int* vote_word, double4* xr, double4* vm, double4* om)
 {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   const double* buf = buf0;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0
     k -= n0;
     if (k >= n1) {
       k -= n1;
-      if (k < nhdr) atomicMin(&flags[F_TRIGGER], (int)recvbuf[hdr_off[k]]);
+      if (k < nhdr) atomicMin(vote_word, (int)recvbuf[hdr_off[k]]);
       return;
     }
     buf = buf1;
@@ -353,27 +353,35 @@ __global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0
 void DemEngine::forward_pack_fused(double shift0, long long off0, double shift1, long long off1, const int* hdr_off,
                                    int nhdr, double* sendbuf)
 {
+  // overlap mode: on the communication stream, header = this rank's accumulated local trigger
+  hipStream_t st = overlap_ ? comm_stream_ : stream_;
   const int tot = (int)(nsend_[0] + nsend_[1]) + nhdr;
   if (tot)
-    k_forward_pack_fused<<<div_up(tot, 256), 256, 0, stream_>>>(
+    k_forward_pack_fused<<<div_up(tot, 256), 256, 0, st>>>(
         sendlist_[0].as<int>(), (int)nsend_[0], shift0, sendbuf + off0, sendlist_[1].as<int>(), (int)nsend_[1],
-        shift1, sendbuf + off1, hdr_off, nhdr, sendbuf, d_flags_, xr_[cur_].as<double4>(),
-        vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+        shift1, sendbuf + off1, hdr_off, nhdr, sendbuf, d_flags_ + (overlap_ ? F_TRIG_LOCAL : F_TRIGGER),
+        xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>());
   if (!external_stream_) sync();
 }
 
 void DemEngine::forward_unpack_fused(const double* recvbuf, long long off0, long long n0, long long off1,
-                                     long long n1, const int* hdr_off, int nhdr)
+                                     long long n1, const int* hdr_off, int nhdr, int kstep)
 {
   if (n0 != recv_count_[0] || n1 != recv_count_[1])
     fail("forward_unpack: got %lld/%lld ghosts, the border exchange set up %d/%d", n0, n1, recv_count_[0],
          recv_count_[1]);
+  hipStream_t st = overlap_ ? comm_stream_ : stream_;
+  // overlap mode: the vote of the exchange that follows sub-step kstep goes to F_VOTE0 + (kstep & 1)
+  int* vote = d_flags_ + (overlap_ ? F_VOTE0 + (kstep & 1) : F_TRIGGER);
   const int tot = (int)(n0 + n1) + nhdr;
   if (tot)
-    k_forward_unpack_fused<<<div_up(tot, 256), 256, 0, stream_>>>(
+    k_forward_unpack_fused<<<div_up(tot, 256), 256, 0, st>>>(
         recvbuf + off0, (int)n0, recv_first_[0], recvbuf + off1, (int)n1, recv_first_[1], hdr_off, nhdr, recvbuf,
-        d_flags_, xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>());
-  launch_ghost_forward(cur_, INT_MIN);   // local y/z images of everything, received ghosts included
+        vote, xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+  if (overlap_)   // images of the received ghosts; images of owned atoms were refreshed by substep_flip
+    launch_ghost_forward(cur_, kstep, 2, F_VOTE0 + ((kstep + 1) & 1), comm_stream_);
+  else
+    launch_ghost_forward(cur_, INT_MIN);   // local y/z images of everything, received ghosts included
 }
 
 void DemEngine::forward_pack2(double shift0, double* buf0, double shift1, double* buf1, long long* n0, long long* n1)

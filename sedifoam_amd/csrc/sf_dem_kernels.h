@@ -289,7 +289,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       wn = wn + dtirot * T;
       const double dx = xn.x - ld_stream(&P.xhold[i]), dy = xn.y - ld_stream(&P.xhold[cap + i]),
                    dz = xn.z - ld_stream(&P.xhold[2 * cap + i]);
-      if (dx * dx + dy * dy + dz * dz > S.trigger_sq) atomicMin(&P.flags[F_TRIGGER], S.kstep);
+      if (dx * dx + dy * dy + dz * dz > S.trigger_sq) atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
+      if (S.margin_sq > 0.0) {
+        const double sx = xn.x - xi.x, sy = xn.y - xi.y, sz = xn.z - xi.z;
+        if (sx * sx + sy * sy + sz * sz > S.margin_sq) P.flags[F_MARGIN_FAIL] = 1;
+      }
     }
   }
 #if SF_NT_OUT
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
-  if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;
+  if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
   // The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
@@ -329,8 +333,16 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int i = bid * blockDim.x + threadIdx.x;
-  if (i >= S.nlocal) return;
+  int i = bid * blockDim.x + threadIdx.x;
+  if (S.part == 2) {          // atoms next to the slab's x faces: a prefix and a suffix of the x-slowest order
+    if (i >= S.nb) return;
+    if (i >= S.n_lo) i += S.n_hi - S.n_lo;
+  } else if (S.part == 1) {   // everything in between
+    i += S.n_lo;
+    if (i >= S.n_hi) return;
+  } else if (i >= S.nlocal) {
+    return;
+  }
   substep_particle<STYLE, COHE, LUB, false>(P, S, i, nullptr, nullptr, nullptr);
 }
 
@@ -344,7 +356,7 @@ template <int STYLE, bool COHE, bool LUB>
 __global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
 {
   extern __shared__ double4 lds4[];
-  if (__atomic_load_n(&P.flags[F_TRIGGER], __ATOMIC_RELAXED) < S.kstep) return;
+  if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
   int tile = blockIdx.x;
   if (S.xcd_remap) {
     const int nb = gridDim.x, xcd = tile & 7, q = nb >> 3, r = nb & 7;
@@ -396,21 +408,24 @@ __global__ __launch_bounds__(256) void k_initial_integrate(double4* xr, double4*
   vm[i] = v;
   om[i] = w;
   const double dx = x.x - xhold[i], dy = x.y - xhold[cap + i], dz = x.z - xhold[2 * cap + i];
-  if (dx * dx + dy * dy + dz * dz > trigger_sq) atomicMin(&flags[F_TRIGGER], -1);
+  if (dx * dx + dy * dy + dz * dz > trigger_sq) atomicMin(flags, -1);   // flags: the trigger word to use
 }
 
 // [3P] Comm::forward_comm for images owned by this GPU: ghost = root atom + accumulated shift
 __global__ __launch_bounds__(256) void k_ghost_forward(double4* xr, double4* vm, double4* om,
                                                        const int* gsrc, const double* gshift,
                                                        int nlocal, int nghost, size_t cap,
-                                                       const int* flags, int kstep)
+                                                       const int* flags, int kstep, int trig_word, int phase)
 {
-  if (__atomic_load_n(&flags[F_TRIGGER], __ATOMIC_RELAXED) < kstep) return;
+  if (__atomic_load_n(&flags[trig_word], __ATOMIC_RELAXED) < kstep) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nghost) return;
   const int g = nlocal + k;
   const int src = gsrc[g];
   if (src < 0) return;  // ghost owned by another GPU: filled by sf_dem_forward_unpack
+  // phase 1: images of owned atoms only ; phase 2: images of ghosts owned by another GPU only ; 0: both
+  if (phase == 1 && src >= nlocal) return;
+  if (phase == 2 && src < nlocal) return;
   double4 x = xr[src];
   x.x += gshift[g];
   x.y += gshift[cap + g];
@@ -418,6 +433,46 @@ __global__ __launch_bounds__(256) void k_ghost_forward(double4* xr, double4* vm,
   xr[g] = x;
   vm[g] = vm[src];
   om[g] = om[src];
+}
+
+// overlapped halo: an owned atom is a BOUNDARY atom when the forward halo sends it or when its list holds a ghost
+// whose root is owned by another GPU (gsrc < 0, or an image of such a ghost); everything else is interior and
+// never reads what the halo exchange writes.
+__global__ __launch_bounds__(256) void k_mark_boundary(const int* neigh, const int* numneigh, const int* gsrc,
+                                                       const int* send0, int n0, const int* send1, int n1,
+                                                       int nlocal, size_t cap, unsigned char* isb, int phase)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (phase == 0) {
+    if (t >= nlocal) return;
+    const int nn = numneigh[t];
+    unsigned char b = 0;
+    for (int s = 0; s < nn; s++) {
+      const int j = neigh[(size_t)s * cap + t] & kNeighMask;
+      if (j >= nlocal) {
+        const int r = gsrc[j];
+        if (r < 0 || r >= nlocal) {
+          b = 1;
+          break;
+        }
+      }
+    }
+    isb[t] = b;
+  } else {
+    if (t < n0) isb[send0[t]] = 1;
+    else if (t < n0 + n1) isb[send1[t - n0]] = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_boundary_keys(const unsigned char* isb, int nlocal, unsigned* keys, int* idx,
+                                                       int* counter)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const unsigned k = isb[i] ? 0u : 1u;
+  keys[i] = k;
+  idx[i] = i;
+  if (!k) atomicAdd(counter, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,6 +515,25 @@ __device__ __forceinline__ int bin_of(const double4& x, const BinGrid& g, int& l
   const int cy = bin_coord(x.y, g.lo[1], g.inv[1], g.n[1], lost);
   const int cz = bin_coord(x.z, g.lo[2], g.inv[2], g.n[2], lost);
   return bin_key(g, cx, cy, cz);
+}
+
+// x-slowest order: number of owned atoms in cell layers cx < cx_lo and cx < cx_hi (prefix lengths)
+__global__ __launch_bounds__(256) void k_count_layers(const double4* xr, int nlocal, BinGrid g, int cx_lo, int cx_hi,
+                                                      int* counters)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int lost = 0;
+  int a = 0, b = 0;
+  if (i < nlocal) {
+    const int cx = bin_coord(xr[i].x, g.lo[0], g.inv[0], g.n[0], lost);
+    a = cx < cx_lo;
+    b = cx < cx_hi;
+  }
+  const unsigned long long ma = __ballot(a), mb = __ballot(b);
+  if ((threadIdx.x & 63) == 0) {
+    if (ma) atomicAdd(&counters[0], __popcll(ma));
+    if (mb) atomicAdd(&counters[1], __popcll(mb));
+  }
 }
 
 // [3P] Domain::pbc for owned atoms + bin key
@@ -632,12 +706,17 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   const int tx = cx / T, ty = cy / T, tz = cz / T;
   const int* eo = B.eoff ? B.eoff + (size_t)(tx + B.g.nt[0] * (ty + B.g.nt[1] * tz)) * (E * E * E) : nullptr;
   const int R = B.g.stencil;
-  for (int bz = cz - R; bz <= cz + R; bz++) {
-    if (bz < 0 || bz >= B.g.n[2]) continue;
+  // cells are visited with the fastest key dimension innermost (x, or z in the x-slowest order), so consecutive
+  // slots of an atom -- and the same slot of adjacent lanes -- point at consecutive atoms in memory
+  const int co = B.g.xslow ? cx : cz, no = B.g.xslow ? B.g.n[0] : B.g.n[2];
+  const int ci = B.g.xslow ? cz : cx, ni = B.g.xslow ? B.g.n[2] : B.g.n[0];
+  for (int bo = co - R; bo <= co + R; bo++) {
+    if (bo < 0 || bo >= no) continue;
     for (int by = cy - R; by <= cy + R; by++) {
       if (by < 0 || by >= B.g.n[1]) continue;
-      for (int bx = cx - R; bx <= cx + R; bx++) {
-        if (bx < 0 || bx >= B.g.n[0]) continue;
+      for (int bi = ci - R; bi <= ci + R; bi++) {
+        if (bi < 0 || bi >= ni) continue;
+        const int bx = B.g.xslow ? bo : bi, bz = B.g.xslow ? bi : bo;
         const int b = bin_key(B.g, bx, by, bz);
         const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;   // stencil 1 only
         const int nloc_b = cellLE[b] - cellLS[b];

@@ -599,12 +599,56 @@ int sf_dem_forward_pack_fused(void* ptr, double shift0, long long off0, double s
 }
 
 int sf_dem_forward_unpack_fused(void* ptr, const double* dev_recvbuf, long long off_from_left, long long n_from_left,
-                                long long off_from_right, long long n_from_right, const int* dev_hdr_off, int nhdr)
+                                long long off_from_right, long long n_from_right, const int* dev_hdr_off, int nhdr,
+                                int kstep)
 {
   SF_API_BEGIN
   H(ptr)->eng.forward_unpack_fused(dev_recvbuf, off_from_left, n_from_left, off_from_right, n_from_right,
-                                   dev_hdr_off, nhdr);
+                                   dev_hdr_off, nhdr, kstep);
   SF_API_END(0)
+}
+
+int sf_dem_set_overlap(void* ptr, int on, void* comm_stream)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_overlap(on != 0, (hipStream_t)comm_stream);
+  SF_API_END(0)
+}
+
+int sf_dem_overlap_begin(void* ptr)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.overlap_begin();
+  SF_API_END(0)
+}
+
+int sf_dem_substep_part(void* ptr, int part, int last, int kstep)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.substep_part(part, last != 0, kstep);
+  SF_API_END(0)
+}
+
+int sf_dem_substep_flip(void* ptr, int kstep)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.substep_flip(kstep);
+  SF_API_END(0)
+}
+
+int sf_dem_overlap_batch_end(void* ptr, int first_k, int launched, int last_kstep, int* trigger)
+{
+  SF_API_BEGIN
+  if (!trigger) sf::fail("sf_dem_overlap_batch_end: null output");
+  *trigger = H(ptr)->eng.overlap_batch_end(first_k, launched, last_kstep);
+  SF_API_END(0)
+}
+
+int sf_dem_boundary_count(void* ptr)
+{
+  SF_API_BEGIN
+  return H(ptr)->eng.boundary_count();
+  SF_API_END(-1)
 }
 
 long long sf_dem_migrate_pack(void* ptr, int side, double xshift, double* dev_buf, long long max_doubles)

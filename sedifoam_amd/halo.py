@@ -124,15 +124,76 @@ class HipSlabEngine:
         self.check(self.L.sf_dem_forward_pack_fused(self.lmp.ptr, shift0, int(off0), shift1, int(off1),
                                                     hdr_off.data_ptr(), hdr_off.numel(), sendbuf.data_ptr()))
 
-    def forward_unpack_fused(self, recvbuf, off_l, n_l, off_r, n_r, hdr_off):
+    def forward_unpack_fused(self, recvbuf, off_l, n_l, off_r, n_r, hdr_off, kstep=-1):
         self.check(self.L.sf_dem_forward_unpack_fused(self.lmp.ptr, recvbuf.data_ptr(), int(off_l), int(n_l),
-                                                      int(off_r), int(n_r), hdr_off.data_ptr(), hdr_off.numel()))
+                                                      int(off_r), int(n_r), hdr_off.data_ptr(), hdr_off.numel(),
+                                                      int(kstep)))
+
+    # ---- the per-sub-step loop in C++ over RCCL (csrc/sf_halo_rccl.hip) ----
+    def comm_init(self, dist, rank, world):
+        """one RCCL communicator per engine; the 128-byte id travels through the torch process group"""
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            self.check(self.L.sf_dem_comm_unique_id(buf))
+            ident[0] = buf.raw
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self.check(self.L.sf_dem_comm_init(self.lmp.ptr, ident[0], int(rank), int(world)))
+
+    def halo_run(self, first_k, n, lay):
+        from . import _lib
+        W = len(lay["in_split"])
+        LL = C.c_longlong * W
+        so, ro = [0] * W, [0] * W
+        for p in range(1, W):
+            so[p] = so[p - 1] + lay["in_split"][p - 1]
+            ro[p] = ro[p - 1] + lay["out_split"][p - 1]
+        keep = (LL(*so), LL(*lay["in_split"]), LL(*ro), LL(*lay["out_split"]))
+        h = _lib.HaloLayout()
+        h.world = W
+        h.shift_left, h.shift_right = lay["shift_left"], lay["shift_right"]
+        h.soff_l, h.soff_r = lay["soff_l"], lay["soff_r"]
+        h.roff_l, h.n_from_left = lay["roff_l"], lay["n_from_left"]
+        h.roff_r, h.n_from_right = lay["roff_r"], lay["n_from_right"]
+        h.send_off, h.send_cnt, h.recv_off, h.recv_cnt = keep
+        h.dev_shdr, h.dev_rhdr = lay["shdr"].data_ptr(), lay["rhdr"].data_ptr()
+        h.dev_tx, h.dev_rx = lay["tx"].data_ptr(), lay["rx"].data_ptr()
+        t = C.c_int()
+        self.check(self.L.sf_dem_halo_run(self.lmp.ptr, int(first_k), int(n), C.byref(h), C.byref(t)))
+        return t.value
+
+    # ---- overlapped halo: boundary atoms, then [exchange on comm_stream || interior atoms on the main stream] ----
+    def enable_overlap(self):
+        torch = self.torch
+        # high priority: the small pack / exchange / unpack kernels must not queue behind the interior kernel's
+        # workgroups for compute units
+        self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        self.ev_boundary = torch.cuda.Event()
+        self.ev_halo = torch.cuda.Event()
+        self.check(self.L.sf_dem_set_overlap(self.lmp.ptr, 1, self.comm_stream.cuda_stream))
+
+    def overlap_begin(self):
+        self.check(self.L.sf_dem_overlap_begin(self.lmp.ptr))
+
+    def substep_part(self, part, last, kstep):
+        self.check(self.L.sf_dem_substep_part(self.lmp.ptr, int(part), int(last), int(kstep)))
+
+    def substep_flip(self, kstep):
+        self.check(self.L.sf_dem_substep_flip(self.lmp.ptr, int(kstep)))
+
+    def overlap_batch_end(self, first_k, launched, last_kstep):
+        t = C.c_int()
+        self.check(self.L.sf_dem_overlap_batch_end(self.lmp.ptr, int(first_k), int(launched), int(last_kstep),
+                                                   C.byref(t)))
+        return t.value
 
 
 class SlabDriver:
     """lammps_step() for one slab of an x-decomposed domain.  All methods are collective over the ranks."""
 
-    def __init__(self, eng, dist, rank, world, xlo, xhi, periodic_x=True, halo_atoms=None, transport="direct"):
+    def __init__(self, eng, dist, rank, world, xlo, xhi, periodic_x=True, halo_atoms=None, transport="direct",
+                 overlap=None):
         import torch
         # "direct": P2P on the engine's own (device) buffers = RCCL over xGMI.  "host": stage through CPU tensors
         # (lets a gloo process group carry the halo of GPU engines, e.g. two ranks sharing one GPU in a test).
@@ -159,6 +220,19 @@ class SlabDriver:
                           and os.environ.get("SF_HALO_SELF_COMM", "0") == "1")
         # one all-to-all per sub-step (halo + rebuild vote) instead of an all-reduce and a P2P group
         self.fused = hasattr(eng, "forward_pack_fused") and os.environ.get("SF_HALO_FUSED", "1") != "0"
+        # exchange under the interior kernel (see sf_dem_set_overlap in include/sedifoam_amd.h)
+        if overlap is None:
+            overlap = os.environ.get("SF_HALO_OVERLAP", "0") == "1"
+        self.overlap = bool(overlap) and self.fused and hasattr(eng, "enable_overlap") and (world > 1 or self.self_comm)
+        if self.overlap:
+            eng.enable_overlap()
+        # transport "rccl": the per-sub-step loop runs in C++ on its own RCCL communicator (rebuild-time exchanges
+        # stay on torch.distributed, they are rare)
+        if self.transport == "rccl":
+            if not (self.fused and hasattr(eng, "comm_init") and (world > 1 or self.self_comm)):
+                self.transport = "direct"
+            else:
+                eng.comm_init(dist, rank, world)
         self._cap_atoms = int(halo_atoms) if halo_atoms else max(eng.info().nlocal, 4096)
         self._bufs = {}
         self._nrecv = [0, 0]
@@ -177,7 +251,7 @@ class SlabDriver:
         if self.world == 1 and not self.self_comm:
             return int(v)
         t = self.torch.tensor([int(v)], dtype=self.torch.int64,
-                              device=self.e.device if self.transport == "direct" else "cpu")
+                              device=self.e.device if self.transport != "host" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
@@ -195,7 +269,7 @@ class SlabDriver:
             n_l = 0
         if self.right is None:
             n_r = 0
-        tdev = self.e.device if self.transport == "direct" else torch.device("cpu")
+        tdev = self.e.device if self.transport != "host" else torch.device("cpu")
         if known is None:
             cs_l = torch.tensor([n_l], dtype=torch.int64, device=tdev)
             cs_r = torch.tensor([n_r], dtype=torch.int64, device=tdev)
@@ -217,7 +291,7 @@ class SlabDriver:
             m_l, m_r = known
         recv_l = self._buf("recv_l", m_l)
         recv_r = self._buf("recv_r", m_r)
-        if self.transport == "direct":
+        if self.transport != "host":
             tx_l, tx_r, rx_l, rx_r = send_l, send_r, recv_l, recv_r
         else:
             if self.e.device.type == "cuda":
@@ -237,7 +311,7 @@ class SlabDriver:
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
-        if self.transport != "direct":
+        if self.transport == "host":
             recv_l[:m_l].copy_(rx_l[:m_l])
             recv_r[:m_r].copy_(rx_r[:m_r])
         return recv_l, m_l, recv_r, m_r
@@ -310,6 +384,8 @@ class SlabDriver:
             scratch += ns[1] * F
         lay["roff_r"] = rbase[self.right] + 1 if self.right is not None else 0
         lay["roff_l"] = (rbase[self.left] + 1 + (nr[1] * F if same else 0)) if self.left is not None else 0
+        lay["shift_left"], lay["shift_right"] = self.shift_left, self.shift_right
+        lay["n_from_left"], lay["n_from_right"] = nr[0], nr[1]
         lay["shdr"] = self.e.index_table(sbase)
         lay["rhdr"] = self.e.index_table(rbase)
         lay["tx"] = self._buf("a2a_tx", lay["ntx"] + scratch)
@@ -320,7 +396,7 @@ class SlabDriver:
         """rx[chunk p] <- what rank p put into its chunk for me."""
         torch, dist = self.torch, self.dist
         tx, rx = lay["tx"][:lay["ntx"]], lay["rx"][:lay["nrx"]]
-        if self.transport == "direct":
+        if self.transport != "host":
             dist.all_to_all_single(rx, tx, lay["out_split"], lay["in_split"])
             return
         # gloo has no all-to-all: the same chunks as point-to-point messages through host memory
@@ -344,12 +420,70 @@ class SlabDriver:
                 r.wait()
         rx.copy_(hrx)
 
-    def forward_fused(self, lay):
+    def forward_fused(self, lay, kstep=-1):
         """rebuild vote + forward halo of one sub-step: pack kernel, ONE collective, unpack kernel."""
         e = self.e
         e.forward_pack_fused(self.shift_left, lay["soff_l"], self.shift_right, lay["soff_r"], lay["shdr"], lay["tx"])
         self._all_to_all(lay)
-        e.forward_unpack_fused(lay["rx"], lay["roff_l"], self._nrecv[0], lay["roff_r"], self._nrecv[1], lay["rhdr"])
+        e.forward_unpack_fused(lay["rx"], lay["roff_l"], self._nrecv[0], lay["roff_r"], self._nrecv[1], lay["rhdr"],
+                               kstep)
+
+    def _exchange_overlapped(self, lay, kstep):
+        """the exchange that follows sub-step kstep, on the communication stream, after the boundary kernel"""
+        e = self.e
+        cs = getattr(e, "comm_stream", None)
+        if cs is None:                      # CPU stand-in engine: no streams
+            self.forward_fused(lay, kstep)
+            return
+        torch = self.torch
+        e.ev_boundary.record(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            cs.wait_event(e.ev_boundary)
+            self.forward_fused(lay, kstep)
+            e.ev_halo.record(cs)
+
+    def _wait_halo(self):
+        e = self.e
+        if getattr(e, "comm_stream", None) is not None:
+            self.torch.cuda.current_stream().wait_event(e.ev_halo)
+
+    def _step_overlapped(self, n):
+        e = self.e
+        e.run_begin()
+        k = 0
+        while k < n:
+            lay = self._fused_layout()
+            self._exchange_overlapped(lay, k - 1)          # ghosts + vote before sub-step k
+            for s in range(k, n):
+                last = s == n - 1
+                self._wait_halo()
+                e.substep_part(2, last, s)                 # boundary atoms (read the ghosts of exchange s-1)
+                # (the event recorded inside _exchange_overlapped sits between the two parts on the main stream)
+                if getattr(e, "comm_stream", None) is not None:
+                    e.ev_boundary.record(self.torch.cuda.current_stream())
+                e.substep_part(1, last, s)                 # interior atoms, under the exchange of sub-step s
+                e.substep_flip(s)
+                self._exchange_after_boundary(lay, s)
+            self._wait_halo()
+            trig = e.overlap_batch_end(k, n - k, n - 1)
+            if trig >= n:
+                break
+            k = trig + 1
+            self.rebuild()
+            e.overlap_begin()
+
+    def _exchange_after_boundary(self, lay, kstep):
+        """like _exchange_overlapped, but the boundary event has already been recorded (before the interior kernel)"""
+        e = self.e
+        cs = getattr(e, "comm_stream", None)
+        if cs is None:
+            self.forward_fused(lay, kstep)
+            return
+        torch = self.torch
+        with torch.cuda.stream(cs):
+            cs.wait_event(e.ev_boundary)
+            self.forward_fused(lay, kstep)
+            e.ev_halo.record(cs)
 
     def forward(self):
         e = self.e
@@ -380,7 +514,7 @@ class SlabDriver:
         if self.world == 1 and not self.self_comm:
             return
         trig = self.e.trigger
-        if self.transport == "direct":
+        if self.transport != "host":
             self.dist.all_reduce(trig, op=self.dist.ReduceOp.MIN)
         else:
             h = trig.cpu()
@@ -397,6 +531,21 @@ class SlabDriver:
             self.setup()
         n = int(n)
         e = self.e
+        if self.transport == "rccl":
+            e.run_begin()
+            k = 0
+            while k < n:
+                trig = e.halo_run(k, n, self._fused_layout())
+                if trig >= n:
+                    break
+                k = trig + 1
+                self.rebuild()
+                if self.overlap:
+                    e.overlap_begin()
+            return
+        if self.overlap:
+            self._step_overlapped(n)
+            return
         e.run_begin()
         k = 0
         fused = self.fused and (self.world > 1 or self.self_comm)
@@ -427,9 +576,11 @@ class SlabDriver:
         return self.e.lmp.get_profile()
 
     @classmethod
-    def from_bed(cls, bed, script, dist, rank, world, transport="direct"):
+    def from_bed(cls, bed, script, dist, rank, world, transport=None):
         """bench.py: every rank owns one copy of `bed` (its own seed), laid side by side along x."""
         from . import Lammps
+        if transport is None:
+            transport = os.environ.get("SF_HALO_TRANSPORT", "rccl")
         lx = float(bed["boxhi"][0] - bed["boxlo"][0])
         x = np.array(bed["x"], copy=True)
         x[:, 0] += rank * lx

@@ -39,6 +39,7 @@ def _case(periodic_x=True, vmax=0.5, skin=0.05e-3, seed=31):
 def _worker(rank, world, port, outdir, periodic_x, steps, mode):
     sys.path.insert(0, ROOT)
     os.environ["SF_HALO_FUSED"] = "0" if mode == "p2p+allreduce" else "1"
+    os.environ["SF_HALO_OVERLAP"] = "1" if mode == "overlap" else "0"
     import torch.distributed as dist
     from oracle import binding as ob
     from sedifoam_amd.halo import SlabDriver
@@ -64,7 +65,7 @@ def _worker(rank, world, port, outdir, periodic_x, steps, mode):
     dem.timestep(cfg["dt"])
     drv = SlabDriver(ob.OracleSlabEngine(dem), dist, rank, world, lo, hi, periodic_x=periodic_x,
                      transport="host" if mode == "fused-p2p" else "direct")
-    assert drv.fused == (mode != "p2p+allreduce")
+    assert drv.fused == (mode != "p2p+allreduce") and drv.overlap == (mode == "overlap")
     drv.setup()
     for n in steps:
         drv.step(n)
@@ -79,9 +80,11 @@ def _worker(rank, world, port, outdir, periodic_x, steps, mode):
 
 
 # mode: "fused" = one all_to_all_single per sub-step (halo + rebuild vote; what RCCL runs), "fused-p2p" = the same
-# chunks as point-to-point messages (transport="host"), "p2p+allreduce" = the older two-collective protocol
+# chunks as point-to-point messages (transport="host"), "p2p+allreduce" = the older two-collective protocol,
+# "overlap" = the boundary / exchange / interior schedule of the overlapped halo (control flow only on the CPU twin)
 @pytest.mark.parametrize("world,periodic_x,mode", [(2, True, "fused"), (3, True, "fused"), (2, False, "fused"),
-                                                   (3, False, "fused-p2p"), (3, True, "p2p+allreduce")])
+                                                   (3, False, "fused-p2p"), (3, True, "p2p+allreduce"),
+                                                   (3, True, "overlap"), (2, False, "overlap")])
 def test_decomposed_run_matches_single_domain(world, periodic_x, mode):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)

@@ -44,7 +44,7 @@ def test_self_halo_matches_internal_periodic_and_oracle(vmax, skin, steps):
         assert drv.n_rebuilds >= 3      # migration across the periodic face + history carry-over exercised
 
 
-def _two_rank_worker(rank, world, port, outdir, steps):
+def _two_rank_worker(rank, world, port, outdir, steps, overlap=False):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import numpy as np
@@ -68,8 +68,13 @@ def _two_rank_worker(rank, world, port, outdir, steps):
                      tag=(np.nonzero(mine)[0] + 1))
     for line in dc.script_lines(bed, cfg):
         lmp.command(line)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host",
+                     overlap=overlap)
+    assert drv.overlap == overlap
     drv.setup()
+    if overlap:
+        nb = lmp.L.sf_dem_boundary_count(lmp.ptr)
+        assert 0 < nb < lmp.info().nlocal       # some atoms talk to the other rank, most do not
     for n in steps:
         drv.step(n)
     st = lmp.get_state()
@@ -81,9 +86,11 @@ def _two_rank_worker(rank, world, port, outdir, steps):
     dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_one_gpu_match_single_domain():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_sharing_one_gpu_match_single_domain(overlap):
     """Two HIP engines (two processes on the same GPU) exchanging their halo through the driver -- the
-    decomposed N > 1 path with the real kernels; only the wire is gloo-through-host instead of RCCL."""
+    decomposed N > 1 path with the real kernels; only the wire is gloo-through-host instead of RCCL.
+    overlap=True: boundary kernel / exchange on a second stream / interior kernel (sf_dem_set_overlap)."""
     import os, socket, tempfile
     import torch.multiprocessing as mp
     steps = (50, 50)
@@ -98,7 +105,7 @@ def test_two_ranks_sharing_one_gpu_match_single_domain():
     assert ref.info().nbuilds >= 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_two_rank_worker, args=(2, port, out, steps), nprocs=2, join=True)
+        mp.spawn(_two_rank_worker, args=(2, port, out, steps, overlap), nprocs=2, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
     tag = np.concatenate([p["tag"] for p in parts])
     assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
@@ -120,7 +127,7 @@ def test_two_ranks_sharing_one_gpu_match_single_domain():
     assert set(hb) == set(ha)
 
 
-def _rccl_self_worker(port, outdir):
+def _rccl_self_worker(port, outdir, overlap=False, transport="direct"):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["SF_HALO_SELF_COMM"] = "1"
@@ -138,8 +145,8 @@ def _rccl_self_worker(port, outdir):
     cfg["walls"] = T._walls(bed)
     lmp = dc.make_hip(bed, cfg)
     drv = SlabDriver(HipSlabEngine(lmp), dist, 0, 1, float(bed["boxlo"][0]), float(bed["boxhi"][0]),
-                     periodic_x=True, transport="direct")
-    assert drv.self_comm
+                     periodic_x=True, transport=transport, overlap=overlap)
+    assert drv.self_comm and drv.overlap == overlap and drv.transport == transport
     drv.setup()
     for n in (70, 70):
         drv.step(n)
@@ -148,13 +155,16 @@ def _rccl_self_worker(port, outdir):
     dist.destroy_process_group()
 
 
-def test_rccl_transport_self_images(tmp_path):
-    """transport="direct" (torch.distributed nccl = RCCL, P2P + all-reduce on the engine's device buffers and
-    stream) with one rank sending its periodic images to itself: same protocol and code path as N > 1."""
+@pytest.mark.parametrize("overlap,transport", [(False, "direct"), (True, "direct"), (False, "rccl"), (True, "rccl")])
+def test_rccl_transport_self_images(tmp_path, overlap, transport):
+    """One rank sending its periodic images to itself through RCCL: same protocol and code path as N > 1.
+    transport="direct": torch.distributed (nccl = RCCL) all_to_all_single on the engine's device buffers, driven
+    from Python; transport="rccl": the whole sub-step loop in C++ (sf_dem_halo_run, grouped ncclSend/ncclRecv on
+    the engine's own communicator)."""
     import torch.multiprocessing as mp
     port = 29600 + (hash(str(tmp_path)) % 300)
     ctx = mp.get_context("spawn")
-    p = ctx.Process(target=_rccl_self_worker, args=(port, str(tmp_path)))
+    p = ctx.Process(target=_rccl_self_worker, args=(port, str(tmp_path), overlap, transport))
     p.start()
     p.join(300)
     if p.is_alive():
