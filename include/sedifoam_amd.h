@@ -178,6 +178,10 @@ int sf_dem_forward_unpack_fused(void *ptr, const double *dev_recvbuf, long long 
  * skin in this mode so that it stays a superset of the interacting pairs for that extra sub-step (checked:
  * sf_dem_overlap_batch_end fails if any atom moved more than 5 % of the skin in one sub-step). */
 int sf_dem_set_overlap(void *ptr, int on, void *comm_stream);
+/* Compute-unit partition for the overlapped halo: creates (once) two streams with disjoint CU masks -- the exchange
+ * gets comm_cus_per_xcd (1 or 2) CUs of each of the 8 XCDs, the sub-step kernels the other 240-248 -- makes them the
+ * engine's main and communication stream and returns both so the caller can enqueue its own work on them. */
+int sf_dem_partition_streams(void *ptr, int comm_cus_per_xcd, void **main_stream, void **comm_stream);
 int sf_dem_overlap_begin(void *ptr);
 int sf_dem_substep_part(void *ptr, int part, int last, int kstep);
 int sf_dem_substep_flip(void *ptr, int kstep);

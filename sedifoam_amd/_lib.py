@@ -127,6 +127,7 @@ _SIGS = {
     "sf_dem_forward_unpack_fused": (C.c_int, [vp, vp, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, vp,
                                               C.c_int, C.c_int]),
     "sf_dem_set_overlap": (C.c_int, [vp, C.c_int, vp]),
+    "sf_dem_partition_streams": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "sf_dem_overlap_begin": (C.c_int, [vp]),
     "sf_dem_substep_part": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     "sf_dem_substep_flip": (C.c_int, [vp, C.c_int]),

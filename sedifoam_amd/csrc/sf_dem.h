@@ -24,8 +24,20 @@
 
 namespace sf {
 
+// neighbour word: bit 30 = the reference's touch[] flag.  Root mode (default): bits 0-24 = index of the ROOT atom (an
+// owned atom, or a ghost owned by another GPU), bits 25-29 = periodic image code (sx+1) + 3(sy+1) + 9(sz+1) of the
+// neighbour relative to its root, 13 = the root itself: the kernel gathers the root's record and adds the shift, so
+// periodic images are never materialised between rebuilds (no forward copy per sub-step).  Index mode (LDS-staged
+// kernel): bits 0-29 = index of the owned or ghost atom.
 constexpr int kNeighMask = 0x3FFFFFFF;
 constexpr int kTouchBit = 0x40000000;
+constexpr int kIdxBits = 25;
+constexpr int kIdxMask = (1 << kIdxBits) - 1;
+constexpr int kNoShift = 13;
+__host__ __device__ __forceinline__ int neigh_index(int word, int roots)
+{
+  return roots ? (word & kIdxMask) : (word & kNeighMask);
+}
 constexpr int kMaxWalls = 6;
 
 enum Flag {
@@ -87,6 +99,8 @@ struct DemPtrs {
 struct StepParams {
   int nlocal, cap, mode;   // mode 0: force + final + next initial ; 1: last (force + final, store f) ; 2: setup
   int kstep;
+  int roots;         // neighbour words hold (root, image code), see kIdxMask
+  double prd[3];     // box lengths (image shift = code component * prd)
   int part, nb;      // 0: every owned atom ; 1: interior atoms [n_lo, n_hi) ; 2: boundary atoms [0, n_lo) + [n_hi, nlocal)
   int n_lo, n_hi;
   int trig_test;     // flag word whose value < kstep means "list stale, do nothing"
@@ -179,6 +193,7 @@ class DemEngine {
   // overlapped halo (decomposed domain, see sf_dem_halo.hip): boundary atoms first, the exchange of their new
   // records runs on comm_stream while the interior atoms are advanced on the main stream
   void set_overlap(bool on, hipStream_t comm_stream);
+  void make_partitioned_streams(int comm_cus_per_xcd, hipStream_t* main_out, hipStream_t* comm_out);
   void overlap_begin();                         // after run_begin: reset the local / voted trigger words
   void substep_part(int part, bool last, int kstep);   // part 2 = boundary, 1 = interior; same buffers for both
   void substep_flip(int kstep);                 // images of owned atoms + buffer parity, after both parts
@@ -353,7 +368,9 @@ private:
   int nb_ = 0;                         // boundary atoms = [0, n_lo_) and [n_hi_, nlocal_) of the x-slowest order
   int n_lo_ = 0, n_hi_ = 0;
   bool overlap_ = false;
+  bool roots_ = true;                  // neighbour words are (root, image code); false with the LDS-staged kernel
   hipStream_t comm_stream_ = nullptr;
+  hipStream_t masked_main_ = nullptr, masked_comm_ = nullptr;   // CU-partitioned pair (make_partitioned_streams)
   void mark_boundary();
   double lskin() const { return overlap_ ? 1.1 * skin_ : skin_; }   // list skin: +10 % margin in overlap mode
   long long nsend_[2] = {0, 0};

@@ -95,6 +95,8 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
+  roots_ = !opt_lds_;
+  if (const char* e = getenv("SF_ROOTS")) roots_ = atoi(e) != 0 && !opt_lds_;
   if (const char* e = getenv("SF_ROWTILE")) opt_rowtile_ = atoi(e);
   if (const char* e = getenv("SF_OCC")) opt_occ_ = atoi(e);
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
@@ -124,6 +126,8 @@ DemEngine::~DemEngine()
   if (ev1_) (void)hipEventDestroy(ev1_);
   for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
+  if (masked_main_) (void)hipStreamDestroy(masked_main_);
+  if (masked_comm_) (void)hipStreamDestroy(masked_comm_);
 }
 
 void DemEngine::set_stream(hipStream_t s)
@@ -429,6 +433,8 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.kstep = kstep;
   S.dt = dt_;
   S.trigger_sq = (0.5 * skin_) * (0.5 * skin_);
+  S.roots = roots_ ? 1 : 0;
+  for (int k = 0; k < 3; k++) S.prd[k] = boxhi_[k] - boxlo_[k];
   S.part = 0;
   S.nb = 0;
   S.trig_test = F_TRIGGER;
@@ -586,7 +592,8 @@ void DemEngine::get_profile(long long* launches, double* kernel_ms)
 
 void DemEngine::launch_ghost_forward(int buf, int kstep, int phase, int trig_word, hipStream_t s)
 {
-  if (!nghost_) return;
+  // root mode: the neighbour words point at the roots, periodic images are not refreshed between rebuilds
+  if (!nghost_ || roots_) return;
   k_ghost_forward<<<div_up(nghost_, 256), 256, 0, s ? s : stream_>>>(
       xr_[buf].as<double4>(), vm_[buf].as<double4>(), om_[buf].as<double4>(), gsrc_.as<int>(),
       gshift_.as<double>(), nlocal_, nghost_, cap_, d_flags_, kstep, trig_word, phase);
@@ -649,7 +656,7 @@ void DemEngine::compute_partner_tags()
   if (have_list_ && nlocal_ && max_neigh_used_ > 0)
     k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
                                                               tag_.as<int>(), ptag_.as<int>(), nlocal_, cap_,
-                                                              max_neigh_used_);
+                                                              max_neigh_used_, roots_ ? 1 : 0);
 }
 
 void DemEngine::rebuild_begin()
@@ -864,6 +871,11 @@ void DemEngine::bin_and_build()
     B.g = grid_;
     B.eoff = lds_active_ ? eoff_ : nullptr;
     B.nloc = nloc_.as<unsigned short>();
+    B.roots = roots_ ? 1 : 0;
+    B.gsrc = gsrc_.as<int>();
+    B.gshift = gshift_.as<double>();
+    for (int k = 0; k < 3; k++) B.inv_prd[k] = 1.0 / (boxhi_[k] - boxlo_[k]);
+    if (roots_ && cap_ > (size_t)kIdxMask) fail("more than %d atom slots per GPU: not addressable by the neighbour word", kIdxMask);
     k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
         have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_.as<double>(), neigh_.as<int>(),
@@ -990,6 +1002,33 @@ void DemEngine::set_overlap(bool on, hipStream_t comm_stream)
   comm_stream_ = on ? comm_stream : nullptr;
 }
 
+void DemEngine::make_partitioned_streams(int comm_cus_per_xcd, hipStream_t* main_out, hipStream_t* comm_out)
+{
+  // Two streams on disjoint compute units: the small pack / RCCL / unpack kernels get `comm_cus_per_xcd` CUs of
+  // every XCD to themselves, the sub-step kernels the rest.  Without the reservation the exchange kernels only get
+  // compute units when the interior kernel's workgroups drain, i.e. nothing overlaps (measured, DESIGN.md section 7;
+  // stream priority does not change that).  Bits 33k + 16j (k = XCD, j < comm_cus_per_xcd) address one CU per XCD
+  // whether the mask numbers CUs XCD-major (bit / 32) or XCD-interleaved (bit % 8).
+  sync();
+  if (comm_cus_per_xcd < 1 || comm_cus_per_xcd > 2) fail("make_partitioned_streams: 1 or 2 CUs per XCD");
+  uint32_t comm_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, main_mask[8];
+  for (int k = 0; k < 8; k++)
+    for (int j = 0; j < comm_cus_per_xcd; j++) {
+      const int bit = 33 * k + 16 * j;
+      comm_mask[bit / 32] |= 1u << (bit % 32);
+    }
+  for (int w = 0; w < 8; w++) main_mask[w] = ~comm_mask[w];
+  if (!masked_main_) {
+    SF_HIP(hipExtStreamCreateWithCUMask(&masked_main_, 8, main_mask));
+    SF_HIP(hipExtStreamCreateWithCUMask(&masked_comm_, 8, comm_mask));
+  }
+  stream_ = masked_main_;
+  external_stream_ = true;   // the caller orders its own work against these streams (no per-call syncs)
+  comm_stream_ = masked_comm_;
+  *main_out = masked_main_;
+  *comm_out = masked_comm_;
+}
+
 void DemEngine::mark_boundary()
 {
   // Boundary atoms = owned atoms within the list cutoff of one of the slab's two x faces, rounded up to whole cell
@@ -1020,12 +1059,12 @@ void DemEngine::mark_boundary()
     // list-derived classification (sent, or has a neighbour rooted on another GPU) must be inside the two ranges
     k_mark_boundary<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
                                                                gsrc_.as<int>(), nullptr, 0, nullptr, 0, nlocal_, cap_,
-                                                               isb_.as<unsigned char>(), 0);
+                                                               isb_.as<unsigned char>(), 0, roots_ ? 1 : 0);
     const int ns = (int)(nsend_[0] + nsend_[1]);
     if (ns)
       k_mark_boundary<<<div_up(ns, 256), 256, 0, stream_>>>(nullptr, nullptr, nullptr, sendlist_[0].as<int>(),
                                                             (int)nsend_[0], sendlist_[1].as<int>(), (int)nsend_[1],
-                                                            nlocal_, cap_, isb_.as<unsigned char>(), 1);
+                                                            nlocal_, cap_, isb_.as<unsigned char>(), 1, roots_ ? 1 : 0);
     std::vector<unsigned char> h(nlocal_);
     SF_HIP(hipMemcpyAsync(h.data(), isb_.ptr, nlocal_, hipMemcpyDeviceToHost, stream_));
     sync();
@@ -1243,7 +1282,7 @@ long long DemEngine::get_history(long long max, int* tag_i, int* tag_j, double* 
   ScratchD sh(3 * (size_t)max);
   k_collect_history<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
                                                                shear_.as<double>(), tag_.as<int>(), nlocal_, cap_,
-                                                               d, max, ti.p, tj.p, sh.p);
+                                                               d, max, ti.p, tj.p, sh.p, roots_ ? 1 : 0);
   unsigned long long h = 0;
   SF_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream_));
   sync();

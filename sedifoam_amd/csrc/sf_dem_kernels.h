@@ -104,7 +104,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (LDS) {
       R.l = P.nloc[slot];
     } else {
-      const int j = jraw & kNeighMask;
+      const int j = neigh_index(jraw, S.roots);
       R.x = P.xr_in[j];
       if (NEED_VW) {
         R.v = P.vm_in[j];
@@ -124,7 +124,6 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const size_t slot = (size_t)s * cap + i;
     const size_t sbase = (size_t)(3 * s) * cap + i;
     const int jraw = jraw_n1;
-    const int j = jraw & kNeighMask;
     Vec3 sh = {0.0, 0.0, 0.0};
     if (STYLE != 0 && (jraw & kTouchBit)) {
       sh.x = ld_stream(&P.shear[sbase]);
@@ -142,6 +141,16 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         wj4 = {lw[3 * cur.l], lw[3 * cur.l + 1], lw[3 * cur.l + 2], 0.0};
       }
     }
+    if (S.roots) {
+      // periodic image of the root: the same x_root + shift the reference's forward_comm would have stored
+      const int code = (jraw >> kIdxBits) & 31;
+      if (code != kNoShift) {
+        const int cz = code / 9, cy = (code - 9 * cz) / 3, cx = code - 9 * cz - 3 * cy;
+        xj4.x += (double)(cx - 1) * S.prd[0];
+        xj4.y += (double)(cy - 1) * S.prd[1];
+        xj4.z += (double)(cz - 1) * S.prd[2];
+      }
+    }
     const Vec3 del = xi - v3(xj4);
     const double rsq = dot(del, del);
     const double radj = xj4.w;
@@ -150,7 +159,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (STYLE != 0) {
       if (rsq >= radsum * radsum) {
         // unset non-touching neighbours (:131-139); the stale shear is ignored once the bit is clear
-        if (jraw & kTouchBit) P.neigh[slot] = j;
+        if (jraw & kTouchBit) P.neigh[slot] = jraw & ~kTouchBit;
       } else {
         ContactIn c;
         c.del = del;
@@ -175,7 +184,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         st_stream(&P.shear[sbase], sh.x);
         st_stream(&P.shear[sbase + cap], sh.y);
         st_stream(&P.shear[sbase + 2 * cap], sh.z);
-        if (!(jraw & kTouchBit)) P.neigh[slot] = j | kTouchBit;
+        if (!(jraw & kTouchBit)) P.neigh[slot] = jraw | kTouchBit;
         F = F + o.F;
         T = T - radi * o.tor;
       }
@@ -440,7 +449,8 @@ __global__ __launch_bounds__(256) void k_ghost_forward(double4* xr, double4* vm,
 // never reads what the halo exchange writes.
 __global__ __launch_bounds__(256) void k_mark_boundary(const int* neigh, const int* numneigh, const int* gsrc,
                                                        const int* send0, int n0, const int* send1, int n1,
-                                                       int nlocal, size_t cap, unsigned char* isb, int phase)
+                                                       int nlocal, size_t cap, unsigned char* isb, int phase,
+                                                       int roots)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (phase == 0) {
@@ -448,9 +458,9 @@ __global__ __launch_bounds__(256) void k_mark_boundary(const int* neigh, const i
     const int nn = numneigh[t];
     unsigned char b = 0;
     for (int s = 0; s < nn; s++) {
-      const int j = neigh[(size_t)s * cap + t] & kNeighMask;
+      const int j = neigh_index(neigh[(size_t)s * cap + t], roots);
       if (j >= nlocal) {
-        const int r = gsrc[j];
+        const int r = roots ? -1 : gsrc[j];   // root mode: an index >= nlocal IS a ghost owned by another GPU
         if (r < 0 || r >= nlocal) {
           b = 1;
           break;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256) void k_boundary_keys(const unsigned char* isb,
 // ------------------------------------------------------------------------------------------------
 // FixShearHistory::pre_exchange [3P]: remember each touching partner by tag
 __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const int* numneigh, const int* tag,
-                                                      int* ptag, int nlocal, size_t cap, int M)
+                                                      int* ptag, int nlocal, size_t cap, int M, int roots)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
     int t = -1;
     if (s < nn) {
       const int jraw = neigh[(size_t)s * cap + i];
-      if (jraw & kTouchBit) t = tag[jraw & kNeighMask];
+      if (jraw & kTouchBit) t = tag[neigh_index(jraw, roots)];
     }
     ptag[(size_t)s * cap + i] = t;
   }
@@ -682,6 +692,10 @@ struct BuildParams {
   BinGrid g;
   const int* eoff;    // LDS staging: [tile][(T+2)^3] offsets (nullptr: no staging tables)
   unsigned short* nloc;
+  int roots;          // store (root, image code) instead of the ghost's own index
+  const int* gsrc;    // root of a periodic image (-1: ghost owned by another GPU)
+  const double* gshift;
+  double inv_prd[3];
 };
 
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
@@ -737,6 +751,20 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
             if (rsq > cut * cut) continue;
             if (n < B.M) {
               int entry = j;
+              if (B.roots) {
+                int code = kNoShift;
+                if (j >= B.nlocal) {
+                  const int r = B.gsrc[j];
+                  if (r >= 0) {   // periodic image made on this GPU: refer to its root + which image it is
+                    entry = r;
+                    const int ix = (int)rint(B.gshift[j] * B.inv_prd[0]);
+                    const int iy = (int)rint(B.gshift[B.cap + j] * B.inv_prd[1]);
+                    const int iz = (int)rint(B.gshift[2 * B.cap + j] * B.inv_prd[2]);
+                    code = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
+                  }
+                }
+                entry |= code << kIdxBits;
+              }
               double sx = 0.0, sy = 0.0, sz = 0.0;
               const int tj = tag[j];
               for (int s = 0; s < nold; s++) {
@@ -903,7 +931,7 @@ __global__ __launch_bounds__(256) void k_count_pairs(const int* numneigh, int n,
 __global__ __launch_bounds__(256) void k_collect_history(const int* neigh, const int* numneigh, const double* shear,
                                                          const int* tag, int nlocal, size_t cap,
                                                          unsigned long long* cursor, long long max, int* ti,
-                                                         int* tj, double* sh)
+                                                         int* tj, double* sh, int roots)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
@@ -912,7 +940,7 @@ __global__ __launch_bounds__(256) void k_collect_history(const int* neigh, const
   for (int s = 0; s < nn; s++) {
     const int jraw = neigh[(size_t)s * cap + i];
     if (!(jraw & kTouchBit)) continue;
-    const int tagj = tag[jraw & kNeighMask];
+    const int tagj = tag[neigh_index(jraw, roots)];
     if (tagi >= tagj) continue;  // the j side holds the bitwise-negated copy
     const long long k = (long long)atomicAdd(cursor, 1ull);
     if (k < max) {

@@ -615,6 +615,16 @@ int sf_dem_set_overlap(void* ptr, int on, void* comm_stream)
   SF_API_END(0)
 }
 
+int sf_dem_partition_streams(void* ptr, int comm_cus_per_xcd, void** main_stream, void** comm_stream)
+{
+  SF_API_BEGIN
+  hipStream_t m = nullptr, c = nullptr;
+  H(ptr)->eng.make_partitioned_streams(comm_cus_per_xcd, &m, &c);
+  *main_stream = m;
+  *comm_stream = c;
+  SF_API_END(0)
+}
+
 int sf_dem_overlap_begin(void* ptr)
 {
   SF_API_BEGIN

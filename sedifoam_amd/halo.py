@@ -166,9 +166,17 @@ class HipSlabEngine:
     # ---- overlapped halo: boundary atoms, then [exchange on comm_stream || interior atoms on the main stream] ----
     def enable_overlap(self):
         torch = self.torch
-        # high priority: the small pack / exchange / unpack kernels must not queue behind the interior kernel's
-        # workgroups for compute units
-        self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        ncu = int(os.environ.get("SF_HALO_COMM_CUS", "2"))
+        if ncu > 0:
+            # the engine creates a CU-partitioned stream pair; torch work of the driver runs on the same two streams
+            m = C.c_void_p(); c = C.c_void_p()
+            self.check(self.L.sf_dem_partition_streams(self.lmp.ptr, ncu, C.byref(m), C.byref(c)))
+            self.main_stream = torch.cuda.ExternalStream(m.value, device=self.device)
+            self.comm_stream = torch.cuda.ExternalStream(c.value, device=self.device)
+            torch.cuda.current_stream().synchronize()
+            torch.cuda.set_stream(self.main_stream)
+        else:
+            self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1)
         self.ev_boundary = torch.cuda.Event()
         self.ev_halo = torch.cuda.Event()
         self.check(self.L.sf_dem_set_overlap(self.lmp.ptr, 1, self.comm_stream.cuda_stream))
