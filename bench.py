@@ -186,23 +186,29 @@ def main():
         # cells at least 3 d wide (a centre-counted void fraction above 1 makes every closure return inf)
         mesh_n = np.clip(((bed["boxhi"] - bed["boxlo"]) / 3.0e-3).astype(int), 1, 32)
         dx = (bed["boxhi"] - bed["boxlo"]) / mesh_n
-        cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n,
-                              dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65),
-                              dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"])
         nc = int(np.prod(mesh_n))
-        cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)))
-        cloud.calcTcFields()   # lammpsFoam.C includes liftDragCoeffs.H (alpha cap + calcTcFields) before the time loop
-        for _ in range(2):
-            cloud.evolve(); cloud.calcTcFields()
-        barrier()
-        t1 = time.perf_counter()
-        ncpl = max(3, args.steps // 2)
-        for _ in range(ncpl):
-            cloud.evolve(); cloud.calcTcFields()
-        barrier()
-        out["config"]["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
-        out["config"]["coupled_step"] = "ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc, %dx%dx%d mesh" % (
-            args.substeps, mesh_n[0], mesh_n[1], mesh_n[2])
+        # diffusion smoothing of gamma / Ue / Uf / Asrc with the reference's defaults (createFields.H:126-149:
+        # diffusionBandWidth 0.006, diffusionSteps 6), then the same loop with smoothing off
+        for key, band in (("coupled_steps_per_s", 0.006), ("coupled_steps_per_s_unsmoothed", 0.0)):
+            cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n,
+                                  dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65,
+                                       diffusionBandWidth=band, diffusionSteps=6),
+                                  dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"])
+            cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)))
+            cloud.calcTcFields()   # lammpsFoam.C includes liftDragCoeffs.H (alpha cap + calcTcFields) before the time loop
+            for _ in range(2):
+                cloud.evolve(); cloud.calcTcFields()
+            barrier()
+            t1 = time.perf_counter()
+            ncpl = max(3, args.steps // 2)
+            for _ in range(ncpl):
+                cloud.evolve(); cloud.calcTcFields()
+            barrier()
+            out["config"][key] = ncpl / (time.perf_counter() - t1)
+            cloud.close()
+        out["config"]["coupled_step"] = ("ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc + diffusion smoothing "
+                                         "(b = 6 mm, 6 steps), %dx%dx%d mesh" % (args.substeps, mesh_n[0], mesh_n[1],
+                                                                                  mesh_n[2]))
         # the library.h drop-in boundary (softParticleCloud.C:838-922): per CFD step the caller hands over HOST
         # arrays (lammps_put_local_info), runs the sub-steps and reads HOST arrays back (lammps_get_local_info);
         # this rate includes the PCIe copies and the by-tag scatter, it is reported next to `value`, never as it

@@ -551,8 +551,10 @@ class Cloud {
     k_particle_to_eulerian<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_,
                                                                       cstart_ + mesh_.ncells + 1, idx2_, e.d_xr(),
                                                                       e.d_vm(), V_, gamma_, Ue_);
-    if (props_.alphaSmooth) smoother_.smooth(gamma_, 1);   // :944-948
-    if (props_.UpSmooth) smoother_.smooth(Ue_, 3);         // :950-953
+    // gamma (:944-948) and Ue (:950-953): independent solves, batched through the same launches
+    if (props_.alphaSmooth && props_.UpSmooth) smoother_.smooth2(gamma_, 1, Ue_, 3);
+    else if (props_.alphaSmooth) smoother_.smooth(gamma_, 1);
+    else if (props_.UpSmooth) smoother_.smooth(Ue_, 3);
     k_divide_ue<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, gamma_, Ue_);
   }
 

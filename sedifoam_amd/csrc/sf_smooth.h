@@ -4,8 +4,9 @@
 // `diffusionSteps` implicit-Euler steps with zero-gradient boundaries, each step one
 // `solve(fvm::ddt(phi) - fvm::laplacian(DT, phi))` by PCG (tolerance 1e-10, system/fvSolution: tempDiffScalar).
 // On the uniform hex block that is (I - dtau*L) phi_new = phi_old with the 7-point Laplacian; here it is solved
-// matrix-free by conjugate gradients on the GPU (HBM-bound stencil + deterministic two-stage reductions, all
-// scalars device-resident; the host looks at the residual every 8 iterations).
+// matrix-free on the GPU: by default with the Chebyshev semi-iteration (spectrum of A known in closed form, no
+// inner products, fixed iteration count, nothing for the host to check), optionally by conjugate gradients
+// (SF_SMOOTH_CG=1: deterministic two-stage reductions, the host looks at the residual every 8 iterations).
 #pragma once
 #include "sf_common.h"
 
@@ -20,6 +21,8 @@ class DiffusionSmoother {
   bool enabled() const { return enabled_; }
   // field: ncells*ncomp doubles, component-interleaved (AoS); smoothed in place
   void smooth(double* field, int ncomp);
+  // two fields through the same launches (e.g. gamma [n] and Ue [n][3]); nb = 0: one field
+  void smooth2(double* fa, int na, double* fb, int nb);
   long long iterations() const { return iters_; }
 
  private:
@@ -32,6 +35,12 @@ class DiffusionSmoother {
   double *r_ = nullptr, *p_ = nullptr, *ap_ = nullptr, *partial_ = nullptr, *scal_ = nullptr;
   double* h_scal_ = nullptr;  // pinned
   long long iters_ = 0;
+  // Chebyshev iteration (default; SF_SMOOTH_CG=1 selects conjugate gradients)
+  static constexpr int kMaxCheb = 4;
+  bool use_cg_ = false;
+  double lmin_ = 1.0, lmax_ = 1.0;
+  int cheb_iters_ = 0;
+  double* cheb_ = nullptr;    // r, d (two buffers): 3 x [kMaxCheb][ncells]
 };
 
 }  // namespace sf

@@ -279,3 +279,30 @@ def test_xiaocase3_golden_through_hip_path():
     for row in gold[1:]:
         assert np.interp(row[0], t, vy) == pytest.approx(row[2], rel=0.25 if row[0] < 1e-3 else 0.04)
     assert vy[-1] == pytest.approx(0.0500031, rel=2e-3)
+
+
+def test_smooth_field_chebyshev_equals_cg_and_is_bitwise_reproducible(monkeypatch):
+    """the default solver (Chebyshev semi-iteration, fixed count, no reductions) against conjugate gradients
+    (SF_SMOOTH_CG=1) on the same system, at a stiff setting (band >> cell: condition number ~ 100)"""
+    from sedifoam_amd import Lammps, enhancedCloud
+
+    def make():
+        lmp = Lammps()
+        lmp.set_box([0, 0, 0], [1e-2, 1e-2, 1e-2])
+        lmp.create_atoms([[5e-3, 5e-3, 5e-3]], [1e-4], [2500.0])
+        lmp.commands("atom_style sphere\nboundary ff ff ff\nnewton off\npair_style gran/hooke/history 1e4 NULL 10 NULL 0.5 1\n"
+                     "pair_coeff * *\nneighbor 1e-4 bin\ntimestep 1e-6\nfix 1 all nve/sphere\nfix 2 all fdrag")
+        return enhancedCloud(lmp, np.zeros(3), np.array([5e-4, 5e-4, 5e-4]), np.array([20, 20, 20], np.int32),
+                             dict(dragModel="ErgunWenYu", subCycles=1, g=(0, 0, 0), diffusionBandWidth=1.2e-2,
+                                  diffusionSteps=3), dict(rhob=1000.0, nub=1e-6), 1e-5)
+    rng = np.random.default_rng(9)
+    f = rng.uniform(size=(8000, 3))
+    monkeypatch.delenv("SF_SMOOTH_CG", raising=False)
+    cheb = make()
+    a1 = cheb.smoothField(f); a2 = cheb.smoothField(f)
+    monkeypatch.setenv("SF_SMOOTH_CG", "1")
+    cg = make()
+    b = cg.smoothField(f)
+    assert np.array_equal(a1, a2)
+    assert dc.rel_err(a1, b) <= 1e-12
+    assert np.sum(a1, axis=0) == pytest.approx(np.sum(f, axis=0), rel=1e-12)
