@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--slab-driver", action="store_true",
                     help="drive the sub-steps through the multi-rank SlabDriver even at N=1 (self halo)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
+    ap.add_argument("--coupled-multi", action="store_true",
+                    help="with --gpus N > 1 also time coupled steps: enhancedCloud over the decomposed particles, "
+                         "whole mesh on every rank, per-cell sums all-reduced")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,6 +231,32 @@ def main():
         out["config"]["host_boundary_substeps_per_s"] = n_loc * args.substeps * nlib / (time.perf_counter() - t2)
         out["config"]["host_boundary"] = ("lammps_put_local_info + lammps_step(%d) + lammps_get_local_info on host "
                                           "arrays (PCIe-inclusive)" % args.substeps)
+    if (world > 1 or args.slab_driver) and args.coupled_multi:
+        from sedifoam_amd import enhancedCloud
+        glo = np.array(bed["boxlo"], dtype=np.float64)
+        ghi = np.array(bed["boxhi"], dtype=np.float64)
+        ghi[0] = glo[0] + world * (bed["boxhi"][0] - bed["boxlo"][0])
+        mesh_n = np.clip(((bed["boxhi"] - bed["boxlo"]) / 3.0e-3).astype(int), 1, 32)
+        mesh_n[0] *= world
+        dx = (ghi - glo) / mesh_n
+        nc = int(np.prod(mesh_n))
+        cloud = enhancedCloud(lmp.e.lmp, glo, dx, mesh_n,
+                              dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65,
+                                   diffusionBandWidth=0.006, diffusionSteps=6),
+                              dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"], driver=lmp)
+        cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)))
+        cloud.calcTcFields()
+        cloud.evolve(); cloud.calcTcFields()
+        barrier()
+        t1 = time.perf_counter()
+        ncpl = max(3, args.steps // 2)
+        for _ in range(ncpl):
+            cloud.evolve(); cloud.calcTcFields()
+        barrier()
+        out["config"]["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
+        out["config"]["coupled_step"] = ("decomposed particles, %dx%dx%d mesh on every rank, all-reduced per-cell sums; "
+                                         "ErgunWenYu + %d sub-steps + scatter + Asrc + smoothing (6 mm, 6 steps)"
+                                         % (mesh_n[0], mesh_n[1], mesh_n[2], args.substeps))
     if rank == 0 and not args.no_cpu_baseline:
         sample_n = args.cpu_sample or 1000000
         sub = 50

@@ -307,6 +307,15 @@ int sf_cloud_evolve(void *cloud);
 int sf_cloud_calc_tc_fields(void *cloud);
 /* stand-alone smoothField on a host field [ncells][ncomp] (ncomp 1 or 3), in place */
 int sf_cloud_smooth_field(void *cloud, double *field, int ncomp);
+/* evolve() / calcTcFields() in pieces, for a decomposed domain (one engine per GPU, every rank holds the whole mesh):
+ *   phase 0 UfSmoothed ; per sub-cycle: phase 1 drag on this rank's particles -> the caller runs subSteps DEM
+ *   sub-steps through the halo driver -> (first sub-cycle) phase 2 per-cell sums of this rank's particles -> the
+ *   caller adds gamma [ncells] and Ue [ncells][3] over the ranks in place -> phase 3 smoothing + Ue/gamma.
+ *   calcTcFields: phase 4 (alpha cap, local Asrc sums) -> add Asrc [ncells][3] over the ranks -> phase 5.
+ * sf_cloud_device_fields returns the device arrays to reduce (MPI_Allreduce / ncclAllReduce / torch.distributed). */
+int sf_cloud_phase(void *cloud, int phase);
+int sf_cloud_sub_cycling(void *cloud, int *subCycles, int *subSteps);
+int sf_cloud_device_fields(void *cloud, double **gamma, double **Ue, double **Asrc, int *ncells);
 /* accessors: gamma (alpha) [ncells], Ue [ncells][3], Asrc [ncells][3], Omega [ncells] to host */
 int sf_cloud_get_fields(void *cloud, double *gamma, double *Ue, double *Asrc, double *Omega);
 /* per-particle results of the last evolve sub-cycle in tag order (n = particle count):

@@ -159,6 +159,9 @@ _SIGS = {
     "sf_cloud_evolve": (C.c_int, [vp]),
     "sf_cloud_calc_tc_fields": (C.c_int, [vp]),
     "sf_cloud_smooth_field": (C.c_int, [vp, dp, C.c_int]),
+    "sf_cloud_phase": (C.c_int, [vp, C.c_int]),
+    "sf_cloud_sub_cycling": (C.c_int, [vp, ip, ip]),
+    "sf_cloud_device_fields": (C.c_int, [vp, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp), ip]),
     "sf_cloud_get_fields": (C.c_int, [vp, dp, dp, dp, dp]),
     "sf_cloud_get_particles": (C.c_int, [vp, ip, ip, dp, dp]),
     "sf_cloud_particle_count": (C.c_int, [vp]),

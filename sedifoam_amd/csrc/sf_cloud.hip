@@ -391,6 +391,14 @@ class Cloud {
   void calc_tc_fields()
   {
     const double t0 = now();
+    calc_tc_local();
+    calc_tc_finish();
+    t_.calcTc += sync_now() - t0;
+  }
+
+  // per-cell sums over THIS engine's particles (linear in the particles: a decomposed domain adds the ranks up)
+  void calc_tc_local()
+  {
     DemEngine& e = lmp_->eng;
     const int n = e.nlocal();
     ensure_particle_arrays();
@@ -402,9 +410,37 @@ class Cloud {
                                                          e.d_xr(), e.d_vm(), V_, gamma_, UfS_, props_.dragModel,
                                                          props_.nub, props_.rhob, Asrc_, Omega_, e.d_tag(), Jd_,
                                                          maxtag_);
+  }
+
+  void calc_tc_finish()
+  {
     if (props_.dragSmooth) smoother_.smooth(Asrc_, 3);                                         // :410-413
     k_weight<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, 1, gamma_, Asrc_, nullptr);   // :415-416
-    t_.calcTc += sync_now() - t0;
+  }
+
+  // The pieces of evolve() / calcTcFields() for a decomposed domain (one engine per GPU, the whole mesh replicated on
+  // every rank): the caller runs the DEM sub-steps through the halo driver between phase 1 and 2 and sums the
+  // per-cell fields over the ranks between the "local" and the "finish" phases.
+  void phase(int ph)
+  {
+    switch (ph) {
+      case 0: update_uf_smoothed(); break;
+      case 1: drag_on_particles(); break;
+      case 2: scatter_local(); break;
+      case 3: scatter_finish(); break;
+      case 4: calc_tc_local(); break;
+      case 5: calc_tc_finish(); break;
+      default: fail("sf_cloud_phase: unknown phase %d", ph);
+    }
+  }
+  int sub_cycles() const { return subCycles_; }
+  int sub_steps() const { return subSteps_; }
+  void device_fields(double** gamma, double** Ue, double** Asrc, int* ncells)
+  {
+    *gamma = gamma_;
+    *Ue = Ue_;
+    *Asrc = Asrc_;
+    *ncells = mesh_.ncells;
   }
 
   void get_fields(double* gamma, double* Ue, double* Asrc, double* Omega)
@@ -544,6 +580,12 @@ class Cloud {
 
   void particle_to_eulerian()
   {
+    scatter_local();
+    scatter_finish();
+  }
+
+  void scatter_local()
+  {
     DemEngine& e = lmp_->eng;
     const int n = e.nlocal();
     ensure_particle_arrays();
@@ -551,6 +593,10 @@ class Cloud {
     k_particle_to_eulerian<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_,
                                                                       cstart_ + mesh_.ncells + 1, idx2_, e.d_xr(),
                                                                       e.d_vm(), V_, gamma_, Ue_);
+  }
+
+  void scatter_finish()
+  {
     // gamma (:944-948) and Ue (:950-953): independent solves, batched through the same launches
     if (props_.alphaSmooth && props_.UpSmooth) smoother_.smooth2(gamma_, 1, Ue_, 3);
     else if (props_.alphaSmooth) smoother_.smooth(gamma_, 1);
@@ -637,6 +683,28 @@ int sf_cloud_evolve(void* cloud)
 {
   SF_API_BEGIN
   static_cast<Cloud*>(cloud)->evolve();
+  SF_API_END(0)
+}
+
+int sf_cloud_phase(void* cloud, int phase)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->phase(phase);
+  SF_API_END(0)
+}
+
+int sf_cloud_sub_cycling(void* cloud, int* subCycles, int* subSteps)
+{
+  SF_API_BEGIN
+  *subCycles = static_cast<Cloud*>(cloud)->sub_cycles();
+  *subSteps = static_cast<Cloud*>(cloud)->sub_steps();
+  SF_API_END(0)
+}
+
+int sf_cloud_device_fields(void* cloud, double** gamma, double** Ue, double** Asrc, int* ncells)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->device_fields(gamma, Ue, Asrc, ncells);
   SF_API_END(0)
 }
 

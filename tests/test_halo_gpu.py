@@ -183,3 +183,100 @@ def test_rccl_transport_self_images(tmp_path, overlap, transport):
     assert (a["tag"] == b["tag"]).all()
     for k in ("x", "v", "omega", "f", "torque"):
         assert dc.rel_err(a[k], b[k]) <= 1e-11, k
+
+
+def _coupled_setup(bed):
+    mesh_n = np.maximum(((bed["boxhi"] - bed["boxlo"]) / 3.0e-3).astype(np.int32), 1)
+    dx = (bed["boxhi"] - bed["boxlo"]) / mesh_n
+    nc = int(np.prod(mesh_n))
+    rng = np.random.default_rng(17)
+    fluid = dict(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)) + 0.01 * rng.normal(size=(nc, 3)),
+                 DDtUf=rng.normal(scale=0.5, size=(nc, 3)),
+                 gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)) + rng.normal(scale=50.0, size=(nc, 3)),
+                 curlU=rng.normal(scale=5.0, size=(nc, 3)))
+    cloudDict = dict(dragModel="ErgunWenYu", subCycles=2, g=(0.0, -9.81, 0.0), maxPossibleAlpha=0.65,
+                     particleLift=True, diffusionBandWidth=4.0e-3, diffusionSteps=2)
+    return mesh_n, dx, fluid, cloudDict, dict(rhob=1000.0, nub=1.0e-6)
+
+
+def _coupled_worker(rank, world, port, outdir, ncfd):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sedifoam_amd import Lammps, enhancedCloud
+    from sedifoam_amd.halo import SlabDriver, HipSlabEngine
+    from tests import dem_cases as dc
+    import tests.test_dem_gpu as T
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.3)
+    cfg = dict(T.BASE, skin=0.05e-3)
+    cfg["walls"] = T._walls(bed)
+    lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
+    w = (hi - lo) / world
+    mine = (bed["x"][:, 0] >= lo + rank * w) & ((bed["x"][:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
+    lmp = Lammps()
+    lmp.set_box(bed["boxlo"], bed["boxhi"])
+    lmp.create_atoms(bed["x"][mine], bed["diameter"][mine], bed["density"][mine], v=bed["v"][mine],
+                     tag=(np.nonzero(mine)[0] + 1))
+    for line in dc.script_lines(bed, cfg):
+        lmp.command(line)
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
+    mesh_n, dx, fluid, cloudDict, transDict = _coupled_setup(bed)
+    cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, driver=drv)
+    cloud.setFluid(**fluid)
+    g0 = cloud.gamma()
+    for _ in range(ncfd):
+        cloud.evolve()
+        cloud.calcTcFields()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), g0=g0, gamma=cloud.gamma(), Ue=cloud.Ue(), Asrc=cloud.Asrc(),
+             **lmp.get_state())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coupled_cloud_on_two_ranks_matches_single_domain():
+    """enhancedCloud over a decomposed particle set (sf_cloud_phase + all-reduce of the per-cell sums, whole mesh on
+    every rank) against the single-GPU cloud: drag closure, 2 sub-cycles of DEM sub-steps through the halo driver,
+    void fraction / Ue scatter, diffusion smoothing, Asrc."""
+    import os, socket, tempfile
+    import torch.multiprocessing as mp
+    from sedifoam_amd import enhancedCloud
+    ncfd = 3
+    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.3)
+    cfg = dict(T.BASE, skin=0.05e-3)
+    cfg["walls"] = T._walls(bed)
+    ref = dc.make_hip(bed, cfg)
+    mesh_n, dx, fluid, cloudDict, transDict = _coupled_setup(bed)
+    cloud = enhancedCloud(ref, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6)
+    cloud.setFluid(**fluid)
+    g0 = cloud.gamma()
+    assert g0.max() < 0.85
+    for _ in range(ncfd):
+        cloud.evolve()
+        cloud.calcTcFields()
+    a = ref.get_state()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_coupled_worker, args=(2, port, out, ncfd), nprocs=2, join=True)
+        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    for p in parts:     # every rank holds the same global fields
+        assert dc.rel_err(p["g0"], g0) <= 1e-12
+        assert dc.rel_err(p["gamma"], cloud.gamma()) <= 1e-9
+        assert dc.rel_err(p["Ue"], cloud.Ue()) <= 1e-8
+        assert dc.rel_err(p["Asrc"], cloud.Asrc()) <= 1e-8
+    assert np.array_equal(parts[0]["gamma"], parts[1]["gamma"])
+    tag = np.concatenate([p["tag"] for p in parts])
+    order = np.argsort(tag)
+    assert len(np.unique(tag)) == bed["n"]
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    for k in ("x", "v", "omega"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        want = a[k].copy()
+        if k == "x":
+            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            assert np.max(np.abs(got - want)) <= 1e-11
+        else:
+            assert dc.rel_err(got, want) <= 1e-8, k
