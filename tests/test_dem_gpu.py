@@ -129,6 +129,16 @@ def test_polydisperse_cohesive_lubricate():
     _run_case(bed, cfg, steps=(1, 30))
 
 
+def test_mid_size_polydisperse_cohesive_lubricate_32k():
+    """BASELINE config C4's physics (polydisperse grains, fix cohesive + pair lubricate/poly overlay) at 32 k grains,
+    through a rebuild"""
+    bed = _bed((20, 20, 20), periodic=True, seed=13, poly=(0.85e-3, 1.0e-3), spacing=0.95, vmax=0.5)
+    cfg = dict(BASE, skin=0.06e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
+               lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1))
+    lmp, orc = _run_case(bed, cfg, steps=(1, 70), tol_f=5e-12)
+    assert lmp.info().nbuilds >= 2 and orc.nbuilds == lmp.info().nbuilds
+
+
 def test_cohesive_opt0():
     bed = _bed((4, 4, 4), periodic=True, seed=12)
     cfg = dict(BASE, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 0))
