@@ -86,8 +86,6 @@ struct DemPtrs {
   const int* mask;
   int* flags;
   // boundary / interior split of the overlapped halo
-  const unsigned char* isb;     // [cap] 1 = boundary atom (is sent, or has a neighbour owned by another GPU)
-  const int* blist;             // boundary atoms, ascending
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -113,7 +111,6 @@ struct StepParams {
   LubParams lub;
   int nwalls;
   int stage_cap;   // LDS slots per workgroup in k_substep_lds
-  int occ;         // register-budget variant of k_substep (waves per SIMD the compiler must allow)
   int xcd_remap;   // blockIdx -> contiguous chunk per XCD (8 XCDs, block b runs on XCD b % 8)
   WallParams wall[kMaxWalls];
   int have_gravity;
@@ -133,19 +130,12 @@ struct BinGrid {
   int nt[3];       // close in space are close in memory in all three directions; tile <= 1: plain x-fastest
   int xslow;       // 1: z fastest, x slowest (decomposed domain: the atoms next to the two x faces of the slab are
                    // then a prefix and a suffix of the sorted array = the boundary part of the overlapped halo)
-  int rowtile;     // > 1: whole x-rows of cells, bundled rowtile x rowtile in (y, z): consecutive rows in memory
-                   // are neighbours in y AND z (lane-contiguous gathers stay contiguous along x)
 };
 
 // bin coordinates -> sort key / cell index
 __host__ __device__ __forceinline__ int bin_key(const BinGrid& g, int cx, int cy, int cz)
 {
   if (g.xslow) return cz + g.n[2] * (cy + g.n[1] * cx);
-  if (g.rowtile > 1) {
-    const int R = g.rowtile;
-    const int ty = cy / R, tz = cz / R;
-    return cx + g.n[0] * ((cy - ty * R) + R * ((cz - tz * R) + R * (ty + g.nt[1] * tz)));
-  }
   if (g.tile <= 1) return cx + g.n[0] * (cy + g.n[1] * cz);
   const int T = g.tile;
   const int tx = cx / T, ty = cy / T, tz = cz / T;
@@ -314,7 +304,9 @@ private:
   int rank_ = 0, nranks_ = 1;
   double sublo_x_ = 0.0, subhi_x_ = 1.0;
   bool have_subdomain_ = false;   // true: the x halo is external (driven through sf_dem_border_* etc.)
-  int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_occ_ = 0, opt_sub_ = 2, opt_rowtile_ = 0;   // SF_SUB: cells per cutoff length; SF_TILE / SF_XCD_REMAP / SF_LDS overrides (LDS staging: see DESIGN.md, measured slower so far)   // SF_TILE / SF_XCD_REMAP environment overrides
+  // environment overrides, all measured: SF_SUB sort cells per cutoff length, SF_TILE tile-major
+  // sort, SF_XCD_REMAP contiguous block range per XCD, SF_LDS the LDS-staged kernel
+  int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;
   DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x
@@ -364,7 +356,7 @@ private:
   BinGrid grid_{};
   // halo bookkeeping: send lists for forward comm [side] (device index arrays) and ghost slot ranges
   DevArray sendlist_[2];
-  DevArray isb_, blist_;               // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
+  DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
   int nb_ = 0;                         // boundary atoms = [0, n_lo_) and [n_hi_, nlocal_) of the x-slowest order
   int n_lo_ = 0, n_hi_ = 0;
   bool overlap_ = false;

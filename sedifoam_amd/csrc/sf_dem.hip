@@ -97,8 +97,6 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
   roots_ = !opt_lds_;
   if (const char* e = getenv("SF_ROOTS")) roots_ = atoi(e) != 0 && !opt_lds_;
-  if (const char* e = getenv("SF_ROWTILE")) opt_rowtile_ = atoi(e);
-  if (const char* e = getenv("SF_OCC")) opt_occ_ = atoi(e);
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
@@ -107,7 +105,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &blist_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_};
 }
 
 DemEngine::~DemEngine()
@@ -185,7 +183,6 @@ void DemEngine::alloc_all(size_t cap)
   leave_.alloc(sizeof(int), 1, cap, s);
   nloc_.alloc(sizeof(unsigned short), M_, cap, s);
   isb_.alloc(sizeof(unsigned char), 1, cap, s);
-  blist_.alloc(sizeof(int), 1, cap, s);
   cap_ = cap;
 }
 
@@ -413,8 +410,6 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.xhold = xhold_.as<double>();
   P.mask = mask_.as<int>();
   P.flags = d_flags_;
-  P.isb = isb_.as<unsigned char>();
-  P.blist = blist_.as<int>();
   P.nloc = nloc_.as<unsigned short>();
   P.tile_first = tile_tab_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
@@ -447,7 +442,6 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.nwalls = nwalls_;
   S.xcd_remap = opt_xcd_remap_;
   S.stage_cap = stage_cap_;
-  S.occ = opt_occ_;
   for (int w = 0; w < nwalls_; w++) S.wall[w] = walls_[w];
   S.have_gravity = have_gravity_;
   for (int k = 0; k < 3; k++) S.gacc[k] = gacc_[k];
@@ -630,19 +624,11 @@ void DemEngine::compute_grid()
   }
   grid_.stencil = opt_sub_;
   grid_.tile = opt_tile_ > 1 ? opt_tile_ * opt_sub_ : 1;   // tiles keep their physical size
-  grid_.rowtile = (grid_.tile <= 1 && opt_rowtile_ > 1) ? opt_rowtile_ * opt_sub_ : 0;
-  grid_.xslow = (have_subdomain_ && grid_.tile <= 1 && grid_.rowtile <= 1) ? 1 : 0;
+  grid_.xslow = (have_subdomain_ && grid_.tile <= 1) ? 1 : 0;
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
     grid_.nt[k] = (grid_.n[k] + grid_.tile - 1) / grid_.tile;
     grid_.nbins *= grid_.nt[k] * grid_.tile;
-  }
-  if (grid_.rowtile > 1) {
-    const int R = grid_.rowtile;
-    grid_.nt[0] = 1;
-    grid_.nt[1] = (grid_.n[1] + R - 1) / R;
-    grid_.nt[2] = (grid_.n[2] + R - 1) / R;
-    grid_.nbins = grid_.n[0] * grid_.nt[1] * R * grid_.nt[2] * R;
   }
   if ((size_t)grid_.nbins > cell_alloc_) {
     if (cell_start_) SF_HIP(hipFree(cell_start_));
@@ -1038,7 +1024,7 @@ void DemEngine::mark_boundary()
   nb_ = n_lo_ = 0;
   n_hi_ = nlocal_;
   if (!nlocal_) return;
-  if (!grid_.xslow) fail("overlapped halo: needs the x-slowest atom order (no SF_TILE / SF_ROWTILE)");
+  if (!grid_.xslow) fail("overlapped halo: needs the x-slowest atom order (no SF_TILE)");
   const double cut = cutneighmax();
   const double cell = 1.0 / grid_.inv[0];
   int cx_lo = (int)std::ceil((sublo_x_ + cut - grid_.lo[0]) / cell - 1e-9);

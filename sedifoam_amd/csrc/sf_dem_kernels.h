@@ -335,10 +335,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
   int bid = blockIdx.x;
-  // xcd_remap & 2: odd sub-steps sweep the atoms in descending order, so the rows written last by the previous
-  // sub-step (still in L2 / the 256 MB memory-side cache) are the first ones read by this one
-  if ((S.xcd_remap & 2) && (S.kstep & 1)) bid = gridDim.x - 1 - bid;
-  if (S.xcd_remap & 1) {
+  if (S.xcd_remap) {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -472,17 +469,6 @@ __global__ __launch_bounds__(256) void k_mark_boundary(const int* neigh, const i
     if (t < n0) isb[send0[t]] = 1;
     else if (t < n0 + n1) isb[send1[t - n0]] = 1;
   }
-}
-
-__global__ __launch_bounds__(256) void k_boundary_keys(const unsigned char* isb, int nlocal, unsigned* keys, int* idx,
-                                                       int* counter)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlocal) return;
-  const unsigned k = isb[i] ? 0u : 1u;
-  keys[i] = k;
-  idx[i] = i;
-  if (!k) atomicAdd(counter, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
