@@ -143,6 +143,23 @@ __host__ __device__ __forceinline__ int bin_key(const BinGrid& g, int cx, int cy
   return ((tx + g.nt[0] * (ty + g.nt[1] * tz)) * T + lz) * T * T + ly * T + lx;
 }
 
+// Block-level aggregation of counters: same-address global atomics from different XCDs are resolved at the memory
+// side at ~11 ns each, so per-wave atomics of a 1 M-atom kernel cost hundreds of microseconds.  1024-thread blocks,
+// one global atomic per block.
+__device__ __forceinline__ int block_sum_int_1024(int v)
+{
+  __shared__ int ws[16];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) ws[w] = v;
+  __syncthreads();
+  int t = 0;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += ws[k];
+  return t;   // valid in thread 0
+}
+
 class DemEngine {
  public:
   DemEngine();
@@ -343,7 +360,7 @@ private:
   void build_stage_tables();
   DevArray tmp4_, tmpd_, tmpi_;        // gather scratch
   DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
-  int* cell_start_ = nullptr;          // [4][nbins]: local start/end, ghost start/end
+  int* cell_start_ = nullptr;          // [nbins][4]: owned start/end, ghost start/end of every cell (hipMalloc: 16-byte aligned)
   size_t cell_alloc_ = 0;
   int* tagmap_ = nullptr;
   size_t tagmap_alloc_ = 0;

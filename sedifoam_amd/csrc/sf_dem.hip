@@ -662,9 +662,11 @@ void DemEngine::permute_locals(const int* perm, int n_new)
 {
   if (n_new <= 0) return;
   const int nb = div_up(n_new, 256);
+  // gather into the scratch array of the same shape, then swap the two allocations (no copy back): everything
+  // beyond the owned atoms -- ghosts -- is re-created by the rebuild that follows
   auto g4 = [&](DevArray& a) {
     k_gather4<<<nb, 256, 0, stream_>>>(tmp4_.as<double4>(), a.as<double4>(), perm, n_new);
-    SF_HIP(hipMemcpyAsync(a.ptr, tmp4_.ptr, sizeof(double4) * n_new, hipMemcpyDeviceToDevice, stream_));
+    std::swap(a.ptr, tmp4_.ptr);
   };
   auto gd = [&](DevArray& a, int rows) {
     k_gather_rows<double><<<nb, 256, 0, stream_>>>(tmpd_.as<double>(), a.as<double>(), perm, n_new, rows, cap_);
@@ -672,7 +674,7 @@ void DemEngine::permute_locals(const int* perm, int n_new)
   };
   auto gi = [&](DevArray& a) {
     k_gather_rows<int><<<nb, 256, 0, stream_>>>(tmpi_.as<int>(), a.as<int>(), perm, n_new, 1, cap_);
-    SF_HIP(hipMemcpyAsync(a.ptr, tmpi_.ptr, sizeof(int) * n_new, hipMemcpyDeviceToDevice, stream_));
+    std::swap(a.ptr, tmpi_.ptr);
   };
   g4(xr_[cur_]);
   g4(vm_[cur_]);
@@ -729,7 +731,7 @@ void DemEngine::rebuild_sort()
   // sorted bin keys -> cell ranges of owned atoms
   SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
   k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
-                                                   cell_start_ + cell_alloc_);
+                                                   cell_start_ + 1, 4);
   // owned range of every tile (bin keys are tile-major: key >> log2(T^3) is the tile id)
   const int T = grid_.tile;
   ntiles_ = grid_.nt[0] * grid_.nt[1] * grid_.nt[2];
@@ -743,7 +745,7 @@ void DemEngine::rebuild_sort()
     while ((1 << shift) < T * T * T) shift++;
     SF_HIP(hipMemsetAsync(tile_tab_, 0, sizeof(int) * 4 * tile_alloc_, stream_));
     k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, shift, tile_tab_,
-                                                     tile_tab_ + tile_alloc_);
+                                                     tile_tab_ + tile_alloc_, 1);
   }
 }
 
@@ -762,16 +764,22 @@ void DemEngine::make_periodic_ghosts()
       if (dim == 0 && have_subdomain_) continue;  // x images come from the neighbour GPUs (or the driver's self loop)
       GhostPtrs G{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
                   type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
+      // F_GHOST_COUNT counts ghosts (external ones included); list slot = ghost slot
+      const int before = nall0 - nlocal_;
       if (nall0)
-        k_make_ghosts<<<div_up(nall0, 256), 256, 0, stream_>>>(G, nlocal_, nall0, dim, boxlo_[dim], boxhi_[dim],
-                                                               cut, cap_, d_flags_);
+        k_ghost_select<<<div_up(nall0, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nall0, dim, boxlo_[dim],
+                                                                boxhi_[dim], cut, perm_.as<int>(),
+                                                                d_flags_ + F_GHOST_COUNT);
       read_flags();
-      if (h_flags_[F_GHOST_OVER]) {
+      const int created = h_flags_[F_GHOST_COUNT] - before;
+      if ((size_t)nlocal_ + h_flags_[F_GHOST_COUNT] > cap_) {
         over = true;
-        // count how many we would need and grow
         ensure_capacity((size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] * 2 + 1024);
         break;
       }
+      if (created > 0)
+        k_ghost_create<<<div_up(created, 256), 256, 0, stream_>>>(G, perm_.as<int>(), before, created, nlocal_, dim,
+                                                                  boxhi_[dim] - boxlo_[dim], cap_, d_flags_);
       nall0 = nlocal_ + h_flags_[F_GHOST_COUNT];
     }
     if (!over) {
@@ -799,10 +807,10 @@ void DemEngine::build_stage_tables()
   }
   int* tcount = tile_tab_ + 2 * tile_alloc_;
   int* tstart = tile_tab_ + 3 * tile_alloc_;
-  int* cellLS = cell_start_;
-  int* cellLE = cell_start_ + cell_alloc_;
-  int* cellGS = cell_start_ + 2 * cell_alloc_;
-  int* cellGE = cell_start_ + 3 * cell_alloc_;
+  int* cellLS = cell_start_;        // interleaved per cell: {owned start, owned end, ghost start, ghost end}
+  int* cellLE = cell_start_ + 1;
+  int* cellGS = cell_start_ + 2;
+  int* cellGE = cell_start_ + 3;
   reset_flag(F_STAGE_MAX, 0);
   k_tile_stage_count<<<div_up(ntiles_, 128), 128, 0, stream_>>>(grid_, cellLS, cellLE, cellGS, cellGE, ntiles_,
                                                                tcount, d_flags_);
@@ -829,10 +837,10 @@ void DemEngine::bin_and_build()
     have_list_ = true;
     return;
   }
-  int* cellLS = cell_start_;
-  int* cellLE = cell_start_ + cell_alloc_;
-  int* cellGS = cell_start_ + 2 * cell_alloc_;
-  int* cellGE = cell_start_ + 3 * cell_alloc_;
+  int* cellLS = cell_start_;        // interleaved per cell: {owned start, owned end, ghost start, ghost end}
+  int* cellLE = cell_start_ + 1;
+  int* cellGS = cell_start_ + 2;
+  int* cellGE = cell_start_ + 3;
   if (nghost_) {
     k_ghost_keys<<<div_up(nghost_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), tag_.as<int>(), nlocal_,
                                                             nghost_, grid_, keys64_.as<unsigned long long>(),
@@ -841,7 +849,7 @@ void DemEngine::bin_and_build()
                    keys64_alt_.as<unsigned long long>(), perm_.as<int>(), perm_alt_.as<int>(), nghost_, 64,
                    stream_);
     k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-        keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE);
+        keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
   }
   build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {
@@ -866,6 +874,7 @@ void DemEngine::bin_and_build()
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
         have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_.as<double>(), neigh_.as<int>(),
         numneigh_old_.as<int>(), shear_old_.as<double>(), d_flags_);
+    k_max_int<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_old_.as<int>(), nlocal_, d_flags_ + F_MAXNEIGH);
     read_flags();
     if (h_flags_[F_NEIGH_OVER] > M_) {
       // more neighbours than slots: widen the slot-major arrays and build again.  The old-history
@@ -1034,7 +1043,7 @@ void DemEngine::mark_boundary()
   reset_flag(F_SEND_COUNT, 0);
   reset_flag(F_SEND_COUNT2, 0);
   static_assert(F_SEND_COUNT2 == F_SEND_COUNT + 1, "adjacent counters");
-  k_count_layers<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, grid_, cx_lo, cx_hi,
+  k_count_layers<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, grid_, cx_lo, cx_hi,
                                                             d_flags_ + F_SEND_COUNT);
   read_flags();
   n_lo_ = h_flags_[F_SEND_COUNT];
@@ -1250,7 +1259,7 @@ long long DemEngine::npairs_full()
   unsigned long long* d = nullptr;
   SF_HIP(hipMalloc(&d, sizeof(unsigned long long)));
   SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), stream_));
-  k_count_pairs<<<div_up(nlocal_, 256), 256, 0, stream_>>>(numneigh_.as<int>(), nlocal_, d);
+  k_count_pairs<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_.as<int>(), nlocal_, d);
   unsigned long long h = 0;
   SF_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream_));
   sync();

@@ -24,16 +24,19 @@ constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec
 
 // key 0 = selected, 1 = not (a stable 1-bit sort then lists the selected atoms first, ascending)
 // mode 0: x < bound ; mode 1: x >= bound
-__global__ __launch_bounds__(256) void k_select_keys(const double4* xr, int n, int mode, double bound,
-                                                     unsigned* keys, int* idx, int* counter)
+__global__ __launch_bounds__(1024) void k_select_keys(const double4* xr, int n, int mode, double bound,
+                                                      unsigned* keys, int* idx, int* counter)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double x = xr[i].x;
-  const bool sel = mode == 0 ? (x < bound) : (x >= bound);
-  keys[i] = sel ? 0u : 1u;
-  idx[i] = i;
-  if (sel) atomicAdd(counter, 1);
+  bool sel = false;
+  if (i < n) {
+    const double x = xr[i].x;
+    sel = mode == 0 ? (x < bound) : (x >= bound);
+    keys[i] = sel ? 0u : 1u;
+    idx[i] = i;
+  }
+  const int t = block_sum_int_1024(sel ? 1 : 0);   // one global atomic per block (sf_dem_kernels.h)
+  if (threadIdx.x == 0 && t) atomicAdd(counter, t);
 }
 
 __global__ __launch_bounds__(256) void k_border_pack(const int* list, int n, double xshift, const double4* xr,
@@ -178,7 +181,7 @@ int DemEngine::select_locals(int mode, double bound, DevArray& list)
 {
   if (!nlocal_) return 0;
   reset_flag(F_SEND_COUNT, 0);
-  k_select_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, mode, bound,
+  k_select_keys<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, mode, bound,
                                                            keys_.as<unsigned>(), perm_.as<int>(),
                                                            d_flags_ + F_SEND_COUNT);
   sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),

@@ -513,9 +513,24 @@ __device__ __forceinline__ int bin_of(const double4& x, const BinGrid& g, int& l
   return bin_key(g, cx, cy, cz);
 }
 
+__global__ __launch_bounds__(1024) void k_max_int(const int* v, int n, int* out)
+{
+  __shared__ int ws[16];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = i < n ? v[i] : 0;
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) ws[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < (int)(blockDim.x >> 6); k++) m = max(m, ws[k]);
+    atomicMax(out, m);
+  }
+}
+
 // x-slowest order: number of owned atoms in cell layers cx < cx_lo and cx < cx_hi (prefix lengths)
-__global__ __launch_bounds__(256) void k_count_layers(const double4* xr, int nlocal, BinGrid g, int cx_lo, int cx_hi,
-                                                      int* counters)
+__global__ __launch_bounds__(1024) void k_count_layers(const double4* xr, int nlocal, BinGrid g, int cx_lo, int cx_hi,
+                                                       int* counters)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lost = 0;
@@ -525,10 +540,11 @@ __global__ __launch_bounds__(256) void k_count_layers(const double4* xr, int nlo
     a = cx < cx_lo;
     b = cx < cx_hi;
   }
-  const unsigned long long ma = __ballot(a), mb = __ballot(b);
-  if ((threadIdx.x & 63) == 0) {
-    if (ma) atomicAdd(&counters[0], __popcll(ma));
-    if (mb) atomicAdd(&counters[1], __popcll(mb));
+  const int ta = block_sum_int_1024(a);
+  const int tb = block_sum_int_1024(b);
+  if (threadIdx.x == 0) {
+    if (ta) atomicAdd(&counters[0], ta);
+    if (tb) atomicAdd(&counters[1], tb);
   }
 }
 
@@ -598,52 +614,88 @@ struct GhostPtrs {
   double* gshift;
 };
 
-__global__ __launch_bounds__(256) void k_make_ghosts(GhostPtrs G, int nlocal, int nall0, int dim, double lo,
-                                                     double hi, double cut, size_t cap, int* flags)
+// [3P] Comm::borders for the periodic images this GPU makes itself, one dimension per pass (so that images of
+// images give the edge/corner ghosts).  Two kernels: the atoms within `cut` of a periodic face are first listed
+// (4 bytes each; along the fastest sort dimension they are scattered one per row of atoms, and letting each of them
+// write its ~150 bytes of ghost record next to another XCD's took 360 us at 1 M atoms), then one thread per listed
+// atom writes the complete ghost, coalesced.
+__global__ __launch_bounds__(1024) void k_ghost_select(const double4* xr, int nall0, int dim, double lo, double hi,
+                                                       double cut, int* list, int* counter)
 {
+  // ONE global atomic per 1024-thread block: same-address atomics from different XCDs cost ~11 ns each, and along
+  // the fastest sort dimension nearly every wave holds a taker (one atomic per wave was 360 us at 1 M atoms)
+  __shared__ int wcount[16];
+  __shared__ int wbase[16];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= nall0) return;
-  const double4 x = G.xr[p];
-  const double xp = (dim == 0) ? x.x : (dim == 1) ? x.y : x.z;
-  const double prd = hi - lo;
-  for (int dir = 0; dir < 2; dir++) {
-    const bool take = (dir == 0) ? (xp >= lo && xp <= lo + cut) : (xp >= hi - cut && xp <= hi);
-    if (!take) continue;
-    const int k = atomicAdd(&flags[F_GHOST_COUNT], 1);
-    const size_t g = (size_t)nlocal + k;
-    if (g >= cap) {
-      flags[F_GHOST_OVER] = 1;
-      continue;
-    }
-    const double sh = (dir == 0) ? prd : -prd;
-    double4 xg = x;
-    if (dim == 0) xg.x += sh;
-    else if (dim == 1) xg.y += sh;
-    else xg.z += sh;
-    G.xr[g] = xg;
-    G.vm[g] = G.vm[p];
-    G.om[g] = G.om[p];
-    G.tag[g] = G.tag[p];
-    G.type[g] = G.type[p];
-    G.mask[g] = G.mask[p];
-    // root = an owned atom or a ghost owned by another GPU (gsrc < 0): always current before
-    // k_ghost_forward runs
-    int root = p;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    if (p >= nlocal && G.gsrc[p] >= 0) {
-      root = G.gsrc[p];
-      s0 = G.gshift[p];
-      s1 = G.gshift[cap + p];
-      s2 = G.gshift[2 * cap + p];
-    }
-    if (dim == 0) s0 += sh;
-    else if (dim == 1) s1 += sh;
-    else s2 += sh;
-    G.gsrc[g] = root;
-    G.gshift[g] = s0;
-    G.gshift[cap + g] = s1;
-    G.gshift[2 * cap + g] = s2;
+  const bool valid = p < nall0;
+  double xp = 0.0;
+  if (valid) {
+    const double4 x = xr[p];
+    xp = (dim == 0) ? x.x : (dim == 1) ? x.y : x.z;
   }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool t0 = valid && xp >= lo && xp <= lo + cut;
+  const bool t1 = valid && xp >= hi - cut && xp <= hi;
+  const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
+  const int n0 = __popcll(m0), n1 = __popcll(m1);
+  if (lane == 0) wcount[w] = n0 + n1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; k++) {
+      wbase[k] = tot;
+      tot += wcount[k];
+    }
+    const int base = tot ? atomicAdd(counter, tot) : 0;
+    for (int k = 0; k < nw; k++) wbase[k] += base;
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (t0) list[wbase[w] + __popcll(m0 & below)] = p;
+  if (t1) list[wbase[w] + n0 + __popcll(m1 & below)] = p | 0x40000000;
+}
+
+__global__ __launch_bounds__(256) void k_ghost_create(GhostPtrs G, const int* list, int first, int count, int nlocal,
+                                                      int dim, double prd, size_t cap, int* flags)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int e = list[first + k];
+  const int p = e & 0x3FFFFFFF;
+  const int dir = (e >> 30) & 1;
+  const size_t g = (size_t)nlocal + first + k;
+  if (g >= cap) {
+    flags[F_GHOST_OVER] = 1;
+    return;
+  }
+  const double sh = (dir == 0) ? prd : -prd;
+  double4 xg = G.xr[p];
+  if (dim == 0) xg.x += sh;
+  else if (dim == 1) xg.y += sh;
+  else xg.z += sh;
+  G.xr[g] = xg;
+  G.vm[g] = G.vm[p];
+  G.om[g] = G.om[p];
+  G.tag[g] = G.tag[p];
+  G.type[g] = G.type[p];
+  G.mask[g] = G.mask[p];
+  // root = an owned atom or a ghost owned by another GPU (gsrc < 0)
+  int root = p;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  if (p >= nlocal && G.gsrc[p] >= 0) {
+    root = G.gsrc[p];
+    s0 = G.gshift[p];
+    s1 = G.gshift[cap + p];
+    s2 = G.gshift[2 * cap + p];
+  }
+  if (dim == 0) s0 += sh;
+  else if (dim == 1) s1 += sh;
+  else s2 += sh;
+  G.gsrc[g] = root;
+  G.gshift[g] = s0;
+  G.gshift[cap + g] = s1;
+  G.gshift[2 * cap + g] = s2;
 }
 
 // ghosts are not moved: they are index-sorted by (bin, tag) so the list order is deterministic
@@ -660,14 +712,17 @@ __global__ __launch_bounds__(256) void k_ghost_keys(const double4* xr, const int
 }
 
 // cell_start/cell_end from sorted keys (key >> shift = bin)
+// (stride 4: the cell table interleaves {owned start, owned end, ghost start, ghost end} per cell, one 16-byte load
+// in the list build instead of four loads from four 32 MB arrays)
 template <class K>
-__global__ __launch_bounds__(256) void k_cell_bounds(const K* keys, int n, int shift, int* cstart, int* cend)
+__global__ __launch_bounds__(256) void k_cell_bounds(const K* keys, int n, int shift, int* cstart, int* cend,
+                                                     int stride)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int b = (int)(keys[i] >> shift);
-  if (i == 0 || (int)(keys[i - 1] >> shift) != b) cstart[b] = i;
-  if (i == n - 1 || (int)(keys[i + 1] >> shift) != b) cend[b] = i + 1;
+  if (i == 0 || (int)(keys[i - 1] >> shift) != b) cstart[(size_t)b * stride] = i;
+  if (i == n - 1 || (int)(keys[i + 1] >> shift) != b) cend[(size_t)b * stride] = i + 1;
 }
 
 struct BuildParams {
@@ -719,10 +774,11 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
         const int bx = B.g.xslow ? bo : bi, bz = B.g.xslow ? bi : bo;
         const int b = bin_key(B.g, bx, by, bz);
         const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;   // stencil 1 only
-        const int nloc_b = cellLE[b] - cellLS[b];
+        const int4 cb = reinterpret_cast<const int4*>(cellLS)[b];   // {owned start, end, ghost start, end}
+        const int nloc_b = cb.y - cb.x;
         for (int pass = 0; pass < 2; pass++) {
-          const int ks = pass ? cellGS[b] : cellLS[b];
-          const int ke = pass ? cellGE[b] : cellLE[b];
+          const int ks = pass ? cb.z : cb.x;
+          const int ke = pass ? cb.w : cb.y;
           for (int k = ks; k < ke; k++) {
             const int j = pass ? ghost_order[k] : k;
             if (j == i) continue;
@@ -780,8 +836,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     atomicMax(&flags[F_NEIGH_OVER], n);
     n = B.M;
   }
-  numneigh[i] = n;
-  atomicMax(&flags[F_MAXNEIGH], n);
+  numneigh[i] = n;   // F_MAXNEIGH: k_max_int over numneigh afterwards (a same-address atomic per atom costs ~11 ns each)
 }
 
 // ---- LDS staging tables: which atoms a tile's workgroup copies into LDS, bin by bin ----
@@ -804,7 +859,7 @@ __global__ __launch_bounds__(128) void k_tile_stage_count(BinGrid g, const int* 
         const int bx = tx * T - 1 + ex;
         if (bx < 0 || bx >= g.n[0]) continue;
         const int b = bin_key(g, bx, by, bz);
-        total += (cellLE[b] - cellLS[b]) + (cellGE[b] - cellGS[b]);
+        total += (cellLE[4 * b] - cellLS[4 * b]) + (cellGE[4 * b] - cellGS[4 * b]);
       }
     }
   }
@@ -832,8 +887,8 @@ __global__ __launch_bounds__(128) void k_tile_stage_fill(BinGrid g, const int* c
         eoff[(size_t)t * (E * E * E) + (ez * E + ey) * E + ex] = run;
         if (bz < 0 || bz >= g.n[2] || by < 0 || by >= g.n[1] || bx < 0 || bx >= g.n[0]) continue;
         const int b = bin_key(g, bx, by, bz);
-        for (int k = cellLS[b]; k < cellLE[b]; k++) out[run++] = k;
-        for (int k = cellGS[b]; k < cellGE[b]; k++) out[run++] = ghost_order[k];
+        for (int k = cellLS[4 * b]; k < cellLE[4 * b]; k++) out[run++] = k;
+        for (int k = cellGS[4 * b]; k < cellGE[4 * b]; k++) out[run++] = ghost_order[k];
       }
     }
   }
@@ -905,12 +960,11 @@ __global__ __launch_bounds__(256) void k_set_velocity(double4* vm, int n, double
   vm[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_count_pairs(const int* numneigh, int n, unsigned long long* out)
+__global__ __launch_bounds__(1024) void k_count_pairs(const int* numneigh, int n, unsigned long long* out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long c = (i < n) ? (unsigned long long)numneigh[i] : 0ull;
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  const int t = block_sum_int_1024(i < n ? numneigh[i] : 0);
+  if (threadIdx.x == 0 && t) atomicAdd(out, (unsigned long long)t);
 }
 
 // touching pairs (i-side copy) -> (tag_i, tag_j, shear) compacted with an atomic cursor
