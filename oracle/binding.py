@@ -83,6 +83,8 @@ def _declare(L):
     L.orc_dem_fix_wall.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                    C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                    C.c_double, C.c_double, C.c_int]
+    L.orc_dem_set_mask.argtypes = [C.c_void_p, ip]
+    L.orc_dem_set_groups.argtypes = [C.c_void_p] + [C.c_int] * 6
     L.orc_dem_neighbor.argtypes = [C.c_void_p, C.c_double]
     L.orc_dem_timestep.argtypes = [C.c_void_p, C.c_double]
     L.orc_dem_threads.argtypes = [C.c_void_p, C.c_int]
@@ -220,6 +222,14 @@ class OracleDem:
         self.L.orc_dem_fix_wall(self.h, dim, lo is None, lo or 0.0, hi is None, hi or 0.0, kn,
                                 kt is None, kt or 0.0, gamman, gammat is None, gammat or 0.0,
                                 xmu, dampflag)
+
+    def set_mask(self, mask):
+        """per-atom group bits in creation order (bit 0 = all is always set)"""
+        self.L.orc_dem_set_mask(self.h, P(i32(mask)))
+
+    def set_groups(self, nve=1, gravity=1, fdrag=1, wall=1, cohesive=1, freeze=0):
+        """group bit of every registered fix kind (call after the fix_* registrations); freeze = 0: no fix freeze"""
+        self.L.orc_dem_set_groups(self.h, nve, gravity, fdrag, wall, cohesive, freeze)
 
     def neighbor(self, skin):
         self.L.orc_dem_neighbor(self.h, skin)
@@ -375,7 +385,7 @@ class OracleSlabEngine:
         self.L.orc_dem_migrate_unpack(self.h, buf.data_ptr(), int(ndoubles))
 
     def border_pack(self, side, xshift, buf):
-        n = self.L.orc_dem_border_pack(self.h, side, xshift, buf.data_ptr(), buf.numel() // 13)
+        n = self.L.orc_dem_border_pack(self.h, side, xshift, buf.data_ptr(), buf.numel() // 14)
         if n < 0:
             raise RuntimeError("border buffer too small")
         return n

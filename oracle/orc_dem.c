@@ -61,6 +61,7 @@ orc_dem *orc_dem_create(int n, const double *x, const double *v, const double *o
                         const double boxlo[3], const double boxhi[3], const int periodic[3])
 {
   orc_dem *d = calloc(1, sizeof(orc_dem));
+  d->nve_bit = 1;
   int i, k;
   orc__grow_atoms(d, n);
   d->nlocal = n;
@@ -135,6 +136,7 @@ static orc_fix *new_fix(orc_dem *d, int kind)
   orc_fix *fx = &d->fix[d->nfix++];
   memset(fx, 0, sizeof(*fx));
   fx->kind = kind;
+  fx->groupbit = 1;
   return fx;
 }
 
@@ -167,6 +169,27 @@ void orc_dem_fix_wall(orc_dem *d, int wallstyle, int lo_null, double lo, int hi_
   fx->hi = hi_null ? 1.0e20 : hi;
   orc_gran_settings(&fx->wp, kn, kt_null, kt, gamman, gammat_null, gammat, xmu, dampflag, 1.0);
   fx->wshear = calloc(3 * (size_t)d->nmax, sizeof(double));
+}
+
+void orc_dem_set_mask(orc_dem *d, const int *mask)
+{
+  int i;
+  for (i = 0; i < d->nlocal; i++) d->mask[i] = mask[i] | 1;
+}
+
+void orc_dem_set_groups(orc_dem *d, int nve_bit, int gravity_bit, int fdrag_bit, int wall_bit, int cohesive_bit,
+                        int freeze_bit)
+{
+  int w;
+  d->nve_bit = nve_bit;
+  d->freeze_bit = freeze_bit;
+  for (w = 0; w < d->nfix; w++) {
+    orc_fix *fx = &d->fix[w];
+    if (fx->kind == FIX_GRAVITY) fx->groupbit = gravity_bit;
+    else if (fx->kind == FIX_FDRAG) fx->groupbit = fdrag_bit;
+    else if (fx->kind == FIX_WALL) fx->groupbit = wall_bit;
+    else if (fx->kind == FIX_COHESIVE) fx->groupbit = cohesive_bit;
+  }
 }
 
 void orc_dem_neighbor(orc_dem *d, double skin) { d->skin = skin; }
@@ -474,10 +497,10 @@ void orc__compute_forces(orc_dem *d, int setupflag)
   gl.touch = d->touch; gl.shear = d->shear;
   if (d->pair_style == 2)
     orc_pair_gran_hertzfix_history(&d->gp, d->dt, shearupdate, d->nlocal, d->x, d->v, d->omega,
-                                   d->radius, d->rmass, d->mask, 0, &gl, d->f, d->torque);
+                                   d->radius, d->rmass, d->mask, d->freeze_bit, &gl, d->f, d->torque);
   else if (d->pair_style == 1)
     orc_pair_gran_hooke_history(&d->gp, d->dt, shearupdate, d->nlocal, d->x, d->v, d->omega,
-                                d->radius, d->rmass, d->mask, 0, &gl, d->f, d->torque);
+                                d->radius, d->rmass, d->mask, d->freeze_bit, &gl, d->f, d->torque);
   if (d->have_lub) {
     orc_neighlist fl;
     fl.inum = d->nlocal; fl.ilist = d->ilist; fl.first = d->ffirst; fl.jlist = d->fjlist;
@@ -489,17 +512,17 @@ void orc__compute_forces(orc_dem *d, int setupflag)
     orc_fix *fx = &d->fix[w];
     switch (fx->kind) {
       case FIX_GRAVITY:
-        orc_fix_gravity(d->nlocal, fx->gmag, fx->gdir, d->rmass, d->f);
+        orc_fix_gravity_group(d->nlocal, fx->gmag, fx->gdir, d->rmass, d->mask, fx->groupbit, d->f);
         break;
       case FIX_FDRAG:
         orc_fix_fluid_drag(d->nlocal, d->dt, fx->carrier_rho, d->v, d->rmass, d->radius, d->mask,
-                           1, d->ffluiddrag, d->DuDt, d->vOld, d->f);
+                           fx->groupbit, d->ffluiddrag, d->DuDt, d->vOld, d->f);
         break;
       case FIX_WALL:
         /* wall/granFix follows the pair style (fix_wall_granFix.cpp:217-229) */
         orc_fix_wall_gran(&fx->wp, d->pair_style == 2 ? 2 : 1, fx->wallstyle, fx->lo, fx->hi,
                           d->dt, shearupdate, d->nlocal, d->x, d->v, d->omega, d->radius,
-                          d->rmass, d->mask, 1, fx->wshear, d->f, d->torque);
+                          d->rmass, d->mask, fx->groupbit, fx->wshear, d->f, d->torque);
         break;
       case FIX_COHESIVE:
         /* FixCohe::setup() has the wrong signature (fix_cohesive.cpp:117) so the fix is
@@ -509,11 +532,13 @@ void orc__compute_forces(orc_dem *d, int setupflag)
           hl.inum = d->nlocal; hl.ilist = d->ilist; hl.first = d->hfirst; hl.jlist = d->hjlist;
           hl.touch = NULL; hl.shear = NULL;
           orc_fix_cohesive(fx->ah, fx->lam, fx->smin, fx->smax, fx->opt, d->nlocal, 0, d->x,
-                           d->radius, d->mask, 1, &hl, d->f);
+                           d->radius, d->mask, fx->groupbit, &hl, d->f);
         }
         break;
     }
   }
+  /* fix freeze comes last in every input script of the reference (cases/example-cases in.lammps: "fix 4 bottom freeze") */
+  if (d->freeze_bit) orc_fix_freeze(d->nlocal, d->mask, d->freeze_bit, d->f, d->torque);
 }
 
 void orc_dem_setup(orc_dem *d)
@@ -537,8 +562,8 @@ void orc_dem_run(orc_dem *d, int nsteps)
   int s;
   if (!d->setup_done) orc_dem_setup(d);
   for (s = 0; s < nsteps; s++) {
-    orc_nve_sphere_initial(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius,
-                           d->rmass);
+    orc_nve_sphere_initial_group(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius,
+                                 d->rmass, d->mask, d->nve_bit);
     if (orc__check_distance(d)) {
       /* Verlet::run order [3P]: pre_exchange (FixShearHistory copies the history out of the OLD
        * list, whose ghost indices are still valid) -> pbc -> borders -> build */
@@ -550,7 +575,8 @@ void orc_dem_run(orc_dem *d, int nsteps)
     } else
       orc__forward_comm(d);
     orc__compute_forces(d, 0);
-    orc_nve_sphere_final(d->nlocal, d->dt, d->v, d->omega, d->f, d->torque, d->radius, d->rmass);
+    orc_nve_sphere_final_group(d->nlocal, d->dt, d->v, d->omega, d->f, d->torque, d->radius, d->rmass, d->mask,
+                               d->nve_bit);
   }
 }
 

@@ -4,10 +4,11 @@
 #define ORC_DEM_PRIV_H
 #include "sedifoam_oracle.h"
 
-enum { FIX_GRAVITY = 1, FIX_FDRAG, FIX_WALL, FIX_COHESIVE };
+enum { FIX_GRAVITY = 1, FIX_FDRAG, FIX_WALL, FIX_COHESIVE, FIX_FREEZE };
 
 typedef struct {
   int kind;
+  int groupbit;   /* fix ID <group> ...: bit of the group in mask[] (1 = all) */
   /* gravity */
   double gmag, gdir[3];
   /* fdrag */
@@ -57,6 +58,7 @@ struct orc_dem {
   int nbins_alloc;
   int nbuilds;
   int setup_done;
+  int nve_bit, freeze_bit;   /* group of fix nve/sphere (default all), of fix freeze (0: none) */
   int nthreads;
   /* ---- external x halo (orc_halo.c): this driver is one slab of an x-decomposed domain ---- */
   int external_x;

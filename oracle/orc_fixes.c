@@ -239,3 +239,59 @@ void orc_fix_gravity(int nlocal, double magnitude, const double dir[3], const do
   for (i = 0; i < nlocal; i++)
     for (k = 0; k < 3; k++) f[3 * i + k] += rmass[i] * acc[k];
 }
+
+/* ---- group-aware variants ([3P] LAMMPS 1Feb14: every fix acts on the atoms whose mask has the fix's group bit) ---- */
+void orc_nve_sphere_initial_group(int nlocal, double dt, double *x, double *v, double *omega, const double *f,
+                                  const double *torque, const double *radius, const double *rmass,
+                                  const int *mask, int groupbit)
+{
+  const double dtv = dt, dtf = 0.5 * dt;
+  const double dtfrotate = dtf / 0.4;
+  int i, k;
+  for (i = 0; i < nlocal; i++) {
+    if (!(mask[i] & groupbit)) continue;                            /* fix_nve_sphere.cpp: if (mask[i] & groupbit) */
+    double dtfm = dtf / rmass[i];
+    for (k = 0; k < 3; k++) v[3 * i + k] += dtfm * f[3 * i + k];
+    for (k = 0; k < 3; k++) x[3 * i + k] += dtv * v[3 * i + k];
+    double dtirotate = dtfrotate / (radius[i] * radius[i] * rmass[i]);
+    for (k = 0; k < 3; k++) omega[3 * i + k] += dtirotate * torque[3 * i + k];
+  }
+}
+
+void orc_nve_sphere_final_group(int nlocal, double dt, double *v, double *omega, const double *f,
+                                const double *torque, const double *radius, const double *rmass,
+                                const int *mask, int groupbit)
+{
+  const double dtf = 0.5 * dt;
+  const double dtfrotate = dtf / 0.4;
+  int i, k;
+  for (i = 0; i < nlocal; i++) {
+    if (!(mask[i] & groupbit)) continue;
+    double dtfm = dtf / rmass[i];
+    for (k = 0; k < 3; k++) v[3 * i + k] += dtfm * f[3 * i + k];
+    double dtirotate = dtfrotate / (radius[i] * radius[i] * rmass[i]);
+    for (k = 0; k < 3; k++) omega[3 * i + k] += dtirotate * torque[3 * i + k];
+  }
+}
+
+void orc_fix_gravity_group(int nlocal, double magnitude, const double dir[3], const double *rmass,
+                           const int *mask, int groupbit, double *f)
+{
+  double len = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+  double acc[3];
+  int i, k;
+  for (k = 0; k < 3; k++) acc[k] = (len > 0.0) ? magnitude * (dir[k] / len) : 0.0;
+  for (i = 0; i < nlocal; i++)
+    if (mask[i] & groupbit)
+      for (k = 0; k < 3; k++) f[3 * i + k] += rmass[i] * acc[k];
+}
+
+/* [3P] FixFreeze::post_force (fix_freeze.cpp): force and torque of the group's atoms are zeroed; the granular pair
+ * styles additionally treat a frozen partner as infinitely heavy (pair_gran_hertzFix_history.cpp:188-189) */
+void orc_fix_freeze(int nlocal, const int *mask, int groupbit, double *f, double *torque)
+{
+  int i, k;
+  for (i = 0; i < nlocal; i++)
+    if (mask[i] & groupbit)
+      for (k = 0; k < 3; k++) f[3 * i + k] = torque[3 * i + k] = 0.0;
+}

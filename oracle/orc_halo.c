@@ -12,7 +12,7 @@
 #include <string.h>
 #include "orc_dem_priv.h"
 
-#define BORDER_DOUBLES 13
+#define BORDER_DOUBLES 14   /* x r | v m | omega | tag type mask */
 #define FORWARD_DOUBLES 9
 
 static int nwalls_of(const orc_dem *d)
@@ -76,7 +76,8 @@ int orc_dem_max_partners(const orc_dem *d)
 /* ---- step phases ---- */
 void orc_dem_run_begin(orc_dem *d)
 {
-  orc_nve_sphere_initial(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius, d->rmass);
+  orc_nve_sphere_initial_group(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius, d->rmass, d->mask,
+                               d->nve_bit);
   d->flag = orc__check_distance(d);
   orc__forward_comm(d);
 }
@@ -84,9 +85,11 @@ void orc_dem_run_begin(orc_dem *d)
 void orc_dem_substep(orc_dem *d, int last)
 {
   orc__compute_forces(d, 0);
-  orc_nve_sphere_final(d->nlocal, d->dt, d->v, d->omega, d->f, d->torque, d->radius, d->rmass);
+  orc_nve_sphere_final_group(d->nlocal, d->dt, d->v, d->omega, d->f, d->torque, d->radius, d->rmass, d->mask,
+                             d->nve_bit);
   if (!last) {
-    orc_nve_sphere_initial(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius, d->rmass);
+    orc_nve_sphere_initial_group(d->nlocal, d->dt, d->x, d->v, d->omega, d->f, d->torque, d->radius, d->rmass, d->mask,
+                               d->nve_bit);
     d->flag = orc__check_distance(d);
   }
   orc__forward_comm(d);
@@ -304,7 +307,7 @@ long orc_dem_border_pack(orc_dem *d, int side, double xshift, double *buf, long 
     b[0] = x + xshift; b[1] = d->x[3 * i + 1]; b[2] = d->x[3 * i + 2]; b[3] = d->radius[i];
     b[4] = d->v[3 * i]; b[5] = d->v[3 * i + 1]; b[6] = d->v[3 * i + 2]; b[7] = d->rmass[i];
     b[8] = d->omega[3 * i]; b[9] = d->omega[3 * i + 1]; b[10] = d->omega[3 * i + 2];
-    b[11] = d->tag[i]; b[12] = 1;
+    b[11] = d->tag[i]; b[12] = 1; b[13] = d->mask[i];
     push_send(d, side, i);
   }
   return d->nsend[side];
@@ -327,7 +330,7 @@ void orc_dem_border_unpack(orc_dem *d, int side, const double *buf, long natoms)
       d->gshift[3 * g + c] = 0.0;
     }
     d->radius[g] = b[3]; d->rmass[g] = b[7];
-    d->tag[g] = (int)b[11]; d->mask[g] = 1;
+    d->tag[g] = (int)b[11]; d->mask[g] = (int)b[13];   /* group bits: the pair style asks for the freeze group of j */
     d->gsrc[g] = -1;
   }
   d->next_ghost += n;

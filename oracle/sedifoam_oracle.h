@@ -117,6 +117,16 @@ void orc_fix_gravity(int nlocal, double magnitude, const double dir[3], const do
 /* ---- DEM driver: a restatement of what `lammps_step(n)` does to the particles ---- */
 typedef struct orc_dem orc_dem;
 
+void orc_nve_sphere_initial_group(int nlocal, double dt, double *x, double *v, double *omega, const double *f,
+                                  const double *torque, const double *radius, const double *rmass,
+                                  const int *mask, int groupbit);
+void orc_nve_sphere_final_group(int nlocal, double dt, double *v, double *omega, const double *f,
+                                const double *torque, const double *radius, const double *rmass,
+                                const int *mask, int groupbit);
+void orc_fix_gravity_group(int nlocal, double magnitude, const double dir[3], const double *rmass,
+                           const int *mask, int groupbit, double *f);
+void orc_fix_freeze(int nlocal, const int *mask, int groupbit, double *f, double *torque);
+
 orc_dem *orc_dem_create(int n, const double *x, const double *v, const double *omega,
                         const double *radius, const double *rmass, const int *tag,
                         const double boxlo[3], const double boxhi[3], const int periodic[3]);
@@ -133,6 +143,11 @@ void orc_dem_fix_fdrag(orc_dem *d, double carrier_rho);
 void orc_dem_fix_wall(orc_dem *d, int wallstyle, int lo_null, double lo, int hi_null, double hi,
                       double kn, int kt_null, double kt, double gamman, int gammat_null,
                       double gammat, double xmu, int dampflag);
+/* groups: per-atom group bits (bit 0 = all) in creation order, then the group of every fix kind registered so far
+ * (LAMMPS: `fix ID group style ...`); freeze_bit = 0: no fix freeze */
+void orc_dem_set_mask(orc_dem *d, const int *mask);
+void orc_dem_set_groups(orc_dem *d, int nve_bit, int gravity_bit, int fdrag_bit, int wall_bit, int cohesive_bit,
+                        int freeze_bit);
 void orc_dem_neighbor(orc_dem *d, double skin);
 void orc_dem_timestep(orc_dem *d, double dt);
 /* threads > 1: split the i-loop of the pair kernel over pthreads (bench cpu_baseline only) */

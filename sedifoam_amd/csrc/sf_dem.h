@@ -15,6 +15,9 @@
 // deterministic.  This is the reference's own `newton off` semantics for owned-ghost pairs
 // (pair_gran_hertzFix_history.cpp:273) applied to every pair.
 #pragma once
+#include <map>
+#include <string>
+#include <vector>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -61,6 +64,7 @@ enum Flag {
 
 struct WallParams {
   int dim;
+  int bit;         // group of the fix (mask bit, 1 = all)
   double lo, hi;
   GranParams gp;
 };
@@ -118,7 +122,9 @@ struct StepParams {
   int have_fdrag;
   double carrier_rho;
   int have_nve;
-  int freeze_bit;
+  // LAMMPS groups: every fix acts on the atoms whose mask has the fix's group bit (bit 0 = all).  use_groups = 0:
+  // every fix is on `all`, the mask is not even read.  freeze_bit != 0: fix freeze; frozen atoms carry omega.w = 1
+  int use_groups, nve_bit, grav_bit, fdrag_bit, cohe_bit, freeze_bit;
 };
 
 struct BinGrid {
@@ -174,13 +180,24 @@ class DemEngine {
                      double gammat, double xmu, int dampflag);
   void set_pair_lubricate(double mu, int flaglog, int flagfld, double cut_inner, double cut_global,
                           int flagHI, int flagVF);
-  void set_cohesive(double ah, double lam, double smin, double smax, int opt);
-  void set_gravity(double mag, double gx, double gy, double gz);
-  void set_fdrag(double carrier_rho);
+  void set_cohesive(double ah, double lam, double smin, double smax, int opt, int groupbit = 1);
+  void set_gravity(double mag, double gx, double gy, double gz, int groupbit = 1);
+  void set_fdrag(double carrier_rho, int groupbit = 1);
+  void set_freeze(int groupbit);                      // [3P] fix freeze
+  // [3P] group command: styles type / subtract / union / intersect (what the reference's cases use)
+  int group_bit(const std::string& name) const;
+  void group_type(const std::string& name, int op, int v1, int v2, const std::vector<int>& list);
+  void group_combine(const std::string& name, int mode, const std::vector<std::string>& args);
+  void set_velocity_group(int groupbit, double vx, double vy, double vz);
   void add_wall(int dim, bool lo_null, double lo, bool hi_null, double hi, double kn, bool kt_null,
                 double kt, double gamman, bool gammat_null, double gammat, double xmu, int dampflag,
-                bool granfix);
-  void set_nve_sphere() { have_nve_ = true; }
+                bool granfix, int groupbit = 1);
+  void set_nve_sphere(int groupbit = 1)
+  {
+    have_nve_ = true;
+    nve_bit_ = groupbit;
+    use_groups_ = use_groups_ || groupbit != 1;
+  }
   void set_skin(double s) { skin_ = s; }
   void set_timestep(double dt) { dt_ = dt; }
   double timestep() const { return dt_; }
@@ -337,6 +354,11 @@ private:
   int nwalls_ = 0;
   WallParams walls_[kMaxWalls];
   bool have_gravity_ = false, have_fdrag_ = false, have_nve_ = false;
+  std::map<std::string, int> groups_{{"all", 1}};
+  bool use_groups_ = false;
+  int nve_bit_ = 1, grav_bit_ = 1, fdrag_bit_ = 1, cohe_bit_ = 1, freeze_bit_ = 0;
+  int new_group_bit(const std::string& name);
+  void mark_frozen();
   double gacc_[3] = {0, 0, 0};
   double carrier_rho_ = 0.0;
 

@@ -322,30 +322,101 @@ void DemEngine::set_pair_lubricate(double mu, int flaglog, int flagfld, double c
   lub_.vxmu2f = 1.0;
 }
 
-void DemEngine::set_cohesive(double ah, double lam, double smin, double smax, int opt)
+void DemEngine::set_cohesive(double ah, double lam, double smin, double smax, int opt, int groupbit)
 {
   if (opt != 0 && opt != 1) fail("invalid option for cohesive force model");  // fix_cohesive.cpp:262
   cohe_ = {ah, lam, smin, smax, opt, 1};
+  cohe_bit_ = groupbit;
+  use_groups_ = use_groups_ || groupbit != 1;
 }
 
-void DemEngine::set_gravity(double mag, double gx, double gy, double gz)
+void DemEngine::set_gravity(double mag, double gx, double gy, double gz, int groupbit)
 {
   const double len = std::sqrt(gx * gx + gy * gy + gz * gz);
   have_gravity_ = true;
+  grav_bit_ = groupbit;
+  use_groups_ = use_groups_ || groupbit != 1;
   gacc_[0] = len > 0 ? mag * (gx / len) : 0.0;
   gacc_[1] = len > 0 ? mag * (gy / len) : 0.0;
   gacc_[2] = len > 0 ? mag * (gz / len) : 0.0;
 }
 
-void DemEngine::set_fdrag(double carrier_rho)
+void DemEngine::set_fdrag(double carrier_rho, int groupbit)
 {
   have_fdrag_ = true;
   carrier_rho_ = carrier_rho;
+  fdrag_bit_ = groupbit;
+  use_groups_ = use_groups_ || groupbit != 1;
+}
+
+void DemEngine::set_freeze(int groupbit)
+{
+  if (freeze_bit_) fail("More than one fix freeze");   // [3P] fix_freeze.cpp
+  if (!roots_) fail("fix freeze is not available with the LDS-staged kernel (SF_LDS)");
+  freeze_bit_ = groupbit;
+  use_groups_ = true;
+  mark_frozen();
+}
+
+void DemEngine::mark_frozen()
+{
+  if (!freeze_bit_ || !nlocal_) return;
+  k_mark_frozen<<<div_up(nlocal_, 256), 256, 0, stream_>>>(om_[0].as<double4>(), om_[1].as<double4>(), mask_.as<int>(),
+                                                           nlocal_, freeze_bit_);
+}
+
+int DemEngine::group_bit(const std::string& name) const
+{
+  auto it = groups_.find(name);
+  if (it == groups_.end()) fail("Could not find group ID %s", name.c_str());
+  return it->second;
+}
+
+int DemEngine::new_group_bit(const std::string& name)
+{
+  auto it = groups_.find(name);
+  if (it != groups_.end()) return it->second;          // LAMMPS adds atoms to an existing group
+  if (groups_.size() >= 30) fail("Too many groups");
+  const int bit = 1 << (int)groups_.size();
+  groups_[name] = bit;
+  return bit;
+}
+
+void DemEngine::group_type(const std::string& name, int op, int v1, int v2, const std::vector<int>& list)
+{
+  const int bit = new_group_bit(name);
+  GroupTypeArgs A;
+  A.op = op;
+  A.v1 = v1;
+  A.v2 = v2;
+  A.nlist = (int)list.size();
+  if (A.nlist > 16) fail("group %s type: more than 16 types", name.c_str());
+  for (int k = 0; k < A.nlist; k++) A.list[k] = list[k];
+  if (nlocal_)
+    k_group_type<<<div_up(nlocal_, 256), 256, 0, stream_>>>(mask_.as<int>(), type_.as<int>(), nlocal_, bit, A);
+}
+
+void DemEngine::group_combine(const std::string& name, int mode, const std::vector<std::string>& args)
+{
+  if (args.empty() || args.size() > 16) fail("Illegal group command");
+  GroupCombineArgs A;
+  A.mode = mode;
+  A.n = (int)args.size();
+  for (int k = 0; k < A.n; k++) A.bits[k] = group_bit(args[k]);
+  const int bit = new_group_bit(name);
+  if (nlocal_) k_group_combine<<<div_up(nlocal_, 256), 256, 0, stream_>>>(mask_.as<int>(), nlocal_, bit, A);
+}
+
+void DemEngine::set_velocity_group(int groupbit, double vx, double vy, double vz)
+{
+  if (!nlocal_) return;
+  k_set_velocity_group<<<div_up(nlocal_, 256), 256, 0, stream_>>>(vm_[cur_].as<double4>(), mask_.as<int>(), groupbit,
+                                                                  nlocal_, vx, vy, vz);
 }
 
 void DemEngine::add_wall(int dim, bool lo_null, double lo, bool hi_null, double hi, double kn, bool kt_null,
                          double kt, double gamman, bool gammat_null, double gammat, double xmu, int dampflag,
-                         bool granfix)
+                         bool granfix, int groupbit)
 {
   if (nwalls_ >= kMaxWalls) fail("too many wall fixes (max %d)", kMaxWalls);
   if (periodic_[dim]) fail("Cannot use wall in periodic dimension");  // fix_wall_granFix.cpp:143-148
@@ -353,6 +424,8 @@ void DemEngine::add_wall(int dim, bool lo_null, double lo, bool hi_null, double 
     fail("Fix wall/gran is incompatible with Pair style");  // stock wall/gran does not know hertzFix
   WallParams& W = walls_[nwalls_++];
   W.dim = dim;
+  W.bit = groupbit;
+  use_groups_ = use_groups_ || groupbit != 1;
   W.lo = lo_null ? -1.0e20 : lo;
   W.hi = hi_null ? 1.0e20 : hi;
   gran_settings(W.gp, gran_.style ? gran_.style : 1, kn, kt_null, kt, gamman, gammat_null, gammat, xmu,
@@ -448,7 +521,12 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.have_fdrag = have_fdrag_;
   S.carrier_rho = carrier_rho_;
   S.have_nve = have_nve_;
-  S.freeze_bit = 0;
+  S.use_groups = use_groups_ ? 1 : 0;
+  S.nve_bit = nve_bit_;
+  S.grav_bit = grav_bit_;
+  S.fdrag_bit = fdrag_bit_;
+  S.cohe_bit = cohe_bit_;
+  S.freeze_bit = freeze_bit_;
   return S;
 }
 
@@ -599,7 +677,7 @@ void DemEngine::launch_initial_integrate()
   k_initial_integrate<<<div_up(nlocal_, 256), 256, 0, stream_>>>(
       xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), force_.as<double4>(),
       torque_.as<double4>(), xhold_.as<double>(), d_flags_ + (overlap_ ? F_TRIG_LOCAL : F_TRIGGER), nlocal_, cap_,
-      dt_, (0.5 * skin_) * (0.5 * skin_));
+      dt_, (0.5 * skin_) * (0.5 * skin_), use_groups_ ? mask_.as<int>() : nullptr, nve_bit_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -728,6 +806,7 @@ void DemEngine::rebuild_sort()
   sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
                  perm_alt_.as<int>(), nlocal_, bits, stream_);
   permute_locals(perm_alt_.as<int>(), nlocal_);
+  mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   // sorted bin keys -> cell ranges of owned atoms
   SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
   k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,

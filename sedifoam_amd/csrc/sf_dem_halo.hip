@@ -18,7 +18,7 @@
 
 namespace sf {
 
-constexpr int kBorderDoubles = 13;
+constexpr int kBorderDoubles = 14;   // x r | v m | omega | tag type mask
 constexpr int kForwardDoubles = 9;
 constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec
 
@@ -41,13 +41,14 @@ __global__ __launch_bounds__(1024) void k_select_keys(const double4* xr, int n, 
 
 __global__ __launch_bounds__(256) void k_border_pack(const int* list, int n, double xshift, const double4* xr,
                                                      const double4* vm, const double4* om, const int* tag,
-                                                     const int* type, double* buf)
+                                                     const int* type, const int* mask, double* buf)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int i = list[k];
   const double4 x = xr[i], v = vm[i], w = om[i];
   double* b = buf + (size_t)k * kBorderDoubles;
+  b[13] = (double)mask[i];
   b[0] = x.x + xshift; b[1] = x.y; b[2] = x.z; b[3] = x.w;
   b[4] = v.x; b[5] = v.y; b[6] = v.z; b[7] = v.w;
   b[8] = w.x; b[9] = w.y; b[10] = w.z;
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) void k_border_pack(const int* list, int n, dou
 }
 
 __global__ __launch_bounds__(256) void k_border_unpack(const double* buf, int n, int first, double4* xr, double4* vm,
-                                                       double4* om, double4* xr_b, double4* vm_b, int* tag,
-                                                       int* type, int* mask, int* gsrc)
+                                                       double4* om, double4* xr_b, double4* vm_b, double4* om_b,
+                                                       int* tag, int* type, int* mask, int* gsrc, int freeze_bit)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -65,14 +66,18 @@ __global__ __launch_bounds__(256) void k_border_unpack(const double* buf, int n,
   const int g = first + k;
   xr[g] = {b[0], b[1], b[2], b[3]};
   vm[g] = {b[4], b[5], b[6], b[7]};
-  om[g] = {b[8], b[9], b[10], 0.0};
-  // radius and mass (.w) must also be valid in the other ping-pong buffer: the forward halo only
+  // omega.w = 1 marks an atom of the fix-freeze group (the pair kernel gathers it with omega)
+  const int m = (int)b[13];
+  const double frozen = (m & freeze_bit) ? 1.0 : 0.0;
+  om[g] = {b[8], b[9], b[10], frozen};
+  // radius, mass and the frozen mark (.w) must also be valid in the other ping-pong buffer: the forward halo only
   // carries x, v, omega
   xr_b[g] = {b[0], b[1], b[2], b[3]};
   vm_b[g] = {b[4], b[5], b[6], b[7]};
+  om_b[g] = {b[8], b[9], b[10], frozen};
   tag[g] = (int)b[11];
   type[g] = (int)b[12];
-  mask[g] = 1;
+  mask[g] = m;
   gsrc[g] = -1;  // owned by another GPU
 }
 
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void k_forward_unpack(const double* buf, int n
   v.x = b[3]; v.y = b[4]; v.z = b[5];
   xr[g] = x;   // radius / mass (.w) were set by the border exchange
   vm[g] = v;
-  om[g] = {b[6], b[7], b[8], 0.0};
+  om[g] = {b[6], b[7], b[8], om[g].w};   // .w: frozen mark, set by the border exchange
 }
 
 struct MigratePtrs {
@@ -200,7 +205,7 @@ long long DemEngine::border_pack(int side, double xshift, double* buf, long long
   if (n)
     k_border_pack<<<div_up(n, 256), 256, 0, stream_>>>(sendlist_[side].as<int>(), n, xshift, xr_[cur_].as<double4>(),
                                                        vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
-                                                       tag_.as<int>(), type_.as<int>(), buf);
+                                                       tag_.as<int>(), type_.as<int>(), mask_.as<int>(), buf);
   if (!external_stream_) sync();
   return n;
 }
@@ -217,8 +222,8 @@ void DemEngine::border_unpack(int side, const double* buf, long long natoms)
     k_border_unpack<<<div_up(n, 256), 256, 0, stream_>>>(buf, n, first, xr_[cur_].as<double4>(),
                                                          vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
                                                          xr_[cur_ ^ 1].as<double4>(), vm_[cur_ ^ 1].as<double4>(),
-                                                         tag_.as<int>(), type_.as<int>(), mask_.as<int>(),
-                                                         gsrc_.as<int>());
+                                                         om_[cur_ ^ 1].as<double4>(), tag_.as<int>(), type_.as<int>(),
+                                                         mask_.as<int>(), gsrc_.as<int>(), freeze_bit_);
   next_ghost_ += n;
   if (!external_stream_) sync();
 }
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void k_forward_unpack2(const double* buf0, int
   v.x = b[3]; v.y = b[4]; v.z = b[5];
   xr[g] = x;
   vm[g] = v;
-  om[g] = {b[6], b[7], b[8], 0.0};
+  om[g] = {b[6], b[7], b[8], om[g].w};   // .w: frozen mark, set by the border exchange
 }
 
 // Fused forward halo for ONE all-to-all per sub-step: the send buffer holds, for every peer rank, a header word
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0
   v.x = b[3]; v.y = b[4]; v.z = b[5];
   xr[g] = x;
   vm[g] = v;
-  om[g] = {b[6], b[7], b[8], 0.0};
+  om[g] = {b[6], b[7], b[8], om[g].w};   // .w: frozen mark, set by the border exchange
 }
 
 void DemEngine::forward_pack_fused(double shift0, long long off0, double shift1, long long off1, const int* hdr_off,

@@ -86,6 +86,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
   const int nn = ld_stream(&P.numneigh[i]);
+  const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
@@ -179,6 +180,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         c.meff = mi * mj / (mi + mj);
         c.reff = (radsum - c.r) * radi * radj / radsum;
 #endif
+        if (S.freeze_bit) {   // pair_gran_hertzFix_history.cpp:188-189: a frozen partner is infinitely heavy
+          if (wi4.w != 0.0) c.meff = mj;
+          if (wj4.w != 0.0) c.meff = mi;
+        }
         ContactOut o;
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
         st_stream(&P.shear[sbase], sh.x);
@@ -192,7 +197,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (COHE) {
       // fix cohesive is skipped during setup (FixCohe::setup() never runs, fix_cohesive.cpp:117)
       const double rc = radsum + S.cohe.smax;
-      if (S.mode != 2 && rsq < rc * rc) {
+      if (S.mode != 2 && (mk & S.cohe_bit) && rsq < rc * rc) {   // fix_cohesive.cpp:167 group of i
         const double r = sqrt(rsq);
         const double cc = cohesive_ccel(S.cohe, r, radsum) * (1 / r);
         F = F + Vec3{del.x * cc, del.y * cc, del.z * cc};
@@ -228,8 +233,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
 
   // ---- post_force fixes, in script order gravity -> fdrag -> walls ----
-  if (S.have_gravity) F = F + Vec3{mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
-  if (S.have_fdrag) {
+  if (S.have_gravity && (mk & S.grav_bit)) F = F + Vec3{mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
+  if (S.have_fdrag && (mk & S.fdrag_bit)) {   // fix_fluid_drag.cpp:145
     Vec3 fd = {P.fdrag[i], P.fdrag[cap + i], P.fdrag[2 * cap + i]};
     if (S.carrier_rho != 0.0) {
       const double rho = 3.0 * mi / (4.0 * kPiTypo * radi * radi * radi);
@@ -249,6 +254,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     unsigned wt = P.wtouch[i], wt_new = 0;
     for (int w = 0; w < S.nwalls; w++) {
       const WallParams& W = S.wall[w];
+      if (!(mk & W.bit)) continue;   // fix_wall_granFix.cpp:290
       const double xc = (W.dim == 0) ? xi.x : (W.dim == 1) ? xi.y : xi.z;
       const double del1 = xc - W.lo, del2 = W.hi - xc;
       const double d = (del1 < del2) ? del1 : -del2;
@@ -285,8 +291,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
 
   // ---- integrate: final(k) [+ initial(k+1)]  ([3P] FixNVESphere, dtf = dt/2, INERTIA = 0.4) ----
+  // [3P] fix freeze (last post_force fix in every script of the reference): no force, no torque
+  if (mk & S.freeze_bit) {
+    F = {0.0, 0.0, 0.0};
+    T = {0.0, 0.0, 0.0};
+  }
   Vec3 vn = vi, wn = wi, xn = xi;
-  if (S.mode != 2 && S.have_nve) {
+  if (S.mode != 2 && S.have_nve && (mk & S.nve_bit)) {
     const double dtf = 0.5 * S.dt;
     const double dtfm = dtf / mi;
     const double dtirot = (dtf / 0.4) / (radi * radi * mi);
@@ -308,11 +319,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 #if SF_NT_OUT
   st_stream4(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
   st_stream4(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
-  st_stream4(&P.om_out[i], double4{wn.x, wn.y, wn.z, 0.0});
+  st_stream4(&P.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
 #else
   P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
   P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
-  P.om_out[i] = {wn.x, wn.y, wn.z, 0.0};
+  P.om_out[i] = {wn.x, wn.y, wn.z, wi4.w};   // .w: frozen mark travels with the record
 #endif
   if (S.mode != 0) {
     P.force[i] = {F.x, F.y, F.z, 0.0};
@@ -392,10 +403,12 @@ __global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
 __global__ __launch_bounds__(256) void k_initial_integrate(double4* xr, double4* vm, double4* om,
                                                            const double4* force, const double4* torque,
                                                            const double* xhold, int* flags, int nlocal,
-                                                           size_t cap, double dt, double trigger_sq)
+                                                           size_t cap, double dt, double trigger_sq,
+                                                           const int* mask, int nve_bit)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
+  if (mask && !(mask[i] & nve_bit)) return;   // not in the group of fix nve/sphere
   double4 x = xr[i], v = vm[i], w = om[i];
   const double4 f = force[i], t = torque[i];
   const double dtf = 0.5 * dt;
@@ -949,6 +962,76 @@ __global__ __launch_bounds__(256) void k_put_fdrag(const double* in, const int* 
   fdrag[cap + i] = in[3 * k + 1];
   fdrag[2 * cap + i] = in[3 * k + 2];
   if (cpuIn) foamCpuId[i] = cpuIn[k];
+}
+
+// [3P] group ID type ... : op 0 = list of types, 1 <, 2 <=, 3 >, 4 >=, 5 ==, 6 !=, 7 <> (between, inclusive)
+struct GroupTypeArgs {
+  int op, v1, v2, nlist;
+  int list[16];
+};
+__global__ __launch_bounds__(256) void k_group_type(int* mask, const int* type, int n, int bit, GroupTypeArgs A)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = type[i];
+  bool in = false;
+  switch (A.op) {
+    case 0:
+      for (int k = 0; k < A.nlist; k++) in = in || (t == A.list[k]);
+      break;
+    case 1: in = t < A.v1; break;
+    case 2: in = t <= A.v1; break;
+    case 3: in = t > A.v1; break;
+    case 4: in = t >= A.v1; break;
+    case 5: in = t == A.v1; break;
+    case 6: in = t != A.v1; break;
+    default: in = t >= A.v1 && t <= A.v2; break;
+  }
+  if (in) mask[i] |= bit;
+}
+
+// group ID subtract A B.. (in A, in none of the others) / union / intersect
+struct GroupCombineArgs {
+  int mode, n;
+  int bits[16];
+};
+__global__ __launch_bounds__(256) void k_group_combine(int* mask, int n, int bit, GroupCombineArgs A)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int m = mask[i];
+  bool in;
+  if (A.mode == 0) {
+    in = (m & A.bits[0]) != 0;
+    for (int k = 1; k < A.n; k++) in = in && !(m & A.bits[k]);
+  } else if (A.mode == 1) {
+    in = false;
+    for (int k = 0; k < A.n; k++) in = in || (m & A.bits[k]);
+  } else {
+    in = true;
+    for (int k = 0; k < A.n; k++) in = in && (m & A.bits[k]);
+  }
+  if (in) mask[i] |= bit;
+}
+
+// omega.w = 1 for the atoms of the fix-freeze group, in both ping-pong buffers
+__global__ __launch_bounds__(256) void k_mark_frozen(double4* om0, double4* om1, const int* mask, int n, int bit)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double f = (mask[i] & bit) ? 1.0 : 0.0;
+  om0[i].w = f;
+  om1[i].w = f;
+}
+
+__global__ __launch_bounds__(256) void k_set_velocity_group(double4* vm, const int* mask, int bit, int n, double vx,
+                                                            double vy, double vz)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !(mask[i] & bit)) return;
+  double4 v = vm[i];
+  v.x = vx; v.y = vy; v.z = vz;
+  vm[i] = v;
 }
 
 __global__ __launch_bounds__(256) void k_set_velocity(double4* vm, int n, double vx, double vy, double vz)

@@ -133,24 +133,24 @@ void cmd_pair_style(SfLammps& L, const std::vector<std::string>& w, size_t a)
 void cmd_fix(SfLammps& L, const std::vector<std::string>& w)
 {
   if (w.size() < 4) sf::fail("Illegal fix command");
-  if (w[2] != "all") sf::fail("fix %s: only group `all` is supported by this engine", w[1].c_str());
+  const int gb = L.eng.group_bit(w[2]);   // "Could not find fix group ID" in LAMMPS
   const std::string& st = w[3];
   const int narg = (int)w.size() - 1;  // LAMMPS narg counts ID group style ...
   if (st == "nve/sphere") {
-    L.eng.set_nve_sphere();
+    L.eng.set_nve_sphere(gb);
   } else if (st == "gravity") {
     // fix ID group gravity magnitude vector x y z
     if (narg < 8 || w[5] != "vector") sf::fail("Illegal fix gravity command (only `vector` style)");
-    L.eng.set_gravity(num(w[4]), num(w[6]), num(w[7]), num(w[8]));
+    L.eng.set_gravity(num(w[4]), num(w[6]), num(w[7]), num(w[8]), gb);
   } else if (st == "fdrag") {
     if (narg < 3) sf::fail("Illegal fix fdrag command");  // fix_fluid_drag.cpp:34
     double carrier = 0.0;
     if (narg == 4) carrier = (double)std::atoi(w[4].c_str());  // integer parse, fix_fluid_drag.cpp:53
-    L.eng.set_fdrag(carrier);
+    L.eng.set_fdrag(carrier, gb);
   } else if (st == "cohesive") {
     if (narg != 8) sf::fail("Illegal fix cohesive command");  // fix_cohesive.cpp:41
     L.eng.set_cohesive(std::atof(w[4].c_str()), std::atof(w[5].c_str()), std::atof(w[6].c_str()),
-                       std::atof(w[7].c_str()), std::atoi(w[8].c_str()));
+                       std::atof(w[7].c_str()), std::atoi(w[8].c_str()), gb);
   } else if (st == "wall/gran" || st == "wall/granFix") {
     if (narg < 10) sf::fail("Illegal fix %s command", st.c_str());  // fix_wall_granFix.cpp:47
     const bool ktn = w[5] == "NULL", gtn = w[7] == "NULL";
@@ -164,9 +164,38 @@ void cmd_fix(SfLammps& L, const std::vector<std::string>& w)
     const bool lon = w[11] == "NULL", hin = w[12] == "NULL";
     L.eng.add_wall(dim, lon, lon ? 0.0 : num(w[11]), hin, hin ? 0.0 : num(w[12]), num(w[4]), ktn,
                    ktn ? 0.0 : num(w[5]), num(w[6]), gtn, gtn ? 0.0 : num(w[7]), num(w[8]), inum(w[9]),
-                   st == "wall/granFix");
+                   st == "wall/granFix", gb);
+  } else if (st == "freeze") {
+    if (narg != 3) sf::fail("Illegal fix freeze command");   // [3P] fix_freeze.cpp
+    L.eng.set_freeze(gb);
   } else
     sf::fail("Unknown fix style %s", st.c_str());
+}
+
+// [3P] group ID style args: the styles the reference's input scripts use (type, subtract, union, intersect)
+void cmd_group(SfLammps& L, const std::vector<std::string>& w)
+{
+  if (w.size() < 4) sf::fail("Illegal group command");
+  const std::string& name = w[1];
+  const std::string& style = w[2];
+  if (style == "type") {
+    static const char* ops[] = {"<", "<=", ">", ">=", "==", "!=", "<>"};
+    int op = 0;
+    for (int k = 0; k < 7; k++)
+      if (w[3] == ops[k]) op = k + 1;
+    if (op) {
+      if (w.size() < (op == 7 ? 6u : 5u)) sf::fail("Illegal group command");
+      L.eng.group_type(name, op, inum(w[4]), op == 7 ? inum(w[5]) : 0, {});
+    } else {
+      std::vector<int> list;
+      for (size_t k = 3; k < w.size(); k++) list.push_back(inum(w[k]));
+      L.eng.group_type(name, 0, 0, 0, list);
+    }
+  } else if (style == "subtract" || style == "union" || style == "intersect") {
+    std::vector<std::string> args(w.begin() + 3, w.end());
+    L.eng.group_combine(name, style == "subtract" ? 0 : (style == "union" ? 1 : 2), args);
+  } else
+    sf::fail("group style %s is not supported by this engine (type, subtract, union, intersect are)", style.c_str());
 }
 
 void command(SfLammps& L, const std::string& line)
@@ -202,8 +231,10 @@ void command(SfLammps& L, const std::string& line)
     if (w.size() != 2) sf::fail("Illegal timestep command");
     L.eng.set_timestep(num(w[1]));
   } else if (c == "velocity") {
-    if (w.size() >= 6 && w[1] == "all" && w[2] == "set") L.eng.set_velocity_all(num(w[3]), num(w[4]), num(w[5]));
+    if (w.size() >= 6 && w[2] == "set") L.eng.set_velocity_group(L.eng.group_bit(w[1]), num(w[3]), num(w[4]), num(w[5]));
     else sf::fail("velocity: only `velocity all set vx vy vz` is supported");
+  } else if (c == "group") {
+    cmd_group(L, w);
   } else if (c == "fix") {
     cmd_fix(L, w);
   } else if (c == "run") {
@@ -211,7 +242,7 @@ void command(SfLammps& L, const std::string& line)
     L.eng.run(inum(w[1]));
   } else if (c == "pair_coeff" || c == "atom_modify" || c == "processors" || c == "thermo" ||
              c == "thermo_style" || c == "thermo_modify" || c == "dump" || c == "dump_modify" ||
-             c == "restart" || c == "group" || c == "echo" || c == "log" || c == "dimension") {
+             c == "restart" || c == "echo" || c == "log" || c == "dimension") {
     // accepted, nothing to do on this path
   } else
     sf::fail("Unknown command: %s", c.c_str());

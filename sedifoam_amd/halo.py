@@ -18,7 +18,7 @@ import os
 
 import numpy as np
 
-BORDER_DOUBLES = 13
+BORDER_DOUBLES = 14
 FORWARD_DOUBLES = 9
 
 

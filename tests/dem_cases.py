@@ -20,6 +20,13 @@ def make_oracle(bed, cfg):
         dem.fix_wall(dim, lo, hi, cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], cfg.get("dampflag", 1))
     if cfg.get("cohesive"):
         dem.fix_cohesive(*cfg["cohesive"])
+    if cfg.get("frozen_types") is not None:
+        # group bottom type 2 / group active subtract all bottom (bits 2 and 4), as in the reference's bed cases
+        t = np.asarray(bed["type"])
+        bottom = np.isin(t, cfg["frozen_types"])
+        dem.set_mask(1 + 2 * bottom + 4 * (~bottom))
+        dem.set_groups(nve=4, gravity=4, fdrag=1 if cfg.get("fdrag_group", "all") == "all" else 4, wall=1,
+                       cohesive=1, freeze=2)
     dem.neighbor(cfg["skin"])
     dem.timestep(cfg["dt"])
     return dem
@@ -37,18 +44,26 @@ def script_lines(bed, cfg):
     else:
         pair = "pair_style " + gran
     p = bed["periodic"]
+    frozen = cfg.get("frozen_types") is not None
+    act = "active" if frozen else "all"
     lines = ["atom_style sphere", "boundary %s %s %s" % tuple("p" if q else "f" for q in p), "newton off",
              "communicate single vel yes", "neighbor %.17g bin" % cfg["skin"], "neigh_modify delay 0", pair,
-             "pair_coeff * *", "timestep %.17g" % cfg["dt"], "fix 1 all nve/sphere",
-             "fix 2 all gravity %.17g vector 0 -1 0" % cfg["g"]]
+             "pair_coeff * *", "timestep %.17g" % cfg["dt"]]
+    if frozen:   # cases/example-cases/*/in.lammps: a bed resting on a layer of fixed particles
+        lines += ["group bottom type " + " ".join(str(t) for t in cfg["frozen_types"]),
+                  "group active subtract all bottom"]
+    lines += ["fix 1 %s nve/sphere" % act, "fix 2 %s gravity %.17g vector 0 -1 0" % (act, cfg["g"])]
     cr = cfg.get("carrier_rho", 0.0)
-    lines.append("fix 3 all fdrag" + (" %d" % int(cr) if cr else ""))
+    lines.append("fix 3 %s fdrag" % (act if cfg.get("fdrag_group", "all") != "all" else "all")
+                 + (" %d" % int(cr) if cr else ""))
     for k, (dim, lo, hi) in enumerate(cfg["walls"]):
         lines.append("fix w%d all %s %.17g NULL %.17g NULL %.17g %d %splane %s %s" % (
             k, wall, cfg["kn"], cfg["gamman"], cfg["xmu"], cfg.get("dampflag", 1), "xyz"[dim],
             "NULL" if lo is None else "%.17g" % lo, "NULL" if hi is None else "%.17g" % hi))
     if cfg.get("cohesive"):
         lines.append("fix coh all cohesive %.17g %.17g %.17g %.17g %d" % tuple(cfg["cohesive"]))
+    if frozen:
+        lines.append("fix 4 bottom freeze")
     return lines
 
 
@@ -56,7 +71,8 @@ def make_hip(bed, cfg):
     from sedifoam_amd import Lammps
     lmp = Lammps()
     lmp.set_box(bed["boxlo"], bed["boxhi"])
-    lmp.create_atoms(bed["x"], bed["diameter"], bed["density"], v=bed["v"], omega=bed.get("omega"))
+    lmp.create_atoms(bed["x"], bed["diameter"], bed["density"], v=bed["v"], omega=bed.get("omega"),
+                     type_=bed.get("type"))
     for line in script_lines(bed, cfg):
         lmp.command(line)
     return lmp

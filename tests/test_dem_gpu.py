@@ -115,6 +115,28 @@ def test_mid_size_100k_bed_with_rebuilds():
     assert lmp.info().nbuilds >= 3 and orc.nbuilds == lmp.info().nbuilds
 
 
+@pytest.mark.parametrize("pair,fdrag_group", [("hertz", "all"), ("hooke", "active")])
+def test_frozen_bottom_layer_groups(pair, fdrag_group):
+    """The bed set-up of the reference's example cases (cases/example-cases/*/in.lammps): `group bottom type 2`,
+    `group active subtract all bottom`, nve/sphere + gravity (+ fdrag) on `active`, `fix 4 bottom freeze`.  Frozen
+    atoms do not move, feel no force, and count as infinitely heavy in the contact law
+    (pair_gran_hertzFix_history.cpp:188-189)."""
+    bed = _bed((6, 5, 6), periodic=True, seed=29, vmax=0.3)
+    bed["type"] = np.where(bed["x"][:, 1] < 0.9e-3, 2, 1).astype(np.int32)     # the two bottom lattice layers
+    assert 0 < (bed["type"] == 2).sum() < bed["n"] // 2
+    bed["v"][bed["type"] == 2] = 0.0
+    cfg = dict(BASE, pair=pair, skin=0.08e-3, frozen_types=[2], fdrag_group=fdrag_group)
+    if pair == "hooke":
+        cfg.update(kn=2.0e3, gamman=50.0)
+    lmp, orc = _run_case(bed, cfg, steps=(1, 80), tol_f=5e-12)
+    a = lmp.get_state()
+    bottom = bed["type"][a["tag"] - 1] == 2
+    assert np.array_equal(a["x"][bottom], bed["x"][a["tag"] - 1][bottom])      # frozen atoms never move
+    assert np.all(a["f"][bottom] == 0.0) and np.all(a["torque"][bottom] == 0.0) and np.all(a["v"][bottom] == 0.0)
+    assert np.abs(a["f"][~bottom]).max() > 0.0
+    assert lmp.info().nbuilds >= 2
+
+
 def test_carrier_rho_added_mass_term():
     bed = _bed((4, 4, 4), periodic=True, seed=5)
     _run_case(bed, dict(BASE, carrier_rho=1000.0), steps=(1, 20))

@@ -44,6 +44,30 @@ def test_self_halo_matches_internal_periodic_and_oracle(vmax, skin, steps):
         assert drv.n_rebuilds >= 3      # migration across the periodic face + history carry-over exercised
 
 
+def test_self_halo_with_frozen_bottom_layer():
+    """groups + fix freeze across the halo: the border record carries the group mask, ghosts of frozen atoms must
+    count as infinitely heavy on the receiving side too"""
+    bed = T._bed((6, 6, 6), periodic=True, seed=78, vmax=0.4)
+    bed["type"] = np.where(bed["x"][:, 1] < 0.9e-3, 2, 1).astype(np.int32)
+    bed["v"][bed["type"] == 2] = 0.0
+    cfg = dict(T.BASE, skin=0.06e-3, frozen_types=[2])
+    cfg["walls"] = T._walls(bed)
+    ref = dc.make_hip(bed, cfg)
+    orc = dc.make_oracle(bed, cfg)
+    lmp, drv = _driver(bed, cfg)
+    ref.setup(); orc.setup(); drv.setup()
+    for n in (1, 60):
+        ref.step(n); orc.run(n); drv.step(n)
+        a, b, c = lmp.get_state(), ref.get_state(), orc.get()
+        assert (a["tag"] == b["tag"]).all()
+        for k in ("x", "v", "omega", "f", "torque"):
+            assert dc.rel_err(a[k], b[k]) <= 1e-11, k
+            assert dc.rel_err(a[k], c[k]) <= 1e-9, k
+    assert drv.n_rebuilds >= 2
+    bottom = bed["type"][a["tag"] - 1] == 2
+    assert np.array_equal(a["x"][bottom], bed["x"][a["tag"] - 1][bottom])
+
+
 def _two_rank_worker(rank, world, port, outdir, steps, overlap=False):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
