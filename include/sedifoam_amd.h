@@ -287,6 +287,7 @@ typedef struct {
   int diffusionSteps;
   int UfSmooth, UpSmooth, dragSmooth, alphaSmooth;
   double smoothDirection[3];
+  int particleHistoryForce;   /* reduced-order Basset history force, enhancedCloud.C:197-233 */
 } sf_cloud_props;
 /* uniform hex block mesh (blockMeshDict: hex (...) (nx ny nz) simpleGrading (1 1 1)) */
 typedef struct {
@@ -308,7 +309,7 @@ int sf_cloud_calc_tc_fields(void *cloud);
 /* stand-alone smoothField on a host field [ncells][ncomp] (ncomp 1 or 3), in place */
 int sf_cloud_smooth_field(void *cloud, double *field, int ncomp);
 /* evolve() / calcTcFields() in pieces, for a decomposed domain (one engine per GPU, every rank holds the whole mesh):
- *   phase 0 UfSmoothed ; per sub-cycle: phase 1 drag on this rank's particles -> the caller runs subSteps DEM
+ *   phase 0 next time step + UfSmoothed (phase 6: UfSmoothed only, for initialisation) ; per sub-cycle: phase 1 drag on this rank's particles -> the caller runs subSteps DEM
  *   sub-steps through the halo driver -> (first sub-cycle) phase 2 per-cell sums of this rank's particles -> the
  *   caller adds gamma [ncells] and Ue [ncells][3] over the ranks in place -> phase 3 smoothing + Ue/gamma.
  *   calcTcFields: phase 4 (alpha cap, local Asrc sums) -> add Asrc [ncells][3] over the ranks -> phase 5.

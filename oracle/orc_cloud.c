@@ -77,12 +77,34 @@ void orc_cell_owner(int n, const double *x, const double origin[3], const double
   }
 }
 
+/* enhancedCloud::g1n  enhancedCloud.C:1372-1384 */
+static double g1n(double n)
+{
+  if (n < 1) return 0.9279;
+  return 0.9279 * (2 * n - 1) / n * pow(n, -n / (2 * n - 1)) + 0.001531;
+}
+
 void orc_drag_on_particles(const orc_cloud_flags *fl, int dragModel, int n, const int *cell,
                            const double *pos, const double *d, const double *U,
                            const double *UOld, const double *gamma, const double *UfSmoothed,
                            const double *gradp, const double *DDtUf, const double *curlU,
                            double *Uri, double *magUri, double *Jd, double *pDrag,
                            double *pDuDt)
+{
+  orc_drag_on_particles_hist(fl, dragModel, n, cell, pos, d, U, UOld, gamma, UfSmoothed, gradp, DDtUf, curlU,
+                             -1, NULL, NULL, NULL, Uri, magUri, Jd, pDrag, pDuDt);
+}
+
+/* the same with the reduced-order history (Basset) force of :197-233 (particleHistoryForce): timeIndex =
+ * runTime().timeIndex(), UfSmoothedOld = UfSmoothed_.oldTime(), sumDeltaFb [3n] and n0 [n] = the per-particle state
+ * of softParticle.H:104-107 (both start at zero); timeIndex < 0 switches the term off */
+void orc_drag_on_particles_hist(const orc_cloud_flags *fl, int dragModel, int n, const int *cell,
+                                const double *pos, const double *d, const double *U,
+                                const double *UOld, const double *gamma, const double *UfSmoothed,
+                                const double *gradp, const double *DDtUf, const double *curlU,
+                                int timeIndex, const double *UfSmoothedOld, double *sumDeltaFb, double *n0,
+                                double *Uri, double *magUri, double *Jd, double *pDrag,
+                                double *pDuDt)
 {
   int i, k;
   /* updateParticleUr :83-109 ; updateParticleAlpha :56-76 (alpha buffered in pDuDt[0..n)) */
@@ -137,6 +159,37 @@ void orc_drag_on_particles(const orc_cloud_flags *fl, int dragModel, int n, cons
       double magw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
       for (k = 0; k < 3; k++)
         F[k] += 1.6 * fl->rhob * sqrt(fl->nub) * (d[i] * d[i]) * cr[k] / sqrt(magw + ROOTVSMALL);
+    }
+    if (timeIndex >= 0) {                                           /* :197-234 Elghannay & Tafti 2016 */
+      double tau_d = d[i] * d[i] / fl->nub;
+      double uri[3], uriOld[3], m1 = 0.0, m2 = 0.0;
+      for (k = 0; k < 3; k++) {
+        uri[k] = UfSmoothed[3 * c + k] - U[3 * i + k];
+        uriOld[k] = UfSmoothedOld[3 * c + k] - UOld[3 * i + k];
+        m1 += uri[k] * uri[k];
+        m2 += uriOld[k] * uriOld[k];
+      }
+      double ReP = sqrt(m1) * d[i] / fl->nub, RePOld = sqrt(m2) * d[i] / fl->nub;
+      double a1 = 0.632 / (ReP + ROOTVSMALL) + 0.087, a2 = 0.632 / (RePOld + ROOTVSMALL) + 0.087;
+      double tau_h = tau_d * (a1 * a1), tau_h_old = tau_d * (a2 * a2);
+      double Cb = -1.5 * (d[i] * d[i]) * fl->rhob * pow(3.1416 * fl->nub, 0.5);
+      double deltaT = fl->deltaT;
+      double tau_t = deltaT * (timeIndex - n0[i]);
+      double delta_fb[3], FH[3];
+      for (k = 0; k < 3; k++) delta_fb[k] = Cb * ((U[3 * i + k] - UOld[3 * i + k]) / deltaT) / sqrt(deltaT);
+      if (tau_t < tau_h) {
+        double delta_n_h = timeIndex - n0[i];
+        for (k = 0; k < 3; k++) sumDeltaFb[3 * i + k] = sumDeltaFb[3 * i + k] + delta_fb[k];
+        for (k = 0; k < 3; k++) FH[k] = g1n(delta_n_h) * sumDeltaFb[3 * i + k];
+      } else {
+        double delta_n_h = tau_h / deltaT;
+        for (k = 0; k < 3; k++) sumDeltaFb[3 * i + k] = tau_h / tau_h_old * sumDeltaFb[3 * i + k];
+        for (k = 0; k < 3; k++) sumDeltaFb[3 * i + k] = (delta_n_h - 1) / delta_n_h * sumDeltaFb[3 * i + k];
+        n0[i] = timeIndex - delta_n_h;
+        for (k = 0; k < 3; k++) sumDeltaFb[3 * i + k] = sumDeltaFb[3 * i + k] + delta_fb[k];
+        for (k = 0; k < 3; k++) FH[k] = g1n(delta_n_h) * sumDeltaFb[3 * i + k];
+      }
+      for (k = 0; k < 3; k++) F[k] += FH[k] * deltaT;
     }
     if (fl->lubricationForce) {                                     /* :235-248 (y wall at 0) */
       double distMin = 0.0001 * d[i], distMax = 0.1 * d[i];

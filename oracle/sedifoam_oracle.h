@@ -218,6 +218,13 @@ void orc_drag_on_particles(const orc_cloud_flags *fl, int dragModel, int n, cons
                            const double *gradp, const double *DDtUf, const double *curlU,
                            double *Uri, double *magUri, double *Jd, double *pDrag,
                            double *pDuDt);
+void orc_drag_on_particles_hist(const orc_cloud_flags *fl, int dragModel, int n, const int *cell,
+                                const double *pos, const double *d, const double *U,
+                                const double *UOld, const double *gamma, const double *UfSmoothed,
+                                const double *gradp, const double *DDtUf, const double *curlU,
+                                int timeIndex, const double *UfSmoothedOld, double *sumDeltaFb, double *n0,
+                                double *Uri, double *magUri, double *Jd, double *pDrag,
+                                double *pDuDt);
 
 /* A8: particleToEulerianField  enhancedCloud.C:911-980 (no diffusion smoothing) */
 void orc_particle_to_eulerian(int n, const int *cell, const double *d, const double *U,

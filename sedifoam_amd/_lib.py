@@ -64,7 +64,7 @@ class CloudProps(C.Structure):
                 ("rhob", C.c_double), ("nub", C.c_double), ("maxPossibleAlpha", C.c_double),
                 ("diffusionBandWidth", C.c_double), ("diffusionSteps", C.c_int), ("UfSmooth", C.c_int),
                 ("UpSmooth", C.c_int), ("dragSmooth", C.c_int), ("alphaSmooth", C.c_int),
-                ("smoothDirection", C.c_double * 3)]
+                ("smoothDirection", C.c_double * 3), ("particleHistoryForce", C.c_int)]
 
 
 class CloudMesh(C.Structure):

@@ -59,7 +59,7 @@ class enhancedCloud:
     """enhancedCloud(U, p, Ue, Uf, DDtUf, nu, alpha, cloudDict, transDict, ...) on a uniform hex block.
 
     cloudDict keys (constant/cloudProperties): dragModel, subCycles, particleDrag, particlePressureGrad,
-    particleBuoyancy, particleAddedMass, particleLift, lubricationForce, g, maxPossibleAlpha, diffusionBandWidth,
+    particleBuoyancy, particleAddedMass, particleLift, particleHistoryForce, lubricationForce, g, maxPossibleAlpha, diffusionBandWidth,
     diffusionSteps, UfSmooth, UpSmooth, dragSmooth, alphaSmooth, smoothDirection.
     transDict keys (constant/transportProperties): rhob, nub."""
 
@@ -83,6 +83,7 @@ class enhancedCloud:
         pr.particleAddedMass = int(cloudDict.get("particleAddedMass", False))         # :591
         pr.particleLift = int(cloudDict.get("particleLift", False))                   # :593
         pr.lubricationForce = int(cloudDict.get("lubricationForce", False))           # :597
+        pr.particleHistoryForce = int(cloudDict.get("particleHistoryForce", False))   # :595-596
         g = cloudDict.get("g", (0.0, 0.0, 0.0))
         pr.gravity = (C.c_double * 3)(*g)
         pr.rhob = float(transDict["rhob"])
@@ -120,7 +121,7 @@ class enhancedCloud:
                              Ue=(C.cast(u, C.c_void_p).value, 3 * nc.value),
                              Asrc=(C.cast(a, C.c_void_p).value, 3 * nc.value))
             # the constructor scattered this rank's particles only: redo it over all ranks
-            self._phase(2); self._sum_over_ranks("gamma", "Ue"); self._phase(3); self._phase(0)
+            self._phase(2); self._sum_over_ranks("gamma", "Ue"); self._phase(3); self._phase(6)
 
     def close(self):
         if getattr(self, "ptr", None):

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
     int n, size_t cap, const double4* xr, const double4* vm, const int* tag, MeshDev m, CloudFlagsDev fl,
     const double* gamma, const double* UfS, const double* gradp, const double* DDtUf, const double* curlU,
     double* UOld_bytag, int maxtag, int first_call, int* cell_bytag, double* Jd_bytag, double* pDrag_bytag,
-    double* fdrag, double* DuDt)
+    double* fdrag, double* DuDt, int timeIndex, const double* UfSold, double* sumFb_bytag, double* n0_bytag)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -146,6 +146,46 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
       const double magw = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
       for (int k = 0; k < 3; k++)
         F[k] += 1.6 * fl.rhob * sqrt(fl.nub) * (d * d) * cr[k] / sqrt(magw + kRootVSmall);
+    }
+    if (timeIndex >= 0 && t >= 1 && t <= maxtag) {
+      // reduced-order history (Basset) force, Elghannay & Tafti 2016 -- enhancedCloud.C:197-233; per-particle state
+      // sumDeltaFb / n0 (softParticle.H:104-107) kept by tag
+      const double tau_d = d * d / fl.nub;
+      double m1 = 0.0, m2 = 0.0;
+      for (int k = 0; k < 3; k++) {
+        const double o = UfSold[3 * c + k] - uold[k];
+        m1 += Uri[k] * Uri[k];
+        m2 += o * o;
+      }
+      const double ReP = sqrt(m1) * d / fl.nub, RePOld = sqrt(m2) * d / fl.nub;
+      const double a1 = 0.632 / (ReP + kRootVSmall) + 0.087, a2 = 0.632 / (RePOld + kRootVSmall) + 0.087;
+      const double tau_h = tau_d * (a1 * a1), tau_h_old = tau_d * (a2 * a2);
+      const double Cb = -1.5 * (d * d) * fl.rhob * pow(3.1416 * fl.nub, 0.5);
+      const double n0 = n0_bytag[t - 1];
+      const double tau_t = fl.deltaT * (timeIndex - n0);
+      double sfb[3], dfb[3];
+      for (int k = 0; k < 3; k++) {
+        sfb[k] = sumFb_bytag[(size_t)k * maxtag + (t - 1)];
+        dfb[k] = Cb * ((U[k] - uold[k]) / fl.deltaT) / sqrt(fl.deltaT);
+      }
+      double dnh;
+      if (tau_t < tau_h) {
+        dnh = timeIndex - n0;
+        for (int k = 0; k < 3; k++) sfb[k] = sfb[k] + dfb[k];
+      } else {
+        dnh = tau_h / fl.deltaT;
+        for (int k = 0; k < 3; k++) {
+          sfb[k] = tau_h / tau_h_old * sfb[k];
+          sfb[k] = (dnh - 1) / dnh * sfb[k];
+          sfb[k] = sfb[k] + dfb[k];
+        }
+        n0_bytag[t - 1] = timeIndex - dnh;
+      }
+      const double g1 = dnh < 1 ? 0.9279 : 0.9279 * (2 * dnh - 1) / dnh * pow(dnh, -dnh / (2 * dnh - 1)) + 0.001531;
+      for (int k = 0; k < 3; k++) {
+        sumFb_bytag[(size_t)k * maxtag + (t - 1)] = sfb[k];
+        F[k] += (g1 * sfb[k]) * fl.deltaT;
+      }
     }
     if (fl.lubricationForce) {
       const double distMin = 0.0001 * d, distMax = 0.1 * d;
@@ -337,6 +377,7 @@ class Cloud {
     alloc(gradp_, 3 * nc);
     alloc(curlU_, 3 * nc);
     alloc(UfS_, 3 * nc);
+    alloc(UfSold_, 3 * nc);
     smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_);
     SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
     std::vector<double> hV(nc, mesh.dx[0] * mesh.dx[1] * mesh.dx[2]);
@@ -350,7 +391,7 @@ class Cloud {
 
   ~Cloud()
   {
-    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_, UfS_})
+    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_, UfS_, UfSold_, sumFb_, n0_})
       if (p) (void)hipFree(p);
     for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_})
       if (p) (void)hipFree(p);
@@ -363,6 +404,9 @@ class Cloud {
     if (DDtUf) SF_HIP(hipMemcpyAsync(DDtUf_, DDtUf, nb, hipMemcpyHostToDevice, s_));
     if (gradp) SF_HIP(hipMemcpyAsync(gradp_, gradp, nb, hipMemcpyHostToDevice, s_));
     if (curlU) SF_HIP(hipMemcpyAsync(curlU_, curlU, nb, hipMemcpyHostToDevice, s_));
+    // before the first step the fields are the initial condition: UfSmoothed_ (whose oldTime() the history force
+    // reads in the first step) is built from them, as the reference does at construction (:641-655)
+    if (Uf && time_index_ == 0) update_uf_smoothed();
     SF_HIP(hipStreamSynchronize(s_));
   }
 
@@ -370,6 +414,7 @@ class Cloud {
   {
     const double t0 = now();
     DemEngine& e = lmp_->eng;
+    advance_time();
     update_uf_smoothed();   // :675-690
     for (int k = 0; k < subCycles_; k++) {
       double t1 = now();
@@ -424,7 +469,8 @@ class Cloud {
   void phase(int ph)
   {
     switch (ph) {
-      case 0: update_uf_smoothed(); break;
+      case 0: advance_time(); update_uf_smoothed(); break;
+      case 6: update_uf_smoothed(); break;   // (re-)initialisation, no time advance
       case 1: drag_on_particles(); break;
       case 2: scatter_local(); break;
       case 3: scatter_finish(); break;
@@ -531,6 +577,25 @@ class Cloud {
       re2((void**)&Jd_, sizeof(double) * newmax);
       re2((void**)&cell_, sizeof(int) * newmax);
       re2((void**)&pDragT_, sizeof(double) * 3 * (size_t)newmax);
+      if (props_.particleHistoryForce) {
+        // history state by tag, kept across growth
+        double *ns = nullptr, *nn = nullptr;
+        SF_HIP(hipMalloc(&ns, sizeof(double) * 3 * (size_t)newmax));
+        SF_HIP(hipMalloc(&nn, sizeof(double) * (size_t)newmax));
+        SF_HIP(hipMemsetAsync(ns, 0, sizeof(double) * 3 * (size_t)newmax, s_));
+        SF_HIP(hipMemsetAsync(nn, 0, sizeof(double) * (size_t)newmax, s_));
+        if (sumFb_) {
+          for (int k = 0; k < 3; k++)
+            SF_HIP(hipMemcpyAsync(ns + (size_t)k * newmax, sumFb_ + (size_t)k * maxtag_, sizeof(double) * maxtag_,
+                                  hipMemcpyDeviceToDevice, s_));
+          SF_HIP(hipMemcpyAsync(nn, n0_, sizeof(double) * maxtag_, hipMemcpyDeviceToDevice, s_));
+          SF_HIP(hipStreamSynchronize(s_));
+          SF_HIP(hipFree(sumFb_));
+          SF_HIP(hipFree(n0_));
+        }
+        sumFb_ = ns;
+        n0_ = nn;
+      }
       maxtag_ = newmax;
     }
   }
@@ -561,7 +626,9 @@ class Cloud {
     k_drag_on_particles<<<div_up(n, 256), 256, 0, s_>>>(n, e.capacity(), e.d_xr(), e.d_vm(), e.d_tag(), mesh_,
                                                         flags(), gamma_, UfS_, gradp_, DDtUf_, curlU_, UOld_,
                                                         maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, pDragT_,
-                                                        e.d_fdrag(), e.d_DuDt());
+                                                        e.d_fdrag(), e.d_DuDt(),
+                                                        props_.particleHistoryForce ? time_index_ : -1, UfSold_,
+                                                        sumFb_, n0_);
     first_drag_ = false;
   }
 
@@ -605,6 +672,13 @@ class Cloud {
   }
 
   // UfSmoothed_ = Uf_ [ * (1 - gamma), smoothed, / (1 - gamma) ]   enhancedCloud.C:675-690
+  // ++runTime: UfSmoothed_ of the previous step becomes its oldTime(), the time index advances
+  void advance_time()
+  {
+    SF_HIP(hipMemcpyAsync(UfSold_, UfS_, sizeof(double) * 3 * (size_t)mesh_.ncells, hipMemcpyDeviceToDevice, s_));
+    time_index_++;
+  }
+
   void update_uf_smoothed()
   {
     const int nb = div_up(mesh_.ncells, 256);
@@ -642,6 +716,9 @@ public:
   double *Uf_ = nullptr, *DDtUf_ = nullptr, *gradp_ = nullptr, *curlU_ = nullptr, *UfS_ = nullptr;
   DiffusionSmoother smoother_;
   double *Jd_ = nullptr, *UOld_ = nullptr, *pDragT_ = nullptr;   // by tag
+  double *sumFb_ = nullptr, *n0_ = nullptr;                      // history-force state by tag
+  double* UfSold_ = nullptr;                                     // UfSmoothed_.oldTime()
+  int time_index_ = 0;                                           // runTime().timeIndex()
   int *cstart_ = nullptr, *cell_ = nullptr, *idx_ = nullptr, *idx2_ = nullptr;
   unsigned *keys_ = nullptr, *keys2_ = nullptr;
   void* sort_tmp_ = nullptr;

@@ -69,7 +69,7 @@ def test_cell_owner_bit_exact_1m():
     assert (ref == -1).sum() > 1000 and np.array_equal(got, ref)
 
 
-def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None):
+def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=50e-6):
     """10k-class bed in a 32^3-style mesh (BASELINE config C2 scaled to test size): HIP cloud+DEM vs oracle."""
     from sedifoam_amd import synthetic, enhancedCloud
     bed = synthetic.fcc_bed((8, 7, 8), seed=21, vmax=0.05)
@@ -86,7 +86,6 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None):
     DDtUf = rng.normal(scale=0.5, size=(ncells, 3))
     gradp = np.tile([0.0, -9810.0, 0.0], (ncells, 1)) + rng.normal(scale=50.0, size=(ncells, 3))
     curlU = rng.normal(scale=5.0, size=(ncells, 3))
-    deltaT = 50e-6
     cloudDict = dict(dragModel=drag_name, subCycles=sub_cycles, g=(0.0, -9.81, 0.0), maxPossibleAlpha=0.65, **flags)
     sm = None
     if smooth:
@@ -119,6 +118,8 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None):
     fl.particleDrag = int(flags.get("particleDrag", True)); fl.particlePressureGrad = int(flags.get("particlePressureGrad", True))
     fl.particleBuoyancy = int(flags.get("particleBuoyancy", False)); fl.particleAddedMass = int(flags.get("particleAddedMass", False))
     fl.particleLift = int(flags.get("particleLift", False)); fl.lubricationForce = int(flags.get("lubricationForce", False))
+    hist = bool(flags.get("particleHistoryForce", False))
+    sumFb = np.zeros((n, 3)); n0 = np.zeros(n)
     fl.gravity = (C.c_double * 3)(0.0, -9.81, 0.0); fl.rhob = 1000.0; fl.nub = 1e-6; fl.deltaT = deltaT
     gamma = np.zeros(ncells); Ue = np.zeros((ncells, 3)); cell = np.zeros(n, np.int32)
     st = orc.get()
@@ -133,17 +134,20 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None):
     tol_s = 1e-9 if smooth else 1e-12      # two different CG solvers of the same system
     assert dc.rel_err(g0, gamma) <= tol_s and dc.rel_err(cloud.Ue(), Ue) <= tol_s
     UfS = np.zeros((ncells, 3))
+    L.orc_uf_smoothed(ncells, ob.P(Uf), ob.P(gamma), smp, ob.P(UfS))          # construction value = first oldTime()
     dmodel = 0 if drag_name == "ErgunWenYu" else 1
     Uri = np.zeros((n, 3)); mag = np.zeros(n); Jd = np.zeros(n); pDrag = np.zeros((n, 3)); pDuDt = np.zeros((n, 3))
     UOld = st["v"].copy()
     for it in range(n_cfd):
         cloud.evolve()
+        UfS_old = UfS.copy()                                                  # UfSmoothed_.oldTime()
         L.orc_uf_smoothed(ncells, ob.P(Uf), ob.P(gamma), smp, ob.P(UfS))     # enhancedCloud.C:675-690
         for k in range(sc.value):
             L.orc_cell_owner(n, ob.P(st["x"]), ob.P(origin), ob.P(dxm), ob.P(mesh_n), ob.P(cell))
-            L.orc_drag_on_particles(C.byref(fl), dmodel, n, ob.P(cell), ob.P(st["x"]), ob.P(d), ob.P(st["v"]),
-                                    ob.P(UOld), ob.P(gamma), ob.P(UfS), ob.P(gradp), ob.P(DDtUf), ob.P(curlU),
-                                    ob.P(Uri), ob.P(mag), ob.P(Jd), ob.P(pDrag), ob.P(pDuDt))
+            L.orc_drag_on_particles_hist(C.byref(fl), dmodel, n, ob.P(cell), ob.P(st["x"]), ob.P(d), ob.P(st["v"]),
+                                         ob.P(UOld), ob.P(gamma), ob.P(UfS), ob.P(gradp), ob.P(DDtUf), ob.P(curlU),
+                                         (it + 1) if hist else -1, ob.P(UfS_old), ob.P(sumFb), ob.P(n0),
+                                         ob.P(Uri), ob.P(mag), ob.P(Jd), ob.P(pDrag), ob.P(pDuDt))
             cell_before, pDrag_before, Jd_before = cell.copy(), pDrag.copy(), Jd.copy()
             orc.put_fdrag(pDrag, st["tag"])
             orc.run(ss.value)
@@ -187,6 +191,67 @@ def test_coupled_ergun_wenyu_default_forces():
 def test_coupled_syamlal_all_forces():
     _coupled_case("SyamlalOBrien", dict(particleBuoyancy=True, particleAddedMass=True, particleLift=True,
                                         lubricationForce=True), sub_cycles=1)
+
+
+def test_coupled_with_history_force():
+    """particleHistoryForce (reduced-order Basset force, enhancedCloud.C:197-233) with its per-particle state,
+    through both branches (tau_t < tau_h and the window reset) over 6 CFD steps"""
+    _coupled_case("ErgunWenYu", dict(particleHistoryForce=True, particleAddedMass=True), sub_cycles=2, n_cfd=6)
+
+
+def test_history_force_window_reset_branch():
+    """The else branch of enhancedCloud.C:223-231 (history window full: rescale, shrink, reset n0) needs
+    timeIndex*deltaT >= tau_h ~ 10 ms, i.e. ~200 CFD steps -- too long for a trajectory-level comparison of a
+    colliding bed, so this drives the drag evaluation alone: particles at rest in space, their velocity reset to a
+    new uniform value every CFD step (`velocity all set`), 320 steps, HIP vs oracle on every step's pDrag."""
+    from sedifoam_amd import synthetic, enhancedCloud
+    bed = synthetic.fcc_bed((5, 5, 5), seed=31, vmax=0.0)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    mesh_n = np.array([3, 3, 3], np.int32)
+    origin = bed["boxlo"].copy(); dxm = (bed["boxhi"] - bed["boxlo"]) / mesh_n
+    ncells = 27
+    rng = np.random.default_rng(8)
+    Uf = np.tile([0.0, 0.05, 0.0], (ncells, 1)) + 0.01 * rng.normal(size=(ncells, 3))
+    zeros = np.zeros((ncells, 3))
+    deltaT = 50e-6
+    lmp = dc.make_hip(bed, cfg)
+    cloud = enhancedCloud(lmp, origin, dxm, mesh_n,
+                          dict(dragModel="ErgunWenYu", subCycles=1, g=(0.0, -9.81, 0.0), particleDrag=False,
+                               particlePressureGrad=False, particleHistoryForce=True),
+                          dict(rhob=1000.0, nub=1.0e-6), deltaT)
+    cloud.setFluid(Uf=Uf, DDtUf=zeros, gradp=zeros, curlU=zeros)
+    L = ob.lib()
+    n = bed["n"]
+    d = bed["diameter"].copy()
+    x = np.ascontiguousarray(bed["x"])
+    cell = np.zeros(n, np.int32)
+    L.orc_cell_owner(n, ob.P(x), ob.P(origin), ob.P(dxm), ob.P(mesh_n), ob.P(cell))
+    gamma = cloud.gamma()       # (not used by the history term; the drag closure is switched off here)
+    fl = ob.CloudFlags()
+    fl.particleDrag = 0; fl.particlePressureGrad = 0; fl.particleBuoyancy = 0; fl.particleAddedMass = 0
+    fl.particleLift = 0; fl.lubricationForce = 0
+    fl.gravity = (C.c_double * 3)(0.0, -9.81, 0.0); fl.rhob = 1000.0; fl.nub = 1e-6; fl.deltaT = deltaT
+    sumFb = np.zeros((n, 3)); n0 = np.zeros(n)
+    Uri = np.zeros((n, 3)); mag = np.zeros(n); Jd = np.zeros(n); pDrag = np.zeros((n, 3)); pDuDt = np.zeros((n, 3))
+    U = np.zeros((n, 3)); UOld = U.copy()
+    branch_seen = False
+    for it in range(1, 321):
+        v = 0.02 * np.array([np.sin(0.05 * it), np.cos(0.031 * it), np.sin(0.017 * it + 1.0)])
+        lmp.command("velocity all set %.17g %.17g %.17g" % tuple(v))
+        cloud._phase(0)      # ++runTime, UfSmoothed
+        cloud._phase(1)      # updateDragOnParticles
+        UOld = U.copy(); U = np.tile(v, (n, 1))
+        if it == 1:
+            UOld = U.copy()      # softParticle.C:74: UOld_ = U_ at construction
+        L.orc_drag_on_particles_hist(C.byref(fl), 0, n, ob.P(cell), ob.P(x), ob.P(d), ob.P(U), ob.P(UOld), ob.P(gamma),
+                                     ob.P(Uf), ob.P(zeros), ob.P(zeros), ob.P(zeros), it, ob.P(Uf), ob.P(sumFb),
+                                     ob.P(n0), ob.P(Uri), ob.P(mag), ob.P(Jd), ob.P(pDrag), ob.P(pDuDt))
+        branch_seen = branch_seen or bool(np.any(n0 > 0))
+        if it % 16 == 0 or it > 300:
+            P = cloud.particles()
+            assert dc.rel_err(P["pDrag"], pDrag) <= 1e-11, it
+    assert branch_seen and np.abs(pDrag).max() > 0.0
 
 
 def test_coupled_with_diffusion_smoothing():
