@@ -240,7 +240,12 @@ class SlabDriver:
             if not (self.fused and hasattr(eng, "comm_init") and (world > 1 or self.self_comm)):
                 self.transport = "direct"
             else:
-                eng.comm_init(dist, rank, world)
+                try:
+                    eng.comm_init(dist, rank, world)
+                except Exception as ex:      # e.g. librccl not loadable: the same on every rank
+                    import warnings
+                    warnings.warn("RCCL sub-step loop unavailable (%s); using torch.distributed from Python" % ex)
+                    self.transport = "direct"
         self._cap_atoms = int(halo_atoms) if halo_atoms else max(eng.info().nlocal, 4096)
         self._bufs = {}
         self._nrecv = [0, 0]
