@@ -257,7 +257,7 @@ def main():
         out["config"]["coupled_step"] = ("decomposed particles, %dx%dx%d mesh on every rank, all-reduced per-cell sums; "
                                          "ErgunWenYu + %d sub-steps + scatter + Asrc + smoothing (6 mm, 6 steps)"
                                          % (mesh_n[0], mesh_n[1], mesh_n[2], args.substeps))
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (the CPU baseline is an N = 1 measurement)
         sample_n = args.cpu_sample or 1000000
         sub = 50
         v, n_s, secs = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub)
