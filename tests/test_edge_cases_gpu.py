@@ -157,3 +157,62 @@ def test_create_and_delete_particles():
     st = lmp.get_state()
     assert np.isfinite(st["x"]).all() and len(st["tag"]) == n0 - 1
     assert all(t not in dead for pair in lmp.history() for t in pair)
+
+
+def test_bed_script_with_groups_read_data_and_comments(tmp_path):
+    """The command set of the reference's bed cases through the parser end to end: `read_data` of a sphere data file
+    with two atom types, `boundary pp ff pp`, `group .. type`, `group .. subtract`, fixes on a group, trailing `#`
+    comments, ignored thermo/dump lines.  Atoms outside the `active` group are neither integrated nor pulled by
+    gravity; the others fall."""
+    from sedifoam_amd import Lammps
+    d = 5.0e-4
+    rng = np.random.default_rng(4)
+    pts = []
+    for iy in range(4):
+        for ix in range(6):
+            for iz in range(6):
+                pts.append((0.5 * d + ix * 1.05 * d, 0.5 * d + iy * 1.05 * d, 0.5 * d + iz * 1.05 * d))
+    pts = np.array(pts)
+    types = np.where(pts[:, 1] < d, 2, 1)
+    data = tmp_path / "bed.in"
+    with open(data, "w") as f:
+        f.write(" sphere data\n\n   %d    atoms\n   2    atom types\n\n 0.0 %g  xlo xhi\n 0.0 %g  ylo yhi\n 0.0 %g  zlo zhi\n\nAtoms\n\n"
+                % (len(pts), 6.3 * d, 8.0 * d, 6.3 * d))
+        for k, (p, t) in enumerate(zip(pts, types)):
+            f.write(" %d %d %g 2500 %.12g %.12g %.12g\n" % (7 * (k + 1), t, d, p[0], p[1], p[2]))
+    lmp = Lammps()
+    lmp.commands("""
+        atom_style   sphere
+        atom_modify  map array
+        boundary     pp ff pp
+        newton       off
+        communicate single vel yes
+        read_data    %s
+        neighbor     1.0e-4 bin
+        neigh_modify delay 0
+        pair_style   gran/hooke/history 2000.0 NULL 50.0 NULL 0.4 0
+        pair_coeff   * *
+        timestep     1e-6
+        group        bottom type 2
+        group        active subtract all bottom
+        velocity     all set 0.0 0.0 0.0 units box
+        fix   1 active nve/sphere
+        fix   2 active gravity 9.8 vector 0 -1 0   # spherical 90.0 -180.0
+        fix   3 active fdrag
+        fix   ywall all wall/gran 2000.0 NULL 50.0 NULL 0.4 0 yplane 0.0 0.004
+        thermo_style one   # ignored
+        thermo       2000
+        thermo_modify lost error
+        dump  id all custom 100 snapshot id type x y z
+    """ % data)
+    info0 = lmp.get_initial_info()
+    assert sorted(info0["tag"]) == [7 * (k + 1) for k in range(len(pts))]
+    x0 = lmp.get_state()
+    lmp.step(200)
+    x1 = lmp.get_state()
+    t_sorted = types[np.argsort(7 * (np.arange(len(pts)) + 1))]
+    bottom = t_sorted == 2
+    assert np.array_equal(x1["x"][bottom], x0["x"][bottom]) and np.all(x1["v"][bottom] == 0.0)
+    assert np.all(x1["v"][~bottom][:, 1] < 0.0)          # free fall / settling under gravity
+    with pytest.raises(Exception, match="Could not find group ID"):
+        lmp.command("fix 9 nosuchgroup nve/sphere")
