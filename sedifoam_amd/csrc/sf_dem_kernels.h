@@ -71,8 +71,11 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // ------------------------------------------------------------------------------------------------
 // One owned atom: neighbour loop + post_force fixes + integration.  LDS = false: the neighbour's records are
 // gathered from HBM/L2 by global index; LDS = true: from the tile's staged copy in LDS (k_substep_lds).
-template <int STYLE, bool COHE, bool LUB, bool LDS>
-__device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i,
+// LPA lanes per atom (1, 2 or 4): lane q of an atom's group handles the slots q, q + LPA, ...; the partial force and
+// torque sums are combined with a fixed shuffle tree and lane 0 integrates.  Small systems (< ~3 waves per SIMD at
+// one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
+template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA>
+__device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw)
 {
   const size_t cap = (size_t)S.cap;
@@ -85,7 +88,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const double radi = xi4.w, mi = vi4.w;
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
-  const int nn = ld_stream(&P.numneigh[i]);
+  const int nn_all = ld_stream(&P.numneigh[i]);
+  const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
@@ -113,17 +117,18 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       }
     }
   };
-  int jraw_n1 = nn > 0 ? ld_stream(&P.neigh[i]) : 0;
-  int jraw_n2 = nn > 1 ? ld_stream(&P.neigh[cap + i]) : 0;
+  int jraw_n1 = nn > 0 ? ld_stream(&P.neigh[(size_t)q * cap + i]) : 0;
+  int jraw_n2 = nn > 1 ? ld_stream(&P.neigh[(size_t)(q + LPA) * cap + i]) : 0;
   Rec RA, RB;
   RA.x = RA.v = RA.w = RB.x = RB.v = RB.w = double4{0, 0, 0, 0};
   RA.l = RB.l = 0;
-  if (nn > 0) fetch(jraw_n1, (size_t)i, RA);
+  if (nn > 0) fetch(jraw_n1, (size_t)q * cap + i, RA);
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
   auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more) {
-    const size_t slot = (size_t)s * cap + i;
-    const size_t sbase = (size_t)(3 * s) * cap + i;
+    const int sl = q + LPA * s;   // the list slot this iteration works on
+    const size_t slot = (size_t)sl * cap + i;
+    const size_t sbase = (size_t)(3 * sl) * cap + i;
     const int jraw = jraw_n1;
     Vec3 sh = {0.0, 0.0, 0.0};
     if (STYLE != 0 && (jraw & kTouchBit)) {
@@ -132,8 +137,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       sh.z = ld_stream(&P.shear[sbase + 2 * cap]);
     }
     jraw_n1 = jraw_n2;
-    if (s + 2 < nn) jraw_n2 = ld_stream(&P.neigh[slot + 2 * cap]);
-    if (more) fetch(jraw_n1, slot + cap, nxt);
+    if (s + 2 < nn) jraw_n2 = ld_stream(&P.neigh[slot + (size_t)(2 * LPA) * cap]);
+    if (more) fetch(jraw_n1, slot + (size_t)LPA * cap, nxt);
     double4 xj4 = cur.x, vj4 = cur.v, wj4 = cur.w;
     if (LDS) {
       xj4 = lx[cur.l];
@@ -223,6 +228,14 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     RA = RB;
   }
 #endif
+  if (LPA > 1) {
+    // fixed tree: (q0 + q1) [+ (q2 + q3)] -- the same bits on every run
+    for (int off = 1; off < LPA; off <<= 1) {
+      F.x += __shfl_xor(F.x, off, 64); F.y += __shfl_xor(F.y, off, 64); F.z += __shfl_xor(F.z, off, 64);
+      T.x += __shfl_xor(T.x, off, 64); T.y += __shfl_xor(T.y, off, 64); T.z += __shfl_xor(T.z, off, 64);
+    }
+    if (q != 0) return;
+  }
   if (LUB) {
     if (S.lub.flagfld) {  // isotropic FLD terms, pair_lubricate_poly.cpp:213-220
       const double a = S.lub.vxmu2f * S.lub.R0 * radi;
@@ -336,7 +349,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 #else
 #define SF_SUBSTEP_ATTR
 #endif
-template <int STYLE, bool COHE, bool LUB>
+template <int STYLE, bool COHE, bool LUB, int LPA>
 __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
@@ -350,7 +363,9 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  int i = bid * blockDim.x + threadIdx.x;
+  const int tid = bid * blockDim.x + threadIdx.x;
+  int i = tid / LPA;          // LPA consecutive lanes share an atom
+  const int q = tid % LPA;
   if (S.part == 2) {          // atoms next to the slab's x faces: a prefix and a suffix of the x-slowest order
     if (i >= S.nb) return;
     if (i >= S.n_lo) i += S.n_hi - S.n_lo;
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   } else if (i >= S.nlocal) {
     return;
   }
-  substep_particle<STYLE, COHE, LUB, false>(P, S, i, nullptr, nullptr, nullptr);
+  substep_particle<STYLE, COHE, LUB, false, LPA>(P, S, i, q, nullptr, nullptr, nullptr);
 }
 
 // LDS-staged cell bins: one workgroup per tile of T x T x T bins.  The x/v/omega records of every atom in
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
   }
   __syncthreads();
   for (int i = first + threadIdx.x; i < last; i += blockDim.x)
-    substep_particle<STYLE, COHE, LUB, true>(P, S, i, lx, lv, lw);
+    substep_particle<STYLE, COHE, LUB, true, 1>(P, S, i, 0, lx, lv, lw);
 }
 
 // first half-kick of a run with the forces stored by the previous run's last sub-step
