@@ -137,6 +137,38 @@ def test_frozen_bottom_layer_groups(pair, fdrag_group):
     assert lmp.info().nbuilds >= 2
 
 
+def test_random_dilute_gas_collisions():
+    """Not a lattice: 1500 spheres at random non-overlapping positions (volume fraction ~0.2) with 1 m/s random
+    velocities in a periodic box with y walls -- neighbour counts from 0 to ~8, contacts that open and close
+    (touch flag set / cleared, history created and dropped), a rebuild every ~25 sub-steps."""
+    rng = np.random.default_rng(77)
+    d = 1.0e-3
+    L = np.array([18e-3, 18e-3, 18e-3])
+    pts = []
+    cell = {}
+    while len(pts) < 1500:
+        p = rng.uniform(0.6 * d, L - 0.6 * d)
+        key = tuple((p // d).astype(int))
+        ok = True
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    for q in cell.get((key[0] + dx, key[1] + dy, key[2] + dz), ()):
+                        if np.sum((pts[q] - p) ** 2) < (1.02 * d) ** 2:
+                            ok = False
+        if ok:
+            cell.setdefault(key, []).append(len(pts))
+            pts.append(p)
+    x = np.array(pts)
+    n = len(x)
+    bed = dict(x=x, v=rng.uniform(-1.0, 1.0, size=(n, 3)), diameter=np.full(n, d), density=np.full(n, 2650.0),
+               boxlo=np.zeros(3), boxhi=L.copy(), periodic=(1, 0, 1), n=n)
+    lmp, orc = _run_case(bed, dict(BASE, skin=0.1e-3, g=0.0), steps=(1, 149), tol_f=1e-11)
+    assert lmp.info().nbuilds >= 4 and orc.nbuilds == lmp.info().nbuilds
+    h = lmp.history()
+    assert 0 < len(h) < n       # some contacts are open at the end, far fewer than in a packed bed
+
+
 def test_carrier_rho_added_mass_term():
     bed = _bed((4, 4, 4), periodic=True, seed=5)
     _run_case(bed, dict(BASE, carrier_rho=1000.0), steps=(1, 20))
