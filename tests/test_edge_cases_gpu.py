@@ -216,3 +216,32 @@ def test_bed_script_with_groups_read_data_and_comments(tmp_path):
     assert np.all(x1["v"][~bottom][:, 1] < 0.0)          # free fall / settling under gravity
     with pytest.raises(Exception, match="Could not find group ID"):
         lmp.command("fix 9 nosuchgroup nve/sphere")
+
+
+@pytest.mark.parametrize("e", [0.5, 0.9])
+def test_hertz_head_on_collision_restitution(e):
+    """binary head-on collision through the HIP engine: coefficient of restitution = gamman (see the oracle twin in
+    tests/test_oracle_known_answers.py)"""
+    from sedifoam_amd import Lammps
+    R, rho, u = 0.5e-3, 2500.0, 0.2
+    lmp = Lammps()
+    lmp.set_box([0, 0, 0], [4e-3, 4e-3, 4e-3])
+    lmp.create_atoms([[1.0e-3, 2.0e-3, 2.0e-3], [2.2e-3, 2.0e-3, 2.0e-3]], [2 * R, 2 * R], [rho, rho],
+                     v=[[u / 2, 0, 0], [-u / 2, 0, 0]])
+    lmp.commands("""
+        atom_style sphere
+        boundary f f f
+        newton off
+        communicate single vel yes
+        neighbor 0.3e-3 bin
+        neigh_modify delay 0
+        pair_style gran/hertzFix/history 1.0e7 NULL %.17g NULL 0.0 1
+        pair_coeff * *
+        timestep 2.0e-8
+        fix 1 all nve/sphere
+        fix 3 all fdrag
+    """ % e)
+    lmp.step(int((0.2e-3 / u + 4.0e-4) / 2.0e-8))
+    st = lmp.get_state()
+    assert st["x"][1, 0] - st["x"][0, 0] > 2 * R
+    assert (st["v"][1, 0] - st["v"][0, 0]) / u == pytest.approx(e, abs=2e-3)

@@ -214,3 +214,30 @@ def test_smooth_field_neumann_eigenmode():
     g = f0.copy()
     L.orc_smooth_field(ob.P(n), ob.P(dx), ob.P(D), 0.0, steps, 1, ob.P(g))
     assert np.array_equal(g, f0)
+
+
+@pytest.mark.parametrize("e", [0.3, 0.5, 0.9])
+def test_hertz_head_on_collision_restitution_equals_gamman(e):
+    """Physics-level check of the hertzFix damping (pair_gran_hertzFix_history.cpp:192-200): with
+    beta = -ln(e)/sqrt(ln^2 e + pi^2) and the damping 2 sqrt(5/6) beta sqrt(sn meff) v_n the coefficient of restitution
+    of a binary head-on collision is e, independent of the impact speed (Antypov & Elliott 2011) -- here through
+    the oracle's full DEM loop (nve/sphere + list + history), two impact speeds."""
+    R, rho, kn = 0.5e-3, 2500.0, 1.0e7
+    m = 4.0 / 3.0 * np.pi * R ** 3 * rho
+    for u in (0.05, 0.4):
+        x = np.array([[1.0e-3, 2.0e-3, 2.0e-3], [2.2e-3, 2.0e-3, 2.0e-3]])
+        v = np.array([[u / 2, 0, 0], [-u / 2, 0, 0]])
+        dem = ob.OracleDem(x, [R, R], [m, m], [0, 0, 0], [4e-3, 4e-3, 4e-3], periodic=(0, 0, 0), v=v)
+        dem.pair_gran("hertz", kn, None, e, None, 0.0, 1)
+        dem.fix_gravity(0.0, 0.0, -1.0, 0.0)
+        dem.fix_fdrag(0.0)
+        dem.neighbor(0.3e-3)
+        dem.timestep(2.0e-8)
+        dem.setup()
+        gap = 0.2e-3
+        steps = int((gap / u + 4.0e-4) / 2.0e-8)          # approach + a generous contact time
+        dem.run(steps)
+        st = dem.get()
+        assert st["x"][1, 0] - st["x"][0, 0] > 2 * R          # separated again
+        e_meas = (st["v"][1, 0] - st["v"][0, 0]) / u
+        assert e_meas == pytest.approx(e, abs=2e-3), (u, e_meas)
