@@ -346,6 +346,62 @@ def test_xiaocase3_golden_through_hip_path():
     assert vy[-1] == pytest.approx(0.0500031, rel=2e-3)
 
 
+def test_single_sphere_relaxation_with_ergun_wenyu_is_the_standard_drag_law():
+    """ErgunWenYu has no golden curve in the reference (xiaocase3 uses SyamlalOBrien), so the dilute limit is checked
+    against what it must reduce to: a single sphere in a uniform stream feels the standard drag
+    F = Cd(Re) (pi d^2/8) rho_f |U-v| (U-v) beta^-1.65, Cd = 24 (1 + 0.15 Re^0.687)/Re, Re = beta |U-v| d / nu (Wen-Yu
+    branch, beta > 0.8).  The product path (drag kernel -> fix fdrag -> nve/sphere sub-steps, force frozen over each
+    CFD step) must follow the same explicit recursion (v += dt F(v)/m with LAMMPS' half-kick bookkeeping) to rounding, and the continuous ODE within the
+    O(dt/tau) of that explicit coupling."""
+    from scipy.integrate import solve_ivp
+    from sedifoam_amd import Lammps, enhancedCloud
+    d, rho, rhof, nu, U, dT = 8.3e-5, 2000.0, 1000.0, 1.0e-6, 0.05, 2.0e-5
+    lmp = Lammps()
+    lmp.set_box([0, 0, 0], [4e-3, 4e-3, 5e-4])
+    lmp.create_atoms([[2e-3, 1.9e-3, 2.5e-4]], [d], [rho])
+    lmp.commands("""
+        atom_style sphere
+        boundary ff ff ff
+        newton off
+        communicate single vel yes
+        neighbor 5.0e-4 bin
+        pair_style gran/hertzFix/history 1.0e7 NULL 0.5 NULL 0.4 1
+        pair_coeff * *
+        timestep 2e-7
+        fix 1 all nve/sphere
+        fix 3 all fdrag
+    """)
+    cloud = enhancedCloud(lmp, [0, 0, 0], [4e-4, 4e-4, 5e-4], [10, 10, 1],
+                          dict(dragModel="ErgunWenYu", subCycles=1, g=(0, 0, 0)), dict(rhob=rhof, nub=nu), deltaT=dT)
+    cloud.setFluid(Uf=np.tile([0.0, U, 0.0], (100, 1)))
+    m = np.pi * d ** 3 / 6.0 * rho
+    beta = 1.0 - (np.pi * d ** 3 / 6.0) / (4e-4 * 4e-4 * 5e-4)
+    assert beta > 0.99
+
+    def force(v):
+        ur = abs(U - v)
+        Re = beta * ur * d / nu
+        Cd = 24.0 * (1.0 + 0.15 * Re ** 0.687) / Re
+        return Cd * (np.pi * d ** 2 / 8.0) * rhof * ur * (U - v) * beta ** (-1.65)
+    # `run n pre no post no` keeps the force of the previous run for the first half-kick (library.cpp:372-386), so of
+    # the 100 sub-steps' 200 half-kicks one still carries the previous CFD step's drag
+    vy, v_rec = [0.0], [0.0]
+    f_prev = 0.0
+    nsub, dts = 100, 2.0e-7
+    for it in range(150):
+        cloud.evolve()
+        vy.append(lmp.get_local_info()["v"][0, 1])
+        f_new = force(v_rec[-1])
+        v_rec.append(v_rec[-1] + dts * (0.5 * f_prev + (nsub - 0.5) * f_new) / m)
+        f_prev = f_new
+    vy = np.array(vy); v_rec = np.array(v_rec)
+    assert np.max(np.abs(vy - v_rec)) <= 1e-9 * U
+    sol = solve_ivp(lambda t, y: [force(y[0]) / m], (0.0, 150 * dT), [0.0], rtol=1e-10, atol=1e-14, dense_output=True)
+    v_ode = sol.sol(np.arange(151) * dT)[0]
+    assert np.max(np.abs(vy - v_ode)) <= 0.03 * U            # explicit coupling: O(dT / tau) with tau ~ 5e-4 s
+    assert 0.9 * U < vy[-1] < U
+
+
 def test_smooth_field_chebyshev_equals_cg_and_is_bitwise_reproducible(monkeypatch):
     """the default solver (Chebyshev semi-iteration, fixed count, no reductions) against conjugate gradients
     (SF_SMOOTH_CG=1) on the same system, at a stiff setting (band >> cell: condition number ~ 100)"""
