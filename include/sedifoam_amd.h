@@ -323,6 +323,9 @@ int sf_cloud_get_fields(void *cloud, double *gamma, double *Ue, double *Asrc, do
  * cell [n], pDrag [n][3], Jd [n] ; any may be NULL */
 int sf_cloud_get_particles(void *cloud, int *tag, int *cell, double *pDrag, double *Jd);
 int sf_cloud_particle_count(void *cloud);
+/* enhancedCloud::averageInfo (enhancedCloud.C:1341-1370): out[0] total particle volume, out[1..3] sum of Vol*U,
+ * out[4..6] volume-averaged particle velocity (of this engine's particles; a decomposed run adds out[0..3] over ranks) */
+int sf_cloud_average_info(void *cloud, double *out7);
 /* softParticleCloud::adjustLampTimestep  softParticleCloud.C:209-261 (done by sf_cloud_create;
  * exposed for tests) */
 int sf_cloud_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double *dtLampAdj,

@@ -165,6 +165,7 @@ _SIGS = {
     "sf_cloud_get_fields": (C.c_int, [vp, dp, dp, dp, dp]),
     "sf_cloud_get_particles": (C.c_int, [vp, ip, ip, dp, dp]),
     "sf_cloud_particle_count": (C.c_int, [vp]),
+    "sf_cloud_average_info": (C.c_int, [vp, dp]),
     "sf_cloud_adjust_timestep": (C.c_int, [C.c_double, C.c_double, C.c_int, dp, ip, ip, ip]),
     "sf_cloud_get_timers": (C.c_int, [vp, C.POINTER(CloudTimers)]),
 }

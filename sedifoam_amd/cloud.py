@@ -209,6 +209,12 @@ class enhancedCloud:
     def Omega(self):
         return self._fields()[3]
 
+    def averageInfo(self):
+        """enhancedCloud::averageInfo: dict(totalVolume, totalVel[3], averageVel[3])"""
+        out = np.zeros(7)
+        check(self.L.sf_cloud_average_info(self.ptr, _p(out)))
+        return dict(totalVolume=out[0], totalVel=out[1:4].copy(), averageVel=out[4:7].copy())
+
     def particleCount(self):
         return check(self.L.sf_cloud_particle_count(self.ptr))
 

@@ -206,6 +206,32 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
   }
 }
 
+// enhancedCloud::averageInfo  enhancedCloud.C:1341-1370: sum of Vol and Vol*U over the particles.  One partial sum
+// per block (fixed shuffle tree), added on the host in block order: deterministic.
+__global__ __launch_bounds__(256) void k_average_info(int n, const double4* xr, const double4* vm, double* partial)
+{
+  __shared__ double ws[4][4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < n) {
+    const double d = 2.0 * xr[i].w;
+    const double Vol = kPi * d * d * d / 6.0;
+    const double4 v = vm[i];
+    a[0] = Vol;
+    a[1] = Vol * v.x;
+    a[2] = Vol * v.y;
+    a[3] = Vol * v.z;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = 0; k < 4; k++) {
+    double t = a[k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) ws[w][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) partial[4 * blockIdx.x + threadIdx.x] = ws[0][threadIdx.x] + ws[1][threadIdx.x] + ws[2][threadIdx.x] + ws[3][threadIdx.x];
+}
+
 // sort keys for the particle -> cell scatter: cell id (outside = ncells, sorts last)
 __global__ __launch_bounds__(256) void k_cell_keys(int n, const double4* xr, MeshDev m, unsigned* keys, int* idx)
 {
@@ -487,6 +513,27 @@ class Cloud {
     *Ue = Ue_;
     *Asrc = Asrc_;
     *ncells = mesh_.ncells;
+  }
+
+  // out[0] total particle volume, out[1..3] sum of Vol*U, out[4..6] volume-averaged velocity (:1365 with ROOTVSMALL)
+  void average_info(double out[7])
+  {
+    DemEngine& e = lmp_->eng;
+    const int n = e.nlocal();
+    for (int k = 0; k < 7; k++) out[k] = 0.0;
+    if (n) {
+      const int nb = div_up(n, 256);
+      double* dpart = nullptr;
+      SF_HIP(hipMalloc(&dpart, sizeof(double) * 4 * nb));
+      k_average_info<<<nb, 256, 0, s_>>>(n, e.d_xr(), e.d_vm(), dpart);
+      std::vector<double> h(4 * (size_t)nb);
+      SF_HIP(hipMemcpyAsync(h.data(), dpart, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost, s_));
+      SF_HIP(hipStreamSynchronize(s_));
+      (void)hipFree(dpart);
+      for (int b = 0; b < nb; b++)
+        for (int k = 0; k < 4; k++) out[k] += h[4 * (size_t)b + k];
+    }
+    for (int k = 0; k < 3; k++) out[4 + k] = out[1 + k] / (out[0] + kRootVSmall);
   }
 
   void get_fields(double* gamma, double* Ue, double* Asrc, double* Omega)
@@ -796,6 +843,13 @@ int sf_cloud_smooth_field(void* cloud, double* field, int ncomp)
 {
   SF_API_BEGIN
   static_cast<Cloud*>(cloud)->smooth_host_field(field, ncomp);
+  SF_API_END(0)
+}
+
+int sf_cloud_average_info(void* cloud, double* out7)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->average_info(out7);
   SF_API_END(0)
 }
 

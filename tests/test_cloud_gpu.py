@@ -165,6 +165,12 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
         assert np.max(np.abs(a["x"] - st["x"])) <= 1e-12 and dc.rel_err(a["v"], st["v"]) <= 1e-9
         assert dc.rel_err(cloud.gamma(), gamma) <= tol_s
         assert dc.rel_err(cloud.Ue(), Ue) <= max(tol_s, 1e-10)
+    # enhancedCloud::averageInfo (:1341-1370)
+    ai = cloud.averageInfo()
+    vol_p = np.pi * d ** 3 / 6.0
+    assert ai["totalVolume"] == pytest.approx(vol_p.sum(), rel=1e-13)
+    assert np.allclose(ai["totalVel"], (vol_p[:, None] * st["v"]).sum(axis=0), rtol=1e-9, atol=1e-18)
+    assert np.allclose(ai["averageVel"], ai["totalVel"] / ai["totalVolume"], rtol=1e-14)
     # conservation check the reference prints (enhancedCloud.C:964-976): solid volume is preserved
     vol = np.pi * d ** 3 / 6.0
     assert np.sum(cloud.gamma() * V) == pytest.approx(np.sum(vol), rel=1e-12)
