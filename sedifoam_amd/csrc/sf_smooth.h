@@ -4,7 +4,8 @@
 // `diffusionSteps` implicit-Euler steps with zero-gradient boundaries, each step one
 // `solve(fvm::ddt(phi) - fvm::laplacian(DT, phi))` by PCG (tolerance 1e-10, system/fvSolution: tempDiffScalar).
 // On the uniform hex block that is (I - dtau*L) phi_new = phi_old with the 7-point Laplacian; here it is solved
-// matrix-free on the GPU: by default with the Chebyshev semi-iteration (spectrum of A known in closed form, no
+// directly in the cosine-transform basis that diagonalises it (all steps at once, sf_smooth.hip), or, on meshes
+// too wide for dense transforms, matrix-free: with the Chebyshev semi-iteration (spectrum of A known in closed form, no
 // inner products, fixed iteration count, nothing for the host to check), optionally by conjugate gradients
 // (SF_SMOOTH_CG=1: deterministic two-stage reductions, the host looks at the residual every 8 iterations).
 #pragma once
@@ -41,6 +42,11 @@ class DiffusionSmoother {
   double lmin_ = 1.0, lmax_ = 1.0;
   int cheb_iters_ = 0;
   double* cheb_ = nullptr;    // r, d (two buffers): 3 x [kMaxCheb][ncells]
+  // spectral direct solve (default up to 128 cells per direction; SF_SMOOTH_SPECTRAL=0: Chebyshev)
+  void smooth_spectral(double* fa, int na, double* fb, int nb);
+  bool use_spectral_ = false;
+  double* spec_ = nullptr;    // DCT matrices, eigenvalues, two planar work arrays
+  size_t specC_off_[3] = {0, 0, 0}, specL_off_[3] = {0, 0, 0}, spec_work_off_ = 0;
 };
 
 }  // namespace sf

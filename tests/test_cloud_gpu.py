@@ -408,10 +408,14 @@ def test_single_sphere_relaxation_with_ergun_wenyu_is_the_standard_drag_law():
     assert 0.9 * U < vy[-1] < U
 
 
-def test_smooth_field_chebyshev_equals_cg_and_is_bitwise_reproducible(monkeypatch):
-    """the default solver (Chebyshev semi-iteration, fixed count, no reductions) against conjugate gradients
-    (SF_SMOOTH_CG=1) on the same system, at a stiff setting (band >> cell: condition number ~ 100)"""
+def test_smooth_field_three_solvers_agree_and_default_is_bitwise_reproducible(monkeypatch):
+    """the default solver (cosine-transform direct solve: all implicit steps as one spectral multiplication), the
+    Chebyshev semi-iteration (SF_SMOOTH_SPECTRAL=0; what meshes wider than 128 cells use) and conjugate gradients
+    (SF_SMOOTH_CG=1) on the same system, at a stiff setting (band >> cell: condition number ~ 100), on a mesh
+    with three different extents and an anisotropic smoothDirection"""
     from sedifoam_amd import Lammps, enhancedCloud
+    mesh_n = np.array([20, 17, 23], np.int32)
+    nc = int(mesh_n.prod())
 
     def make():
         lmp = Lammps()
@@ -419,17 +423,26 @@ def test_smooth_field_chebyshev_equals_cg_and_is_bitwise_reproducible(monkeypatc
         lmp.create_atoms([[5e-3, 5e-3, 5e-3]], [1e-4], [2500.0])
         lmp.commands("atom_style sphere\nboundary ff ff ff\nnewton off\npair_style gran/hooke/history 1e4 NULL 10 NULL 0.5 1\n"
                      "pair_coeff * *\nneighbor 1e-4 bin\ntimestep 1e-6\nfix 1 all nve/sphere\nfix 2 all fdrag")
-        return enhancedCloud(lmp, np.zeros(3), np.array([5e-4, 5e-4, 5e-4]), np.array([20, 20, 20], np.int32),
+        return enhancedCloud(lmp, np.zeros(3), np.array([5e-4, 6e-4, 4.5e-4]), mesh_n,
                              dict(dragModel="ErgunWenYu", subCycles=1, g=(0, 0, 0), diffusionBandWidth=1.2e-2,
-                                  diffusionSteps=3), dict(rhob=1000.0, nub=1e-6), 1e-5)
+                                  diffusionSteps=3, smoothDirection=(1.0, 0, 0, 0, 0.5, 0, 0, 0, 2.0)),
+                             dict(rhob=1000.0, nub=1e-6), 1e-5)
     rng = np.random.default_rng(9)
-    f = rng.uniform(size=(8000, 3))
+    f = rng.uniform(size=(nc, 3))
     monkeypatch.delenv("SF_SMOOTH_CG", raising=False)
+    monkeypatch.delenv("SF_SMOOTH_SPECTRAL", raising=False)
+    spec = make()
+    a1 = spec.smoothField(f); a2 = spec.smoothField(f)
+    s1 = spec.smoothField(f[:, 0].copy())
+    monkeypatch.setenv("SF_SMOOTH_SPECTRAL", "0")
     cheb = make()
-    a1 = cheb.smoothField(f); a2 = cheb.smoothField(f)
+    c = cheb.smoothField(f)
+    assert np.array_equal(cheb.smoothField(f), c)
     monkeypatch.setenv("SF_SMOOTH_CG", "1")
     cg = make()
     b = cg.smoothField(f)
     assert np.array_equal(a1, a2)
-    assert dc.rel_err(a1, b) <= 1e-12
+    assert np.array_equal(s1, a1[:, 0])          # components are independent: batching does not change a bit
+    assert dc.rel_err(a1, b) <= 1e-12 and dc.rel_err(c, b) <= 1e-12
+    assert not np.array_equal(a1, c)             # (really different code paths)
     assert np.sum(a1, axis=0) == pytest.approx(np.sum(f, axis=0), rel=1e-12)
