@@ -35,10 +35,13 @@ __device__ __forceinline__ T ld_stream(const T* p)
   return *p;
 #endif
 }
+#ifndef SF_NT_ST
+#define SF_NT_ST SF_NT
+#endif
 template <class T>
 __device__ __forceinline__ void st_stream(T* p, T v)
 {
-#if SF_NT
+#if SF_NT_ST
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
