@@ -206,8 +206,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       // fix cohesive is skipped during setup (FixCohe::setup() never runs, fix_cohesive.cpp:117)
       const double rc = radsum + S.cohe.smax;
       if (S.mode != 2 && (mk & S.cohe_bit) && rsq < rc * rc) {   // fix_cohesive.cpp:167 group of i
-        const double r = sqrt(rsq);
-        const double cc = cohesive_ccel(S.cohe, r, radsum) * (1 / r);
+        double r, rinv;
+        sf_sqrt_rsqrt(rsq, r, rinv);
+        const double cc = cohesive_ccel(S.cohe, r, radsum) * rinv;
         F = F + Vec3{del.x * cc, del.y * cc, del.z * cc};
       }
     }

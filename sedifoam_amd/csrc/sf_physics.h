@@ -226,29 +226,35 @@ struct CoheParams {
   int enabled;
 };
 
-// scalar cohesive coefficient: force on i = del * ccel / r  (fix_cohesive.cpp:187-203, :239-252)
+// scalar cohesive coefficient: force on i = del * ccel / r  (fix_cohesive.cpp:187-203, :239-252).
+// The reference's chains of divisions (a / b / c / d ...) are evaluated as one product of the denominators and one
+// reciprocal (an f64 divide is ~11 dependent instructions on gfx950): <= a few ulp from the reference's order.
 __device__ __forceinline__ double cohesive_ccel(const CoheParams& p, double r, double radsum)
 {
   const double del = r - radsum;
   double ccel;
   if (p.opt == 0) {
-    const double PInv = 0.25 / atan(1.0);
+    const double PInv = 0.3183098861837907;   // 0.25 / atan(1.0)
     const double lam = p.lam;
-    if (del > lam * PInv)
-      ccel = -p.ah * radsum * lam *
-             (6.4988e-3 - 4.5316e-4 * lam / del + 1.1326e-5 * lam * lam / del / del) / del / del / del;
-    else {
+    if (del > lam * PInv) {
+      const double id = sf_rcp(del);
+      const double ld = lam * id;
+      ccel = -p.ah * radsum * lam * (6.4988e-3 - 4.5316e-4 * ld + 1.1326e-5 * ld * ld) * (id * id * id);
+    } else {
       const double s = (del > p.smin) ? del : p.smin;
-      ccel = -p.ah * (lam + 22.242 * s) * radsum * lam / 24.0 / (lam + 11.121 * s) / (lam + 11.121 * s) / s / s;
+      const double q = lam + 11.121 * s;
+      ccel = -p.ah * (lam + 22.242 * s) * radsum * lam * sf_rcp(24.0 * (q * q) * (s * s));
     }
   } else {
     const double r2 = radsum * radsum;
     const double r6 = r2 * r2 * r2;  // pow(radsum,6)
-    if (del > p.smin)
-      ccel = -p.ah * r6 / 6.0 / del / del / (r + radsum) / (r + radsum) / r / r / r;
-    else
-      ccel = -p.ah * r6 / 6.0 / p.smin / p.smin / (p.smin + 2.0 * radsum) / (p.smin + 2.0 * radsum) /
-             (p.smin + radsum) / (p.smin + radsum) / (p.smin + radsum);
+    if (del > p.smin) {
+      const double rr = r + radsum;
+      ccel = -p.ah * r6 * sf_rcp(6.0 * (del * del) * (rr * rr) * (r * r * r));
+    } else {
+      const double a = p.smin + 2.0 * radsum, b2 = p.smin + radsum;
+      ccel = -p.ah * r6 * sf_rcp(6.0 * (p.smin * p.smin) * (a * a) * (b2 * b2 * b2));
+    }
   }
   return ccel;
 }
@@ -260,12 +266,15 @@ struct LubParams {
 };
 
 // lubrication force/torque on i from neighbour j (full list: only i is updated), Ef = 0.
+// Same algebra as pair_lubricate_poly.cpp:241-399; its ~25 divisions are four reciprocals (1/r, 1/radi, 1/beta1,
+// 1/h_sep) and products, the constant divisors are folded.
 __device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del, double rsq, double radi,
                                                     double radj, Vec3 vi0, Vec3 vj0, Vec3 wi, Vec3 wj,
                                                     Vec3& F, Vec3& T)
 {
-  const double r = sqrt(rsq);
-  const Vec3 n = {del.x / r, del.y / r, del.z / r};
+  double r, rinv;
+  sf_sqrt_rsqrt(rsq, r, rinv);
+  const Vec3 n = {del.x * rinv, del.y * rinv, del.z * rinv};
   const Vec3 xl = {-n.x * radi, -n.y * radi, -n.z * radi};
   const Vec3 jl = {-n.x * radj, -n.y * radj, -n.z * radj};
   const Vec3 vi = {vi0.x + (wi.y * xl.z - wi.z * xl.y), vi0.y + (wi.z * xl.x - wi.x * xl.z),
@@ -274,29 +283,35 @@ __device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del
                    vj0.z - (wj.x * jl.y - wj.y * jl.x)};
   double h_sep = r - radi - radj;
   if (r < p.cut_inner) h_sep = 100 * radi + 100 * radj;  // the reference's edit, :294-295
-  h_sep = h_sep / radi;
-  const double beta0 = radj / radi;
+  const double iradi = sf_rcp(radi);
+  h_sep = h_sep * iradi;
+  const double beta0 = radj * iradi;
   const double beta1 = 1.0 + beta0;
+  const double ib1 = sf_rcp(beta1), ib12 = ib1 * ib1;
+  const double ih = sf_rcp(h_sep);
+  const double b02 = beta0 * beta0;
+  const double mu_r = kPi * p.mu * radi;
   double a_sq, a_sh = 0.0, a_pu = 0.0;
   if (p.flaglog) {
-    const double b02 = beta0 * beta0, b03 = b02 * beta0, b04 = b02 * b02;
-    const double b13 = beta1 * beta1 * beta1, b14 = b13 * beta1;
-    const double lg = log(1.0 / h_sep);
-    a_sq = beta0 * beta0 / beta1 / beta1 / h_sep + (1.0 + 7.0 * beta0 + beta0 * beta0) / 5.0 / b13 * lg;
-    a_sq += (1.0 + 18.0 * beta0 - 29.0 * beta0 * beta0 + 18.0 * b03 + b04) / 21.0 / b14 * h_sep * lg;
-    a_sq *= 6.0 * kPi * p.mu * radi;
-    a_sh = 4.0 * beta0 * (2.0 + beta0 + 2.0 * beta0 * beta0) / 15.0 / b13 * lg;
-    a_sh += 4.0 * (16.0 - 45.0 * beta0 + 58.0 * beta0 * beta0 - 45.0 * b03 + 16.0 * b04) / 375.0 / b14 * h_sep * lg;
-    a_sh *= 6.0 * kPi * p.mu * radi;
-    a_pu = beta0 * (4.0 + beta0) / 10.0 / beta1 / beta1 * lg;
-    a_pu += (32.0 - 33.0 * beta0 + 83.0 * beta0 * beta0 + 43.0 * b03) / 250.0 / b13 * h_sep * lg;
-    a_pu *= 8.0 * kPi * p.mu * (radi * radi * radi);
+    const double b03 = b02 * beta0, b04 = b02 * b02;
+    const double ib13 = ib12 * ib1, ib14 = ib12 * ib12;
+    const double lg = log(ih);             // log(1 / h_sep)
+    const double hl = h_sep * lg;
+    a_sq = b02 * ib12 * ih + (1.0 + 7.0 * beta0 + b02) * (0.2 * ib13) * lg;
+    a_sq += (1.0 + 18.0 * beta0 - 29.0 * b02 + 18.0 * b03 + b04) * ((1.0 / 21.0) * ib14) * hl;
+    a_sq *= 6.0 * mu_r;
+    a_sh = 4.0 * beta0 * (2.0 + beta0 + 2.0 * b02) * ((1.0 / 15.0) * ib13) * lg;
+    a_sh += 4.0 * (16.0 - 45.0 * beta0 + 58.0 * b02 - 45.0 * b03 + 16.0 * b04) * ((1.0 / 375.0) * ib14) * hl;
+    a_sh *= 6.0 * mu_r;
+    a_pu = beta0 * (4.0 + beta0) * (0.1 * ib12) * lg;
+    a_pu += (32.0 - 33.0 * beta0 + 83.0 * b02 + 43.0 * b03) * ((1.0 / 250.0) * ib13) * hl;
+    a_pu *= 8.0 * mu_r * (radi * radi);
   } else
-    a_sq = 6.0 * kPi * p.mu * radi * (beta0 * beta0 / beta1 / beta1 / h_sep);
+    a_sq = 6.0 * mu_r * (b02 * ib12 * ih);
 
   const Vec3 vr = vi - vj;
-  const double vnnr = dot(vr, del) / r;
-  const Vec3 vn = {vnnr * del.x / r, vnnr * del.y / r, vnnr * del.z / r};
+  const double vnnr = dot(vr, n);
+  const Vec3 vn = {vnnr * n.x, vnnr * n.y, vnnr * n.z};
   const Vec3 vt = vr - vn;
   Vec3 f = a_sq * vn;
   if (p.flaglog) f = f + a_sh * vt;
@@ -306,8 +321,8 @@ __device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del
     const Vec3 t = {xl.y * f.z - xl.z * f.y, xl.z * f.x - xl.x * f.z, xl.x * f.y - xl.y * f.x};
     T = T - p.vxmu2f * t;
     const Vec3 dw = wi - wj;
-    const double wdotn = dot(dw, del) / r;
-    const Vec3 wt = {dw.x - wdotn * del.x / r, dw.y - wdotn * del.y / r, dw.z - wdotn * del.z / r};
+    const double wdotn = dot(dw, n);
+    const Vec3 wt = {dw.x - wdotn * n.x, dw.y - wdotn * n.y, dw.z - wdotn * n.z};
     T = T - p.vxmu2f * (a_pu * wt);
   }
 }
