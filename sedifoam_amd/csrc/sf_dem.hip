@@ -53,6 +53,7 @@ void fold_hertz_constants(GranParams& p)
   p.h_cn = 4.0 / 5.46 * p.kn;
   p.h_ct = 8.0 / 8.84 * p.kt;
   p.h_inv_ct = p.kt > 0.0 ? 8.0 / 8.84 / p.kt : 0.0;
+  p.inv_kt = p.kt > 0.0 ? 1.0 / p.kt : 0.0;
   p.h_c56beta = c56 * p.beta;
   p.h_stsn_c56beta = std::sqrt((8.0 * 1.0 / 8.84) / (2.0 * 1.0 / 1.82)) * c56 * p.beta;
 }

@@ -23,6 +23,7 @@ struct GranParams {
   double beta;      // Hertz: -ln(e)/sqrt(ln(e)^2+pi^2), evaluated once on the host (pure function of gamman)
   // host-folded Hertz constants (see hertz_history_law)
   double h_sn, h_cn, h_ct, h_inv_ct, h_c56beta, h_stsn_c56beta;
+  double inv_kt;    // 1 / kt (Hooke law)
   int dampflag;
   int style;        // 0 none, 1 hooke/history, 2 hertzFix/history
 };
@@ -167,11 +168,12 @@ __device__ __forceinline__ void hertz_history_law(const GranParams& p, double dt
            c.rinv * (c.del.x * fs.y - c.del.y * fs.x)};
 }
 
-// Hookean history contact.
+// Hookean history contact (the law all of the reference's example cases run: gran/hooke/history).  Same algebra;
+// 1/rsq = rinv^2, the Coulomb test compares squares, norms only when a contact slides.
 __device__ __forceinline__ void hooke_history_law(const GranParams& p, double dt, bool shearupdate,
                                                   const ContactIn& c, Vec3& sh, ContactOut& o)
 {
-  const double rsqinv = 1.0 / c.rsq;
+  const double rsqinv = c.rinv * c.rinv;
   const double vnnr = dot(c.vr, c.del);
   const double s = vnnr * rsqinv;
   const Vec3 vt = {c.vr.x - c.del.x * s, c.vr.y - c.del.y * s, c.vr.z - c.del.z * s};
@@ -185,7 +187,7 @@ __device__ __forceinline__ void hooke_history_law(const GranParams& p, double dt
     sh.y += vtr.y * dt;
     sh.z += vtr.z * dt;
   }
-  const double shrmag = sqrt(dot(sh, sh));
+  const double shr2 = dot(sh, sh);
   const double rsht = dot(sh, c.del) * rsqinv;
   if (shearupdate) {
     sh.x -= rsht * c.del.x;
@@ -194,12 +196,15 @@ __device__ __forceinline__ void hooke_history_law(const GranParams& p, double dt
   }
   const double mg = c.meff * p.gammat;
   Vec3 fs = {-(p.kt * sh.x + mg * vtr.x), -(p.kt * sh.y + mg * vtr.y), -(p.kt * sh.z + mg * vtr.z)};
-  const double fsmag = sqrt(dot(fs, fs));
+  const double fs2 = dot(fs, fs);
   const double fn = p.xmu * fabs(ccel * c.r);
-  if (fsmag > fn) {
-    if (shrmag != 0.0) {
-      const double ratio = fn / fsmag;
-      const Vec3 q = {mg * vtr.x / p.kt, mg * vtr.y / p.kt, mg * vtr.z / p.kt};
+  if (fs2 > fn * fn) {
+    if (shr2 != 0.0) {
+      double fsmag, fsinv;
+      sf_sqrt_rsqrt(fs2, fsmag, fsinv);
+      const double ratio = fn * fsinv;
+      const double qs = mg * p.inv_kt;
+      const Vec3 q = {qs * vtr.x, qs * vtr.y, qs * vtr.z};
       sh.x = ratio * (sh.x + q.x) - q.x;
       sh.y = ratio * (sh.y + q.y) - q.y;
       sh.z = ratio * (sh.z + q.z) - q.z;
