@@ -121,8 +121,11 @@ void orc_dem_rebuild_begin(orc_dem *d)
     if (ps.pfirst[i + 1] - ps.pfirst[i] > W) W = ps.pfirst[i + 1] - ps.pfirst[i];
   free_ptab(d);
   d->mrec = W; /* provisional; orc_dem_migrate_set_slots widens it to the global maximum */
-  d->pcnt = calloc((size_t)(n ? n : 1), sizeof(int));
-  d->ptab = calloc((size_t)(n ? n : 1) * (W ? W : 1), sizeof(int));
+  {
+    const size_t rows = n > 0 ? (size_t)n : 1, cols = W > 0 ? (size_t)W : 1;
+    d->pcnt = calloc(rows, sizeof(int));
+    d->ptab = calloc(rows * cols, sizeof(int));
+  }
   d->pshtab = calloc((size_t)(n ? n : 1) * (W ? W : 1) * 3, sizeof(double));
   for (i = 0; i < n; i++) {
     d->pcnt[i] = ps.pfirst[i + 1] - ps.pfirst[i];
