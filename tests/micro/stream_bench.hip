@@ -62,6 +62,11 @@ int main()
   run<2, 48, true, false>("read+write 16B/lane 48 rows", in, out, n);
   run<1, 48, true, true>("read+write  8B/lane 48 rows nt", in, out, n);
   run<2, 48, true, true>("read+write 16B/lane 48 rows nt", in, out, n);
+  // same bytes in fewer, wider rows (n elements per row scaled so that every case reads 403 MB)
+  run<4, 12, false, true>("read 32B/lane 12 rows x4 wide nt", in, out, 4 * n);
+  run<4, 12, true, true>("read+write 32B/lane 12 rows x4 wide nt", in, out, 4 * n);
+  run<2, 24, false, true>("read 16B/lane 24 rows x2 wide nt", in, out, 2 * n);
+  run<2, 24, true, true>("read+write 16B/lane 24 rows x2 wide nt", in, out, 2 * n);
   run<1, 12, false, false>("read  8B/lane 12 rows", in, out, n);
   run<2, 12, false, false>("read 16B/lane 12 rows", in, out, n);
   run<1, 12, true, false>("read+write  8B/lane 12 rows", in, out, n);
