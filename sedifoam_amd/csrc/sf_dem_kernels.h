@@ -26,6 +26,9 @@ __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 #ifndef SF_NT_OUT
 #define SF_NT_OUT 0
 #endif
+#ifndef SF_ST_SHUFFLE
+#define SF_ST_SHUFFLE 1
+#endif
 template <class T>
 __device__ __forceinline__ T ld_stream(const T* p)
 {
@@ -333,15 +336,38 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       }
     }
   }
-#if SF_NT_OUT
-  st_stream4(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
-  st_stream4(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
-  st_stream4(&P.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
-#else
-  P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
-  P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
-  P.om_out[i] = {wn.x, wn.y, wn.z, wi4.w};   // .w: frozen mark travels with the record
+#if SF_ST_SHUFFLE
+  // A 32-byte record per lane is two 16-byte stores at a 32-byte stride: each store instruction covers only half
+  // of every cache line it touches.  When the whole wave holds consecutive atoms the halves are exchanged between
+  // lanes so that each instruction writes 1 KiB of contiguous memory (lane l stores chunk l, then chunk 64 + l).
+  if (LPA == 1 && S.part == 0 && __ballot(1) == ~0ull && (i & 63) == (int)(threadIdx.x & 63)) {
+    const int lane = threadIdx.x & 63;
+    const int base = i - lane;
+    auto store_shuffled = [&](double4* arr, double a0, double a1, double a2, double a3) {
+      double2* dst = reinterpret_cast<double2*>(arr + base);
+      for (int half = 0; half < 2; half++) {
+        const int src = 32 * half + (lane >> 1);
+        const double b0 = __shfl(a0, src, 64), b1 = __shfl(a1, src, 64);
+        const double b2 = __shfl(a2, src, 64), b3 = __shfl(a3, src, 64);
+        dst[64 * half + lane] = (lane & 1) ? double2{b2, b3} : double2{b0, b1};
+      }
+    };
+    store_shuffled(P.xr_out, xn.x, xn.y, xn.z, radi);
+    store_shuffled(P.vm_out, vn.x, vn.y, vn.z, mi);
+    store_shuffled(P.om_out, wn.x, wn.y, wn.z, wi4.w);
+  } else
 #endif
+  {
+#if SF_NT_OUT
+    st_stream4(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
+    st_stream4(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
+    st_stream4(&P.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
+#else
+    P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
+    P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
+    P.om_out[i] = {wn.x, wn.y, wn.z, wi4.w};   // .w: frozen mark travels with the record
+#endif
+  }
   if (S.mode != 0) {
     P.force[i] = {F.x, F.y, F.z, 0.0};
     P.torque[i] = {T.x, T.y, T.z, 0.0};
