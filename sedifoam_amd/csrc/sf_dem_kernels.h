@@ -29,6 +29,9 @@ __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 #ifndef SF_ST_SHUFFLE
 #define SF_ST_SHUFFLE 1
 #endif
+#ifndef SF_GATHER_SHUFFLE
+#define SF_GATHER_SHUFFLE 1
+#endif
 template <class T>
 __device__ __forceinline__ T ld_stream(const T* p)
 {
@@ -116,6 +119,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       R.l = P.nloc[slot];
     } else {
       const int j = neigh_index(jraw, S.roots);
+      R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.x = P.xr_in[j];
       if (NEED_VW) {
         R.v = P.vm_in[j];
@@ -137,14 +141,50 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const size_t sbase = (size_t)(3 * sl) * cap + i;
     const int jraw = jraw_n1;
     Vec3 sh = {0.0, 0.0, 0.0};
-    if (STYLE != 0 && (jraw & kTouchBit)) {
+#ifndef SF_EXP_NOSHLD
+#define SF_EXP_NOSHLD 0
+#endif
+    if (STYLE != 0 && (jraw & kTouchBit) && !(SF_EXP_NOSHLD && S.kstep >= 0)) {
       sh.x = ld_stream(&P.shear[sbase]);
       sh.y = ld_stream(&P.shear[sbase + cap]);
       sh.z = ld_stream(&P.shear[sbase + 2 * cap]);
     }
     jraw_n1 = jraw_n2;
     if (s + 2 < nn) jraw_n2 = ld_stream(&P.neigh[slot + (size_t)(2 * LPA) * cap]);
-    if (more) fetch(jraw_n1, slot + (size_t)LPA * cap, nxt);
+    if (more) {
+      bool reuse = false;
+#if SF_GATHER_SHUFFLE
+      // In the sorted order the next neighbour of lane l is very often the CURRENT neighbour of lane l+1 (two
+      // adjacent atoms of a row see the same row of neighbours, shifted by one).  Its three records are then already
+      // in lane l+1's registers: take them by shuffle instead of gathering them from L2 again.  Checked per lane on
+      // the root index, so it is only a shortcut, never a different result.
+      if (!LDS && LPA == 1) {
+        const int jn = neigh_index(jraw_n1, S.roots);
+        const unsigned long long act = __ballot(1);
+        const int lane = threadIdx.x & 63;
+        const int jdn = __shfl_down(cur.l, 1, 64);
+        Rec t;
+        t.x = {__shfl_down(cur.x.x, 1, 64), __shfl_down(cur.x.y, 1, 64), __shfl_down(cur.x.z, 1, 64),
+               __shfl_down(cur.x.w, 1, 64)};
+        if (NEED_VW) {
+          t.v = {__shfl_down(cur.v.x, 1, 64), __shfl_down(cur.v.y, 1, 64), __shfl_down(cur.v.z, 1, 64),
+                 __shfl_down(cur.v.w, 1, 64)};
+          t.w = {__shfl_down(cur.w.x, 1, 64), __shfl_down(cur.w.y, 1, 64), __shfl_down(cur.w.z, 1, 64),
+                 __shfl_down(cur.w.w, 1, 64)};
+        }
+        reuse = lane < 63 && ((act >> (lane + 1)) & 1ull) && jdn == jn;
+        if (reuse) {
+          nxt.x = t.x;
+          if (NEED_VW) {
+            nxt.v = t.v;
+            nxt.w = t.w;
+          }
+          nxt.l = jn;
+        }
+      }
+#endif
+      if (!reuse) fetch(jraw_n1, slot + (size_t)LPA * cap, nxt);
+    }
     double4 xj4 = cur.x, vj4 = cur.v, wj4 = cur.w;
     if (LDS) {
       xj4 = lx[cur.l];
@@ -197,9 +237,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         }
         ContactOut o;
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
+#if !SF_EXP_NOSHST
         st_stream(&P.shear[sbase], sh.x);
         st_stream(&P.shear[sbase + cap], sh.y);
         st_stream(&P.shear[sbase + 2 * cap], sh.z);
+#else
+        if (sh.x == 1.2345) P.shear[sbase] = sh.y + sh.z;
+#endif
         if (!(jraw & kTouchBit)) P.neigh[slot] = jraw | kTouchBit;
         F = F + o.F;
         T = T - radi * o.tor;
