@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles", type=int, default=1000000, help="particles per GPU")
     ap.add_argument("--substeps", type=int, default=50, help="DEM sub-steps per step (per CFD step)")
+    ap.add_argument("--jitter", type=float, default=None, help="sensitivity runs: uniform position jitter / d (default 0.005)")
+    ap.add_argument("--spacing", type=float, default=None, help="sensitivity runs: lattice spacing / d (default 0.98)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coupled", action="store_true")
     ap.add_argument("--slab-driver", action="store_true",
@@ -100,7 +102,12 @@ def main():
     from sedifoam_amd import synthetic
     kw = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
     ncells = synthetic.fcc_cells_for(args.particles)
-    bed = synthetic.fcc_bed(ncells, seed=12345 + 3 + rank)
+    bed_kw = {}
+    if args.jitter is not None:
+        bed_kw["jitter"] = args.jitter
+    if args.spacing is not None:
+        bed_kw["spacing"] = args.spacing
+    bed = synthetic.fcc_bed(ncells, seed=12345 + 3 + rank, **bed_kw)
     script = synthetic.hertz_script(bed, **kw)
     N = bed["n"]
 
@@ -162,6 +169,7 @@ def main():
                         "periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step" % args.substeps,
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
+            **({"bed_override": bed_kw} if bed_kw else {}),
             "decomposition": "x-slabs, ghost halo over RCCL" if world > 1 else
                              ("single slab through the halo driver" if args.slab_driver else "single domain"),
         },

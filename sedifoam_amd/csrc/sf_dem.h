@@ -410,10 +410,11 @@ private:
   bool profiling_ = false;
   std::vector<hipEvent_t> prof_ev_;   // pairs (start, stop) of launches not yet harvested
   size_t prof_used_ = 0;
+  std::vector<int> prof_step_;         // sub-step number of each pair
   bool prof_open_ = false;             // a boundary part recorded its start event, the interior part closes it
   long long prof_launches_ = 0;
   double prof_ms_ = 0.0;
-  void harvest_profile(size_t first_pair, size_t valid_pairs);
+  void harvest_profile(int last_step);
 };
 
 // sf_sort.hip

@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 PMC passes over the default bench (GPU box). usage: tests/pmc.sh TAG "CTR1 CTR2" "CTR3" ...
+# rocprofv3 PMC passes over the default bench (GPU box). usage: [PMC_BENCH_ARGS="--jitter .."] tests/pmc.sh TAG "CTR1 CTR2" "CTR3" ...
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $PMC_BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$i.log 2>&1
 done
 python - <<PY
 import csv, collections, glob
