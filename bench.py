@@ -36,11 +36,20 @@ def build_engine(bed, script):
     return lmp
 
 
-def cpu_baseline(ncells, script_kw, substeps):
+def _synthetic():
+    """sedifoam_amd/synthetic.py without importing the package (the CPU workers need neither torch nor the HIP library)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sf_synthetic", os.path.join(ROOT, "sedifoam_amd", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(ncells, script_kw, substeps, seed=12345 + 3):
     """Oracle (CPU port of the reference algorithm) on the same kind of bed: particle-substeps/s."""
     from oracle import binding as ob
-    from sedifoam_amd import synthetic
-    bed = synthetic.fcc_bed(ncells, seed=12345 + 3)
+    synthetic = _synthetic()
+    bed = synthetic.fcc_bed(ncells, seed=seed)
     r = 0.5 * bed["diameter"]
     m = 4.0 * np.pi / 3.0 * r ** 3 * bed["density"]
     dem = ob.OracleDem(bed["x"], r, m, bed["boxlo"], bed["boxhi"], periodic=bed["periodic"], v=bed["v"])
@@ -58,7 +67,41 @@ def cpu_baseline(ncells, script_kw, substeps):
     return bed["n"] * substeps / dt, bed["n"], dt
 
 
+KW = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
+
+
+def cpu_worker(argv):
+    """`bench.py --cpu-worker NPART SUBSTEPS SEED`: one reference-style rank (its own slab of the bed) on one core."""
+    npart, sub, seed = int(argv[0]), int(argv[1]), int(argv[2])
+    v, n_s, secs = cpu_baseline(_synthetic().fcc_cells_for(npart), KW, sub, seed=seed)
+    print(json.dumps({"value": v, "n": int(n_s), "secs": secs}))
+
+
+def cpu_baseline_all_cores(npart, sub):
+    """What `mpirun -np <cores>` of the reference does on this host, without its halo traffic: one oracle process per
+    core, each with its own slab of `npart` particles (weak, like the GPU ranks); throughput = sum over processes of
+    particles x sub-steps / the slowest process's run time (setup and list build are not timed, as on the GPU)."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(npart), str(sub),
+                               str(777 + c)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for c in range(cores)]
+    res = []
+    for pr in procs:
+        out_s, _ = pr.communicate(timeout=600)
+        if pr.returncode == 0:
+            res.append(json.loads(out_s.strip().splitlines()[-1]))
+    if not res:
+        return None
+    slowest = max(r["secs"] for r in res)
+    return {"value": sum(r["n"] for r in res) * sub / slowest, "unit": "particle-substeps/s", "cores": len(res),
+            "kind": "port", "sample": "%d independent oracle processes (one per core), %d particles x %d sub-steps each, "
+                                      "slowest %.1f s; no halo exchange between them" % (len(res), res[0]["n"], sub, slowest)}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -72,6 +115,8 @@ def main():
     ap.add_argument("--slab-driver", action="store_true",
                     help="drive the sub-steps through the multi-rank SlabDriver even at N=1 (self halo)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
+    ap.add_argument("--cpu-all-particles", type=int, default=100000,
+                    help="particles per process of the all-cores CPU leg (one oracle process per host core), 0 = skip")
     ap.add_argument("--coupled-multi", action="store_true",
                     help="with --gpus N > 1 also time coupled steps: enhancedCloud over the decomposed particles, "
                          "whole mesh on every rank, per-cell sums all-reduced")
@@ -100,7 +145,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sedifoam_amd import synthetic
-    kw = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
+    kw = KW
     ncells = synthetic.fcc_cells_for(args.particles)
     bed_kw = {}
     if args.jitter is not None:
@@ -272,6 +317,9 @@ def main():
         out["cpu_baseline"] = {"value": v, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
                                "sample": "%d-particle bed of the same packing, %d sub-steps, %.1f s, "
                                          "oracle/ (C, gcc -O2) single thread" % (n_s, sub, secs)}
+        allc = cpu_baseline_all_cores(args.cpu_all_particles, 20) if args.cpu_all_particles > 0 else None
+        if allc:
+            out["cpu_baseline_all_cores"] = allc
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
