@@ -384,6 +384,7 @@ private:
   DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
   int* cell_start_ = nullptr;          // [nbins][4]: owned start/end, ghost start/end of every cell (hipMalloc: 16-byte aligned)
   size_t cell_alloc_ = 0;
+  bool row_tables_ = false;   // cell_start_ holds the reversed lower-bound tables (plain keys) instead of cell ranges
   int* tagmap_ = nullptr;
   size_t tagmap_alloc_ = 0;
   void* sort_tmp_ = nullptr;
@@ -421,6 +422,7 @@ private:
 void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
                     int* vals_out, int n, int end_bit, hipStream_t s);
 void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s);
+void inclusive_min_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s);
 void sort_pairs_u64(void*& tmp, size_t& tmp_bytes, unsigned long long* keys_in,
                     unsigned long long* keys_out, int* vals_in, int* vals_out, int n, int end_bit,
                     hipStream_t s);

@@ -731,7 +731,7 @@ void DemEngine::compute_grid()
   }
   if ((size_t)grid_.nbins > cell_alloc_) {
     if (cell_start_) SF_HIP(hipFree(cell_start_));
-    cell_alloc_ = (size_t)grid_.nbins + grid_.nbins / 8;
+    cell_alloc_ = (size_t)grid_.nbins + grid_.nbins / 8 + 16;
     SF_HIP(hipMalloc(&cell_start_, sizeof(int) * 4 * cell_alloc_));
   }
 }
@@ -829,9 +829,19 @@ void DemEngine::rebuild_sort()
   permute_locals(perm_alt_.as<int>(), nlocal_);
   mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   // sorted bin keys -> cell ranges of owned atoms
-  SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
-  k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
-                                                   cell_start_ + 1, 4);
+  // Plain keys (no tiles, no LDS staging): lower bound of every cell in the sorted order, stored reversed so that a
+  // forward min-scan fills the cells without atoms: [0] first positions, [1] owned table, [2], [3] the same for ghosts
+  row_tables_ = grid_.tile <= 1 && !opt_lds_;
+  if (row_tables_) {
+    const int ne = grid_.nbins + 1;
+    SF_HIP(hipMemsetAsync(cell_start_, 0x7f, sizeof(int) * ne, stream_));
+    k_cell_first<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_, grid_.nbins);
+    inclusive_min_scan_i32(sort_tmp_, sort_tmp_bytes_, cell_start_, cell_start_ + cell_alloc_, ne, stream_);
+  } else {
+    SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
+    k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
+                                                     cell_start_ + 1, 4);
+  }
   // owned range of every tile (bin keys are tile-major: key >> log2(T^3) is the tile id)
   const int T = grid_.tile;
   ntiles_ = grid_.nt[0] * grid_.nt[1] * grid_.nt[2];
@@ -948,8 +958,17 @@ void DemEngine::bin_and_build()
     sort_pairs_u64(sort_tmp_, sort_tmp_bytes_, keys64_.as<unsigned long long>(),
                    keys64_alt_.as<unsigned long long>(), perm_.as<int>(), perm_alt_.as<int>(), nghost_, 64,
                    stream_);
-    k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-        keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
+    if (row_tables_) {
+      const int ne = grid_.nbins + 1;
+      int* first = cell_start_ + 2 * cell_alloc_;
+      SF_HIP(hipMemsetAsync(first, 0x7f, sizeof(int) * ne, stream_));
+      k_cell_first<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
+          keys64_alt_.as<unsigned long long>(), nghost_, 32, first, grid_.nbins);
+      inclusive_min_scan_i32(sort_tmp_, sort_tmp_bytes_, first, cell_start_ + 3 * cell_alloc_, ne, stream_);
+    } else {
+      k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
+          keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
+    }
   }
   build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {
@@ -965,6 +984,8 @@ void DemEngine::bin_and_build()
     B.g = grid_;
     B.eoff = lds_active_ ? eoff_ : nullptr;
     B.nloc = nloc_.as<unsigned short>();
+    B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
+    B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;
     B.roots = roots_ ? 1 : 0;
     B.gsrc = gsrc_.as<int>();
     B.gshift = gshift_.as<double>();

@@ -839,7 +839,22 @@ struct BuildParams {
   const int* gsrc;    // root of a periodic image (-1: ghost owned by another GPU)
   const double* gshift;
   double inv_prd[3];
+  // lower-bound tables over ALL cells, stored reversed (entry nbins - b = first sorted atom with cell >= b), or
+  // nullptr (tile-major keys, LDS staging): see the flattened candidate loop in k_build_neigh
+  const int* lb_own;
+  const int* lb_ghost;
 };
+
+// first sorted position of every cell, reversed layout, before the min-scan (cells without atoms keep the fill)
+template <class K>
+__global__ __launch_bounds__(256) void k_cell_first(const K* keys, int n, int shift, int* rfirst, int nbins)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)(keys[i] >> shift);
+  if (i == 0 || (int)(keys[i - 1] >> shift) != b) rfirst[nbins - b] = i;
+  if (i == 0) rfirst[0] = n;   // "cell nbins": one past the last atom
+}
 
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
 // history re-injected by partner tag (FixShearHistory)
@@ -873,102 +888,147 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   // slots of an atom -- and the same slot of adjacent lanes -- point at consecutive atoms in memory
   const int co = B.g.xslow ? cx : cz, no = B.g.xslow ? B.g.n[0] : B.g.n[2];
   const int ci = B.g.xslow ? cz : cx, ni = B.g.xslow ? B.g.n[2] : B.g.n[0];
-  // candidates k of [ks, ke) (owned: the atom index itself; ghosts: through their (bin, tag) order)
-  auto visit = [&](const int ks, const int ke, const bool ghosts, const int ebase, const int nloc_b) {
-    for (int k = ks; k < ke; k++) {
-      const int j = ghosts ? ghost_order[k] : k;
-      if (j == i) continue;
-      const double4 xj = xr[j];
-      const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      double cut = B.cut_lub;
-      if (B.skin_gran >= 0.0) {
-        const double cg = xi.w + xj.w + B.skin_gran;
-        cut = cg > cut ? cg : cut;
-      }
-      if (rsq > cut * cut) continue;
-      if (n < B.M) {
-        int entry = j;
-        if (B.roots) {
-          int code = kNoShift;
-          if (j >= B.nlocal) {
-            const int r = B.gsrc[j];
-            if (r >= 0) {   // periodic image made on this GPU: refer to its root + which image it is
-              entry = r;
-              const int ix = (int)rint(B.gshift[j] * B.inv_prd[0]);
-              const int iy = (int)rint(B.gshift[B.cap + j] * B.inv_prd[1]);
-              const int iz = (int)rint(B.gshift[2 * B.cap + j] * B.inv_prd[2]);
-              code = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
-            }
-          }
-          entry |= code << kIdxBits;
-        }
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        const int tj = tag[j];
-        int found = -1;
-#pragma unroll
-        for (int s = 0; s < kPT; s++)
-          if (pt[s] == tj) found = s;             // tags are unique: at most one match
-        if (found < 0)
-          for (int s = kPT; s < nold; s++)
-            if (ptag_old[(size_t)s * B.cap + i] == tj) {
-              found = s;
-              break;
-            }
-        if (found >= 0) {
-          entry |= kTouchBit;
-          const size_t ob = (size_t)(3 * found) * B.cap + i;
-          sx = shear_old[ob];
-          sy = shear_old[ob + B.cap];
-          sz = shear_old[ob + 2 * B.cap];
-        }
-        neigh[(size_t)n * B.cap + i] = entry;
-        if (eo) B.nloc[(size_t)n * B.cap + i] = (unsigned short)(ebase + (ghosts ? nloc_b + (k - ks) : (k - ks)));
-        const size_t nb = (size_t)(3 * n) * B.cap + i;
-        shear[nb] = sx;
-        shear[nb + B.cap] = sy;
-        shear[nb + 2 * B.cap] = sz;
-      }
-      n++;
+  // distance test of one candidate
+  auto in_range = [&](const int j, const double4 xj) {
+    const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    double cut = B.cut_lub;
+    if (B.skin_gran >= 0.0) {
+      const double cg = xi.w + xj.w + B.skin_gran;
+      cut = cg > cut ? cg : cut;
     }
+    return j != i && rsq <= cut * cut;
   };
-  const int4* cells = reinterpret_cast<const int4*>(cellLS);   // {owned start, end, ghost start, end} per cell
-  // Without tiles the 2R+1 cells of one stencil row have consecutive keys, so their owned atoms are ONE contiguous
-  // index range (and their ghosts one range of the ghost order): the cell entries of a row are loaded together
-  // instead of one dependent load + loop per cell (125 -> 25 steps at R = 2).
-  const bool row_ranges = !eo && (B.g.xslow || B.g.tile <= 1) && R <= 3;
-  for (int bo = co - R; bo <= co + R; bo++) {
-    if (bo < 0 || bo >= no) continue;
-    for (int by = cy - R; by <= cy + R; by++) {
-      if (by < 0 || by >= B.g.n[1]) continue;
-      const int bi0 = ci - R < 0 ? 0 : ci - R, bi1 = ci + R >= ni ? ni - 1 : ci + R;
-      if (row_ranges) {
-        const int b0 = B.g.xslow ? bin_key(B.g, bo, by, bi0) : bin_key(B.g, bi0, by, bo);
-        int olo = INT_MAX, ohi = 0, glo = INT_MAX, ghi = 0;
-#pragma unroll
-        for (int c = 0; c < 7; c++) {
-          if (c > bi1 - bi0) continue;
-          const int4 cb = cells[b0 + c];
-          if (cb.y > cb.x) {
-            olo = cb.x < olo ? cb.x : olo;
-            ohi = cb.y > ohi ? cb.y : ohi;
-          }
-          if (cb.w > cb.z) {
-            glo = cb.z < glo ? cb.z : glo;
-            ghi = cb.w > ghi ? cb.w : ghi;
+  // neighbour j enters the list; pos = its position in the tile's staged copy (LDS kernel only)
+  auto accept = [&](const int j, const int tj, const int pos) {
+    if (n < B.M) {
+      int entry = j;
+      if (B.roots) {
+        int code = kNoShift;
+        if (j >= B.nlocal) {
+          const int r = B.gsrc[j];
+          if (r >= 0) {   // periodic image made on this GPU: refer to its root + which image it is
+            entry = r;
+            const int ix = (int)rint(B.gshift[j] * B.inv_prd[0]);
+            const int iy = (int)rint(B.gshift[B.cap + j] * B.inv_prd[1]);
+            const int iz = (int)rint(B.gshift[2 * B.cap + j] * B.inv_prd[2]);
+            code = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
           }
         }
-        visit(olo, ohi, false, 0, 0);
-        visit(glo, ghi, true, 0, 0);
-        continue;
+        entry |= code << kIdxBits;
       }
-      for (int bi = bi0; bi <= bi1; bi++) {
-        const int bx = B.g.xslow ? bo : bi, bz = B.g.xslow ? bi : bo;
-        const int b = bin_key(B.g, bx, by, bz);
-        const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;   // stencil 1 only
-        const int4 cb = cells[b];
-        visit(cb.x, cb.y, false, ebase, cb.y - cb.x);
-        visit(cb.z, cb.w, true, ebase, cb.y - cb.x);
+      double sx = 0.0, sy = 0.0, sz = 0.0;
+      int found = -1;
+#pragma unroll
+      for (int s = 0; s < kPT; s++)
+        if (pt[s] == tj) found = s;             // tags are unique: at most one match
+      if (found < 0)
+        for (int s = kPT; s < nold; s++)
+          if (ptag_old[(size_t)s * B.cap + i] == tj) {
+            found = s;
+            break;
+          }
+      if (found >= 0) {
+        entry |= kTouchBit;
+        const size_t ob = (size_t)(3 * found) * B.cap + i;
+        sx = shear_old[ob];
+        sy = shear_old[ob + B.cap];
+        sz = shear_old[ob + 2 * B.cap];
+      }
+      neigh[(size_t)n * B.cap + i] = entry;
+      if (eo) B.nloc[(size_t)n * B.cap + i] = (unsigned short)pos;
+      const size_t nb = (size_t)(3 * n) * B.cap + i;
+      shear[nb] = sx;
+      shear[nb + B.cap] = sy;
+      shear[nb + 2 * B.cap] = sz;
+    }
+    n++;
+  };
+  auto candidate = [&](const int j, const int pos) {
+    if (in_range(j, xr[j])) accept(j, tag[j], pos);
+  };
+  int n_total = 0;   // row path: accepted candidates of the first sweep (may exceed the slots: overflow report)
+  auto note = [&](const int j) {
+    if (n_total < B.M) neigh[(size_t)n_total * B.cap + i] = j;
+    n_total++;
+  };
+  if (B.lb_own) {
+    // Plain (non-tiled) keys: the 2R+1 cells of one stencil row have consecutive keys, so their atoms are ONE
+    // contiguous range of the sorted array, [lb(first cell), lb(last cell + 1)) -- two loads per row instead of one
+    // dependent load + loop per cell, requested one row ahead.  The records of a row are consecutive in memory: four
+    // are loaded at once, then tested and entered in order.
+    const int W = 2 * R + 1;
+    const int bi0 = ci - R < 0 ? 0 : ci - R, bi1 = ci + R >= ni ? ni - 1 : ci + R;
+    for (int pass = 0; pass < 2; pass++) {
+      const int* lb = pass ? B.lb_ghost : B.lb_own;   // owned atoms first, then ghosts in their (cell, tag) order
+      if (!lb) break;
+      auto row_range = [&](const int ro, const int ry, int& lo, int& hi) {
+        const int bo = co - R + ro, by = cy - R + ry;
+        lo = hi = 0;
+        if (ro >= W || bo < 0 || bo >= no || by < 0 || by >= B.g.n[1]) return;
+        const int b0 = B.g.xslow ? bin_key(B.g, bo, by, bi0) : bin_key(B.g, bi0, by, bo);
+        lo = lb[B.g.nbins - b0];
+        hi = lb[B.g.nbins - (b0 + (bi1 - bi0) + 1)];
+      };
+      int nlo, nhi;
+      row_range(0, 0, nlo, nhi);
+      for (int ro = 0; ro < W; ro++) {
+        for (int ry = 0; ry < W; ry++) {
+          const int lo = nlo, hi = nhi;
+          if (ry + 1 < W) row_range(ro, ry + 1, nlo, nhi);
+          else row_range(ro + 1, 0, nlo, nhi);
+          if (pass) {
+            for (int k = lo; k < hi; k++) {
+              const int j = ghost_order[k];
+              if (in_range(j, xr[j])) note(j);
+            }
+            continue;
+          }
+          for (int k = lo; k < hi; k += 4) {
+            const double4 z4 = {0.0, 0.0, 0.0, 0.0};
+            const double4 x0 = xr[k];
+            const double4 x1 = k + 1 < hi ? xr[k + 1] : z4;
+            const double4 x2 = k + 2 < hi ? xr[k + 2] : z4;
+            const double4 x3 = k + 3 < hi ? xr[k + 3] : z4;
+            if (in_range(k, x0)) note(k);
+            if (k + 1 < hi && in_range(k + 1, x1)) note(k + 1);
+            if (k + 2 < hi && in_range(k + 2, x2)) note(k + 2);
+            if (k + 3 < hi && in_range(k + 3, x3)) note(k + 3);
+          }
+        }
+      }
+    }
+    // second sweep, slot by slot: every lane of the wave is at the same row of the slot-major arrays, so the history
+    // re-injection reads and the neigh/shear stores are coalesced even when the lanes found their neighbours at
+    // different moments of the candidate walk (disordered beds)
+    const int nacc = n_total < B.M ? n_total : B.M;
+    n = 0;
+    int jn = nacc > 0 ? neigh[i] : 0;
+    int tn = nacc > 0 ? tag[jn] : 0;
+    for (int s = 0; s < nacc; s++) {
+      const int j = jn, tj = tn;
+      if (s + 1 < nacc) {
+        jn = neigh[(size_t)(s + 1) * B.cap + i];
+        tn = tag[jn];
+      }
+      accept(j, tj, 0);
+    }
+    n = n_total;
+  } else {
+    const int4* cells = reinterpret_cast<const int4*>(cellLS);   // {owned start, end, ghost start, end} per cell
+    for (int bo = co - R; bo <= co + R; bo++) {
+      if (bo < 0 || bo >= no) continue;
+      for (int by = cy - R; by <= cy + R; by++) {
+        if (by < 0 || by >= B.g.n[1]) continue;
+        for (int bi = ci - R; bi <= ci + R; bi++) {
+          if (bi < 0 || bi >= ni) continue;
+          const int bx = B.g.xslow ? bo : bi, bz = B.g.xslow ? bi : bo;
+          const int b = bin_key(B.g, bx, by, bz);
+          const int ebase = eo ? eo[((bz - (tz * T - 1)) * E + (by - (ty * T - 1))) * E + (bx - (tx * T - 1))] : 0;   // stencil 1 only
+          const int4 cb = cells[b];
+          for (int k = cb.x; k < cb.y; k++) candidate(k, ebase + (k - cb.x));
+          for (int k = cb.z; k < cb.w; k++) candidate(ghost_order[k], ebase + (cb.y - cb.x) + (k - cb.z));
+        }
       }
     }
   }
