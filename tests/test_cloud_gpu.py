@@ -352,6 +352,71 @@ def test_xiaocase3_golden_through_hip_path():
     assert vy[-1] == pytest.approx(0.0500031, rel=2e-3)
 
 
+@pytest.mark.parametrize("case,ds,rhos,x0", [
+    ("Rho", [1.5e-3] * 4, [4650.0, 3650.0, 2650.0, 1650.0],
+     [[5e-2, 7.5e-2, 5e-2], [9e-2, 8.5e-2, 5e-2], [9.1e-2, 8.5e-2, 5e-2], [1.7e-1, 7.5e-2, 5e-2]]),
+    ("Dia", [3.5e-3, 3.0e-3, 2.5e-3, 2.0e-3], [2650.0] * 4,
+     [[5e-2, 7.5e-2, 5e-2], [9e-2, 8.5e-2, 5e-2], [9.2e-2, 8.5e-2, 5e-2], [1.7e-1, 6.5e-2, 5e-2]]),
+])
+def test_multi_particles_collide_golden_through_hip_path(case, ds, rhos, x0):
+    """cases/auto-testing/test-cases/multiParticlesCollide{Rho,Dia} through the product path (in.lammps commands,
+    SyamlalOBrien, subCycles 2, deltaT 1e-3) in a frozen quiescent fluid with the hydrostatic pressure gradient, against
+    the reference's own dump rows data/origin/p[1-4].dat (id type diameter mass x y z vx vy vz).  Same gates as the
+    oracle's test of this case (tests/test_oracle_golden.py): the reference run is two-way coupled, so the settling
+    speed is held to 5 % and the positions to a few mm."""
+    from sedifoam_amd import Lammps, enhancedCloud
+    lmp = Lammps()
+    lmp.set_box([0, 0, 0], [0.2, 0.1, 0.1])
+    lmp.create_atoms(x0, ds, rhos)
+    lmp.commands("""
+        atom_style sphere
+        atom_modify map array
+        boundary ff ff ff
+        newton off
+        communicate single vel yes
+        neighbor 0.02 bin
+        neigh_modify delay 0
+        pair_style gran/hooke/history 4910.0 NULL 0 NULL 0.15 0
+        pair_coeff * *
+        timestep 1e-5
+        velocity all set 0.0 0.0 0.0 units box
+        fix 1 all nve/sphere
+        fix 2 all gravity 9.8 vector 0 -1 0
+        fix 3 all fdrag
+        fix xwall all wall/gran 4910.0 NULL 0 NULL 0 0 xplane 0.00 0.20
+        fix ywall all wall/gran 4910.0 NULL 0 NULL 0 0 yplane 0.00 0.10
+        fix zwall all wall/gran 4910.0 NULL 0 NULL 0 0 zplane 0.00 0.10
+        thermo_style one
+        thermo 2000
+        thermo_modify lost error
+    """)
+    mesh_n = [40, 20, 1]
+    cloud = enhancedCloud(lmp, [0, 0, 0], [0.2 / 40, 0.1 / 20, 0.1], mesh_n,
+                          dict(dragModel="SyamlalOBrien", subCycles=2, g=(0, -9.8, 0)),
+                          dict(rhob=1000.0, nub=1e-6), deltaT=1e-3)
+    assert lmp.get_timestep() == pytest.approx(1e-5)
+    nc = int(np.prod(mesh_n))
+    cloud.setFluid(Uf=np.zeros((nc, 3)), gradp=np.tile([0.0, -9.8 * 1000.0, 0.0], (nc, 1)))
+    xs, vs = [], []
+    for it in range(200):
+        cloud.evolve()
+        if (it + 1) % 10 == 0:
+            st = lmp.get_local_info()
+            order = np.argsort(st["tag"])
+            xs.append(st["x"][order]); vs.append(st["v"][order])
+    x = np.array(xs); v = np.array(vs)     # row k = time (k + 1) * 10 * deltaT = dump row k + 1
+    for pid in (1, 2, 3, 4):
+        gold = np.loadtxt(os.path.join(GOLD, "multiParticlesCollide%s_p%d.dat" % (case, pid)))
+        m = 4.0 * np.pi / 3.0 * (0.5 * ds[pid - 1]) ** 3 * rhos[pid - 1]
+        assert m == pytest.approx(gold[0, 3], rel=2e-6)
+        for k in range(2, min(len(gold), len(x) + 1)):
+            assert v[k - 1, pid - 1, 1] == pytest.approx(gold[k, 8], rel=0.05), (pid, k)
+            assert x[k - 1, pid - 1, 1] == pytest.approx(gold[k, 5], abs=1.0e-3), (pid, k)
+            assert x[k - 1, pid - 1, 0] == pytest.approx(gold[k, 4], abs=3.5e-3), (pid, k)
+    if case == "Rho":
+        assert v[-1, 0, 1] == pytest.approx(-0.314177, rel=3e-3)
+
+
 def test_single_sphere_relaxation_with_ergun_wenyu_is_the_standard_drag_law():
     """ErgunWenYu has no golden curve in the reference (xiaocase3 uses SyamlalOBrien), so the dilute limit is checked
     against what it must reduce to: a single sphere in a uniform stream feels the standard drag
