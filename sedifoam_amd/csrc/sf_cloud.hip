@@ -243,6 +243,92 @@ __global__ __launch_bounds__(256) void k_cell_keys(int n, const double4* xr, Mes
   idx[i] = i;
 }
 
+// ---- counting sort of the particles by cell (replaces a 25-launch merge sort per CFD step) ----
+// The atoms are already in spatial order, so the 64 lanes of a wave fall into a handful of cells: lanes of the same
+// cell are grouped with ballots and ONE atomic per group is issued (a same-address atomic per particle would
+// serialise across the XCDs).  grp_leader / grp_rank / grp_size describe the lane's group.
+__device__ __forceinline__ void wave_groups(const int c, const bool valid, int& leader, int& rank, int& size)
+{
+  const int lane = threadIdx.x & 63;
+  bool done = !valid;
+  leader = -1;
+  rank = size = 0;
+  for (;;) {
+    const unsigned long long rem = __ballot(!done);
+    if (!rem) break;
+    const int l = __ffsll((long long)rem) - 1;
+    const int cl = __shfl(c, l, 64);
+    const bool mine = !done && c == cl;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
+      leader = l;
+      rank = __popcll(m & ((1ull << lane) - 1ull));
+      size = __popcll(m);
+      done = true;
+    }
+  }
+}
+
+// pass 1: cell id of every particle (outside the mesh = ncells, the last bin) and the particle count per cell
+__global__ __launch_bounds__(256) void k_cell_count(int n, const double4* xr, MeshDev m, unsigned* cellid, int* count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  int c = 0;
+  if (valid) {
+    const double4 x = xr[i];
+    c = cell_of(m, x.x, x.y, x.z);
+    if (c < 0) c = m.ncells;
+    cellid[i] = (unsigned)c;
+  }
+  int leader, rank, size;
+  wave_groups(c, valid, leader, rank, size);
+  if (valid && (int)(threadIdx.x & 63) == leader) atomicAdd(&count[c], size);
+}
+
+// pass 2: cursor[c] starts at cstart[c] and ends at cend[c]; the slots inside a cell are handed out in arrival order
+__global__ __launch_bounds__(256) void k_cell_place(int n, const unsigned* cellid, int* cursor, int* order)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  const int c = valid ? (int)cellid[i] : 0;
+  int leader, rank, size;
+  wave_groups(c, valid, leader, rank, size);
+  int base = 0;
+  if (valid && (int)(threadIdx.x & 63) == leader) base = atomicAdd(&cursor[c], size);
+  base = __shfl(base, leader < 0 ? 0 : leader, 64);
+  if (valid) order[base + rank] = i;
+}
+
+// pass 3: arrival order -> ascending particle index inside every cell, so that the per-cell sums are the same bits on
+// every run.  One wave per cell: rank sort through shuffles (<= 64 particles), through memory otherwise.
+__global__ __launch_bounds__(256) void k_cell_sort_segments(int nbins, const int* cstart, const int* cend, int* order,
+                                                            int* scratch)
+{
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (c >= nbins) return;
+  const int s = cstart[c], len = cend[c] - s;
+  if (len <= 1) return;
+  if (len <= 64) {
+    const int v = lane < len ? order[s + lane] : 0x7fffffff;
+    int r = 0;
+    for (int k = 0; k < len; k++) r += __shfl(v, k, 64) < v ? 1 : 0;
+    if (lane < len) order[s + r] = v;
+    return;
+  }
+  for (int a = lane; a < len; a += 64) {
+    const int v = order[s + a];
+    int r = 0;
+    for (int k = 0; k < len; k++) r += order[s + k] < v ? 1 : 0;
+    scratch[s + r] = v;
+  }
+  // (the wave reads `order` of its own segment only; copy back once every lane has written its ranks)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_wave_barrier();
+  for (int a = lane; a < len; a += 64) order[s + a] = scratch[s + a];
+}
+
 __global__ __launch_bounds__(256) void k_cell_ranges(const unsigned* keys, int n, int* cstart, int* cend)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,13 +769,15 @@ class Cloud {
   {
     DemEngine& e = lmp_->eng;
     const int nc = mesh_.ncells;
+    // cstart_ = [start | end] per cell (+ the "outside" bin); idx2_ = particle indices cell by cell, ascending inside
     SF_HIP(hipMemsetAsync(cstart_, 0, sizeof(int) * 2 * ((size_t)nc + 1), s_));
     if (!n) return;
-    k_cell_keys<<<div_up(n, 256), 256, 0, s_>>>(n, e.d_xr(), mesh_, keys_, idx_);
-    int bits = 1;
-    while ((1 << bits) <= nc) bits++;
-    sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_, keys2_, idx_, idx2_, n, bits, s_);
-    k_cell_ranges<<<div_up(n, 256), 256, 0, s_>>>(keys2_, n, cstart_, cstart_ + nc + 1);
+    int* cend = cstart_ + nc + 1;
+    k_cell_count<<<div_up(n, 256), 256, 0, s_>>>(n, e.d_xr(), mesh_, keys_, cend);              // counts in `end`
+    exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, cend, cstart_, nc + 1, s_);
+    SF_HIP(hipMemcpyAsync(cend, cstart_, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, s_));
+    k_cell_place<<<div_up(n, 256), 256, 0, s_>>>(n, keys_, cend, idx2_);                       // end = start + count
+    k_cell_sort_segments<<<div_up((nc + 1) * 64, 256), 256, 0, s_>>>(nc + 1, cstart_, cend, idx2_, idx_);
   }
 
   void particle_to_eulerian()
