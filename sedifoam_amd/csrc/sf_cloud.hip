@@ -340,24 +340,40 @@ __global__ __launch_bounds__(256) void k_cell_ranges(const unsigned* keys, int n
 
 // particleToEulerianField: one cell per lane walks its (cell-sorted) particles -- deterministic,
 // no atomics.  gamma = sum Vol / V ; Ue = sum Vol U / V, then Ue /= gamma where gamma > ROOTVSMALL.
+// L lanes (1, 8 or 64) share a cell: they fetch the particles' records in parallel -- the latency of the gathers is
+// what a one-lane-per-cell walk spends its time on -- and then add the contributions one by one in the cell's
+// particle order, every lane the same sum, so the result is bit-for-bit the sequential one.
+template <int L>
 __global__ __launch_bounds__(256) void k_particle_to_eulerian(int ncells, const int* cstart, const int* cend,
                                                               const int* order, const double4* xr,
                                                               const double4* vm, const double* V, double* gamma,
                                                               double* Ue)
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = t / L, q = t % L;
   if (c >= ncells) return;
   double g = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
-  for (int k = cstart[c]; k < cend[c]; k++) {
-    const int i = order[k];
-    const double d = 2.0 * xr[i].w;
-    const double Vol = kPi * d * d * d / 6.0;
-    const double4 v = vm[i];
-    g += Vol;
-    u0 += Vol * v.x;
-    u1 += Vol * v.y;
-    u2 += Vol * v.z;
+  const int ks = cstart[c], ke = cend[c];
+  for (int base = ks; base < ke; base += L) {
+    const int k = base + q;
+    double Vol = 0.0;
+    double4 v = {0.0, 0.0, 0.0, 0.0};
+    if (k < ke) {
+      const int i = order[k];
+      const double d = 2.0 * xr[i].w;
+      Vol = kPi * d * d * d / 6.0;
+      v = vm[i];
+    }
+    const int m = ke - base < L ? ke - base : L;
+    for (int s = 0; s < m; s++) {
+      const double Vs = L == 1 ? Vol : __shfl(Vol, s, L);
+      g += Vs;
+      u0 += Vs * (L == 1 ? v.x : __shfl(v.x, s, L));
+      u1 += Vs * (L == 1 ? v.y : __shfl(v.y, s, L));
+      u2 += Vs * (L == 1 ? v.z : __shfl(v.z, s, L));
+    }
   }
+  if (q != 0) return;
   const double Vc = V[c];
   g /= Vc;
   u0 /= Vc;
@@ -370,32 +386,46 @@ __global__ __launch_bounds__(256) void k_particle_to_eulerian(int ncells, const 
 }
 
 // calcTcFields: Asrc[c] = sum (Vol Jd / V)(U - UfSmoothed[c]) ; Omega accumulated then zeroed (:391)
+template <int L>
 __global__ __launch_bounds__(256) void k_calc_tc(int ncells, const int* cstart, const int* cend, const int* order,
                                                  const double4* xr, const double4* vm, const double* V,
                                                  const double* gamma, const double* UfS, int dragModel,
                                                  double nub, double rhob, double* Asrc, double* Omega,
                                                  const int* tag, double* Jd_bytag, int maxtag)
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = t / L, q = t % L;
   if (c >= ncells) return;
   const double alpha = gamma[c];
   const double uf[3] = {UfS[3 * c], UfS[3 * c + 1], UfS[3 * c + 2]};
+  const double Vc = V[c];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int k = cstart[c]; k < cend[c]; k++) {
-    const int i = order[k];
-    const double d = 2.0 * xr[i].w;
-    const double Vol = kPi * d * d * d / 6.0;
-    const double4 v = vm[i];
-    const double r0 = uf[0] - v.x, r1 = uf[1] - v.y, r2 = uf[2] - v.z;
-    const double mag = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-    const double jd = jd_model(dragModel, mag, alpha, d, nub, rhob);
-    const int t = tag[i];
-    if (t >= 1 && t <= maxtag) Jd_bytag[t - 1] = jd;
-    const double omg = Vol * jd / V[c];
-    a0 += omg * (v.x - uf[0]);
-    a1 += omg * (v.y - uf[1]);
-    a2 += omg * (v.z - uf[2]);
+  const int ks = cstart[c], ke = cend[c];
+  for (int base = ks; base < ke; base += L) {
+    const int k = base + q;
+    double omg = 0.0;
+    double4 v = {0.0, 0.0, 0.0, 0.0};
+    if (k < ke) {
+      const int i = order[k];
+      const double d = 2.0 * xr[i].w;
+      const double Vol = kPi * d * d * d / 6.0;
+      v = vm[i];
+      const double r0 = uf[0] - v.x, r1 = uf[1] - v.y, r2 = uf[2] - v.z;
+      const double mag = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+      const double jd = jd_model(dragModel, mag, alpha, d, nub, rhob);
+      const int tg = tag[i];
+      if (tg >= 1 && tg <= maxtag) Jd_bytag[tg - 1] = jd;
+      omg = Vol * jd / Vc;
+    }
+    const int m = ke - base < L ? ke - base : L;
+    for (int s = 0; s < m; s++) {
+      const double os = L == 1 ? omg : __shfl(omg, s, L);
+      a0 += os * ((L == 1 ? v.x : __shfl(v.x, s, L)) - uf[0]);
+      a1 += os * ((L == 1 ? v.y : __shfl(v.y, s, L)) - uf[1]);
+      a2 += os * ((L == 1 ? v.z : __shfl(v.z, s, L)) - uf[2]);
+    }
   }
+  if (q != 0) return;
   // weighted by (1 - gamma) for the smoothing step (:407-408); k_unweight divides again (:415-416)
   const double w = 1 - alpha;
   Asrc[3 * c] = a0 * w;
@@ -563,10 +593,27 @@ class Cloud {
     if (props_.maxPossibleAlpha > 0.0)
       k_cap_alpha<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, gamma_, props_.maxPossibleAlpha);
     sort_by_cell(n);
-    k_calc_tc<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_, cstart_ + mesh_.ncells + 1, idx2_,
-                                                         e.d_xr(), e.d_vm(), V_, gamma_, UfS_, props_.dragModel,
-                                                         props_.nub, props_.rhob, Asrc_, Omega_, e.d_tag(), Jd_,
-                                                         maxtag_);
+    const int L = lanes_per_cell(n);
+    auto launch = [&](auto kern) {
+      kern<<<div_up((size_t)mesh_.ncells * L, 256), 256, 0, s_>>>(mesh_.ncells, cstart_, cstart_ + mesh_.ncells + 1,
+                                                                  idx2_, e.d_xr(), e.d_vm(), V_, gamma_, UfS_,
+                                                                  props_.dragModel, props_.nub, props_.rhob, Asrc_,
+                                                                  Omega_, e.d_tag(), Jd_, maxtag_);
+    };
+    if (L == 64) launch(k_calc_tc<64>);
+    else if (L == 8) launch(k_calc_tc<8>);
+    else launch(k_calc_tc<1>);
+  }
+
+  // lanes that share one cell in the per-cell sums: by the mean number of particles per cell
+  int lanes_per_cell(int n) const
+  {
+    static const int env = getenv("SF_CELL_LANES") ? atoi(getenv("SF_CELL_LANES")) : 0;
+    if (env) return env;
+    const double per_cell = (double)n / (double)std::max(mesh_.ncells, 1);
+    // measured at 37 particles per cell (1 M particles, 29x32x29 cells): k_calc_tc 130 / 46 / 96 us and
+    // k_particle_to_eulerian 62 / 26 / 91 us with 1 / 8 / 64 lanes per cell
+    return per_cell >= 256.0 ? 64 : (per_cell >= 2.0 ? 8 : 1);
   }
 
   void calc_tc_finish()
@@ -792,9 +839,14 @@ class Cloud {
     const int n = e.nlocal();
     ensure_particle_arrays();
     sort_by_cell(n);
-    k_particle_to_eulerian<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, cstart_,
-                                                                      cstart_ + mesh_.ncells + 1, idx2_, e.d_xr(),
-                                                                      e.d_vm(), V_, gamma_, Ue_);
+    const int L = lanes_per_cell(n);
+    auto launch = [&](auto kern) {
+      kern<<<div_up((size_t)mesh_.ncells * L, 256), 256, 0, s_>>>(mesh_.ncells, cstart_, cstart_ + mesh_.ncells + 1,
+                                                                  idx2_, e.d_xr(), e.d_vm(), V_, gamma_, Ue_);
+    };
+    if (L == 64) launch(k_particle_to_eulerian<64>);
+    else if (L == 8) launch(k_particle_to_eulerian<8>);
+    else launch(k_particle_to_eulerian<1>);
   }
 
   void scatter_finish()

@@ -10,8 +10,32 @@
 
 #include "sf_dem.h"
 
+// Compile-time variants of the sub-step kernel; the defaults are the measured best, the
+// others are built next to the shipped library by tests/build_variant.sh for A/B runs.
 #ifndef SF_UNROLL2
-#define SF_UNROLL2 1
+#define SF_UNROLL2 1          // neighbour loop unrolled by two: the prefetch ping-pongs between two register sets
+#endif
+#ifndef SF_NT
+#define SF_NT 1               // read-once rows as non-temporal loads
+#endif
+#ifndef SF_NT_ST
+#define SF_NT_ST SF_NT        // write-once rows as non-temporal stores
+#endif
+#ifndef SF_NT_OUT
+#define SF_NT_OUT 0           // output records non-temporal too (slower: the next sub-step gathers them)
+#endif
+#ifndef SF_ST_SHUFFLE
+#define SF_ST_SHUFFLE 1       // output records exchanged between lanes so that every store covers whole cache lines
+#endif
+#ifndef SF_GATHER_SHUFFLE
+#define SF_GATHER_SHUFFLE 1   // neighbour records taken from the next lane's registers when it holds them
+#endif
+// Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md)
+#ifndef SF_EXP_NOSHLD
+#define SF_EXP_NOSHLD 0       // skip the shear-history loads
+#endif
+#ifndef SF_EXP_NOSHST
+#define SF_EXP_NOSHST 0       // skip the shear-history stores
 #endif
 
 namespace sf {
@@ -20,18 +44,6 @@ __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 
 // Streamed (read-once / write-once per sub-step) rows.  SF_NT=1 marks them non-temporal so that they do not
 // evict the neighbour records the gathers want to find again in the 32 KB vector L1.
-#ifndef SF_NT
-#define SF_NT 1
-#endif
-#ifndef SF_NT_OUT
-#define SF_NT_OUT 0
-#endif
-#ifndef SF_ST_SHUFFLE
-#define SF_ST_SHUFFLE 1
-#endif
-#ifndef SF_GATHER_SHUFFLE
-#define SF_GATHER_SHUFFLE 1
-#endif
 template <class T>
 __device__ __forceinline__ T ld_stream(const T* p)
 {
@@ -41,9 +53,6 @@ __device__ __forceinline__ T ld_stream(const T* p)
   return *p;
 #endif
 }
-#ifndef SF_NT_ST
-#define SF_NT_ST SF_NT
-#endif
 template <class T>
 __device__ __forceinline__ void st_stream(T* p, T v)
 {
@@ -141,9 +150,6 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const size_t sbase = (size_t)(3 * sl) * cap + i;
     const int jraw = jraw_n1;
     Vec3 sh = {0.0, 0.0, 0.0};
-#ifndef SF_EXP_NOSHLD
-#define SF_EXP_NOSHLD 0
-#endif
     if (STYLE != 0 && (jraw & kTouchBit) && !(SF_EXP_NOSHLD && S.kstep >= 0)) {
       sh.x = ld_stream(&P.shear[sbase]);
       sh.y = ld_stream(&P.shear[sbase + cap]);
