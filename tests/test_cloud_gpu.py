@@ -190,6 +190,56 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
     return cloud
 
 
+@pytest.mark.parametrize("mesh_n", [(1, 2, 2), (2, 2, 2), (12, 12, 12)])
+def test_scatter_on_coarse_and_fine_meshes(mesh_n):
+    """particleToEulerianField / calcTcFields with ~450, ~220 and ~1 particles per cell: the three lanes-per-cell
+    variants of the per-cell sums and both paths of the per-cell index sort (<= 64 through shuffles, more through
+    memory); results equal the oracle's and are the same bits when repeated."""
+    from sedifoam_amd import synthetic, enhancedCloud
+    bed = synthetic.fcc_bed((8, 7, 8), seed=22, vmax=0.05)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    mesh_n = np.array(mesh_n, np.int32)
+    origin = bed["boxlo"].copy(); dxm = (bed["boxhi"] - bed["boxlo"]) / mesh_n
+    ncells = int(np.prod(mesh_n))
+    n = bed["n"]
+    d = bed["diameter"].copy()
+    V = np.full(ncells, float(np.prod(dxm)))
+    L = ob.lib()
+    cell = np.zeros(n, np.int32); gamma = np.zeros(ncells); Ue = np.zeros((ncells, 3))
+    results = []
+    for rep in range(2):
+        lmp = dc.make_hip(bed, cfg)
+        cloud = enhancedCloud(lmp, origin, dxm, mesh_n, dict(dragModel="ErgunWenYu", subCycles=1, g=(0, -9.81, 0)),
+                              dict(rhob=1000.0, nub=1e-6), 50e-6)
+        st = lmp.get_state()
+        L.orc_cell_owner(n, ob.P(st["x"]), ob.P(origin), ob.P(dxm), ob.P(mesh_n), ob.P(cell))
+        L.orc_particle_to_eulerian(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), ob.P(gamma), ob.P(Ue))
+        g, u = cloud.gamma(), cloud.Ue()
+        assert dc.rel_err(g, gamma) <= 1e-12 and dc.rel_err(u, Ue) <= 1e-11
+        assert np.sum(g * V) == pytest.approx(np.sum(np.pi * d ** 3 / 6.0), rel=1e-12)
+        out = [g, u]
+        if gamma.max() < 0.85:      # (finer meshes put alpha above 1: every closure returns inf, as in the reference)
+            Uf = np.tile([0.02, 0.05, -0.01], (ncells, 1))
+            cloud.setFluid(Uf=Uf)
+            cloud.evolve()          # refreshes UfSmoothed = Uf (no smoothing) and the particle state
+            cloud.calcTcFields()
+            st = lmp.get_state()
+            L.orc_cell_owner(n, ob.P(st["x"]), ob.P(origin), ob.P(dxm), ob.P(mesh_n), ob.P(cell))
+            L.orc_particle_to_eulerian(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), ob.P(gamma), ob.P(Ue))
+            Ur = np.linalg.norm(Uf[cell] - st["v"], axis=1)
+            Jd = np.zeros(n)
+            L.orc_ergun_wenyu_jd(n, ob.P(Ur), ob.P(np.ascontiguousarray(gamma[cell])), ob.P(d), 1e-6, 1000.0, ob.P(Jd))
+            Asrc = np.zeros((ncells, 3)); Omega = np.ones(ncells)
+            L.orc_calc_tc_fields_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ob.P(Jd), ncells, ob.P(V), ob.P(gamma),
+                                        ob.P(Uf), None, ob.P(Asrc), ob.P(Omega))
+            assert dc.rel_err(cloud.Asrc(), Asrc) <= 1e-10
+            out.append(cloud.Asrc())
+        results.append(out)
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+
+
 def test_coupled_ergun_wenyu_default_forces():
     _coupled_case("ErgunWenYu", {})
 
