@@ -227,12 +227,12 @@ def main():
         },
     }
     # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes
-    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_f_pmc_summary.json for the calibration note)
-    pmc = os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")
+    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_g_pmc_summary.json for the calibration note)
+    pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json")
     if os.path.exists(pmc) and args.particles == 1000000:
         try:
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]["total_raw"]
-            out["roofline"]["traffic_source"] = "profiles/r01_f_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+            out["roofline"]["traffic_source"] = "profiles/r01_g_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
         except Exception:
             pass
     # secondary metric of BASELINE.json: coupled CFD-DEM steps/s (drag closure + drag assembly + S sub-steps +
