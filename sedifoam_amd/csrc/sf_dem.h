@@ -422,7 +422,6 @@ private:
 void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
                     int* vals_out, int n, int end_bit, hipStream_t s);
 void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s);
-void inclusive_min_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s);
 void sort_pairs_u64(void*& tmp, size_t& tmp_bytes, unsigned long long* keys_in,
                     unsigned long long* keys_out, int* vals_in, int* vals_out, int n, int end_bit,
                     hipStream_t s);

@@ -822,22 +822,29 @@ void DemEngine::rebuild_sort()
   const int nb = div_up(nlocal_, 256);
   k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
                                       perm_.as<int>(), d_flags_);
-  int bits = 1;
-  while ((1 << bits) < grid_.nbins) bits++;
-  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
-                 perm_alt_.as<int>(), nlocal_, bits, stream_);
-  permute_locals(perm_alt_.as<int>(), nlocal_);
-  mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
-  // sorted bin keys -> cell ranges of owned atoms
-  // Plain keys (no tiles, no LDS staging): lower bound of every cell in the sorted order, stored reversed so that a
-  // forward min-scan fills the cells without atoms: [0] first positions, [1] owned table, [2], [3] the same for ghosts
+  // Plain keys (no tiles, no LDS staging): counting sort.  cell_start_ = [0] counts, then cursors | [1] first sorted
+  // position of every cell (owned) | [2] counts of the ghosts | [3] first position in the ghost order
   row_tables_ = grid_.tile <= 1 && !opt_lds_;
   if (row_tables_) {
     const int ne = grid_.nbins + 1;
-    SF_HIP(hipMemsetAsync(cell_start_, 0x7f, sizeof(int) * ne, stream_));
-    k_cell_first<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_, grid_.nbins);
-    inclusive_min_scan_i32(sort_tmp_, sort_tmp_bytes_, cell_start_, cell_start_ + cell_alloc_, ne, stream_);
+    int* count = cell_start_;
+    int* first = cell_start_ + cell_alloc_;
+    SF_HIP(hipMemsetAsync(count, 0, sizeof(int) * ne, stream_));
+    k_key_count<unsigned><<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, 0, count);
+    exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, first, ne, stream_);
+    SF_HIP(hipMemcpyAsync(count, first, sizeof(int) * ne, hipMemcpyDeviceToDevice, stream_));   // cursors
+    k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, perm_.as<int>());
+    k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), perm_alt_.as<int>());
+    permute_locals(perm_alt_.as<int>(), nlocal_);
+    mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   } else {
+    int bits = 1;
+    while ((1 << bits) < grid_.nbins) bits++;
+    sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
+                   perm_alt_.as<int>(), nlocal_, bits, stream_);
+    permute_locals(perm_alt_.as<int>(), nlocal_);
+    mark_frozen();
+    // sorted bin keys -> cell ranges of owned atoms
     SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
     k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
                                                      cell_start_ + 1, 4);
@@ -960,11 +967,11 @@ void DemEngine::bin_and_build()
                    stream_);
     if (row_tables_) {
       const int ne = grid_.nbins + 1;
-      int* first = cell_start_ + 2 * cell_alloc_;
-      SF_HIP(hipMemsetAsync(first, 0x7f, sizeof(int) * ne, stream_));
-      k_cell_first<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-          keys64_alt_.as<unsigned long long>(), nghost_, 32, first, grid_.nbins);
-      inclusive_min_scan_i32(sort_tmp_, sort_tmp_bytes_, first, cell_start_ + 3 * cell_alloc_, ne, stream_);
+      int* count = cell_start_ + 2 * cell_alloc_;
+      SF_HIP(hipMemsetAsync(count, 0, sizeof(int) * ne, stream_));
+      k_key_count<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
+          keys64_alt_.as<unsigned long long>(), nghost_, 32, count);
+      exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, cell_start_ + 3 * cell_alloc_, ne, stream_);
     } else {
       k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
           keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);

@@ -845,21 +845,39 @@ struct BuildParams {
   const int* gsrc;    // root of a periodic image (-1: ghost owned by another GPU)
   const double* gshift;
   double inv_prd[3];
-  // lower-bound tables over ALL cells, stored reversed (entry nbins - b = first sorted atom with cell >= b), or
-  // nullptr (tile-major keys, LDS staging): see the flattened candidate loop in k_build_neigh
+  // first sorted position of EVERY cell (entry nbins = one past the last atom), or nullptr (tile-major keys, LDS
+  // staging): see the row walk in k_build_neigh
   const int* lb_own;
   const int* lb_ghost;
 };
 
-// first sorted position of every cell, reversed layout, before the min-scan (cells without atoms keep the fill)
+// ---- counting sort of the owned atoms by cell key (plain keys): a by-product is first[b], the first sorted position
+// of EVERY cell b (with or without atoms), which the list build reads instead of per-cell ranges ----
 template <class K>
-__global__ __launch_bounds__(256) void k_cell_first(const K* keys, int n, int shift, int* rfirst, int nbins)
+__global__ __launch_bounds__(256) void k_key_count(const K* keys, int n, int shift, int* count)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int b = (int)(keys[i] >> shift);
-  if (i == 0 || (int)(keys[i - 1] >> shift) != b) rfirst[nbins - b] = i;
-  if (i == 0) rfirst[0] = n;   // "cell nbins": one past the last atom
+  atomicAdd(&count[(int)(keys[i] >> shift)], 1);
+}
+// slots inside a cell are handed out in arrival order ...
+__global__ __launch_bounds__(256) void k_key_place(const unsigned* keys, int n, int* cursor, int* arrival)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  arrival[atomicAdd(&cursor[keys[i]], 1)] = i;
+}
+// ... and then put into ascending old index, which is what a stable sort by key gives: perm[new] = old
+__global__ __launch_bounds__(256) void k_key_rank(const unsigned* keys, int n, const int* first, const int* arrival,
+                                                  int* perm)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned b = keys[i];
+  const int s = first[b], e = first[b + 1];
+  int r = 0;
+  for (int k = s; k < e; k++) r += arrival[k] < i ? 1 : 0;
+  perm[s + r] = i;
 }
 
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
@@ -973,8 +991,8 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
         lo = hi = 0;
         if (ro >= W || bo < 0 || bo >= no || by < 0 || by >= B.g.n[1]) return;
         const int b0 = B.g.xslow ? bin_key(B.g, bo, by, bi0) : bin_key(B.g, bi0, by, bo);
-        lo = lb[B.g.nbins - b0];
-        hi = lb[B.g.nbins - (b0 + (bi1 - bi0) + 1)];
+        lo = lb[b0];
+        hi = lb[b0 + (bi1 - bi0) + 1];
       };
       int nlo, nhi;
       row_range(0, 0, nlo, nhi);

@@ -46,23 +46,6 @@ void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, 
   SF_HIP(rocprim::exclusive_scan(tmp, avail, in, out, 0, (size_t)n, rocprim::plus<int>(), s));
 }
 
-void inclusive_min_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s)
-{
-  if (n <= 0) return;
-  size_t need = 0;
-  SF_HIP(rocprim::inclusive_scan(nullptr, need, in, out, (size_t)n, rocprim::minimum<int>(), s));
-  if (need > tmp_bytes) {
-    if (tmp) {
-      SF_HIP(hipStreamSynchronize(s));
-      SF_HIP(hipFree(tmp));
-    }
-    tmp_bytes = need + need / 4 + 4096;
-    SF_HIP(hipMalloc(&tmp, tmp_bytes));
-  }
-  size_t avail = tmp_bytes;
-  SF_HIP(rocprim::inclusive_scan(tmp, avail, in, out, (size_t)n, rocprim::minimum<int>(), s));
-}
-
 void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
                     int* vals_out, int n, int end_bit, hipStream_t s)
 {
