@@ -343,6 +343,7 @@ private:
   int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;
+  int migrate_leavers_ = 0;        // atoms packed by migrate_pack since the last compaction
   DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x
   double skin_ = 0.0, dt_ = 0.0;
   double rmax_ = 0.0;
@@ -422,6 +423,8 @@ private:
 void sort_pairs_u32(void*& tmp, size_t& tmp_bytes, unsigned* keys_in, unsigned* keys_out, int* vals_in,
                     int* vals_out, int n, int end_bit, hipStream_t s);
 void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s);
+void select_zero_keys(void*& tmp, size_t& tmp_bytes, const unsigned* keys, int* out, int* d_count, int n,
+                      hipStream_t s);
 void sort_pairs_u64(void*& tmp, size_t& tmp_bytes, unsigned long long* keys_in,
                     unsigned long long* keys_out, int* vals_in, int* vals_out, int n, int end_bit,
                     hipStream_t s);

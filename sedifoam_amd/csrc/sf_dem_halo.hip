@@ -22,21 +22,14 @@ constexpr int kBorderDoubles = 14;   // x r | v m | omega | tag type mask
 constexpr int kForwardDoubles = 9;
 constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec
 
-// key 0 = selected, 1 = not (a stable 1-bit sort then lists the selected atoms first, ascending)
+// key 0 = selected, 1 = not (a stable compaction then lists the selected atoms, ascending)
 // mode 0: x < bound ; mode 1: x >= bound
-__global__ __launch_bounds__(1024) void k_select_keys(const double4* xr, int n, int mode, double bound,
-                                                      unsigned* keys, int* idx, int* counter)
+__global__ __launch_bounds__(256) void k_select_keys(const double4* xr, int n, int mode, double bound, unsigned* keys)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool sel = false;
-  if (i < n) {
-    const double x = xr[i].x;
-    sel = mode == 0 ? (x < bound) : (x >= bound);
-    keys[i] = sel ? 0u : 1u;
-    idx[i] = i;
-  }
-  const int t = block_sum_int_1024(sel ? 1 : 0);   // one global atomic per block (sf_dem_kernels.h)
-  if (threadIdx.x == 0 && t) atomicAdd(counter, t);
+  if (i >= n) return;
+  const double x = xr[i].x;
+  keys[i] = (mode == 0 ? (x < bound) : (x >= bound)) ? 0u : 1u;
 }
 
 __global__ __launch_bounds__(256) void k_border_pack(const int* list, int n, double xshift, const double4* xr,
@@ -185,12 +178,10 @@ __global__ __launch_bounds__(256) void k_stay_keys(const int* leave, int n, unsi
 int DemEngine::select_locals(int mode, double bound, DevArray& list)
 {
   if (!nlocal_) return 0;
-  reset_flag(F_SEND_COUNT, 0);
-  k_select_keys<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, mode, bound,
-                                                           keys_.as<unsigned>(), perm_.as<int>(),
-                                                           d_flags_ + F_SEND_COUNT);
-  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
-                 list.as<int>(), nlocal_, 1, stream_);
+  k_select_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, mode, bound,
+                                                         keys_.as<unsigned>());
+  select_zero_keys(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), list.as<int>(), d_flags_ + F_SEND_COUNT,
+                   nlocal_, stream_);
   read_flags();
   return h_flags_[F_SEND_COUNT];
 }
@@ -459,6 +450,7 @@ long long DemEngine::migrate_pack(int side, double xshift, double* buf, long lon
     k_migrate_pack<<<div_up(n, 128), 128, 0, stream_>>>(list.as<int>(), n, xshift, P, cap_, nwalls_, mrec_,
                                                         have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1);
   }
+  migrate_leavers_ += n;
   sync();
   return (long long)n * rec;
 }
@@ -466,19 +458,17 @@ long long DemEngine::migrate_pack(int side, double xshift, double* buf, long lon
 void DemEngine::migrate_compact()
 {
   migrate_pending_ = false;
-  if (!nlocal_) return;
+  const int left = migrate_leavers_;
+  migrate_leavers_ = 0;
+  if (!nlocal_ || !left) return;   // (the usual rebuild: nobody crossed a face)
+  // the staying atoms, in their order, move to the front
   k_stay_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(leave_.as<int>(), nlocal_, keys_.as<unsigned>(),
                                                          perm_.as<int>());
-  // count leavers: select on the key itself
-  reset_flag(F_SEND_COUNT2, 0);
-  sort_pairs_u32(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), keys_alt_.as<unsigned>(), perm_.as<int>(),
-                 perm_alt_.as<int>(), nlocal_, 1, stream_);
-  // number staying = first index with key 1
-  std::vector<unsigned> hk(nlocal_);
-  SF_HIP(hipMemcpyAsync(hk.data(), keys_alt_.ptr, sizeof(unsigned) * nlocal_, hipMemcpyDeviceToHost, stream_));
-  sync();
-  const int nstay = (int)(std::lower_bound(hk.begin(), hk.end(), 1u) - hk.begin());
-  if (nstay == nlocal_) return;
+  select_zero_keys(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), perm_alt_.as<int>(), d_flags_ + F_SEND_COUNT2,
+                   nlocal_, stream_);
+  read_flags();
+  const int nstay = h_flags_[F_SEND_COUNT2];
+  if (nstay + left != nlocal_) fail("migration: %d atoms stay + %d leave != %d owned", nstay, left, nlocal_);
   permute_locals(perm_alt_.as<int>(), nstay);
   nlocal_ = nstay;
 }
@@ -575,6 +565,7 @@ void DemEngine::delete_particles(const int* tags, int n)
     compute_partner_tags();
   }
   SF_HIP(hipMemcpyAsync(leave_.ptr, leave.data(), sizeof(int) * nlocal_, hipMemcpyHostToDevice, stream_));
+  migrate_leavers_ = ndel;
   migrate_compact();
   nghost_ = 0;
   if (setup_done_ && !have_subdomain_) {

@@ -23,5 +23,5 @@ for k in range(5):
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 print("decomposed rebuild ms:", ["%.2f" % (1e3 * t) for t in ts])
 pr = cProfile.Profile(); pr.enable(); drv.rebuild(); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 dist.destroy_process_group()
