@@ -77,12 +77,30 @@ def cpu_worker(argv):
     print(json.dumps({"value": v, "n": int(n_s), "secs": secs}))
 
 
+def _usable_cores():
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota of the container"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline_all_cores(npart, sub):
     """What `mpirun -np <cores>` of the reference does on this host, without its halo traffic: one oracle process per
     core, each with its own slab of `npart` particles (weak, like the GPU ranks); throughput = sum over processes of
     particles x sub-steps / the slowest process's run time (setup and list build are not timed, as on the GPU)."""
     import subprocess
-    cores = len(os.sched_getaffinity(0))
+    cores = _usable_cores()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(npart), str(sub),
                                str(777 + c)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for c in range(cores)]
