@@ -207,6 +207,9 @@ typedef struct {
 int sf_dem_comm_unique_id(char *id128);
 int sf_dem_comm_init(void *ptr, const char *id128, int rank, int world);
 int sf_dem_halo_run(void *ptr, int first_k, int n, const sf_halo_layout *lay, int *trigger);
+/* owned atoms that left the slab through either face (>= 0; < 0: error): when it is 0 on every rank the migration
+ * exchange of this rebuild can be skipped */
+long long sf_dem_migrate_count(void *ptr);
 long long sf_dem_migrate_pack(void *ptr, int side, double xshift, double *dev_buf, long long max_doubles);
 int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
 int sf_dem_migrate_record_doubles(void *ptr);

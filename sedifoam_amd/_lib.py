@@ -136,6 +136,7 @@ _SIGS = {
     "sf_dem_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sf_dem_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
     "sf_dem_halo_run": (C.c_int, [vp, C.c_int, C.c_int, vp, ip]),
+    "sf_dem_migrate_count": (C.c_longlong, [vp]),
     "sf_dem_migrate_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp, C.c_longlong]),
     "sf_dem_migrate_unpack": (C.c_int, [vp, vp, C.c_longlong]),
     "sf_dem_migrate_record_doubles": (C.c_int, [vp]),

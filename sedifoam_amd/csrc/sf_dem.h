@@ -311,6 +311,9 @@ private:
   void migrate_compact();
   void compute_partner_tags();
   int select_locals(int mode, double bound, DevArray& list);
+ public:
+  long long migrate_count();   // owned atoms outside [sublo, subhi): what the two migrate_pack calls would send
+ private:
   void make_periodic_ghosts();
   void bin_and_build();
   void read_flags();

@@ -32,6 +32,19 @@ __global__ __launch_bounds__(256) void k_select_keys(const double4* xr, int n, i
   keys[i] = (mode == 0 ? (x < bound) : (x >= bound)) ? 0u : 1u;
 }
 
+// owned atoms that left the slab [lo, hi) through either face
+__global__ __launch_bounds__(1024) void k_count_outside(const double4* xr, int n, double lo, double hi, int* counter)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool out = false;
+  if (i < n) {
+    const double x = xr[i].x;
+    out = x < lo || x >= hi;
+  }
+  const int t = block_sum_int_1024(out ? 1 : 0);   // one global atomic per block (sf_dem.h)
+  if (threadIdx.x == 0 && t) atomicAdd(counter, t);
+}
+
 __global__ __launch_bounds__(256) void k_border_pack(const int* list, int n, double xshift, const double4* xr,
                                                      const double4* vm, const double4* om, const int* tag,
                                                      const int* type, const int* mask, double* buf)
@@ -430,6 +443,16 @@ static MigratePtrs mig_ptrs(DevArray& xr, DevArray& vm, DevArray& om, DevArray& 
   P.wshear = wshear.as<double>(); P.shear = shear.as<double>();
   P.wtouch = wtouch.as<unsigned char>();
   return P;
+}
+
+long long DemEngine::migrate_count()
+{
+  if (!nlocal_) return 0;
+  reset_flag(F_SEND_COUNT, 0);
+  k_count_outside<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, sublo_x_, subhi_x_,
+                                                             d_flags_ + F_SEND_COUNT);
+  read_flags();
+  return h_flags_[F_SEND_COUNT];
 }
 
 long long DemEngine::migrate_pack(int side, double xshift, double* buf, long long max_doubles)

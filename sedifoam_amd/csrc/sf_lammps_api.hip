@@ -699,6 +699,13 @@ long long sf_dem_migrate_pack(void* ptr, int side, double xshift, double* dev_bu
   SF_API_END(n)
 }
 
+long long sf_dem_migrate_count(void* ptr)
+{
+  SF_API_BEGIN
+  const long long n = H(ptr)->eng.migrate_count();
+  SF_API_END(n)
+}
+
 int sf_dem_migrate_unpack(void* ptr, const double* dev_buf, long long ndoubles)
 {
   SF_API_BEGIN

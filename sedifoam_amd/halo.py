@@ -86,6 +86,9 @@ class HipSlabEngine:
     def migrate_record_doubles(self):
         return self.check(self.L.sf_dem_migrate_record_doubles(self.lmp.ptr))
 
+    def migrate_count(self):
+        return self.check(self.L.sf_dem_migrate_count(self.lmp.ptr))
+
     def migrate_pack(self, side, xshift, buf):
         return self.check(self.L.sf_dem_migrate_pack(self.lmp.ptr, side, xshift, buf.data_ptr(), buf.numel()))
 
@@ -333,18 +336,24 @@ class SlabDriver:
     def rebuild(self):
         e = self.e
         e.rebuild_begin()
-        e.migrate_set_slots(self._allreduce_max(e.info().max_neigh_used))
-        rec = e.migrate_record_doubles()
-        nmax = max(self._cap_atoms // 8, 1024)
-        b0 = self._buf("mig_l", nmax * rec)
-        b1 = self._buf("mig_r", nmax * rec)
-        n0 = e.migrate_pack(0, self.shift_left, b0)
-        n1 = e.migrate_pack(1, self.shift_right, b1)
-        rl, ml, rr, mr = self._exchange(b0, n0, b1, n1)
-        if self.world == 1 and not self.periodic_x and (n0 or n1):
-            raise RuntimeError("Lost atoms: an atom left the non-periodic box in x")
-        e.migrate_unpack(rl, ml)
-        e.migrate_unpack(rr, mr)
+        # one all-reduce carries the history slots a migrating atom needs (max over ranks of max_neigh_used) and, in
+        # the bits above, whether any rank has an atom outside its slab: the usual rebuild migrates nothing and then
+        # skips the pack / count exchange / data exchange / unpack round
+        crossed = e.migrate_count() if hasattr(e, "migrate_count") else 1
+        v = self._allreduce_max(int(e.info().max_neigh_used) + ((1 << 20) if crossed else 0))
+        e.migrate_set_slots(v & ((1 << 20) - 1))
+        if v >> 20:
+            rec = e.migrate_record_doubles()
+            nmax = max(self._cap_atoms // 8, 1024)
+            b0 = self._buf("mig_l", nmax * rec)
+            b1 = self._buf("mig_r", nmax * rec)
+            n0 = e.migrate_pack(0, self.shift_left, b0)
+            n1 = e.migrate_pack(1, self.shift_right, b1)
+            rl, ml, rr, mr = self._exchange(b0, n0, b1, n1)
+            if self.world == 1 and not self.periodic_x and (n0 or n1):
+                raise RuntimeError("Lost atoms: an atom left the non-periodic box in x")
+            e.migrate_unpack(rl, ml)
+            e.migrate_unpack(rr, mr)
         e.rebuild_sort()
         cap = max(self._cap_atoms, e.info().nlocal)
         s0 = self._buf("bor_l", cap * BORDER_DOUBLES)

@@ -21,7 +21,7 @@ for rep in range(R):
     e = self.e
     torch.cuda.synchronize(); t = time.perf_counter()
     e.rebuild_begin(); t = tick("begin", t)
-    e.migrate_set_slots(self._allreduce_max(e.info().max_neigh_used)); t = tick("allreduce+slots", t)
+    crossed = e.migrate_count(); v = self._allreduce_max(int(e.info().max_neigh_used) + ((1 << 20) if crossed else 0)); e.migrate_set_slots(v & ((1 << 20) - 1)); t = tick("count+allreduce+slots", t)
     rec = e.migrate_record_doubles()
     nmax = max(self._cap_atoms // 8, 1024)
     b0 = self._buf("mig_l", nmax * rec); b1 = self._buf("mig_r", nmax * rec)
