@@ -146,6 +146,10 @@ class HipSlabEngine:
 
     def halo_run(self, first_k, n, lay):
         from . import _lib
+        t = C.c_int()
+        if "_c" in lay:                      # the ctypes image of a cached layout
+            self.check(self.L.sf_dem_halo_run(self.lmp.ptr, int(first_k), int(n), C.byref(lay["_c"][0]), C.byref(t)))
+            return t.value
         W = len(lay["in_split"])
         LL = C.c_longlong * W
         so, ro = [0] * W, [0] * W
@@ -162,7 +166,7 @@ class HipSlabEngine:
         h.send_off, h.send_cnt, h.recv_off, h.recv_cnt = keep
         h.dev_shdr, h.dev_rhdr = lay["shdr"].data_ptr(), lay["rhdr"].data_ptr()
         h.dev_tx, h.dev_rx = lay["tx"].data_ptr(), lay["rx"].data_ptr()
-        t = C.c_int()
+        lay["_c"] = (h, keep)
         self.check(self.L.sf_dem_halo_run(self.lmp.ptr, int(first_k), int(n), C.byref(h), C.byref(t)))
         return t.value
 
@@ -253,6 +257,7 @@ class SlabDriver:
         self._bufs = {}
         self._nrecv = [0, 0]
         self.n_rebuilds = 0
+        self._lay, self._lay_key = None, -1
         self.is_setup = False
 
     # ---- plumbing ----
@@ -369,8 +374,15 @@ class SlabDriver:
         self.n_rebuilds += 1
 
     def _fused_layout(self):
-        """Send / receive layout of the one-collective forward halo (valid until the next rebuild): per peer rank one
-        header double (rebuild trigger) + the forward records for / from that peer."""
+        """Send / receive layout of the one-collective forward halo (valid until the next rebuild, cached): per peer
+        rank one header double (rebuild trigger) + the forward records for / from that peer."""
+        if self._lay is not None and self._lay_key == self.n_rebuilds:
+            return self._lay
+        self._lay = self._make_fused_layout()
+        self._lay_key = self.n_rebuilds
+        return self._lay
+
+    def _make_fused_layout(self):
         F = FORWARD_DOUBLES
         ns, nr = self._nsend, self._nrecv          # [to left, to right], [from left, from right]
         W = self.world
