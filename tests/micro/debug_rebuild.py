@@ -1,5 +1,7 @@
+"""development helper: step the HIP engine and the oracle side by side through many rebuilds of a fast periodic bed and
+print the first sub-step at which forces, history sets or ghost counts part (how the pre_exchange order bug was found)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from sedifoam_amd import synthetic
 from tests import dem_cases as dc
