@@ -30,6 +30,9 @@
 #ifndef SF_GATHER_SHUFFLE
 #define SF_GATHER_SHUFFLE 1   // neighbour records taken from the next lane's registers when it holds them
 #endif
+#ifndef SF_TOUCH_PREFETCH
+#define SF_TOUCH_PREFETCH 1   // v, omega of a neighbour are prefetched only when the pair touched in the last sub-step
+#endif
 // Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md)
 #ifndef SF_EXP_NOSHLD
 #define SF_EXP_NOSHLD 0       // skip the shear-history loads
@@ -121,6 +124,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   struct Rec {
     double4 x, v, w;
     int l;   // LDS: position of the neighbour in the staged tile
+    bool vw; // v and w were requested
+  };
+  // The contact law needs the neighbour's v and omega only if the pair touches, and a pair that touches now almost
+  // always touched one sub-step ago (its touch bit): for the others only x is gathered, and the rare new contact loads
+  // v and omega on demand.  A settled bed lists about twice as many neighbours as it has contacts.
+  auto wants_vw = [&](const int jraw) {
+    return NEED_VW && (LUB || !SF_TOUCH_PREFETCH || (jraw & kTouchBit) != 0);
   };
   // request the records of the neighbour in `slot` (global gather), or its LDS position
   auto fetch = [&](int jraw, size_t slot, Rec& R) {
@@ -130,7 +140,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       const int j = neigh_index(jraw, S.roots);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.x = P.xr_in[j];
-      if (NEED_VW) {
+      R.vw = wants_vw(jraw);
+      if (R.vw) {
         R.v = P.vm_in[j];
         R.w = P.om_in[j];
       }
@@ -141,6 +152,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   Rec RA, RB;
   RA.x = RA.v = RA.w = RB.x = RB.v = RB.w = double4{0, 0, 0, 0};
   RA.l = RB.l = 0;
+  RA.vw = RB.vw = false;
   if (nn > 0) fetch(jraw_n1, (size_t)q * cap + i, RA);
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
@@ -178,7 +190,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
           t.w = {__shfl_down(cur.w.x, 1, 64), __shfl_down(cur.w.y, 1, 64), __shfl_down(cur.w.z, 1, 64),
                  __shfl_down(cur.w.w, 1, 64)};
         }
-        reuse = lane < 63 && ((act >> (lane + 1)) & 1ull) && jdn == jn;
+        const bool donor_vw = __shfl_down((int)cur.vw, 1, 64) != 0;
+        reuse = lane < 63 && ((act >> (lane + 1)) & 1ull) && jdn == jn && (donor_vw || !wants_vw(jraw_n1));
         if (reuse) {
           nxt.x = t.x;
           if (NEED_VW) {
@@ -186,6 +199,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
             nxt.w = t.w;
           }
           nxt.l = jn;
+          nxt.vw = donor_vw;
         }
       }
 #endif
@@ -219,6 +233,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         // unset non-touching neighbours (:131-139); the stale shear is ignored once the bit is clear
         if (jraw & kTouchBit) P.neigh[slot] = jraw & ~kTouchBit;
       } else {
+        if (!LDS && !cur.vw) {   // a contact that did not exist one sub-step ago
+          vj4 = P.vm_in[cur.l];
+          wj4 = P.om_in[cur.l];
+        }
         ContactIn c;
         c.del = del;
         c.rsq = rsq;
