@@ -53,8 +53,9 @@ int sf_lammps_file(void *ptr, const char *path);
  * the reference's in.lammps files use: units, atom_style sphere, atom_modify, boundary, newton,
  * communicate, processors, read_data (or sf_dem_create_atoms), neighbor, neigh_modify, pair_style {gran/hertzFix/history,
  * gran/hooke/history, lubricate/poly, hybrid/overlay}, pair_coeff, timestep, velocity all set,
- * fix {nve/sphere, gravity, fdrag, wall/gran, wall/granFix, cohesive}, run, thermo*, dump and
- * group (accepted, no effect).  returns NULL like LAMMPS, or an error string. */
+ * fix {nve/sphere, gravity, fdrag, freeze, cohesive, wall/gran and wall/granFix ({x,y,z}plane | zcylinder, wiggle | shear)},
+ * group {type, subtract, union, intersect}, run; thermo*, dump and restart are accepted without effect.
+ * Returns NULL like LAMMPS, or an error string. */
 const char *sf_lammps_command(void *ptr, const char *line);
 /* library.h:34 (debug barrier) -- a stream synchronise here */
 int sf_lammps_sync(void *ptr);

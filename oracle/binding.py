@@ -83,6 +83,8 @@ def _declare(L):
     L.orc_dem_fix_wall.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                    C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                    C.c_double, C.c_double, C.c_int]
+    L.orc_dem_wall_cylinder.argtypes = [C.c_void_p, C.c_double]
+    L.orc_dem_wall_motion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
     L.orc_dem_set_mask.argtypes = [C.c_void_p, ip]
     L.orc_dem_set_groups.argtypes = [C.c_void_p] + [C.c_int] * 6
     L.orc_dem_neighbor.argtypes = [C.c_void_p, C.c_double]
@@ -140,6 +142,10 @@ def _declare(L):
     L.orc_fix_wall_gran.argtypes = [C.POINTER(GranParams), C.c_int, C.c_int, C.c_double,
                                     C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp, dp,
                                     ip, C.c_int, dp, dp, dp]
+    L.orc_fix_wall_gran_moving.argtypes = [C.POINTER(GranParams), C.c_int, C.c_int, C.c_double, C.c_double,
+                                           C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                           C.c_double, C.c_long, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp,
+                                           dp, ip, C.c_int, dp, dp, dp]
     L.orc_nve_sphere_initial.argtypes = [C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp]
     L.orc_nve_sphere_final.argtypes = [C.c_int, C.c_double, dp, dp, dp, dp, dp, dp]
     L.orc_fix_gravity.argtypes = [C.c_int, C.c_double, dp, dp, dp]
@@ -224,6 +230,14 @@ class OracleDem:
         self.L.orc_dem_fix_wall(self.h, dim, lo is None, lo or 0.0, hi is None, hi or 0.0, kn,
                                 kt is None, kt or 0.0, gamman, gammat is None, gammat or 0.0,
                                 xmu, dampflag)
+
+    def wall_cylinder(self, radius):
+        """the wall registered last becomes `zcylinder radius`"""
+        self.L.orc_dem_wall_cylinder(self.h, float(radius))
+
+    def wall_motion(self, kind, axis, a, b=0.0):
+        """the wall registered last: kind "wiggle" (axis, amplitude, period) or "shear" (axis, vshear)"""
+        self.L.orc_dem_wall_motion(self.h, 1 if kind == "wiggle" else 2, int(axis), float(a), float(b))
 
     def set_mask(self, mask):
         """per-atom group bits in creation order (bit 0 = all is always set)"""

@@ -243,24 +243,56 @@ void orc_pair_gran_hooke_history(const orc_gran_params *p, double dt, int shearu
                  freeze_group_bit, list, f, torque);
 }
 
-void orc_fix_wall_gran(const orc_gran_params *p, int pairstyle, int wallstyle, double lo,
-                       double hi, double dt, int shearupdate, int nlocal, const double *x,
-                       const double *v, const double *omega, const double *radius,
-                       const double *rmass, const int *mask, int groupbit, double *shear,
-                       double *f, double *torque)
+/* FixWallGranFix::post_force, fix_wall_granFix.cpp:247-345, with the moving walls of :255-264 (wiggle: the wall
+ * oscillates along `axis`, lo/hi follow when the axis is the wall's normal; shear: the wall slides along `axis`) and the
+ * z cylinder of :309-322 (wallstyle 3; with shear about x or y the cylinder ROTATES: vwall = vshear (y, -x, 0)/|xy|).
+ * steps = update->ntimestep - time_origin. */
+void orc_fix_wall_gran_moving(const orc_gran_params *p, int pairstyle, int wallstyle, double lo, double hi,
+                              double cylradius, int wiggle, int wshear, int axis, double amplitude,
+                              double period, double vshear, long steps, double dt, int shearupdate,
+                              int nlocal, const double *x, const double *v, const double *omega,
+                              const double *radius, const double *rmass, const int *mask, int groupbit,
+                              double *shear, double *f, double *torque)
 {
   int i, k;
+  double wlo = lo, whi = hi;                                        /* :254-264 */
+  double vwall[3] = {0.0, 0.0, 0.0};
+  if (wiggle) {
+    double om = 2.0 * 3.14159265358979323846 / period;              /* :165 (MY_PI) */
+    double arg = om * (double)steps * dt;
+    if (wallstyle == axis) {
+      wlo = lo + amplitude - amplitude * cos(arg);
+      whi = hi + amplitude - amplitude * cos(arg);
+    }
+    vwall[axis] = amplitude * om * sin(arg);
+  } else if (wshear)
+    vwall[axis] = vshear;
   for (i = 0; i < nlocal; i++) {
     if (!(mask[i] & groupbit)) continue;
     contact_in c;
     contact_out o;
-    c.del[0] = c.del[1] = c.del[2] = 0.0;
-    double del1 = x[3 * i + wallstyle] - lo;                        /* :294-308 */
-    double del2 = hi - x[3 * i + wallstyle];
-    if (del1 < del2) c.del[wallstyle] = del1;
-    else c.del[wallstyle] = -del2;
-    c.rsq = c.del[0] * c.del[0] + c.del[1] * c.del[1] + c.del[2] * c.del[2];
     double rad = radius[i];
+    c.del[0] = c.del[1] = c.del[2] = 0.0;
+    if (wallstyle < 3) {
+      double del1 = x[3 * i + wallstyle] - wlo;                     /* :294-308 */
+      double del2 = whi - x[3 * i + wallstyle];
+      if (del1 < del2) c.del[wallstyle] = del1;
+      else c.del[wallstyle] = -del2;
+    } else {                                                        /* :309-322 */
+      double delxy = sqrt(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1]);
+      double delr = cylradius - delxy;
+      if (delr > rad) c.del[2] = cylradius;
+      else {
+        c.del[0] = -delr / delxy * x[3 * i];
+        c.del[1] = -delr / delxy * x[3 * i + 1];
+        if (wshear && axis != 2) {
+          vwall[0] = vshear * x[3 * i + 1] / delxy;
+          vwall[1] = -vshear * x[3 * i] / delxy;
+          vwall[2] = 0.0;
+        }
+      }
+    }
+    c.rsq = c.del[0] * c.del[0] + c.del[1] * c.del[1] + c.del[2] * c.del[2];
     if (c.rsq > rad * rad) {                                        /* :326-331 */
       shear[3 * i] = shear[3 * i + 1] = shear[3 * i + 2] = 0.0;
       continue;
@@ -268,7 +300,7 @@ void orc_fix_wall_gran(const orc_gran_params *p, int pairstyle, int wallstyle, d
     double r = sqrt(c.rsq);
     double rinv = 1.0 / r;
     for (k = 0; k < 3; k++) {
-      c.vr[k] = v[3 * i + k] - 0.0;                                 /* vwall = 0 (no wiggle/shear) */
+      c.vr[k] = v[3 * i + k] - vwall[k];                            /* :457-459, :575-577 */
       c.wr[k] = rad * omega[3 * i + k] * rinv;                      /* :476-478, :594-596 */
     }
     c.meff = rmass[i];                                              /* :482, :600 */
@@ -285,4 +317,14 @@ void orc_fix_wall_gran(const orc_gran_params *p, int pairstyle, int wallstyle, d
       torque[3 * i + k] -= rad * o.tor[k];
     }
   }
+}
+
+void orc_fix_wall_gran(const orc_gran_params *p, int pairstyle, int wallstyle, double lo,
+                       double hi, double dt, int shearupdate, int nlocal, const double *x,
+                       const double *v, const double *omega, const double *radius,
+                       const double *rmass, const int *mask, int groupbit, double *shear,
+                       double *f, double *torque)
+{
+  orc_fix_wall_gran_moving(p, pairstyle, wallstyle, lo, hi, 0.0, 0, 0, 0, 0.0, 1.0, 0.0, 0, dt, shearupdate,
+                           nlocal, x, v, omega, radius, rmass, mask, groupbit, shear, f, torque);
 }

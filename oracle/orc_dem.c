@@ -171,6 +171,29 @@ void orc_dem_fix_wall(orc_dem *d, int wallstyle, int lo_null, double lo, int hi_
   fx->wshear = calloc(3 * (size_t)d->nmax, sizeof(double));
 }
 
+/* the last registered wall becomes a z cylinder of the given radius (wallstyle zcylinder, :107-112) */
+void orc_dem_wall_cylinder(orc_dem *d, double cylradius)
+{
+  orc_fix *fx = &d->fix[d->nfix - 1];
+  fx->wallstyle = 3;
+  fx->cylradius = cylradius;
+  fx->lo = fx->hi = 0.0;
+}
+
+/* the last registered wall wiggles (kind 1: axis, amplitude, period) or shears (kind 2: axis, vshear), :117-141 */
+void orc_dem_wall_motion(orc_dem *d, int kind, int axis, double a, double b)
+{
+  orc_fix *fx = &d->fix[d->nfix - 1];
+  fx->wiggleflag = kind == 1;
+  fx->shearflag = kind == 2;
+  fx->axis = axis;
+  if (kind == 1) {
+    fx->amplitude = a;
+    fx->period = b;
+  } else
+    fx->vshear = a;
+}
+
 void orc_dem_set_mask(orc_dem *d, const int *mask)
 {
   int i;
@@ -488,6 +511,13 @@ int orc__check_distance(const orc_dem *d)
 
 void orc__compute_forces(orc_dem *d, int setupflag)
 {
+  /* update->ntimestep [3P]: incremented at the top of every step, so post_force of step n sees n; the setup
+   * evaluation sees the value the run starts from.  Called exactly once per step and once per setup. */
+  if (!setupflag) d->ntimestep++;
+  else {
+    int k;
+    for (k = 0; k < d->nfix; k++) d->fix[k].time_origin = d->ntimestep;   /* FixWallGranFix::init, :181 */
+  }
   int nall = d->nlocal + d->nghost, i, w;
   int shearupdate = setupflag ? 0 : 1; /* pair_gran_hertzFix_history.cpp:65-66 */
   for (i = 0; i < 3 * nall; i++) d->f[i] = d->torque[i] = 0.0;
@@ -520,9 +550,12 @@ void orc__compute_forces(orc_dem *d, int setupflag)
         break;
       case FIX_WALL:
         /* wall/granFix follows the pair style (fix_wall_granFix.cpp:217-229) */
-        orc_fix_wall_gran(&fx->wp, d->pair_style == 2 ? 2 : 1, fx->wallstyle, fx->lo, fx->hi,
-                          d->dt, shearupdate, d->nlocal, d->x, d->v, d->omega, d->radius,
-                          d->rmass, d->mask, fx->groupbit, fx->wshear, d->f, d->torque);
+        orc_fix_wall_gran_moving(&fx->wp, d->pair_style == 2 ? 2 : 1, fx->wallstyle, fx->lo, fx->hi,
+                                 fx->cylradius, fx->wiggleflag, fx->shearflag, fx->axis, fx->amplitude,
+                                 fx->period > 0.0 ? fx->period : 1.0, fx->vshear,
+                                 d->ntimestep - fx->time_origin, d->dt, shearupdate, d->nlocal, d->x, d->v,
+                                 d->omega, d->radius, d->rmass, d->mask, fx->groupbit, fx->wshear, d->f,
+                                 d->torque);
         break;
       case FIX_COHESIVE:
         /* FixCohe::setup() has the wrong signature (fix_cohesive.cpp:117) so the fix is

@@ -14,8 +14,11 @@ typedef struct {
   /* fdrag */
   double carrier_rho;
   /* wall */
-  int wallstyle;
-  double lo, hi;
+  int wallstyle;                       /* 0/1/2 plane normal, 3 z cylinder */
+  double lo, hi, cylradius;
+  int wiggleflag, shearflag, axis;     /* fix_wall_granFix.cpp:117-141 (wiggle, wshear) */
+  double amplitude, period, vshear;
+  long time_origin;                    /* :181 */
   orc_gran_params wp;
   double *wshear; /* 3*nmax */
   /* cohesive */
@@ -57,6 +60,7 @@ struct orc_dem {
   int *binhead, *binnext;
   int nbins_alloc;
   int nbuilds;
+  long ntimestep;        /* update->ntimestep [3P] */
   int setup_done;
   int nve_bit, freeze_bit;   /* group of fix nve/sphere (default all), of fix freeze (0: none) */
   int nthreads;

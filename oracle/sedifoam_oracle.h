@@ -99,6 +99,12 @@ void orc_fix_fluid_drag(int nlocal, double dt, double carrier_rho, const double 
 /* N2: FixWallGranFix::post_force for plane walls  fix_wall_granFix.cpp:247-345,
  * hooke_history :441-554, hertz_history :558-679.  wallstyle 0/1/2 = x/y/z plane;
  * lo/hi = +-1e20 when NULL.  pairstyle 1 = hooke_history, 2 = hertz_history. */
+void orc_fix_wall_gran_moving(const orc_gran_params *p, int pairstyle, int wallstyle, double lo, double hi,
+                              double cylradius, int wiggle, int wshear, int axis, double amplitude,
+                              double period, double vshear, long steps, double dt, int shearupdate,
+                              int nlocal, const double *x, const double *v, const double *omega,
+                              const double *radius, const double *rmass, const int *mask, int groupbit,
+                              double *shear, double *f, double *torque);
 void orc_fix_wall_gran(const orc_gran_params *p, int pairstyle, int wallstyle, double lo,
                        double hi, double dt, int shearupdate, int nlocal, const double *x,
                        const double *v, const double *omega, const double *radius,
@@ -146,6 +152,10 @@ void orc_dem_fix_wall(orc_dem *d, int wallstyle, int lo_null, double lo, int hi_
 /* groups: per-atom group bits (bit 0 = all) in creation order, then the group of every fix kind registered so far
  * (LAMMPS: `fix ID group style ...`); freeze_bit = 0: no fix freeze */
 void orc_dem_set_mask(orc_dem *d, const int *mask);
+/* the last registered wall becomes `zcylinder radius` (fix_wall_granFix.cpp:107-112) */
+void orc_dem_wall_cylinder(orc_dem *d, double cylradius);
+/* the last registered wall moves: kind 1 = wiggle axis amplitude period, kind 2 = shear axis vshear (:117-141) */
+void orc_dem_wall_motion(orc_dem *d, int kind, int axis, double a, double b);
 void orc_dem_set_groups(orc_dem *d, int nve_bit, int gravity_bit, int fdrag_bit, int wall_bit, int cohesive_bit,
                         int freeze_bit);
 void orc_dem_neighbor(orc_dem *d, double skin);

@@ -63,10 +63,20 @@ enum Flag {
 };
 
 struct WallParams {
-  int dim;
+  int dim;         // 0/1/2: plane normal ; 3: z cylinder (fix_wall_granFix.cpp:107-112)
   int bit;         // group of the fix (mask bit, 1 = all)
-  double lo, hi;
+  double lo, hi;   // planes: the positions for THIS sub-step (a wiggling wall moves them, :259-262)
+  double cylradius;
+  double vwall[3]; // wall velocity for this sub-step (wiggle :263, shear :264)
+  double vrot;     // z cylinder sheared about x or y: the wall ROTATES, vwall = vrot (y, -x, 0)/|xy| (:316-320)
   GranParams gp;
+};
+
+// how a wall moves (host side; WallParams carries the per-sub-step result)
+struct WallMotion {
+  int wiggle = 0, shear = 0, axis = 0;
+  double amplitude = 0.0, period = 1.0, vshear = 0.0;
+  double lo0 = 0.0, hi0 = 0.0;   // the positions of the fix command
 };
 
 struct DemPtrs {
@@ -189,9 +199,13 @@ class DemEngine {
   void group_type(const std::string& name, int op, int v1, int v2, const std::vector<int>& list);
   void group_combine(const std::string& name, int mode, const std::vector<std::string>& args);
   void set_velocity_group(int groupbit, double vx, double vy, double vz);
+  // the wall registered last: `zcylinder radius` instead of a plane pair / wiggle (kind 1: axis amplitude period) or
+  // shear (kind 2: axis vshear)
+  void wall_cylinder(double radius);
+  void wall_motion(int kind, int axis, double a, double b);
   void add_wall(int dim, bool lo_null, double lo, bool hi_null, double hi, double kn, bool kt_null,
                 double kt, double gamman, bool gammat_null, double gammat, double xmu, int dampflag,
-                bool granfix, int groupbit = 1);
+                bool granfix, int groupbit = 1, bool cylinder = false);
   void set_nve_sphere(int groupbit = 1)
   {
     have_nve_ = true;
@@ -357,6 +371,9 @@ private:
   LubParams lub_{};
   int nwalls_ = 0;
   WallParams walls_[kMaxWalls];
+  WallMotion wall_motion_[kMaxWalls];
+  long long wall_time_origin_ = 0;   // sub-step count at setup (FixWallGranFix::init, :181)
+  long long run_base_step_ = 0;      // sub-steps done when the current run / batch sequence started
   bool have_gravity_ = false, have_fdrag_ = false, have_nve_ = false;
   std::map<std::string, int> groups_{{"all", 1}};
   bool use_groups_ = false;

@@ -417,20 +417,57 @@ void DemEngine::set_velocity_group(int groupbit, double vx, double vy, double vz
 
 void DemEngine::add_wall(int dim, bool lo_null, double lo, bool hi_null, double hi, double kn, bool kt_null,
                          double kt, double gamman, bool gammat_null, double gammat, double xmu, int dampflag,
-                         bool granfix, int groupbit)
+                         bool granfix, int groupbit, bool cylinder)
 {
   if (nwalls_ >= kMaxWalls) fail("too many wall fixes (max %d)", kMaxWalls);
-  if (periodic_[dim]) fail("Cannot use wall in periodic dimension");  // fix_wall_granFix.cpp:143-148
+  if (!cylinder && periodic_[dim]) fail("Cannot use wall in periodic dimension");  // fix_wall_granFix.cpp:143-148
   if (!granfix && gran_.style == 2)
     fail("Fix wall/gran is incompatible with Pair style");  // stock wall/gran does not know hertzFix
-  WallParams& W = walls_[nwalls_++];
+  WallParams& W = walls_[nwalls_];
+  wall_motion_[nwalls_] = WallMotion();
+  WallMotion& M = wall_motion_[nwalls_++];
   W.dim = dim;
   W.bit = groupbit;
   use_groups_ = use_groups_ || groupbit != 1;
-  W.lo = lo_null ? -1.0e20 : lo;
-  W.hi = hi_null ? 1.0e20 : hi;
+  W.lo = M.lo0 = lo_null ? -1.0e20 : lo;
+  W.hi = M.hi0 = hi_null ? 1.0e20 : hi;
+  W.cylradius = 0.0;
+  W.vwall[0] = W.vwall[1] = W.vwall[2] = 0.0;
+  W.vrot = 0.0;
   gran_settings(W.gp, gran_.style ? gran_.style : 1, kn, kt_null, kt, gamman, gammat_null, gammat, xmu,
                 dampflag, 1.0);
+}
+
+void DemEngine::wall_cylinder(double radius)
+{
+  if (!nwalls_) fail("wall_cylinder: no wall registered");
+  if (periodic_[0] || periodic_[1]) fail("Cannot use wall in periodic dimension");   // fix_wall_granFix.cpp:149-150
+  WallParams& W = walls_[nwalls_ - 1];
+  W.dim = 3;
+  W.cylradius = radius;
+  W.lo = W.hi = 0.0;
+}
+
+void DemEngine::wall_motion(int kind, int axis, double a, double b)
+{
+  if (!nwalls_) fail("wall_motion: no wall registered");
+  const WallParams& W = walls_[nwalls_ - 1];
+  WallMotion& M = wall_motion_[nwalls_ - 1];
+  if (M.wiggle || M.shear) fail("Cannot wiggle and shear fix wall/granFix");          // :152-153
+  if (axis < 0 || axis > 2) fail("Illegal fix wall/gran command");
+  if (kind == 1) {
+    if (W.dim == 3 && axis != 2) fail("Invalid wiggle direction for fix wall/granFix");   // :154-155
+    if (!(b > 0.0)) fail("Illegal fix wall/gran command");
+    M.wiggle = 1;
+    M.axis = axis;
+    M.amplitude = a;
+    M.period = b;
+  } else {
+    if (W.dim < 3 && axis == W.dim) fail("Invalid shear direction for fix wall/granFix");   // :156-161
+    M.shear = 1;
+    M.axis = axis;
+    M.vshear = a;
+  }
 }
 
 void DemEngine::set_velocity_all(double vx, double vy, double vz)
@@ -516,7 +553,26 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.nwalls = nwalls_;
   S.xcd_remap = opt_xcd_remap_;
   S.stage_cap = stage_cap_;
-  for (int w = 0; w < nwalls_; w++) S.wall[w] = walls_[w];
+  // wall positions / velocities of the LAMMPS step this launch evaluates: post_force of step n sees ntimestep = n,
+  // the setup evaluation sees the value the run starts from (fix_wall_granFix.cpp:255-264)
+  const long long steps = (mode == 2 ? nsteps_ : run_base_step_ + kstep + 1) - wall_time_origin_;
+  for (int w = 0; w < nwalls_; w++) {
+    WallParams W = walls_[w];
+    const WallMotion& M = wall_motion_[w];
+    if (M.wiggle) {
+      const double om = 2.0 * 3.14159265358979323846 / M.period;   // :165
+      const double arg = om * (double)steps * dt_;
+      if (W.dim == M.axis) {
+        W.lo = M.lo0 + M.amplitude - M.amplitude * cos(arg);
+        W.hi = M.hi0 + M.amplitude - M.amplitude * cos(arg);
+      }
+      W.vwall[M.axis] = M.amplitude * om * sin(arg);
+    } else if (M.shear) {
+      if (W.dim == 3 && M.axis != 2) W.vrot = M.vshear;
+      else W.vwall[M.axis] = M.vshear;
+    }
+    S.wall[w] = W;
+  }
   S.have_gravity = have_gravity_;
   for (int k = 0; k < 3; k++) S.gacc[k] = gacc_[k];
   S.have_fdrag = have_fdrag_;
@@ -1076,6 +1132,7 @@ void DemEngine::setup()
     fail("sf_dem_setup on a decomposed domain: run the rebuild protocol (sf_dem_rebuild_*) first");
   // (multi-rank: the driver has already run rebuild_begin / migrate / sort / borders / finish)
   reset_flag(F_TRIGGER, INT_MAX);
+  wall_time_origin_ = nsteps_;   // FixWallGranFix::init, fix_wall_granFix.cpp:181
   launch_substep(cur_, 2, 0);
   launch_ghost_forward(cur_ ^ 1, 0);
   cur_ ^= 1;
@@ -1085,6 +1142,7 @@ void DemEngine::setup()
 
 void DemEngine::run_begin()
 {
+  run_base_step_ = nsteps_;
   if (overlap_) overlap_begin();
   reset_flag(F_TRIGGER, INT_MAX);
   launch_initial_integrate();
@@ -1093,6 +1151,7 @@ void DemEngine::run_begin()
 
 void DemEngine::substep(bool last)
 {
+  run_base_step_ = nsteps_;
   launch_substep(cur_, last ? 1 : 0, 0);
   launch_ghost_forward(cur_ ^ 1, 0);
   cur_ ^= 1;
@@ -1252,6 +1311,7 @@ void DemEngine::run(int nsteps)
   if (!setup_done_) setup();
   if (nsteps <= 0) return;
   if (have_subdomain_) fail("sf_lammps_step on a decomposed domain: drive the sub-steps through sf_dem_*");
+  run_base_step_ = nsteps_;
   reset_flag(F_TRIGGER, INT_MAX);
   launch_initial_integrate();
   launch_ghost_forward(cur_, 0);

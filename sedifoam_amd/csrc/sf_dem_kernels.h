@@ -343,17 +343,28 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     for (int w = 0; w < S.nwalls; w++) {
       const WallParams& W = S.wall[w];
       if (!(mk & W.bit)) continue;   // fix_wall_granFix.cpp:290
-      const double xc = (W.dim == 0) ? xi.x : (W.dim == 1) ? xi.y : xi.z;
-      const double del1 = xc - W.lo, del2 = W.hi - xc;
-      const double d = (del1 < del2) ? del1 : -del2;
-      const double rsq = d * d;
+      Vec3 dw = {0.0, 0.0, 0.0};
+      Vec3 vw = {W.vwall[0], W.vwall[1], W.vwall[2]};   // 0 unless the wall wiggles or shears (:255-264)
+      if (W.dim < 3) {               // :294-308
+        const double xc = (W.dim == 0) ? xi.x : (W.dim == 1) ? xi.y : xi.z;
+        const double del1 = xc - W.lo, del2 = W.hi - xc;
+        const double d = (del1 < del2) ? del1 : -del2;
+        dw = {W.dim == 0 ? d : 0.0, W.dim == 1 ? d : 0.0, W.dim == 2 ? d : 0.0};
+      } else {                       // z cylinder about the origin, :309-322
+        const double delxy = sqrt(xi.x * xi.x + xi.y * xi.y);
+        const double delr = W.cylradius - delxy;
+        if (delr > radi) continue;   // (the reference sets dz = cylradius: no contact, shear reset)
+        dw = {-delr / delxy * xi.x, -delr / delxy * xi.y, 0.0};
+        if (W.vrot != 0.0) vw = {W.vrot * xi.y / delxy, -W.vrot * xi.x / delxy, 0.0};
+      }
+      const double rsq = dot(dw, dw);
       if (rsq > radi * radi) continue;   // shear reset = touch bit cleared
       ContactIn c;
-      c.del = {W.dim == 0 ? d : 0.0, W.dim == 1 ? d : 0.0, W.dim == 2 ? d : 0.0};
+      c.del = dw;
       c.rsq = rsq;
       c.r = sqrt(rsq);
       c.rinv = 1.0 / c.r;
-      c.vr = vi;
+      c.vr = vi - vw;
       c.wsum = radi * wi;
       c.meff = mi;
       c.overlap = radi - c.r;

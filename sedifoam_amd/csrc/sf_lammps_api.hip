@@ -154,17 +154,48 @@ void cmd_fix(SfLammps& L, const std::vector<std::string>& w)
   } else if (st == "wall/gran" || st == "wall/granFix") {
     if (narg < 10) sf::fail("Illegal fix %s command", st.c_str());  // fix_wall_granFix.cpp:47
     const bool ktn = w[5] == "NULL", gtn = w[7] == "NULL";
+    // wallstyle args, fix_wall_granFix.cpp:83-113: {x,y,z}plane lo hi | zcylinder radius
     int dim;
     if (w[10] == "xplane") dim = 0;
     else if (w[10] == "yplane") dim = 1;
     else if (w[10] == "zplane") dim = 2;
-    else sf::fail("fix %s: only xplane/yplane/zplane walls are supported", st.c_str());
-    if (narg < 12) sf::fail("Illegal fix %s command", st.c_str());
-    if (narg > 12) sf::fail("fix %s: wiggle/shear walls are not supported", st.c_str());
-    const bool lon = w[11] == "NULL", hin = w[12] == "NULL";
-    L.eng.add_wall(dim, lon, lon ? 0.0 : num(w[11]), hin, hin ? 0.0 : num(w[12]), num(w[4]), ktn,
-                   ktn ? 0.0 : num(w[5]), num(w[6]), gtn, gtn ? 0.0 : num(w[7]), num(w[8]), inum(w[9]),
-                   st == "wall/granFix", gb);
+    else if (w[10] == "zcylinder") dim = 3;
+    else sf::fail("Illegal fix %s command", st.c_str());
+    size_t iarg;   // index in w of the first optional keyword
+    if (dim < 3) {
+      if (narg < 12) sf::fail("Illegal fix %s command", st.c_str());
+      const bool lon = w[11] == "NULL", hin = w[12] == "NULL";
+      L.eng.add_wall(dim, lon, lon ? 0.0 : num(w[11]), hin, hin ? 0.0 : num(w[12]), num(w[4]), ktn,
+                     ktn ? 0.0 : num(w[5]), num(w[6]), gtn, gtn ? 0.0 : num(w[7]), num(w[8]), inum(w[9]),
+                     st == "wall/granFix", gb);
+      iarg = 13;
+    } else {
+      if (narg < 11) sf::fail("Illegal fix %s command", st.c_str());
+      L.eng.add_wall(2, true, 0.0, true, 0.0, num(w[4]), ktn, ktn ? 0.0 : num(w[5]), num(w[6]), gtn,
+                     gtn ? 0.0 : num(w[7]), num(w[8]), inum(w[9]), st == "wall/granFix", gb, /*z_periodic_ok=*/true);
+      L.eng.wall_cylinder(num(w[11]));
+      iarg = 12;
+    }
+    // optional keywords, :115-141: wiggle dim amplitude period | shear dim vshear
+    auto axis_of = [&](const std::string& a) {
+      if (a == "x") return 0;
+      if (a == "y") return 1;
+      if (a == "z") return 2;
+      sf::fail("Illegal fix %s command", st.c_str());
+      return 0;
+    };
+    while (iarg < w.size()) {
+      if (w[iarg] == "wiggle") {
+        if (iarg + 4 > w.size()) sf::fail("Illegal fix %s command", st.c_str());
+        L.eng.wall_motion(1, axis_of(w[iarg + 1]), num(w[iarg + 2]), num(w[iarg + 3]));
+        iarg += 4;
+      } else if (w[iarg] == "shear") {
+        if (iarg + 3 > w.size()) sf::fail("Illegal fix %s command", st.c_str());
+        L.eng.wall_motion(2, axis_of(w[iarg + 1]), num(w[iarg + 2]), 0.0);
+        iarg += 3;
+      } else
+        sf::fail("Illegal fix %s command", st.c_str());
+    }
   } else if (st == "freeze") {
     if (narg != 3) sf::fail("Illegal fix freeze command");   // [3P] fix_freeze.cpp
     L.eng.set_freeze(gb);

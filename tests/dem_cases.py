@@ -16,8 +16,16 @@ def make_oracle(bed, cfg):
         dem.pair_lubricate(*cfg["lub"])
     dem.fix_gravity(cfg["g"], 0.0, -1.0, 0.0)
     dem.fix_fdrag(cfg.get("carrier_rho", 0.0))
-    for (dim, lo, hi) in cfg["walls"]:
-        dem.fix_wall(dim, lo, hi, cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], cfg.get("dampflag", 1))
+    for wall in cfg["walls"]:
+        dim, lo, hi = wall[:3]
+        extra = wall[3] if len(wall) > 3 else {}
+        dem.fix_wall(min(dim, 2), lo, hi, cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], cfg.get("dampflag", 1))
+        if dim == 3:
+            dem.wall_cylinder(extra["cyl"])
+        if "wiggle" in extra:
+            dem.wall_motion("wiggle", *extra["wiggle"])
+        if "shear" in extra:
+            dem.wall_motion("shear", *extra["shear"])
     if cfg.get("cohesive"):
         dem.fix_cohesive(*cfg["cohesive"])
     if cfg.get("frozen_types") is not None:
@@ -56,10 +64,20 @@ def script_lines(bed, cfg):
     cr = cfg.get("carrier_rho", 0.0)
     lines.append("fix 3 %s fdrag" % (act if cfg.get("fdrag_group", "all") != "all" else "all")
                  + (" %d" % int(cr) if cr else ""))
-    for k, (dim, lo, hi) in enumerate(cfg["walls"]):
-        lines.append("fix w%d all %s %.17g NULL %.17g NULL %.17g %d %splane %s %s" % (
-            k, wall, cfg["kn"], cfg["gamman"], cfg["xmu"], cfg.get("dampflag", 1), "xyz"[dim],
-            "NULL" if lo is None else "%.17g" % lo, "NULL" if hi is None else "%.17g" % hi))
+    for k, wl in enumerate(cfg["walls"]):
+        dim, lo, hi = wl[:3]
+        extra = wl[3] if len(wl) > 3 else {}
+        # walls: (dim, lo, hi[, extra]); dim 3 = zcylinder extra["cyl"]; extra["wiggle"] = (axis, amplitude, period),
+        # extra["shear"] = (axis, vshear)  (fix_wall_granFix.cpp:83-141)
+        geom = ("zcylinder %.17g" % extra["cyl"]) if dim == 3 else "%splane %s %s" % (
+            "xyz"[dim], "NULL" if lo is None else "%.17g" % lo, "NULL" if hi is None else "%.17g" % hi)
+        line = "fix w%d all %s %.17g NULL %.17g NULL %.17g %d %s" % (
+            k, wall, cfg["kn"], cfg["gamman"], cfg["xmu"], cfg.get("dampflag", 1), geom)
+        if "wiggle" in extra:
+            line += " wiggle %s %.17g %.17g" % ("xyz"[extra["wiggle"][0]], extra["wiggle"][1], extra["wiggle"][2])
+        if "shear" in extra:
+            line += " shear %s %.17g" % ("xyz"[extra["shear"][0]], extra["shear"][1])
+        lines.append(line)
     if cfg.get("cohesive"):
         lines.append("fix coh all cohesive %.17g %.17g %.17g %.17g %d" % tuple(cfg["cohesive"]))
     if frozen:

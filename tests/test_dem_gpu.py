@@ -53,9 +53,9 @@ def _compare(lmp, orc, tol_f=1e-12, tol_x=1e-9, check_force=True):
         assert dc.rel_err(sa, sb) <= max(tol_x, tol_f)
 
 
-def _run_case(bed, cfg, steps=(1, 49), fdrag_seed=7, tol_f=1e-12):
+def _run_case(bed, cfg, steps=(1, 49), fdrag_seed=7, tol_f=1e-12, walls=None):
     cfg = dict(cfg)
-    cfg["walls"] = _walls(bed)
+    cfg["walls"] = _walls(bed) if walls is None else walls
     lmp = dc.make_hip(bed, cfg)
     orc = dc.make_oracle(bed, cfg)
     lmp.setup()
@@ -73,6 +73,58 @@ def _run_case(bed, cfg, steps=(1, 49), fdrag_seed=7, tol_f=1e-12):
         orc.run(n)
         _compare(lmp, orc, tol_f=tol_f)
     return lmp, orc
+
+
+@pytest.mark.parametrize("motion", [{"wiggle": (1, 0.05e-3, 2.0e-4)}, {"wiggle": (0, 0.05e-3, 2.0e-4)},
+                                    {"shear": (0, 0.5)}])
+def test_closed_box_with_moving_floor(motion):
+    """fix wall/granFix ... yplane lo hi wiggle|shear (fix_wall_granFix.cpp:117-141, :255-264): the floor and lid
+    oscillate along their normal (positions and velocity follow the step count) or along x (velocity only), or slide
+    along x; 120 sub-steps = 0.6 of a wiggle period."""
+    bed = _bed((5, 5, 5), periodic=False, seed=31)
+    walls = _walls(bed)
+    walls[0] = walls[0] + (motion,)
+    lmp, orc = _run_case(bed, BASE, steps=(1, 60, 59), walls=walls, tol_f=5e-12)   # (torque sums cancel to ~1e-3 of their terms)
+    wa, wb = lmp.wall_shear(0), orc.wall_shear(0)
+    assert (np.abs(wb).sum(axis=1) > 0).sum() >= 10 and dc.rel_err(wa, wb) <= 1e-9
+    # the second run continues the wall's clock (time_origin is set once, at setup)
+    a, b = lmp.get_state(), orc.get()
+    assert dc.rel_err(a["v"], b["v"]) <= 1e-9
+
+
+@pytest.mark.parametrize("rotate", [False, True])
+def test_bed_in_a_z_cylinder(rotate):
+    """fix wall/granFix ... zcylinder R [shear x v] (fix_wall_granFix.cpp:107-112, :309-322): radial contact with the
+    cylinder about the origin; sheared about x or y the wall rotates."""
+    bed = synthetic.fcc_bed((6, 5, 6), seed=41)
+    d = float(bed["diameter"][0])
+    x = bed["x"].copy()
+    ctr = 0.5 * (x.min(axis=0) + x.max(axis=0))
+    x[:, 0] -= ctr[0]
+    x[:, 1] -= ctr[1]
+    rr = np.hypot(x[:, 0], x[:, 1])
+    keep = rr < 2.1e-3
+    R = float(rr[keep].max() + 0.495 * d)                  # the outermost grains press up to 0.5 % of d into the wall
+    n = int(keep.sum())
+    assert n > 100 and (rr[keep] > R - 0.5 * d).sum() >= 4
+    for k in ("diameter", "density", "v"):
+        bed[k] = np.ascontiguousarray(np.asarray(bed[k])[keep])
+    bed["x"] = np.ascontiguousarray(x[keep])
+    bed["n"] = n
+    bed["periodic"] = (0, 0, 0)
+    zlo, zhi = float(bed["x"][:, 2].min() - 0.495 * d), float(bed["x"][:, 2].max() + 0.495 * d)
+    bed["boxlo"] = np.array([-R - d, -R - d, zlo]); bed["boxhi"] = np.array([R + d, R + d, zhi])
+    extra = {"cyl": R}
+    if rotate:
+        extra["shear"] = (0, 0.3)
+    walls = [(3, None, None, extra), (2, zlo, zhi)]
+    lmp, orc = _run_case(bed, BASE, steps=(1, 40), walls=walls, tol_f=5e-12)
+    f = lmp.get_state()["f"]
+    assert np.isfinite(f).all() and np.abs(f).max() > 0.0
+    # the cylinder is really touched, and its history (tangential displacement) agrees
+    wa, wb = lmp.wall_shear(0), orc.wall_shear(0)
+    assert (np.abs(wb).sum(axis=1) > 0).sum() >= 4
+    assert dc.rel_err(wa, wb) <= 1e-9
 
 
 def test_closed_box_hertz():

@@ -241,3 +241,70 @@ def test_hertz_head_on_collision_restitution_equals_gamman(e):
         assert st["x"][1, 0] - st["x"][0, 0] > 2 * R          # separated again
         e_meas = (st["v"][1, 0] - st["v"][0, 0]) / u
         assert e_meas == pytest.approx(e, abs=2e-3), (u, e_meas)
+
+
+def _wall(x, v, r, p, wallstyle, lo=0.0, hi=1.0, cyl=0.0, wiggle=0, shear=0, axis=0, amp=0.0, period=1.0, vshear=0.0,
+          steps=0, dt=1e-6, hertz=True):
+    x = ob.f64([x]); v = ob.f64([v]); w = np.zeros((1, 3)); rr = ob.f64([r]); m = ob.f64([1.0e-6])
+    mask = ob.i32([1]); sh = np.zeros((1, 3)); f = np.zeros((1, 3)); t = np.zeros((1, 3))
+    L.orc_fix_wall_gran_moving(C.byref(p), 2 if hertz else 1, wallstyle, lo, hi, cyl, wiggle, shear, axis, amp, period,
+                               vshear, steps, dt, 1, 1, ob.P(x), ob.P(v), ob.P(w), ob.P(rr), ob.P(m), ob.P(mask), 1,
+                               ob.P(sh), ob.P(f), ob.P(t))
+    return f[0], t[0], sh[0]
+
+
+def test_wall_wiggle_moves_the_plane_and_gives_it_a_velocity():
+    """fix_wall_granFix.cpp:257-263: wlo = lo + A - A cos(omega t), vwall[axis] = A omega sin(omega t), t = steps dt."""
+    p = _params(gamman=1.0 - 1e-12, xmu=0.0)      # no damping (beta -> 0), no friction: pure Hertz spring
+    r, A, T, dt = 0.5e-3, 0.1e-3, 1.0e-3, 1e-6
+    y = r + 0.5 * A                                # half an amplitude above contact with the resting floor
+    f0, _, _ = _wall([0, y, 0], [0, 0, 0], r, p, 1, lo=0.0, hi=1.0, wiggle=1, axis=1, amp=A, period=T, steps=0, dt=dt)
+    assert np.all(f0 == 0.0)                       # t = 0: the floor is at lo
+    # half a period later the floor stands at lo + 2 A: overlap 1.5 A, wall at rest (sin = 0 up to rounding)
+    fh, _, _ = _wall([0, y, 0], [0, 0, 0], r, p, 1, lo=0.0, hi=1.0, wiggle=1, axis=1, amp=A, period=T, steps=500, dt=dt)
+    ov = 1.5 * A
+    fn = np.sqrt(ov * r) * 4.0 / 5.46 * 1e7 * ov   # hertzFix spring of the wall twin (:602-608): polyhertz (4/5.46) kn delta
+    assert fh[1] == pytest.approx(fn, rel=1e-9) and abs(fh[0]) < 1e-12 * fn
+    # a quarter period: floor at lo + A moving up at A omega; with damping the approaching wall pushes harder
+    pd = _params(gamman=0.5, xmu=0.0)
+    fq, _, _ = _wall([0, y, 0], [0, 0, 0], r, pd, 1, lo=0.0, hi=1.0, wiggle=1, axis=1, amp=A, period=T, steps=250, dt=dt)
+    fs, _, _ = _wall([0, y - A, 0], [0, 0, 0], r, pd, 1, lo=0.0, hi=1.0)     # same overlap on a wall at rest
+    fv, _, _ = _wall([0, y - A, 0], [0, -A * 2 * np.pi / T, 0], r, pd, 1, lo=0.0, hi=1.0)   # ... and the same closing speed
+    assert fq[1] > fs[1] > 0.0 and fq[1] == pytest.approx(fv[1], rel=1e-12)
+
+
+def test_wall_shear_drags_the_particle_along_and_is_capped_by_coulomb():
+    """:264 vwall[axis] = vshear; the tangential spring builds up with the relative velocity v - vwall (:457-459)."""
+    p = _params(gamman=0.5, xmu=0.4)
+    r = 0.5e-3
+    f, t, sh = _wall([0, r * 0.98, 0], [0, 0, 0], r, p, 1, lo=0.0, hi=1.0, shear=1, axis=0, vshear=1.0e-3)
+    assert f[0] > 0.0 and f[1] > 0.0              # dragged along +x, pushed off the floor
+    assert sh[0] == pytest.approx(-1.0e-3 * 1e-6, rel=1e-9)   # shear += (v - vwall) dt, below the Coulomb limit
+    assert t[2] > 0.0                              # force +x at the contact point -r y: torque +z
+    # a fast wall saturates at mu * Fn
+    f2, _, _ = _wall([0, r * 0.98, 0], [0, 0, 0], r, p, 1, lo=0.0, hi=1.0, shear=1, axis=0, vshear=2.0e3)
+    fn_only, _, _ = _wall([0, r * 0.98, 0], [0, 0, 0], r, p, 1, lo=0.0, hi=1.0)
+    assert f2[0] == pytest.approx(0.4 * fn_only[1], rel=1e-9)
+
+
+def test_z_cylinder_contact_is_radial_and_rotation_is_tangential():
+    """:309-322: del = -(R - |xy|)/|xy| (x, y, 0); sheared about x or y the wall rotates, vwall = v (y, -x, 0)/|xy|."""
+    p = _params(gamman=0.5, xmu=0.4)
+    r, R = 0.5e-3, 5.0e-3
+    ov = 0.02 * r
+    rad = R - r + ov
+    ang = 0.7
+    x = [rad * np.cos(ang), rad * np.sin(ang), 0.3e-3]
+    f, _, _ = _wall(x, [0, 0, 0], r, p, 3, cyl=R)
+    plane, _, _ = _wall([0, r - ov, 0], [0, 0, 0], r, p, 1, lo=0.0, hi=1.0)
+    assert np.hypot(f[0], f[1]) == pytest.approx(plane[1], rel=1e-9) and f[2] == 0.0
+    assert f[0] * x[0] + f[1] * x[1] < 0.0 and abs(f[0] * x[1] - f[1] * x[0]) < 1e-9 * plane[1] * rad   # inward, radial
+    far, _, _ = _wall([0.1e-3, 0, 0], [0, 0, 0], r, p, 3, cyl=R)
+    assert np.all(far == 0.0)
+    # rotating cylinder: the tangential force points along the wall velocity (y, -x, 0)/|xy| * v
+    g, _, _ = _wall(x, [0, 0, 0], r, p, 3, cyl=R, shear=1, axis=0, vshear=1.5)
+    tang = np.array([x[1], -x[0]]) / rad
+    assert g[0] * tang[0] + g[1] * tang[1] > 0.0
+    # shear along z slides the wall along its axis instead
+    h, _, _ = _wall(x, [0, 0, 0], r, p, 3, cyl=R, shear=1, axis=2, vshear=1.5)
+    assert h[2] > 0.0 and abs(h[0] * tang[0] + h[1] * tang[1]) < 1e-9 * abs(h[2])
