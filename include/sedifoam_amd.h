@@ -271,6 +271,10 @@ int sfk_drag_model_jd(int model, int n, const double *Ur, const double *alpha, c
  * softParticle.C:102-151): cell = ix + nx*(iy + ny*iz), -1 outside.  x AoS [n][3] */
 int sfk_cell_owner(int n, const double *x, const double origin[3], const double dx[3],
                    const int ncell[3], int *cell, void *stream);
+/* the same on a graded (rectilinear) block: dev_faces[k] = DEVICE array of ncell[k]+1 face coordinates, or NULL =
+ * uniform along k (origin/dx) */
+int sfk_cell_owner_graded(int n, const double *x, const double origin[3], const double dx[3],
+                          const int ncell[3], const double *const dev_faces[3], int *cell, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * (3) enhancedCloud surface -- lammpsFoam/enhancedCloud.H:183-249, enhancedCloud.C
@@ -297,6 +301,10 @@ typedef struct {
 typedef struct {
   double origin[3], dx[3];
   int n[3];
+  /* blockMesh simpleGrading: faces[k] = the n[k]+1 ascending face coordinates along axis k (host pointer, copied), or
+   * NULL = uniform cells origin[k] + i dx[k].  The mesh stays a tensor product: cell (ix, iy, iz) = ix + nx*(iy + ny*iz)
+   * spans faces[0][ix..ix+1] x faces[1][iy..iy+1] x faces[2][iz..iz+1]. */
+  const double *faces[3];
 } sf_cloud_mesh;
 
 int sf_cloud_create(void *lmp, const sf_cloud_mesh *mesh, const sf_cloud_props *props,

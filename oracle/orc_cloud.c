@@ -77,6 +77,38 @@ void orc_cell_owner(int n, const double *x, const double origin[3], const double
   }
 }
 
+/* the same on a graded (blockMesh simpleGrading) block: faces[k] = ncell[k]+1 ascending face coordinates, or NULL =
+ * uniform along k.  What the tracking returns on such a mesh is the cell whose face interval holds the point. */
+void orc_cell_owner_graded(int n, const double *x, const double origin[3], const double dx[3],
+                           const int ncell[3], const double *const faces[3], int *cell)
+{
+  int i, k;
+  for (i = 0; i < n; i++) {
+    int c[3], inside = 1;
+    for (k = 0; k < 3; k++) {
+      double xx = x[3 * i + k];
+      const double *f = faces[k];
+      if (!f) {
+        double fl = floor((xx - origin[k]) / dx[k]);
+        if (fl < 0.0 || fl >= (double)ncell[k]) inside = 0;
+        c[k] = (int)fl;
+      } else if (!(xx >= f[0]) || !(xx < f[ncell[k]])) {
+        inside = 0;
+        c[k] = 0;
+      } else {
+        int lo = 0, hi = ncell[k];
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (xx >= f[mid]) lo = mid;
+          else hi = mid;
+        }
+        c[k] = lo;
+      }
+    }
+    cell[i] = inside ? c[0] + ncell[0] * (c[1] + ncell[1] * c[2]) : -1;
+  }
+}
+
 /* enhancedCloud::g1n  enhancedCloud.C:1372-1384 */
 static double g1n(double n)
 {

@@ -68,7 +68,8 @@ class CloudProps(C.Structure):
 
 
 class CloudMesh(C.Structure):
-    _fields_ = [("origin", C.c_double * 3), ("dx", C.c_double * 3), ("n", C.c_int * 3)]
+    _fields_ = [("origin", C.c_double * 3), ("dx", C.c_double * 3), ("n", C.c_int * 3),
+                ("faces", C.POINTER(C.c_double) * 3)]
 
 
 class CloudTimers(C.Structure):
@@ -154,6 +155,7 @@ _SIGS = {
                                                 vp, vp, vp, vp, vp]),
     "sfk_drag_model_jd": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp]),
     "sfk_cell_owner": (C.c_int, [C.c_int, vp, dp, dp, ip, vp, vp]),
+    "sfk_cell_owner_graded": (C.c_int, [C.c_int, vp, dp, dp, ip, C.POINTER(C.c_void_p), vp, vp]),
     "sf_cloud_create": (C.c_int, [vp, C.POINTER(CloudMesh), C.POINTER(CloudProps), C.c_double, C.POINTER(vp)]),
     "sf_cloud_destroy": (C.c_int, [vp]),
     "sf_cloud_set_fluid": (C.c_int, [vp, dp, dp, dp, dp]),

@@ -63,8 +63,11 @@ class enhancedCloud:
     diffusionSteps, UfSmooth, UpSmooth, dragSmooth, alphaSmooth, smoothDirection.
     transDict keys (constant/transportProperties): rhob, nub."""
 
-    def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT, driver=None):
-        """driver: a sedifoam_amd.halo.SlabDriver when the particles are decomposed over several GPUs (lammps is
+    def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT, driver=None,
+                 mesh_faces=None):
+        """mesh_faces: (xf, yf, zf) face coordinates of a graded (blockMesh simpleGrading) block, n+1 ascending values
+        per axis or None for a uniform axis (then mesh_origin / mesh_dx apply along it).
+        driver: a sedifoam_amd.halo.SlabDriver when the particles are decomposed over several GPUs (lammps is
         then the driver's engine).  Every rank holds the whole mesh; the per-cell sums of gamma, Ue and Asrc are
         added over the ranks (torch.distributed all_reduce on the device arrays) inside evolve()/calcTcFields()."""
         self.L = _lib.lib()
@@ -105,6 +108,17 @@ class enhancedCloud:
         m.origin = (C.c_double * 3)(*mesh_origin)
         m.dx = (C.c_double * 3)(*mesh_dx)
         m.n = (C.c_int * 3)(*mesh_n)
+        keep_faces = []
+        for k in range(3):
+            fk = None if mesh_faces is None else mesh_faces[k]
+            if fk is None:
+                m.faces[k] = C.POINTER(C.c_double)()
+            else:
+                a = np.ascontiguousarray(fk, dtype=np.float64)
+                if a.shape != (int(mesh_n[k]) + 1,):
+                    raise SfError("mesh_faces[%d] must hold n + 1 = %d coordinates" % (k, int(mesh_n[k]) + 1))
+                keep_faces.append(a)
+                m.faces[k] = a.ctypes.data_as(C.POINTER(C.c_double))
         self.ncells = int(np.prod(mesh_n))
         h = C.c_void_p()
         if driver is not None and not driver.is_setup:

@@ -67,16 +67,35 @@ struct MeshDev {
   double origin[3], dx[3];
   int n[3];
   int ncells;
+  const double* f[3];   // graded axis: n+1 ascending face coordinates (device); nullptr: uniform origin + i dx
 };
+
+// cell index along one axis, -1 outside: floor((x - origin)/dx) on a uniform axis, the interval [f[i], f[i+1]) that
+// holds x on a graded one (the same comparisons as the oracle's search: bit-exact owners)
+__device__ __forceinline__ int axis_cell(const MeshDev& m, int k, double x)
+{
+  const int n = m.n[k];
+  const double* f = m.f[k];
+  if (!f) {
+    const double fl = floor((x - m.origin[k]) / m.dx[k]);
+    if (fl < 0.0 || fl >= (double)n) return -1;
+    return (int)fl;
+  }
+  if (!(x >= f[0]) || !(x < f[n])) return -1;
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (x >= f[mid]) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
 
 __device__ __forceinline__ int cell_of(const MeshDev& m, double x, double y, double z)
 {
-  const double fx = floor((x - m.origin[0]) / m.dx[0]);
-  const double fy = floor((y - m.origin[1]) / m.dx[1]);
-  const double fz = floor((z - m.origin[2]) / m.dx[2]);
-  if (fx < 0.0 || fx >= (double)m.n[0] || fy < 0.0 || fy >= (double)m.n[1] || fz < 0.0 || fz >= (double)m.n[2])
-    return -1;
-  return (int)fx + m.n[0] * ((int)fy + m.n[1] * (int)fz);
+  const int ix = axis_cell(m, 0, x), iy = axis_cell(m, 1, y), iz = axis_cell(m, 2, z);
+  if (ix < 0 || iy < 0 || iz < 0) return -1;
+  return ix + m.n[0] * (iy + m.n[1] * iz);
 }
 
 __global__ __launch_bounds__(256) void k_cell_owner_aos(int n, const double* x, MeshDev m, int* cell)
@@ -492,9 +511,26 @@ class Cloud {
       mesh_.origin[k] = mesh.origin[k];
       mesh_.dx[k] = mesh.dx[k];
       mesh_.n[k] = mesh.n[k];
+      mesh_.f[k] = nullptr;
     }
     mesh_.ncells = mesh.n[0] * mesh.n[1] * mesh.n[2];
     if (mesh_.ncells <= 0) fail("cloud mesh has no cells");
+    // cell widths per axis (uniform or from the face coordinates of a graded block)
+    std::vector<double> width[3];
+    for (int k = 0; k < 3; k++) {
+      width[k].assign(mesh.n[k], mesh.dx[k]);
+      if (mesh.faces[k]) {
+        for (int i = 0; i < mesh.n[k]; i++) {
+          width[k][i] = mesh.faces[k][i + 1] - mesh.faces[k][i];
+          if (!(width[k][i] > 0.0)) fail("cloud mesh: face coordinates along axis %d are not ascending", k);
+        }
+        SF_HIP(hipMalloc(&faces_dev_[k], sizeof(double) * (mesh.n[k] + 1)));
+        SF_HIP(hipMemcpy(faces_dev_[k], mesh.faces[k], sizeof(double) * (mesh.n[k] + 1), hipMemcpyHostToDevice));
+        mesh_.f[k] = faces_dev_[k];
+        mesh_.origin[k] = mesh.faces[k][0];
+      } else if (!(mesh.dx[k] > 0.0))
+        fail("cloud mesh: dx[%d] must be positive", k);
+    }
     DemEngine& e = lmp_->eng;
     s_ = e.stream();
     // adjustLampTimestep
@@ -520,9 +556,15 @@ class Cloud {
     alloc(curlU_, 3 * nc);
     alloc(UfS_, 3 * nc);
     alloc(UfSold_, 3 * nc);
+    if ((mesh.faces[0] || mesh.faces[1] || mesh.faces[2]) && props.diffusionBandWidth > 0.0 && props.diffusionSteps > 0)
+      fail("diffusion smoothing on a graded block is not available");
     smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_);
     SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
-    std::vector<double> hV(nc, mesh.dx[0] * mesh.dx[1] * mesh.dx[2]);
+    std::vector<double> hV(nc);
+    for (int iz = 0; iz < mesh.n[2]; iz++)
+      for (int iy = 0; iy < mesh.n[1]; iy++)
+        for (int ix = 0; ix < mesh.n[0]; ix++)
+          hV[(size_t)ix + (size_t)mesh.n[0] * (iy + (size_t)mesh.n[1] * iz)] = width[0][ix] * width[1][iy] * width[2][iz];
     SF_HIP(hipMemcpyAsync(V_, hV.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s_));
     SF_HIP(hipStreamSynchronize(s_));
     if (!e.is_setup()) e.setup();  // lammps_step(0) at construction, softParticleCloud.C:189
@@ -535,7 +577,8 @@ class Cloud {
   {
     for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_, UfS_, UfSold_, sumFb_, n0_})
       if (p) (void)hipFree(p);
-    for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_})
+    for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_,
+                    (void*)faces_dev_[0], (void*)faces_dev_[1], (void*)faces_dev_[2]})
       if (p) (void)hipFree(p);
   }
 
@@ -897,6 +940,7 @@ public:
   sf_cloud_props props_;
   double deltaT_;
   MeshDev mesh_{};
+  double* faces_dev_[3] = {nullptr, nullptr, nullptr};
   hipStream_t s_ = nullptr;
   int subCycles_ = 1, subSteps_ = 1;
   double *V_ = nullptr, *gamma_ = nullptr, *Ue_ = nullptr, *Asrc_ = nullptr, *Omega_ = nullptr;
@@ -1042,12 +1086,20 @@ int sfk_drag_model_jd(int model, int n, const double* Ur, const double* alpha, c
 int sfk_cell_owner(int n, const double* x, const double origin[3], const double dx[3], const int ncell[3],
                    int* cell, void* stream)
 {
+  const double* const none[3] = {nullptr, nullptr, nullptr};
+  return sfk_cell_owner_graded(n, x, origin, dx, ncell, none, cell, stream);
+}
+
+int sfk_cell_owner_graded(int n, const double* x, const double origin[3], const double dx[3], const int ncell[3],
+                          const double* const dev_faces[3], int* cell, void* stream)
+{
   SF_API_BEGIN
   sf::MeshDev m;
   for (int k = 0; k < 3; k++) {
     m.origin[k] = origin[k];
     m.dx[k] = dx[k];
     m.n[k] = ncell[k];
+    m.f[k] = dev_faces[k];
   }
   m.ncells = ncell[0] * ncell[1] * ncell[2];
   if (n > 0) {

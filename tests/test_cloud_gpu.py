@@ -240,6 +240,83 @@ def test_scatter_on_coarse_and_fine_meshes(mesh_n):
         assert np.array_equal(a, b)
 
 
+def _graded_faces(lo, hi, n, expansion):
+    """blockMesh simpleGrading: n cells from lo to hi, last cell `expansion` times as wide as the first (geometric)."""
+    if n == 1 or expansion == 1.0:
+        return np.linspace(lo, hi, n + 1)
+    r = expansion ** (1.0 / (n - 1))
+    w = r ** np.arange(n)
+    f = np.concatenate([[0.0], np.cumsum(w)]) / w.sum()
+    return lo + (hi - lo) * f
+
+
+def test_graded_block_mesh_cell_owner_and_scatter():
+    """A block graded like the reference's channel cases (`simpleGrading (1 10 1)`, also graded along z here): cell
+    owner bit-exact against the oracle's interval search, gamma / Ue / Asrc with the per-cell volumes of the graded
+    block, solid volume conserved."""
+    import torch
+    import sedifoam_amd
+    from sedifoam_amd import synthetic, enhancedCloud
+    bed = synthetic.fcc_bed((8, 7, 8), seed=23, vmax=0.05)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    mesh_n = np.array([4, 6, 3], np.int32)
+    lo, hi = bed["boxlo"], bed["boxhi"]
+    faces = [None, _graded_faces(lo[1], hi[1], 6, 10.0), _graded_faces(lo[2], hi[2], 3, 0.3)]
+    dxm = (hi - lo) / mesh_n
+    widths = [np.full(4, dxm[0]), np.diff(faces[1]), np.diff(faces[2])]
+    V = (widths[0][:, None, None] * widths[1][None, :, None] * widths[2][None, None, :]).transpose(2, 1, 0).reshape(-1)
+    ncells = int(mesh_n.prod())
+    lmp = dc.make_hip(bed, cfg)
+    cloud = enhancedCloud(lmp, lo, dxm, mesh_n, dict(dragModel="ErgunWenYu", subCycles=1, g=(0, -9.81, 0)),
+                          dict(rhob=1000.0, nub=1e-6), 50e-6, mesh_faces=faces)
+    L = ob.lib()
+    n = bed["n"]; d = bed["diameter"].copy()
+    fp = (ob.dp * 3)(None, ob.P(faces[1]), ob.P(faces[2]))
+    st = lmp.get_state()
+    cell = np.zeros(n, np.int32)
+    L.orc_cell_owner_graded(n, ob.P(st["x"]), ob.P(lo), ob.P(dxm), ob.P(mesh_n), fp, ob.P(cell))
+    assert cell.min() >= 0 and len(np.unique(cell)) > ncells // 2
+    # stand-alone cell owner kernel on device arrays: bit exact, inside and outside the block
+    S = sedifoam_amd.lib()
+    rng = np.random.default_rng(4)
+    xt = np.concatenate([st["x"], rng.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), size=(5000, 3)),
+                         np.array([[lo[0], faces[1][2], faces[2][1]], [hi[0], hi[1], hi[2]]])])
+    ref = np.zeros(len(xt), np.int32)
+    L.orc_cell_owner_graded(len(xt), ob.P(xt), ob.P(lo), ob.P(dxm), ob.P(mesh_n), fp, ob.P(ref))
+    dxt = _t(xt); dcell = torch.zeros(len(xt), dtype=torch.int32, device="cuda")
+    dfaces = [None, _t(faces[1]), _t(faces[2])]
+    vp = (C.c_void_p * 3)(None, dfaces[1].data_ptr(), dfaces[2].data_ptr())
+    assert S.sfk_cell_owner_graded(len(xt), dxt.data_ptr(), ob.P(lo), ob.P(dxm), ob.P(mesh_n), vp, dcell.data_ptr(),
+                                   None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(dcell.cpu().numpy(), ref) and (ref < 0).any()
+    # scatter with the graded volumes
+    gamma = np.zeros(ncells); Ue = np.zeros((ncells, 3))
+    L.orc_particle_to_eulerian(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), ob.P(gamma), ob.P(Ue))
+    assert dc.rel_err(cloud.gamma(), gamma) <= 1e-12 and dc.rel_err(cloud.Ue(), Ue) <= 1e-11
+    assert np.sum(cloud.gamma() * V) == pytest.approx(np.sum(np.pi * d ** 3 / 6.0), rel=1e-12)
+    # one coupled step + calcTcFields
+    Uf = np.tile([0.02, 0.05, -0.01], (ncells, 1))
+    cloud.setFluid(Uf=Uf)
+    cloud.evolve()
+    P = cloud.particles()
+    st = lmp.get_state()
+    cloud.calcTcFields()
+    L.orc_cell_owner_graded(n, ob.P(st["x"]), ob.P(lo), ob.P(dxm), ob.P(mesh_n), fp, ob.P(cell))
+    L.orc_particle_to_eulerian(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), ob.P(gamma), ob.P(Ue))
+    assert dc.rel_err(cloud.gamma(), gamma) <= 1e-12
+    if gamma.max() < 0.85:
+        Ur = np.linalg.norm(Uf[cell] - st["v"], axis=1)
+        Jd = np.zeros(n)
+        L.orc_ergun_wenyu_jd(n, ob.P(Ur), ob.P(np.ascontiguousarray(gamma[cell])), ob.P(d), 1e-6, 1000.0, ob.P(Jd))
+        Asrc = np.zeros((ncells, 3)); Omega = np.ones(ncells)
+        L.orc_calc_tc_fields_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ob.P(Jd), ncells, ob.P(V), ob.P(gamma),
+                                    ob.P(Uf), None, ob.P(Asrc), ob.P(Omega))
+        assert dc.rel_err(cloud.Asrc(), Asrc) <= 1e-10
+    assert len(P["cell"]) == n
+
+
 def test_coupled_ergun_wenyu_default_forces():
     _coupled_case("ErgunWenYu", {})
 
