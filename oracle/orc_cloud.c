@@ -376,6 +376,103 @@ void orc_smooth_field(const int n[3], const double dx[3], const double D[3], dou
   free(x); free(r); free(p); free(ap);
 }
 
+/* The same smoothing on a graded (blockMesh simpleGrading) block, w[k] = cell widths along k or NULL = uniform dx[k].
+ * Finite volumes on the orthogonal mesh ([3P] fvm::ddt - fvm::laplacian, Gauss linear corrected):
+ *   V_c (phi_new - phi_old)_c = dtau * sum_faces D_k S_f (phi_nb - phi_c)_new / |d_f|
+ * S_f the face area, |d_f| the distance of the two cell centres, zero flux through the boundary.  Written as
+ * (V + dtau K) phi_new = V phi_old the matrix is symmetric positive definite: plain CG to 1e-15. */
+typedef struct {
+  int n[3];
+  const double *w[3];
+  double dx[3], D[3], dtau;
+} orc_gstencil;
+
+static double gwidth(const orc_gstencil *st, int k, int i) { return st->w[k] ? st->w[k][i] : st->dx[k]; }
+
+static void apply_G(const orc_gstencil *st, const double *v, double *out)
+{
+  int idx[3], k;
+  const int stride[3] = {1, st->n[0], st->n[0] * st->n[1]};
+  for (idx[2] = 0; idx[2] < st->n[2]; idx[2]++)
+    for (idx[1] = 0; idx[1] < st->n[1]; idx[1]++)
+      for (idx[0] = 0; idx[0] < st->n[0]; idx[0]++) {
+        int c = idx[0] + st->n[0] * (idx[1] + st->n[1] * idx[2]);
+        double h[3] = {gwidth(st, 0, idx[0]), gwidth(st, 1, idx[1]), gwidth(st, 2, idx[2])};
+        double vc = v[c], acc = h[0] * h[1] * h[2] * vc;
+        for (k = 0; k < 3; k++) {
+          double area = h[(k + 1) % 3] * h[(k + 2) % 3];
+          if (idx[k] > 0) {
+            double d = 0.5 * (h[k] + gwidth(st, k, idx[k] - 1));
+            acc += st->dtau * st->D[k] * area / d * (vc - v[c - stride[k]]);
+          }
+          if (idx[k] < st->n[k] - 1) {
+            double d = 0.5 * (h[k] + gwidth(st, k, idx[k] + 1));
+            acc += st->dtau * st->D[k] * area / d * (vc - v[c + stride[k]]);
+          }
+        }
+        out[c] = acc;
+      }
+}
+
+void orc_smooth_field_graded(const int n[3], const double dx[3], const double *const w[3], const double D[3],
+                             double band, int steps, int ncomp, double *field)
+{
+  int nc = n[0] * n[1] * n[2], s, comp, c, it, k;
+  orc_gstencil st;
+  if (!(band > 0.0) || steps <= 0) return;
+  st.dtau = (band * band / 4.0) / (steps + 1.0e-150);             /* :564-565 */
+  for (k = 0; k < 3; k++) {
+    st.n[k] = n[k];
+    st.w[k] = w ? w[k] : NULL;
+    st.dx[k] = dx[k];
+    st.D[k] = D[k];
+  }
+  double *x = malloc(sizeof(double) * nc), *b = malloc(sizeof(double) * nc), *r = malloc(sizeof(double) * nc),
+         *p = malloc(sizeof(double) * nc), *ap = malloc(sizeof(double) * nc);
+  for (s = 0; s < steps; s++)
+    for (comp = 0; comp < ncomp; comp++) {
+      double rr = 0.0, bb = 0.0;
+      int i0, i1, i2;
+      for (i2 = 0; i2 < n[2]; i2++)
+        for (i1 = 0; i1 < n[1]; i1++)
+          for (i0 = 0; i0 < n[0]; i0++) {
+            c = i0 + n[0] * (i1 + n[1] * i2);
+            x[c] = field[(size_t)c * ncomp + comp];
+            b[c] = gwidth(&st, 0, i0) * gwidth(&st, 1, i1) * gwidth(&st, 2, i2) * x[c];
+          }
+      apply_G(&st, x, ap);
+      for (c = 0; c < nc; c++) {
+        r[c] = b[c] - ap[c];
+        p[c] = r[c];
+        rr += r[c] * r[c];
+        bb += b[c] * b[c];
+      }
+      for (it = 0; it < 20000 && rr > 1e-30 * bb; it++) {
+        double pap = 0.0, rrn = 0.0;
+        apply_G(&st, p, ap);
+        for (c = 0; c < nc; c++) pap += p[c] * ap[c];
+        double alpha = rr / pap;
+        for (c = 0; c < nc; c++) {
+          x[c] += alpha * p[c];
+          r[c] -= alpha * ap[c];
+          rrn += r[c] * r[c];
+        }
+        double beta = rrn / rr;
+        for (c = 0; c < nc; c++) p[c] = r[c] + beta * p[c];
+        rr = rrn;
+      }
+      for (c = 0; c < nc; c++) field[(size_t)c * ncomp + comp] = x[c];
+    }
+  free(x); free(b); free(r); free(p); free(ap);
+}
+
+/* smoothField as the cloud functions below call it: uniform block or graded block (sm->w) */
+static void smooth_any(const orc_smooth *sm, int ncomp, double *field)
+{
+  if (sm->w[0] || sm->w[1] || sm->w[2]) orc_smooth_field_graded(sm->n, sm->dx, sm->w, sm->D, sm->band, sm->steps, ncomp, field);
+  else orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, ncomp, field);
+}
+
 /* particleToEulerianField with the smoothing branches (:944-962) */
 void orc_particle_to_eulerian_smooth(int n, const int *cell, const double *d, const double *U, int ncells,
                                      const double *V, const orc_smooth *sm, double *gamma, double *Ue)
@@ -396,8 +493,8 @@ void orc_particle_to_eulerian_smooth(int n, const int *cell, const double *d, co
     gamma[c] /= V[c];
     for (k = 0; k < 3; k++) Ue[3 * c + k] /= V[c];
   }
-  if (sm && sm->alphaSmooth) orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 1, gamma);
-  if (sm && sm->UpSmooth) orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 3, Ue);
+  if (sm && sm->alphaSmooth) smooth_any(sm, 1, gamma);
+  if (sm && sm->UpSmooth) smooth_any(sm, 3, Ue);
   for (c = 0; c < ncells; c++)
     if (gamma[c] > ROOTVSMALL)
       for (k = 0; k < 3; k++) Ue[3 * c + k] /= gamma[c];
@@ -411,7 +508,7 @@ void orc_uf_smoothed(int ncells, const double *Uf, const double *gamma, const or
   if (!sm || !sm->UfSmooth || !(sm->band > 0.0) || sm->steps <= 0) return;
   for (c = 0; c < ncells; c++)
     for (k = 0; k < 3; k++) UfS[3 * c + k] *= (1 - gamma[c]);
-  orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 3, UfS);
+  smooth_any(sm, 3, UfS);
   for (c = 0; c < ncells; c++)
     for (k = 0; k < 3; k++) UfS[3 * c + k] /= (1 - gamma[c]);
 }
@@ -435,7 +532,7 @@ void orc_calc_tc_fields_smooth(int n, const int *cell, const double *d, const do
   }
   for (c = 0; c < ncells; c++)
     for (k = 0; k < 3; k++) Asrc[3 * c + k] = Asrc[3 * c + k] * (1 - gamma[c]);
-  if (sm && sm->dragSmooth) orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, 3, Asrc);
+  if (sm && sm->dragSmooth) smooth_any(sm, 3, Asrc);
   for (c = 0; c < ncells; c++)
     for (k = 0; k < 3; k++) Asrc[3 * c + k] /= (1 - gamma[c]);
 }

@@ -255,7 +255,10 @@ typedef struct {
   double band;
   int steps;
   int UfSmooth, UpSmooth, dragSmooth, alphaSmooth;
+  const double *w[3];   /* graded block: cell widths along each axis (NULL = uniform dx) */
 } orc_smooth;
+void orc_smooth_field_graded(const int n[3], const double dx[3], const double *const w[3], const double D[3],
+                             double band, int steps, int ncomp, double *field);
 void orc_smooth_field(const int n[3], const double dx[3], const double D[3], double band, int steps, int ncomp,
                       double *field);
 void orc_particle_to_eulerian_smooth(int n, const int *cell, const double *d, const double *U, int ncells,

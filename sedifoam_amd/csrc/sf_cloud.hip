@@ -556,9 +556,10 @@ class Cloud {
     alloc(curlU_, 3 * nc);
     alloc(UfS_, 3 * nc);
     alloc(UfSold_, 3 * nc);
-    if ((mesh.faces[0] || mesh.faces[1] || mesh.faces[2]) && props.diffusionBandWidth > 0.0 && props.diffusionSteps > 0)
-      fail("diffusion smoothing on a graded block is not available");
-    smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_);
+    const double* wptr[3] = {mesh.faces[0] ? width[0].data() : nullptr, mesh.faces[1] ? width[1].data() : nullptr,
+                             mesh.faces[2] ? width[2].data() : nullptr};
+    smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_,
+                        wptr);
     SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
     std::vector<double> hV(nc);
     for (int iz = 0; iz < mesh.n[2]; iz++)

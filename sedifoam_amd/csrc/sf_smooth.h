@@ -4,7 +4,8 @@
 // `diffusionSteps` implicit-Euler steps with zero-gradient boundaries, each step one
 // `solve(fvm::ddt(phi) - fvm::laplacian(DT, phi))` by PCG (tolerance 1e-10, system/fvSolution: tempDiffScalar).
 // On the uniform hex block that is (I - dtau*L) phi_new = phi_old with the 7-point Laplacian; here it is solved
-// directly in the cosine-transform basis that diagonalises it (all steps at once, sf_smooth.hip), or, on meshes
+// directly in the cosine-transform basis that diagonalises it (all steps at once, sf_smooth.hip; on a graded axis of a
+// blockMesh simpleGrading block in the eigenbasis of that axis' finite-volume operator instead), or, on meshes
 // too wide for dense transforms, matrix-free: with the Chebyshev semi-iteration (spectrum of A known in closed form, no
 // inner products, fixed iteration count, nothing for the host to check), optionally by conjugate gradients
 // (SF_SMOOTH_CG=1: deterministic two-stage reductions, the host looks at the residual every 8 iterations).
@@ -18,7 +19,9 @@ class DiffusionSmoother {
   DiffusionSmoother() = default;
   ~DiffusionSmoother();
   // n, dx: the hex block; D: diagonal of smoothDirection; band: diffusionBandWidth; steps: diffusionSteps
-  void configure(const int n[3], const double dx[3], const double D[3], double band, int steps, hipStream_t s);
+  // widths[k]: the n[k] cell widths of a graded axis (blockMesh simpleGrading), or nullptr = uniform dx[k]
+  void configure(const int n[3], const double dx[3], const double D[3], double band, int steps, hipStream_t s,
+                 const double* const widths[3] = nullptr);
   bool enabled() const { return enabled_; }
   // field: ncells*ncomp doubles, component-interleaved (AoS); smoothed in place
   void smooth(double* field, int ncomp);
@@ -42,11 +45,12 @@ class DiffusionSmoother {
   double lmin_ = 1.0, lmax_ = 1.0;
   int cheb_iters_ = 0;
   double* cheb_ = nullptr;    // r, d (two buffers): 3 x [kMaxCheb][ncells]
-  // spectral direct solve (default up to 128 cells per direction; SF_SMOOTH_SPECTRAL=0: Chebyshev)
+  // spectral direct solve (default up to kMaxSpectral cells per direction; SF_SMOOTH_SPECTRAL=0: Chebyshev)
   void smooth_spectral(double* fa, int na, double* fb, int nb);
   bool use_spectral_ = false;
   double* spec_ = nullptr;    // DCT matrices, eigenvalues, two planar work arrays
-  size_t specC_off_[3] = {0, 0, 0}, specL_off_[3] = {0, 0, 0}, spec_work_off_ = 0;
+  size_t specC_off_[3] = {0, 0, 0}, specB_off_[3] = {0, 0, 0}, specL_off_[3] = {0, 0, 0}, spec_work_off_ = 0;
+  static constexpr int kMaxSpectral = 256;   // cells per direction the dense transforms are used for
 };
 
 }  // namespace sf

@@ -207,7 +207,8 @@ struct SpecArgs {
   int n[3];
   int dim;            // direction transformed by this pass
   int inverse;        // 0: out_m = sum_i C[m][i] in_i ; 1: out_i = sum_m C[m][i] in_m
-  const double* C;    // [n_dim][n_dim] orthonormal DCT-II matrix of that direction
+  const double* C;    // forward: [mode][cell]; inverse: [mode][cell] of the back transform.  Uniform direction: the
+                      // orthonormal DCT-II matrix for both; graded direction: Q^T W^1/2 and (W^-1/2 Q)^T (see configure)
   const double* in;   // [ntot][ncells] planar (nullptr: read the interleaved fields)
   double* out;        // [ntot][ncells] planar (nullptr: write the interleaved fields)
   const double* lam[3];   // dtau D_d / dx_d^2 * (2 - 2 cos(pi m / n_d)) ; filter applied when `filter` != 0
@@ -263,19 +264,63 @@ DiffusionSmoother::~DiffusionSmoother()
   if (h_scal_) (void)hipHostFree(h_scal_);
 }
 
+// eigen-decomposition of a symmetric matrix by cyclic Jacobi rotations (n <= 256, set-up time only):
+// a (n x n, row major) is destroyed, its diagonal ends up holding the eigenvalues, q the eigenvectors (columns)
+static void jacobi_eigen(int n, std::vector<double>& a, std::vector<double>& q)
+{
+  q.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) q[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) (i == j ? diag : off) += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    if (off <= 1.0e-32 * diag) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int r = p + 1; r < n; r++) {
+        const double apr = a[(size_t)p * n + r];
+        if (apr == 0.0) continue;
+        const double theta = (a[(size_t)r * n + r] - a[(size_t)p * n + p]) / (2.0 * apr);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; k++) {   // columns p and r
+          const double akp = a[(size_t)k * n + p], akr = a[(size_t)k * n + r];
+          a[(size_t)k * n + p] = c * akp - sn * akr;
+          a[(size_t)k * n + r] = sn * akp + c * akr;
+        }
+        for (int k = 0; k < n; k++) {   // rows p and r
+          const double apk = a[(size_t)p * n + k], ark = a[(size_t)r * n + k];
+          a[(size_t)p * n + k] = c * apk - sn * ark;
+          a[(size_t)r * n + k] = sn * apk + c * ark;
+        }
+        for (int k = 0; k < n; k++) {
+          const double qkp = q[(size_t)k * n + p], qkr = q[(size_t)k * n + r];
+          q[(size_t)k * n + p] = c * qkp - sn * qkr;
+          q[(size_t)k * n + r] = sn * qkp + c * qkr;
+        }
+      }
+  }
+}
+
 void DiffusionSmoother::configure(const int n[3], const double dx[3], const double D[3], double band, int steps,
-                                  hipStream_t s)
+                                  hipStream_t s, const double* const widths[3])
 {
   s_ = s;
   enabled_ = band > 0.0 && steps > 0;
   if (!enabled_) return;
+  const bool graded = widths && (widths[0] || widths[1] || widths[2]);
   ncells_ = n[0] * n[1] * n[2];
   steps_ = steps;
   const double tau = band * band / 4.0;            // enhancedCloud.C:564
   const double dtau = tau / (steps + 1.0e-150);    // :565 (diffusionSteps + ROOTVSMALL)
   for (int k = 0; k < 3; k++) {
     n_[k] = n[k];
-    c_[k] = dtau * D[k] / (dx[k] * dx[k]);
+    double h = dx[k];
+    if (widths && widths[k]) {   // graded: the mean width, only for the spectrum bound of the iterative solvers
+      h = 0.0;
+      for (int i = 0; i < n[k]; i++) h += widths[k][i];
+      h /= n[k];
+    }
+    c_[k] = dtau * D[k] / (h * h);
   }
   nblocks_ = div_up(ncells_, 256);
   SF_HIP(hipMalloc(&r_, sizeof(double) * ncells_));
@@ -294,22 +339,52 @@ void DiffusionSmoother::configure(const int n[3], const double dx[3], const doub
   cheb_iters_ = std::max(cheb_iters_, 2);
   SF_HIP(hipMalloc(&cheb_, sizeof(double) * 3 * kMaxCheb * ncells_));
   // spectral path: DCT-II matrices and scaled eigenvalues of the three directions
-  use_spectral_ = !use_cg_ && std::max(n_[0], std::max(n_[1], n_[2])) <= 128 &&
+  use_spectral_ = !use_cg_ && std::max(n_[0], std::max(n_[1], n_[2])) <= kMaxSpectral &&
                   !(getenv("SF_SMOOTH_SPECTRAL") && atoi(getenv("SF_SMOOTH_SPECTRAL")) == 0);
+  if (graded && !use_spectral_)
+    fail("diffusion smoothing on a graded block needs the dense-transform solver (at most %d cells per direction, "
+         "no SF_SMOOTH_CG / SF_SMOOTH_SPECTRAL=0)", kMaxSpectral);
   if (use_spectral_) {
     size_t off = 0;
-    std::vector<double> h;
+    std::vector<double> h, lam[3];
     for (int d = 0; d < 3; d++) {
       const int nd = n_[d];
       specC_off_[d] = off;
-      for (int m = 0; m < nd; m++)
-        for (int i = 0; i < nd; i++)
-          h.push_back(std::sqrt((m == 0 ? 1.0 : 2.0) / nd) * std::cos(M_PI * m * (i + 0.5) / nd));
+      if (!(widths && widths[d])) {
+        for (int m = 0; m < nd; m++)
+          for (int i = 0; i < nd; i++)
+            h.push_back(std::sqrt((m == 0 ? 1.0 : 2.0) / nd) * std::cos(M_PI * m * (i + 0.5) / nd));
+        off += (size_t)nd * nd;
+        specB_off_[d] = specC_off_[d];   // orthonormal: the back transform is the transpose of the same matrix
+        for (int m = 0; m < nd; m++) lam[d].push_back(c_[d] * (2.0 - 2.0 * std::cos(M_PI * m / nd)));
+        continue;
+      }
+      // Graded direction.  The finite-volume operator of fvm::laplacian on this orthogonal mesh is, along d,
+      //   (L phi)_i = (1/h_i) [ (phi_{i+1} - phi_i)/d_{i+1/2} - (phi_i - phi_{i-1})/d_{i-1/2} ],  d = distance of centres,
+      // zero flux at both ends.  S = W^1/2 (-L) W^-1/2 (W = diag h) is symmetric: S = Q Lambda Q^T, so
+      //   phi_hat = Q^T W^1/2 phi   and   phi = W^-1/2 Q phi_hat
+      // play the roles of the cosine transform and its inverse; the directions still commute (tensor product).
+      const double* w = widths[d];
+      std::vector<double> S((size_t)nd * nd, 0.0), Q;
+      for (int i = 0; i + 1 < nd; i++) {
+        const double dist = 0.5 * (w[i] + w[i + 1]);
+        S[(size_t)i * nd + i] += 1.0 / (w[i] * dist);
+        S[(size_t)(i + 1) * nd + i + 1] += 1.0 / (w[i + 1] * dist);
+        S[(size_t)i * nd + i + 1] = S[(size_t)(i + 1) * nd + i] = -1.0 / (std::sqrt(w[i] * w[i + 1]) * dist);
+      }
+      jacobi_eigen(nd, S, Q);
+      for (int m = 0; m < nd; m++)          // forward [mode m][cell i] = Q[i][m] sqrt(h_i)
+        for (int i = 0; i < nd; i++) h.push_back(Q[(size_t)i * nd + m] * std::sqrt(w[i]));
       off += (size_t)nd * nd;
+      specB_off_[d] = off;
+      for (int m = 0; m < nd; m++)          // back, stored [mode m][cell i] = Q[i][m] / sqrt(h_i)
+        for (int i = 0; i < nd; i++) h.push_back(Q[(size_t)i * nd + m] / std::sqrt(w[i]));
+      off += (size_t)nd * nd;
+      for (int m = 0; m < nd; m++) lam[d].push_back(dtau * D[d] * std::max(S[(size_t)m * nd + m], 0.0));
     }
     for (int d = 0; d < 3; d++) {
       specL_off_[d] = off;
-      for (int m = 0; m < n_[d]; m++) h.push_back(c_[d] * (2.0 - 2.0 * std::cos(M_PI * m / n_[d])));
+      h.insert(h.end(), lam[d].begin(), lam[d].end());
       off += n_[d];
     }
     spec_work_off_ = off;
@@ -339,7 +414,7 @@ void DiffusionSmoother::smooth_spectral(double* fa, int na, double* fb, int nb)
   for (int pass = 0; pass < 6; pass++) {
     A.dim = order[pass];
     A.inverse = pass >= 3;
-    A.C = spec_ + specC_off_[A.dim];
+    A.C = spec_ + (A.inverse ? specB_off_[A.dim] : specC_off_[A.dim]);
     A.in = in;
     A.out = pass == 5 ? nullptr : ((pass & 1) ? w1 : w0);
     A.filter = pass == 2;

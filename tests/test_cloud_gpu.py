@@ -317,6 +317,77 @@ def test_graded_block_mesh_cell_owner_and_scatter():
     assert len(P["cell"]) == n
 
 
+def test_graded_block_mesh_diffusion_smoothing():
+    """enhancedCloud::smoothField on a graded block: the product solves it directly in the eigenbasis of the graded
+    1-D finite-volume operators (dense transforms), the oracle by CG on the volume-weighted system; stand-alone field,
+    smoothed scatter, smoothed Asrc; sum(V phi) is conserved."""
+    from sedifoam_amd import synthetic, enhancedCloud
+    bed = synthetic.fcc_bed((8, 7, 8), seed=24, vmax=0.05)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    mesh_n = np.array([4, 5, 3], np.int32)    # cells stay wider than a grain: alpha < 1 everywhere
+    lo, hi = bed["boxlo"], bed["boxhi"]
+    faces = [None, _graded_faces(lo[1], hi[1], 5, 2.0), _graded_faces(lo[2], hi[2], 3, 0.6)]
+    dxm = (hi - lo) / mesh_n
+    widths = [np.full(4, dxm[0]), np.diff(faces[1]), np.diff(faces[2])]
+    V = (widths[0][:, None, None] * widths[1][None, :, None] * widths[2][None, None, :]).transpose(2, 1, 0).reshape(-1)
+    ncells = int(mesh_n.prod())
+    band, steps = 5.0e-3, 3
+    sd = (1.0, 0, 0, 0, 0.5, 0, 0, 0, 1.0)
+    lmp = dc.make_hip(bed, cfg)
+    cloud = enhancedCloud(lmp, lo, dxm, mesh_n,
+                          dict(dragModel="ErgunWenYu", subCycles=1, g=(0, -9.81, 0), diffusionBandWidth=band,
+                               diffusionSteps=steps, smoothDirection=sd, maxPossibleAlpha=0.65),
+                          dict(rhob=1000.0, nub=1e-6), 50e-6, mesh_faces=faces)
+    L = ob.lib()
+    wkeep = [np.ascontiguousarray(widths[1]), np.ascontiguousarray(widths[2])]
+    wp = (ob.dp * 3)(None, ob.P(wkeep[0]), ob.P(wkeep[1]))
+    D = np.array([1.0, 0.5, 1.0])
+    # stand-alone field
+    rng = np.random.default_rng(6)
+    f = rng.uniform(size=(ncells, 3)) * (rng.uniform(size=(ncells, 1)) < 0.2)
+    got = cloud.smoothField(f)
+    ref = f.copy()
+    L.orc_smooth_field_graded(ob.P(mesh_n), ob.P(dxm), wp, ob.P(D), band, steps, 3, ob.P(ref.reshape(-1)))
+    assert dc.rel_err(got, ref) <= 1e-10
+    assert np.sum(V[:, None] * got, axis=0) == pytest.approx(np.sum(V[:, None] * f, axis=0), rel=1e-11)
+    assert got.std() < f.std()
+    # smoothed scatter and smoothed Asrc through the cloud
+    sm = ob.Smooth()
+    sm.n = (C.c_int * 3)(*[int(k) for k in mesh_n]); sm.dx = (C.c_double * 3)(*dxm); sm.D = (C.c_double * 3)(*D)
+    sm.band = band; sm.steps = steps; sm.UfSmooth = sm.UpSmooth = sm.dragSmooth = sm.alphaSmooth = 1
+    sm.w[0] = ob.dp(); sm.w[1] = ob.P(wkeep[0]); sm.w[2] = ob.P(wkeep[1])
+    n = bed["n"]; d = bed["diameter"].copy()
+    fp = (ob.dp * 3)(None, ob.P(faces[1]), ob.P(faces[2]))
+    st = lmp.get_state()
+    cell = np.zeros(n, np.int32); gamma = np.zeros(ncells); Ue = np.zeros((ncells, 3))
+    L.orc_cell_owner_graded(n, ob.P(st["x"]), ob.P(lo), ob.P(dxm), ob.P(mesh_n), fp, ob.P(cell))
+    L.orc_particle_to_eulerian_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), C.byref(sm), ob.P(gamma),
+                                      ob.P(Ue))
+    assert dc.rel_err(cloud.gamma(), gamma) <= 1e-9 and dc.rel_err(cloud.Ue(), Ue) <= 1e-9
+    assert np.sum(cloud.gamma() * V) == pytest.approx(np.sum(np.pi * d ** 3 / 6.0), rel=1e-11)
+    assert gamma.max() < 0.85
+    Uf = np.tile([0.02, 0.05, -0.01], (ncells, 1)) + 0.01 * np.sin(rng.uniform(0, 6, size=(ncells, 3)))
+    cloud.setFluid(Uf=Uf)
+    cloud.evolve()
+    UfS = np.zeros((ncells, 3))
+    L.orc_uf_smoothed(ncells, ob.P(Uf), ob.P(gamma), C.byref(sm), ob.P(UfS))   # with the gamma of the previous scatter
+    st = lmp.get_state()
+    L.orc_cell_owner_graded(n, ob.P(st["x"]), ob.P(lo), ob.P(dxm), ob.P(mesh_n), fp, ob.P(cell))
+    L.orc_particle_to_eulerian_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), C.byref(sm), ob.P(gamma),
+                                      ob.P(Ue))
+    assert dc.rel_err(cloud.gamma(), gamma) <= 1e-9
+    cloud.calcTcFields()
+    gcap = np.minimum(gamma, 0.65)
+    Ur = np.linalg.norm(UfS[cell] - st["v"], axis=1)
+    Jd = np.zeros(n)
+    L.orc_ergun_wenyu_jd(n, ob.P(Ur), ob.P(np.ascontiguousarray(gcap[cell])), ob.P(d), 1e-6, 1000.0, ob.P(Jd))
+    Asrc = np.zeros((ncells, 3)); Omega = np.ones(ncells)
+    L.orc_calc_tc_fields_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ob.P(Jd), ncells, ob.P(V), ob.P(gcap), ob.P(UfS),
+                                C.byref(sm), ob.P(Asrc), ob.P(Omega))
+    assert dc.rel_err(cloud.Asrc(), Asrc) <= 1e-8
+
+
 def test_coupled_ergun_wenyu_default_forces():
     _coupled_case("ErgunWenYu", {})
 
