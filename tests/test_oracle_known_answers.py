@@ -308,3 +308,39 @@ def test_z_cylinder_contact_is_radial_and_rotation_is_tangential():
     # shear along z slides the wall along its axis instead
     h, _, _ = _wall(x, [0, 0, 0], r, p, 3, cyl=R, shear=1, axis=2, vshear=1.5)
     assert h[2] > 0.0 and abs(h[0] * tang[0] + h[1] * tang[1]) < 1e-9 * abs(h[2])
+
+
+def test_graded_block_cell_owner_and_smoothing():
+    """Graded (simpleGrading) block: the owner is the cell whose face interval [f_i, f_i+1) holds the point; the
+    volume-weighted smoothing solver reproduces the uniform one when the widths are uniform, conserves sum(V phi) and
+    never widens the range on a graded block."""
+    n = np.array([6, 5, 4], np.int32)
+    dx = np.array([1e-3, 1.2e-3, 0.8e-3]); origin = np.array([0.0, -1e-3, 2e-3])
+    yf = origin[1] + np.array([0.0, 0.5, 1.3, 2.5, 4.1, 6.0]) * 1e-3
+    faces = (ob.dp * 3)(None, ob.P(yf), None)
+    pts = np.array([[0.5e-3, yf[0], 2.1e-3],            # on the first face: inside, cell 0
+                    [0.5e-3, yf[2], 2.1e-3],            # on an inner face: the upper cell
+                    [0.5e-3, np.nextafter(yf[2], -1), 2.1e-3],
+                    [0.5e-3, yf[5], 2.1e-3],            # on the last face: outside
+                    [5.5e-3, 0.5 * (yf[3] + yf[4]), 2e-3 + 3.1 * 0.8e-3]])
+    cell = np.zeros(len(pts), np.int32)
+    L.orc_cell_owner_graded(len(pts), ob.P(pts), ob.P(origin), ob.P(dx), ob.P(n), faces, ob.P(cell))
+    assert list(cell) == [0, 0 + 6 * 2, 0 + 6 * 1, -1, 5 + 6 * (3 + 5 * 3)]
+    D = np.array([1.0, 0.5, 2.0])
+    rng = np.random.default_rng(0)
+    f = rng.uniform(size=(int(n.prod()), 3))
+    a = f.copy(); L.orc_smooth_field(ob.P(n), ob.P(dx), ob.P(D), 3e-3, 3, 3, ob.P(a.reshape(-1)))
+    w = [np.full(n[k], dx[k]) for k in range(3)]
+    wp = (ob.dp * 3)(ob.P(w[0]), ob.P(w[1]), ob.P(w[2]))
+    b = f.copy(); L.orc_smooth_field_graded(ob.P(n), ob.P(dx), wp, ob.P(D), 3e-3, 3, 3, ob.P(b.reshape(-1)))
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    w[1] = np.ascontiguousarray(np.diff(yf))
+    wp = (ob.dp * 3)(None, ob.P(w[1]), None)
+    V = (w[0][:, None, None] * w[1][None, :, None] * w[2][None, None, :]).transpose(2, 1, 0).reshape(-1)
+    c = f.copy(); L.orc_smooth_field_graded(ob.P(n), ob.P(dx), wp, ob.P(D), 3e-3, 3, 3, ob.P(c.reshape(-1)))
+    assert np.allclose((V[:, None] * c).sum(0), (V[:, None] * f).sum(0), rtol=1e-13)
+    assert c.min() >= f.min() and c.max() <= f.max() and c.std() < 0.5 * f.std()
+    # a field that is constant stays constant (zero-gradient walls, row sums of the operator vanish)
+    one = np.full(int(n.prod()), 3.25)
+    L.orc_smooth_field_graded(ob.P(n), ob.P(dx), wp, ob.P(D), 3e-3, 3, 1, ob.P(one))
+    assert np.allclose(one, 3.25, rtol=1e-14)
