@@ -305,6 +305,11 @@ typedef struct {
    * NULL = uniform cells origin[k] + i dx[k].  The mesh stays a tensor product: cell (ix, iy, iz) = ix + nx*(iy + ny*iz)
    * spans faces[0][ix..ix+1] x faces[1][iy..iy+1] x faces[2][iz..iz+1]. */
   const double *faces[3];
+  /* multi-block blockMesh cases: OpenFOAM numbers the cells block by block.  cell_label[ix + nx*(iy + ny*iz)] = the
+   * OpenFOAM label of that cell of the merged rectilinear grid (host pointer to a permutation of 0..ncells-1, copied),
+   * NULL = identity.  Every host array that crosses this interface (set_fluid, get_fields, get_particles' cell,
+   * smooth_field) is then in label order; sf_cloud_device_fields stays in grid order. */
+  const int *cell_label;
 } sf_cloud_mesh;
 
 int sf_cloud_create(void *lmp, const sf_cloud_mesh *mesh, const sf_cloud_props *props,

@@ -64,9 +64,11 @@ class enhancedCloud:
     transDict keys (constant/transportProperties): rhob, nub."""
 
     def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT, driver=None,
-                 mesh_faces=None):
+                 mesh_faces=None, mesh_labels=None):
         """mesh_faces: (xf, yf, zf) face coordinates of a graded (blockMesh simpleGrading) block, n+1 ascending values
         per axis or None for a uniform axis (then mesh_origin / mesh_dx apply along it).
+        mesh_labels: OpenFOAM cell label of every cell of the grid, in grid order ix + nx*(iy + ny*iz) (multi-block
+        blockMesh cases number their cells block by block); every field array is then in label order.
         driver: a sedifoam_amd.halo.SlabDriver when the particles are decomposed over several GPUs (lammps is
         then the driver's engine).  Every rank holds the whole mesh; the per-cell sums of gamma, Ue and Asrc are
         added over the ranks (torch.distributed all_reduce on the device arrays) inside evolve()/calcTcFields()."""
@@ -120,6 +122,12 @@ class enhancedCloud:
                 keep_faces.append(a)
                 m.faces[k] = a.ctypes.data_as(C.POINTER(C.c_double))
         self.ncells = int(np.prod(mesh_n))
+        if mesh_labels is not None:
+            lab = np.ascontiguousarray(mesh_labels, dtype=np.int32)
+            if lab.shape != (self.ncells,):
+                raise SfError("mesh_labels must hold one label per cell")
+            keep_faces.append(lab)
+            m.cell_label = lab.ctypes.data_as(C.POINTER(C.c_int))
         h = C.c_void_p()
         if driver is not None and not driver.is_setup:
             driver.setup()

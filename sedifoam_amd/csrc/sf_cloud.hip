@@ -515,6 +515,15 @@ class Cloud {
     }
     mesh_.ncells = mesh.n[0] * mesh.n[1] * mesh.n[2];
     if (mesh_.ncells <= 0) fail("cloud mesh has no cells");
+    if (mesh.cell_label) {
+      label_.assign(mesh.cell_label, mesh.cell_label + mesh_.ncells);
+      std::vector<char> seen(mesh_.ncells, 0);
+      for (int c = 0; c < mesh_.ncells; c++) {
+        const int l = label_[c];
+        if (l < 0 || l >= mesh_.ncells || seen[l]) fail("cloud mesh: cell_label is not a permutation of 0..%d", mesh_.ncells - 1);
+        seen[l] = 1;
+      }
+    }
     // cell widths per axis (uniform or from the face coordinates of a graded block)
     std::vector<double> width[3];
     for (int k = 0; k < 3; k++) {
@@ -583,13 +592,40 @@ class Cloud {
       if (p) (void)hipFree(p);
   }
 
+  // host arrays of the caller are in OpenFOAM label order, the device fields in grid order (label_ empty: the same)
+  void upload_field(double* dev, const double* host, int ncomp)
+  {
+    const size_t nc = (size_t)mesh_.ncells;
+    if (label_.empty()) {
+      SF_HIP(hipMemcpyAsync(dev, host, sizeof(double) * ncomp * nc, hipMemcpyHostToDevice, s_));
+      return;
+    }
+    std::vector<double> tmp(ncomp * nc);
+    for (size_t c = 0; c < nc; c++)
+      for (int k = 0; k < ncomp; k++) tmp[c * ncomp + k] = host[(size_t)label_[c] * ncomp + k];
+    SF_HIP(hipMemcpyAsync(dev, tmp.data(), sizeof(double) * ncomp * nc, hipMemcpyHostToDevice, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+  }
+  void download_field(double* host, const double* dev, int ncomp)
+  {
+    const size_t nc = (size_t)mesh_.ncells;
+    if (label_.empty()) {
+      SF_HIP(hipMemcpyAsync(host, dev, sizeof(double) * ncomp * nc, hipMemcpyDeviceToHost, s_));
+      return;
+    }
+    std::vector<double> tmp(ncomp * nc);
+    SF_HIP(hipMemcpyAsync(tmp.data(), dev, sizeof(double) * ncomp * nc, hipMemcpyDeviceToHost, s_));
+    SF_HIP(hipStreamSynchronize(s_));
+    for (size_t c = 0; c < nc; c++)
+      for (int k = 0; k < ncomp; k++) host[(size_t)label_[c] * ncomp + k] = tmp[c * ncomp + k];
+  }
+
   void set_fluid(const double* Uf, const double* DDtUf, const double* gradp, const double* curlU)
   {
-    const size_t nb = sizeof(double) * 3 * (size_t)mesh_.ncells;
-    if (Uf) SF_HIP(hipMemcpyAsync(Uf_, Uf, nb, hipMemcpyHostToDevice, s_));
-    if (DDtUf) SF_HIP(hipMemcpyAsync(DDtUf_, DDtUf, nb, hipMemcpyHostToDevice, s_));
-    if (gradp) SF_HIP(hipMemcpyAsync(gradp_, gradp, nb, hipMemcpyHostToDevice, s_));
-    if (curlU) SF_HIP(hipMemcpyAsync(curlU_, curlU, nb, hipMemcpyHostToDevice, s_));
+    if (Uf) upload_field(Uf_, Uf, 3);
+    if (DDtUf) upload_field(DDtUf_, DDtUf, 3);
+    if (gradp) upload_field(gradp_, gradp, 3);
+    if (curlU) upload_field(curlU_, curlU, 3);
     // before the first step the fields are the initial condition: UfSmoothed_ (whose oldTime() the history force
     // reads in the first step) is built from them, as the reference does at construction (:641-655)
     if (Uf && time_index_ == 0) update_uf_smoothed();
@@ -715,11 +751,10 @@ class Cloud {
 
   void get_fields(double* gamma, double* Ue, double* Asrc, double* Omega)
   {
-    const size_t nc = (size_t)mesh_.ncells;
-    if (gamma) SF_HIP(hipMemcpyAsync(gamma, gamma_, sizeof(double) * nc, hipMemcpyDeviceToHost, s_));
-    if (Ue) SF_HIP(hipMemcpyAsync(Ue, Ue_, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, s_));
-    if (Asrc) SF_HIP(hipMemcpyAsync(Asrc, Asrc_, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, s_));
-    if (Omega) SF_HIP(hipMemcpyAsync(Omega, Omega_, sizeof(double) * nc, hipMemcpyDeviceToHost, s_));
+    if (gamma) download_field(gamma, gamma_, 1);
+    if (Ue) download_field(Ue, Ue_, 3);
+    if (Asrc) download_field(Asrc, Asrc_, 3);
+    if (Omega) download_field(Omega, Omega_, 1);
     SF_HIP(hipStreamSynchronize(s_));
   }
 
@@ -742,7 +777,7 @@ class Cloud {
       const int t = ht[r] - 1;
       if (tag) tag[r] = ht[r];
       if (t < 0 || t >= maxtag_) continue;
-      if (cell) cell[r] = hc[t];
+      if (cell) cell[r] = (hc[t] >= 0 && !label_.empty()) ? label_[hc[t]] : hc[t];
       if (Jd) Jd[r] = hj[t];
       if (pDrag)
         for (int k = 0; k < 3; k++) pDrag[3 * r + k] = hf[(size_t)k * maxtag_ + t];
@@ -928,9 +963,9 @@ public:
     const size_t nb = sizeof(double) * (size_t)mesh_.ncells * ncomp;
     double* d = nullptr;
     SF_HIP(hipMalloc(&d, nb));
-    SF_HIP(hipMemcpyAsync(d, field, nb, hipMemcpyHostToDevice, s_));
+    upload_field(d, field, ncomp);
     smoother_.smooth(d, ncomp);
-    SF_HIP(hipMemcpyAsync(field, d, nb, hipMemcpyDeviceToHost, s_));
+    download_field(field, d, ncomp);
     SF_HIP(hipStreamSynchronize(s_));
     (void)hipFree(d);
   }
@@ -942,6 +977,7 @@ public:
   double deltaT_;
   MeshDev mesh_{};
   double* faces_dev_[3] = {nullptr, nullptr, nullptr};
+  std::vector<int> label_;   // grid cell -> OpenFOAM cell label (empty: identity)
   hipStream_t s_ = nullptr;
   int subCycles_ = 1, subSteps_ = 1;
   double *V_ = nullptr, *gamma_ = nullptr, *Ue_ = nullptr, *Asrc_ = nullptr, *Omega_ = nullptr;

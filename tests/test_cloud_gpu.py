@@ -388,6 +388,53 @@ def test_graded_block_mesh_diffusion_smoothing():
     assert dc.rel_err(cloud.Asrc(), Asrc) <= 1e-8
 
 
+def test_cell_label_map_of_multi_block_meshes():
+    """sf_cloud_mesh.cell_label: OpenFOAM numbers the cells of a multi-block blockMesh block by block; with the label of
+    every grid cell given, all host fields (fluid inputs, gamma, Ue, Asrc, particle cells, smoothField) are in label
+    order and the physics is the one of the plain grid."""
+    from sedifoam_amd import synthetic, enhancedCloud
+    bed = synthetic.fcc_bed((8, 7, 8), seed=25, vmax=0.05)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    mesh_n = np.array([4, 5, 4], np.int32)
+    lo = bed["boxlo"]; dxm = (bed["boxhi"] - lo) / mesh_n
+    ncells = int(mesh_n.prod())
+    rng = np.random.default_rng(9)
+    # two blocks split at ix = 2, each numbered on its own (what blockMesh does), instead of a random permutation
+    ix, iy, iz = np.meshgrid(np.arange(4), np.arange(5), np.arange(4), indexing="ij")
+    grid = (ix + 4 * (iy + 5 * iz))
+    label = np.zeros(ncells, np.int32)
+    first = ix < 2
+    label[grid[first]] = (ix[first] + 2 * (iy[first] + 5 * iz[first]))
+    label[grid[~first]] = 40 + ((ix[~first] - 2) + 2 * (iy[~first] + 5 * iz[~first]))
+    assert sorted(label) == list(range(ncells))
+    props = dict(dragModel="ErgunWenYu", subCycles=1, g=(0, -9.81, 0), maxPossibleAlpha=0.65, diffusionBandWidth=3e-3,
+                 diffusionSteps=2)
+    Uf = np.tile([0.02, 0.05, -0.01], (ncells, 1)) + 0.01 * np.sin(rng.uniform(0, 6, size=(ncells, 3)))
+    gradp = np.tile([0.0, -9810.0, 0.0], (ncells, 1)) + rng.normal(scale=50.0, size=(ncells, 3))
+    out = []
+    for lab in (None, label):
+        lmp = dc.make_hip(bed, cfg)
+        cloud = enhancedCloud(lmp, lo, dxm, mesh_n, props, dict(rhob=1000.0, nub=1e-6), 50e-6, mesh_labels=lab)
+        def to_label(a):      # grid order -> label order
+            if lab is None:
+                return a
+            b = np.empty_like(a); b[lab] = a
+            return b
+        cloud.setFluid(Uf=to_label(Uf), gradp=to_label(gradp))
+        cloud.evolve()
+        cloud.calcTcFields()
+        f = rng.uniform(size=(ncells, 3)) if not out else out[0]["f_in"]
+        res = dict(gamma=cloud.gamma(), Ue=cloud.Ue(), Asrc=cloud.Asrc(), cell=cloud.particles()["cell"], f_in=f,
+                   f=cloud.smoothField(to_label(f)), x=lmp.get_state()["x"])
+        out.append(res)
+    a, b = out
+    assert np.array_equal(b["gamma"][label], a["gamma"]) and np.array_equal(b["Ue"][label], a["Ue"])
+    assert np.array_equal(b["Asrc"][label], a["Asrc"]) and np.array_equal(b["f"][label], a["f"])
+    assert np.array_equal(b["cell"], label[a["cell"]]) and np.array_equal(a["x"], b["x"])
+    assert np.abs(a["Asrc"]).max() > 0.0
+
+
 def test_coupled_ergun_wenyu_default_forces():
     _coupled_case("ErgunWenYu", {})
 
