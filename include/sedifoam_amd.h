@@ -264,7 +264,7 @@ int sfk_fix_fluid_drag_post_force(int nlocal, double dt, double carrier_rho, con
                                   const double *rmass, const double *radius, const int *mask,
                                   int groupbit, const double *ffluiddrag, const double *DuDt,
                                   double *vOld, double *f, void *stream);
-/* dragModel::Jd  ErgunWenYu.C:86-145 (model 0) / SyamlalOBrien.C:85-144 (model 1) */
+/* dragModel::Jd  ErgunWenYu.C:86-145 (model 0) / SyamlalOBrien.C:85-144 (model 1) / NoCorrection.C:85-146 (model 2) */
 int sfk_drag_model_jd(int model, int n, const double *Ur, const double *alpha, const double *pd,
                       double nuf, double rhof, double *Jd, void *stream);
 /* cell owner of a uniform blockMesh hex block (the result of softParticle::move tracking,
@@ -281,7 +281,7 @@ int sfk_cell_owner_graded(int n, const double *x, const double origin[3], const 
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
   /* constant/cloudProperties + transportProperties keys read at enhancedCloud.C:573-608 */
-  int dragModel;          /* 0 ErgunWenYu, 1 SyamlalOBrien  (cloudProperties: dragModel) */
+  int dragModel;          /* 0 ErgunWenYu, 1 SyamlalOBrien, 2 NoCorrection  (cloudProperties: dragModel) */
   int subCycles;
   int particleDrag, particlePressureGrad, particleBuoyancy, particleAddedMass, particleLift,
       lubricationForce;

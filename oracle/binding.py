@@ -151,6 +151,7 @@ def _declare(L):
     L.orc_fix_gravity.argtypes = [C.c_int, C.c_double, dp, dp, dp]
     L.orc_ergun_wenyu_jd.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
     L.orc_syamlal_obrien_jd.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
+    L.orc_no_correction_jd.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
     L.orc_cell_owner.argtypes = [C.c_int, dp, dp, dp, ip, ip]
     L.orc_cell_owner_graded.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(dp), ip]
     L.orc_drag_on_particles.argtypes = [C.POINTER(CloudFlags), C.c_int, C.c_int, ip] + [dp] * 14

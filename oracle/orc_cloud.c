@@ -61,6 +61,25 @@ void orc_syamlal_obrien_jd(int n, const double *Ur, const double *alpha, const d
   }
 }
 
+/* NoCorrection::Jd  lammpsFoam/dragModels/NoCorrection/NoCorrection.C:85-146: the Syamlal-O'Brien velocity-voidage
+ * correlation with beta >= 1e-6, Re >= 1e-3 and the drag coefficient 24/Re + 4/sqrt(Re) + 0.4 */
+void orc_no_correction_jd(int n, const double *Ur, const double *alpha, const double *pd,
+                          double nuf, double rhof, double *Jd)
+{
+  int i;
+  for (i = 0; i < n; i++) {
+    double beta = dmax(1.0 - alpha[i], 1.0e-6);                     /* :104 */
+    double Ai = pow(beta, 4.14);                                    /* :105 */
+    double Bi = 0.8 * pow(beta, 1.28);                              /* :106 */
+    if (beta > 0.85) Bi = pow(beta, 2.65);                          /* :108-114 */
+    double Re = dmax(Ur[i] * pd[i] / nuf, 1.0e-3);                  /* :116 */
+    double a = 0.06 * Re;
+    double Vr = 0.5 * (Ai - 0.06 * Re + sqrt(a * a + 0.12 * Re * (2.0 * Bi - Ai) + Ai * Ai)); /* :118-124 */
+    double Cds = 24 * 1.0 / Re + 4.0 * pow(Re, -0.5) + 0.4;         /* :126 */
+    Jd[i] = 0.75 * Cds * rhof * Ur[i] / (pd[i] * (Vr * Vr));        /* :144 */
+  }
+}
+
 void orc_cell_owner(int n, const double *x, const double origin[3], const double dx[3],
                     const int ncell[3], int *cell)
 {
@@ -155,6 +174,7 @@ void orc_drag_on_particles_hist(const orc_cloud_flags *fl, int dragModel, int n,
   for (i = 0; i < n; i++) {
     double a = (cell[i] >= 0) ? gamma[cell[i]] : 0.0;
     if (dragModel == 0) orc_ergun_wenyu_jd(1, &magUri[i], &a, &d[i], fl->nub, fl->rhob, &Jd[i]);
+    else if (dragModel == 2) orc_no_correction_jd(1, &magUri[i], &a, &d[i], fl->nub, fl->rhob, &Jd[i]);
     else orc_syamlal_obrien_jd(1, &magUri[i], &a, &d[i], fl->nub, fl->rhob, &Jd[i]);
   }
   for (i = 0; i < n; i++) {

@@ -210,6 +210,8 @@ void orc_syamlal_obrien_jd(int n, const double *Ur, const double *alpha, const d
                            double nuf, double rhof, double *Jd);
 
 /* A7: cell owner for one uniform blockMesh hex block; -1 outside (OpenFOAM drops the particle) */
+void orc_no_correction_jd(int n, const double *Ur, const double *alpha, const double *pd,
+                          double nuf, double rhof, double *Jd);
 void orc_cell_owner_graded(int n, const double *x, const double origin[3], const double dx[3],
                            const int ncell[3], const double *const faces[3], int *cell);
 void orc_cell_owner(int n, const double *x, const double origin[3], const double dx[3],

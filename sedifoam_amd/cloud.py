@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import SfError, check, dp, ip
 
-_DRAG_TABLE = {"ErgunWenYu": 0, "SyamlalOBrien": 1}
+_DRAG_TABLE = {"ErgunWenYu": 0, "SyamlalOBrien": 1, "NoCorrection": 2}
 
 
 def _f64(a):

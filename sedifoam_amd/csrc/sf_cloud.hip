@@ -51,9 +51,26 @@ __device__ __forceinline__ double jd_syamlal_obrien(double Ur, double alpha, dou
   return 0.75 * (s * s) * rhof * Ur / (pd * (Vr * Vr));
 }
 
+// NoCorrection::Jd  dragModels/NoCorrection/NoCorrection.C:85-146
+__device__ __forceinline__ double jd_no_correction(double Ur, double alpha, double pd, double nuf, double rhof)
+{
+  const double beta = fmax(1.0 - alpha, 1.0e-6);
+  const double Ai = pow(beta, 4.14);
+  double Bi = 0.8 * pow(beta, 1.28);
+  if (beta > 0.85) Bi = pow(beta, 2.65);
+  const double Re = fmax(Ur * pd / nuf, 1.0e-3);
+  const double a = 0.06 * Re;
+  const double Vr = 0.5 * (Ai - 0.06 * Re + sqrt(a * a + 0.12 * Re * (2.0 * Bi - Ai) + Ai * Ai));
+  const double Cds = 24 * 1.0 / Re + 4.0 * pow(Re, -0.5) + 0.4;
+  return 0.75 * Cds * rhof * Ur / (pd * (Vr * Vr));
+}
+
+// the run-time selection table of dragModel::New (newDragModel.C:31-64): 0 ErgunWenYu, 1 SyamlalOBrien, 2 NoCorrection
 __device__ __forceinline__ double jd_model(int model, double Ur, double alpha, double pd, double nuf, double rhof)
 {
-  return model == 0 ? jd_ergun_wenyu(Ur, alpha, pd, nuf, rhof) : jd_syamlal_obrien(Ur, alpha, pd, nuf, rhof);
+  return model == 0 ? jd_ergun_wenyu(Ur, alpha, pd, nuf, rhof)
+                    : (model == 2 ? jd_no_correction(Ur, alpha, pd, nuf, rhof)
+                                  : jd_syamlal_obrien(Ur, alpha, pd, nuf, rhof));
 }
 
 __global__ __launch_bounds__(256) void k_jd(int model, int n, const double* Ur, const double* alpha,
@@ -1112,7 +1129,8 @@ int sfk_drag_model_jd(int model, int n, const double* Ur, const double* alpha, c
                       double rhof, double* Jd, void* stream)
 {
   SF_API_BEGIN
-  if (model != 0 && model != 1) sf::fail("Unknown dragModel type %d (valid: 0 ErgunWenYu, 1 SyamlalOBrien)", model);
+  if (model < 0 || model > 2)
+    sf::fail("Unknown dragModel type %d (valid: 0 ErgunWenYu, 1 SyamlalOBrien, 2 NoCorrection)", model);
   if (n > 0) {
     sf::k_jd<<<sf::div_up(n, 256), 256, 0, (hipStream_t)stream>>>(model, n, Ur, alpha, pd, nuf, rhof, Jd);
     SF_HIP(hipGetLastError());
