@@ -890,7 +890,8 @@ void DemEngine::rebuild_sort()
     exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, first, ne, stream_);
     SF_HIP(hipMemcpyAsync(count, first, sizeof(int) * ne, hipMemcpyDeviceToDevice, stream_));   // cursors
     k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, perm_.as<int>());
-    k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), perm_alt_.as<int>());
+    k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), tag_.as<int>(),
+                                        perm_alt_.as<int>());
     permute_locals(perm_alt_.as<int>(), nlocal_);
     mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   } else {

@@ -896,16 +896,19 @@ __global__ __launch_bounds__(256) void k_key_place(const unsigned* keys, int n, 
   if (i >= n) return;
   arrival[atomicAdd(&cursor[keys[i]], 1)] = i;
 }
-// ... and then put into ascending old index, which is what a stable sort by key gives: perm[new] = old
+// ... and then put into ascending TAG inside every cell (tags are unique): perm[new] = old.  The order of the owned
+// atoms -- like that of the ghosts, (cell, tag) -- then depends on nothing but the particles themselves: the same
+// system fed in another order, or arriving through another history of rebuilds, gives the same lists and the same bits.
 __global__ __launch_bounds__(256) void k_key_rank(const unsigned* keys, int n, const int* first, const int* arrival,
-                                                  int* perm)
+                                                  const int* tag, int* perm)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned b = keys[i];
   const int s = first[b], e = first[b + 1];
+  const int ti = tag[i];
   int r = 0;
-  for (int k = s; k < e; k++) r += arrival[k] < i ? 1 : 0;
+  for (int k = s; k < e; k++) r += tag[arrival[k]] < ti ? 1 : 0;
   perm[s + r] = i;
 }
 
