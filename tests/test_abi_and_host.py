@@ -102,3 +102,15 @@ def test_gran_settings_like_pair_style_parser():
     assert L.sfk_gran_settings(C.byref(p), -1.0, 1, 0.0, 0.5, 1, 0.0, 0.4, 1, 1.0) == -1
     assert b"Illegal pair_style" in L.sf_last_error()
     assert L.sfk_gran_settings(C.byref(p), 1.0, 1, 0.0, 0.5, 1, 0.0, 0.4, 2, 1.0) == -1
+
+
+def test_bench_cpu_legs_run_without_a_gpu():
+    """bench.py's CPU baseline legs (the oracle timed on host cores) are plain host code: the single-core leg and the
+    one-process-per-usable-core leg both run here, on tiny samples."""
+    import bench
+    v, n, secs = bench.cpu_baseline((3, 3, 3), bench.KW, 2)
+    assert n == 108 and v > 0 and secs > 0
+    cores = bench._usable_cores()
+    assert 1 <= cores <= len(__import__("os").sched_getaffinity(0))
+    r = bench.cpu_baseline_all_cores(500, 2)
+    assert r["cores"] == cores and r["value"] > 0 and r["kind"] == "port"
