@@ -321,7 +321,9 @@ public:
 private:
   void launch_initial_integrate();
   void rebuild();          // rebuild_begin + rebuild_sort + rebuild_finish
-  void permute_locals(const int* perm, int n_new);
+  // rows = false: the slot-major history rows (numneigh, partner tags, shear) stay where they are and the list build
+  // that follows reads them through hist_perm_ (a copy of perm) -- they are 3/4 of the bytes a re-sort would move
+  void permute_locals(const int* perm, int n_new, bool rows = true);
   void migrate_compact();
   void compute_partner_tags();
   int select_locals(int mode, double bound, DevArray& list);
@@ -405,6 +407,8 @@ private:
   DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
   int* cell_start_ = nullptr;          // [nbins][4]: owned start/end, ghost start/end of every cell (hipMalloc: 16-byte aligned)
   size_t cell_alloc_ = 0;
+  DevArray hist_perm_;        // see permute_locals(rows = false)
+  bool hist_indirect_ = false;
   bool row_tables_ = false;   // cell_start_ holds the reversed lower-bound tables (plain keys) instead of cell ranges
   int* tagmap_ = nullptr;
   size_t tagmap_alloc_ = 0;

@@ -106,7 +106,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_};
 }
 
 DemEngine::~DemEngine()
@@ -177,6 +177,7 @@ void DemEngine::alloc_all(size_t cap)
   keys_alt_.alloc(sizeof(unsigned), 1, cap, s);
   perm_.alloc(sizeof(int), 1, cap, s);
   perm_alt_.alloc(sizeof(int), 1, cap, s);
+  hist_perm_.alloc(sizeof(int), 1, cap, s);
   keys64_.alloc(sizeof(unsigned long long), 1, cap, s);
   keys64_alt_.alloc(sizeof(unsigned long long), 1, cap, s);
   sendlist_[0].alloc(sizeof(int), 1, cap, s);
@@ -813,8 +814,9 @@ void DemEngine::rebuild_begin()
 
 // Re-order (and possibly shrink to n_new) every per-atom array of the owned atoms: dst[i] = src[perm[i]].
 // The old-list rows (partner tags, slot counts, shear) travel with their atom through the B-side buffers.
-void DemEngine::permute_locals(const int* perm, int n_new)
+void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
 {
+  hist_indirect_ = false;
   if (n_new <= 0) return;
   const int nb = div_up(n_new, 256);
   // gather into the scratch array of the same shape, then swap the two allocations (no copy back): everything
@@ -851,7 +853,10 @@ void DemEngine::permute_locals(const int* perm, int n_new)
                                                           perm, n_new, 1, cap_);
     SF_HIP(hipMemcpyAsync(wtouch_.ptr, tmpi_.ptr, n_new, hipMemcpyDeviceToDevice, stream_));
   }
-  if (have_list_ && max_neigh_used_ > 0) {
+  if (have_list_ && max_neigh_used_ > 0 && !rows) {
+    SF_HIP(hipMemcpyAsync(hist_perm_.ptr, perm, sizeof(int) * n_new, hipMemcpyDeviceToDevice, stream_));
+    hist_indirect_ = true;
+  } else if (have_list_ && max_neigh_used_ > 0) {
     k_gather_rows<int><<<nb, 256, 0, stream_>>>(numneigh_old_.as<int>(), numneigh_.as<int>(), perm, n_new, 1, cap_);
     k_gather_rows<int><<<nb, 256, 0, stream_>>>(neigh_old_.as<int>(), ptag_.as<int>(), perm, n_new,
                                                 max_neigh_used_, cap_);
@@ -892,7 +897,7 @@ void DemEngine::rebuild_sort()
     k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, perm_.as<int>());
     k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), tag_.as<int>(),
                                         perm_alt_.as<int>());
-    permute_locals(perm_alt_.as<int>(), nlocal_);
+    permute_locals(perm_alt_.as<int>(), nlocal_, /*rows=*/false);
     mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   } else {
     int bits = 1;
@@ -1048,6 +1053,7 @@ void DemEngine::bin_and_build()
     B.g = grid_;
     B.eoff = lds_active_ ? eoff_ : nullptr;
     B.nloc = nloc_.as<unsigned short>();
+    B.old_index = hist_indirect_ ? hist_perm_.as<int>() : nullptr;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
     B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;
     B.roots = roots_ ? 1 : 0;
@@ -1076,6 +1082,7 @@ void DemEngine::bin_and_build()
   }
   std::swap(numneigh_, numneigh_old_);
   std::swap(shear_, shear_old_);
+  hist_indirect_ = false;   // the old rows are gone with the old list
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
                                                            cap_);

@@ -878,6 +878,7 @@ struct BuildParams {
   // staging): see the row walk in k_build_neigh
   const int* lb_own;
   const int* lb_ghost;
+  const int* old_index;   // new index -> index before the re-sort (history rows not permuted), or nullptr
 };
 
 // ---- counting sort of the owned atoms by cell key (plain keys): a by-product is first[b], the first sorted position
@@ -928,13 +929,16 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   const int cx = bin_coord(xi.x, B.g.lo[0], B.g.inv[0], B.g.n[0], lost);
   const int cy = bin_coord(xi.y, B.g.lo[1], B.g.inv[1], B.g.n[1], lost);
   const int cz = bin_coord(xi.z, B.g.lo[2], B.g.inv[2], B.g.n[2], lost);
-  const int nold = numneigh_old ? numneigh_old[i] : 0;
+  // rows of the OLD list: at this atom's own index, or -- when the re-sort left the history rows where they were
+  // (B.old_index) -- at the index the atom had before the sort
+  const int io = B.old_index ? B.old_index[i] : i;
+  const int nold = numneigh_old ? numneigh_old[io] : 0;
   // the old partner tags of this atom in registers (the re-injection below compares every accepted neighbour with
   // them; reading the rows again per neighbour was 45 % of this kernel)
   constexpr int kPT = 16;
   int pt[kPT];
 #pragma unroll
-  for (int s = 0; s < kPT; s++) pt[s] = s < nold ? ptag_old[(size_t)s * B.cap + i] : -1;
+  for (int s = 0; s < kPT; s++) pt[s] = s < nold ? ptag_old[(size_t)s * B.cap + io] : -1;
   int n = 0;
   const int T = B.g.tile, E = T + 2;
   const int tx = cx / T, ty = cy / T, tz = cz / T;
@@ -980,13 +984,13 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
         if (pt[s] == tj) found = s;             // tags are unique: at most one match
       if (found < 0)
         for (int s = kPT; s < nold; s++)
-          if (ptag_old[(size_t)s * B.cap + i] == tj) {
+          if (ptag_old[(size_t)s * B.cap + io] == tj) {
             found = s;
             break;
           }
       if (found >= 0) {
         entry |= kTouchBit;
-        const size_t ob = (size_t)(3 * found) * B.cap + i;
+        const size_t ob = (size_t)(3 * found) * B.cap + io;
         sx = shear_old[ob];
         sy = shear_old[ob + B.cap];
         sz = shear_old[ob + 2 * B.cap];
