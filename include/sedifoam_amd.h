@@ -216,6 +216,16 @@ int sf_dem_migrate_unpack(void *ptr, const double *dev_buf, long long ndoubles);
 int sf_dem_migrate_record_doubles(void *ptr);
 /* history slots carried by a migrating atom: the max over all ranks of sf_dem_info.max_neigh_used */
 int sf_dem_migrate_set_slots(void *ptr, int mrec);
+/* pair lubricate/poly: its isotropic resistances R0 / RT0 / RS0 depend on the volume fraction of ALL particles
+ * (MPI_Allreduce of volP, pair_lubricate_poly.cpp:540-543).  On a decomposed domain the driver sums
+ * sf_dem_local_particle_volume over the ranks and passes the total to every rank before sf_dem_setup
+ * (sf_dem_setup fails on a decomposed domain with lubricate/poly when it has not been set). */
+int sf_dem_local_particle_volume(void *ptr, double *volP);
+int sf_dem_set_global_particle_volume(void *ptr, double volP);
+/* the neighbour / ghost cutoff 2 r_max + skin needs the largest radius of ALL ranks ([3P] the MPI_Allreduce of
+ * maxrad_dynamic in PairGranHookeHistory::init_one): MAX-reduce the local value, set it before the first rebuild */
+int sf_dem_local_max_radius(void *ptr, double *rmax);
+int sf_dem_set_global_max_radius(void *ptr, double rmax);
 /* refresh the periodic y/z images (also of ghosts received from other GPUs) after a forward unpack */
 int sf_dem_ghost_forward_local(void *ptr);
 /* issue all engine work on a caller-owned hipStream_t (NULL = the legacy default stream, which is torch's

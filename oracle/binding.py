@@ -104,6 +104,12 @@ def _declare(L):
     L.orc_dem_get_wall_shear.argtypes = [C.c_void_p, C.c_int, dp]
     vp = C.c_void_p
     L.orc_dem_set_subdomain.argtypes = [vp, C.c_double, C.c_double]
+    L.orc_dem_local_particle_volume.restype = C.c_double
+    L.orc_dem_local_particle_volume.argtypes = [vp]
+    L.orc_dem_set_global_particle_volume.argtypes = [vp, C.c_double]
+    L.orc_dem_local_max_radius.restype = C.c_double
+    L.orc_dem_local_max_radius.argtypes = [vp]
+    L.orc_dem_set_global_max_radius.argtypes = [vp, C.c_double]
     for name in ("orc_dem_run_begin", "orc_dem_ext_setup", "orc_dem_rebuild_begin", "orc_dem_rebuild_sort",
                  "orc_dem_rebuild_finish", "orc_dem_ghost_forward_local"):
         getattr(L, name).argtypes = [vp]
@@ -346,6 +352,18 @@ class OracleSlabEngine:
 
     def set_subdomain(self, rank, world, lo, hi):
         self.L.orc_dem_set_subdomain(self.h, lo, hi)
+
+    def local_particle_volume(self):
+        return self.L.orc_dem_local_particle_volume(self.h)
+
+    def set_global_particle_volume(self, v):
+        self.L.orc_dem_set_global_particle_volume(self.h, float(v))
+
+    def local_max_radius(self):
+        return self.L.orc_dem_local_max_radius(self.h)
+
+    def set_global_max_radius(self, r):
+        self.L.orc_dem_set_global_max_radius(self.h, float(r))
 
     def setup(self):
         self.L.orc_dem_ext_setup(self.h)

@@ -222,7 +222,7 @@ void orc_dem_threads(orc_dem *d, int nthreads) { d->nthreads = nthreads > 0 ? nt
 /* ---- [3P] neighbor cutoffs: gran pair cutoff = 2*maxrad, lubricate = cut_global ---- */
 static double max_radius(const orc_dem *d)
 {
-  double m = 0.0;
+  double m = d->rmax_global; /* decomposed twin: the MAX over the ranks ([3P] MPI_Allreduce of maxrad_dynamic); else 0 */
   int i;
   for (i = 0; i < d->nlocal; i++)
     if (d->radius[i] > m) m = d->radius[i];

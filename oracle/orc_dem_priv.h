@@ -66,6 +66,7 @@ struct orc_dem {
   int nthreads;
   /* ---- external x halo (orc_halo.c): this driver is one slab of an x-decomposed domain ---- */
   int external_x;
+  double rmax_global;    /* largest radius over all ranks (0: single domain, local maximum) */
   double sublo, subhi;
   int localcap;          /* capacity of the per-owned-atom arrays (xhold, fix fdrag arrays, ilist, wall shear) */
   int next_ghost;        /* ghosts received from the neighbour slabs, appended before the local images */

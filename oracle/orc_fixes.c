@@ -64,11 +64,17 @@ int orc_fix_cohesive(double ah, double lam, double smin, double smax, int opt, i
   return 0;
 }
 
-void orc_lubricate_init(orc_lub_params *p, int nlocal_all, const double *radius, double vol_T)
+double orc_particle_volume(int nlocal, const double *radius)
 {
   int i;
   double volP = 0.0;
-  for (i = 0; i < nlocal_all; i++) volP += (4.0 / 3.0) * ORC_PI * pow(radius[i], 3.0); /* :540-542 */
+  for (i = 0; i < nlocal; i++) volP += (4.0 / 3.0) * ORC_PI * pow(radius[i], 3.0); /* :540-542 */
+  return volP;
+}
+
+/* volP = particle volume of ALL ranks (MPI_Allreduce, pair_lubricate_poly.cpp:543) */
+void orc_lubricate_init_vol(orc_lub_params *p, double volP, double vol_T)
+{
   double vol_f = volP / vol_T;
   double mu = p->mu;
   if (!p->flagVF) vol_f = 0;                                        /* :547 */
@@ -81,6 +87,11 @@ void orc_lubricate_init(orc_lub_params *p, int nlocal_all, const double *radius,
     p->RT0 = 8 * ORC_PI * mu * (1.0 + 0.749 * vol_f - 2.469 * vol_f * vol_f);
     p->RS0 = 20.0 / 3.0 * ORC_PI * mu * (1.0 + 3.64 * vol_f - 6.95 * vol_f * vol_f);
   }
+}
+
+void orc_lubricate_init(orc_lub_params *p, int nlocal_all, const double *radius, double vol_T)
+{
+  orc_lubricate_init_vol(p, orc_particle_volume(nlocal_all, radius), vol_T);
 }
 
 void orc_pair_lubricate_poly(const orc_lub_params *p, int nlocal, const double *x,

@@ -97,6 +97,27 @@ void orc_dem_substep(orc_dem *d, int last)
 
 int orc_dem_need_rebuild(const orc_dem *d) { return d->flag; }
 
+double orc_dem_local_particle_volume(const orc_dem *d) { return orc_particle_volume(d->nlocal, d->radius); }
+
+void orc_dem_set_global_particle_volume(orc_dem *d, double volP)
+{
+  if (d->have_lub) {
+    double vol_T = (d->boxhi[0] - d->boxlo[0]) * (d->boxhi[1] - d->boxlo[1]) * (d->boxhi[2] - d->boxlo[2]);
+    orc_lubricate_init_vol(&d->lub, volP, vol_T);
+  }
+}
+
+double orc_dem_local_max_radius(const orc_dem *d)
+{
+  double m = 0.0;
+  int i;
+  for (i = 0; i < d->nlocal; i++)
+    if (d->radius[i] > m) m = d->radius[i];
+  return m;
+}
+
+void orc_dem_set_global_max_radius(orc_dem *d, double rmax) { d->rmax_global = rmax; }
+
 void orc_dem_ext_setup(orc_dem *d)
 {
   orc__compute_forces(d, 1);

@@ -86,6 +86,8 @@ typedef struct {
 } orc_lub_params;
 /* init_style(): pair_lubricate_poly.cpp:450-577 (volume-fraction constants) */
 void orc_lubricate_init(orc_lub_params *p, int nlocal_all, const double *radius, double vol_T);
+double orc_particle_volume(int nlocal, const double *radius);
+void orc_lubricate_init_vol(orc_lub_params *p, double volP, double vol_T);
 void orc_pair_lubricate_poly(const orc_lub_params *p, int nlocal, const double *x,
                              const double *v, const double *omega, const double *radius,
                              const orc_neighlist *fulllist, double *f, double *torque);
@@ -188,6 +190,11 @@ void orc_dem_run_begin(orc_dem *d);
 void orc_dem_substep(orc_dem *d, int last);
 int orc_dem_need_rebuild(const orc_dem *d);
 void orc_dem_ext_setup(orc_dem *d);
+/* lubricate/poly on a decomposed domain: the twin of MPI_Allreduce(volP) pair_lubricate_poly.cpp:540-543 */
+double orc_dem_local_particle_volume(const orc_dem *d);
+void orc_dem_set_global_particle_volume(orc_dem *d, double volP);
+double orc_dem_local_max_radius(const orc_dem *d);
+void orc_dem_set_global_max_radius(orc_dem *d, double rmax);
 void orc_dem_rebuild_begin(orc_dem *d);
 void orc_dem_rebuild_sort(orc_dem *d);
 void orc_dem_rebuild_finish(orc_dem *d);

@@ -137,6 +137,10 @@ _SIGS = {
     "sf_dem_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sf_dem_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
     "sf_dem_halo_run": (C.c_int, [vp, C.c_int, C.c_int, vp, ip]),
+    "sf_dem_local_particle_volume": (C.c_int, [vp, dp]),
+    "sf_dem_set_global_particle_volume": (C.c_int, [vp, C.c_double]),
+    "sf_dem_local_max_radius": (C.c_int, [vp, dp]),
+    "sf_dem_set_global_max_radius": (C.c_int, [vp, C.c_double]),
     "sf_dem_migrate_count": (C.c_longlong, [vp]),
     "sf_dem_migrate_pack": (C.c_longlong, [vp, C.c_int, C.c_double, vp, C.c_longlong]),
     "sf_dem_migrate_unpack": (C.c_int, [vp, vp, C.c_longlong]),

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
     int n, size_t cap, const double4* xr, const double4* vm, const int* tag, MeshDev m, CloudFlagsDev fl,
     const double* gamma, const double* UfS, const double* gradp, const double* DDtUf, const double* curlU,
     double* UOld_bytag, int maxtag, int first_call, int* cell_bytag, double* Jd_bytag, double* pDrag_bytag,
-    double* fdrag, double* DuDt, int timeIndex, const double* UfSold, double* sumFb_bytag, double* n0_bytag)
+    double* fdrag, int timeIndex, const double* UfSold, double* sumFb_bytag, double* n0_bytag)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
       for (int k = 0; k < 3; k++) uold[k] = UOld_bytag[(size_t)k * maxtag + (t - 1)];
     for (int k = 0; k < 3; k++) UOld_bytag[(size_t)k * maxtag + (t - 1)] = U[k];  // setPositionVeloCpuId: UOld = U
   }
-  double dudt[3] = {0.0, 0.0, 0.0};
+  // pDuDt = DDtUf[c] (enhancedCloud.C:155) is handed to lammps_put_local_info, which drops it (library.cpp:314-367):
+  // fix fdrag's DuDt array stays at the 0 it was created with (fix_fluid_drag.cpp:91), so the in-LAMMPS added-mass
+  // term of `fix fdrag <carrier_rho>` sees DuDt = 0 on this path exactly as through sf_lammps_put_local_info
   if (c >= 0) {
     const double d = 2.0 * x.w;
     const double Vol = kPi * d * d * d / 6.0;  // softParticle.H:270-273
@@ -158,7 +160,6 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
     for (int k = 0; k < 3; k++) Uri[k] = UfS[3 * c + k] - U[k];
     const double mag = sqrt(Uri[0] * Uri[0] + Uri[1] * Uri[1] + Uri[2] * Uri[2]);
     jd = jd_model(fl.dragModel, mag, alpha, d, fl.nub, fl.rhob);
-    for (int k = 0; k < 3; k++) dudt[k] = DDtUf[3 * c + k];
     if (fl.particleDrag)
       for (int k = 0; k < 3; k++) F[k] += jd * (1.0 - alpha) * Vol * Uri[k];
     if (fl.particlePressureGrad)
@@ -230,10 +231,7 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
         F[1] += 6 * 3.1416 * fl.nub * fl.rhob * (-U[1]) / distWall * (d * d) / 4.0 * 1.0;
     }
   }
-  for (int k = 0; k < 3; k++) {
-    fdrag[(size_t)k * cap + i] = F[k];
-    DuDt[(size_t)k * cap + i] = dudt[k];
-  }
+  for (int k = 0; k < 3; k++) fdrag[(size_t)k * cap + i] = F[k];
   // diagnostics kept by tag (the DEM engine may re-sort its atoms at any neighbour rebuild)
   if (t >= 1 && t <= maxtag) {
     cell_bytag[t - 1] = c;
@@ -902,7 +900,7 @@ class Cloud {
     k_drag_on_particles<<<div_up(n, 256), 256, 0, s_>>>(n, e.capacity(), e.d_xr(), e.d_vm(), e.d_tag(), mesh_,
                                                         flags(), gamma_, UfS_, gradp_, DDtUf_, curlU_, UOld_,
                                                         maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, pDragT_,
-                                                        e.d_fdrag(), e.d_DuDt(),
+                                                        e.d_fdrag(),
                                                         props_.particleHistoryForce ? time_index_ : -1, UfSold_,
                                                         sumFb_, n0_);
     first_drag_ = false;

@@ -221,6 +221,13 @@ class DemEngine {
 
   // ---- stepping ----
   void setup();            // first run: build list, forces with shearupdate = 0
+  // pair lubricate/poly's volume fraction needs the particle volume of ALL ranks (pair_lubricate_poly.cpp:540-543)
+  double local_particle_volume();
+  void set_global_particle_volume(double v) { global_volP_ = v; }
+  // the list / ghost cutoff 2 r_max + skin uses the largest radius of ALL ranks ([3P] MPI_Allreduce of maxrad_dynamic
+  // in PairGranHookeHistory::init_one)
+  double local_max_radius() const { return rmax_; }
+  void set_global_max_radius(double r) { rmax_ = r > rmax_ ? r : rmax_; }
   void run(int nsteps);    // "run n pre no post no"
   void run_begin();
   void substep(bool last);
@@ -365,6 +372,7 @@ private:
   int migrate_leavers_ = 0;        // atoms packed by migrate_pack since the last compaction
   DevArray leave_;                 // per owned atom: 0 stay, 1 leaves to -x, 2 leaves to +x
   double skin_ = 0.0, dt_ = 0.0;
+  double global_volP_ = -1.0;      // < 0: not set (single domain: the local sum is the global one)
   double rmax_ = 0.0;
 
   // styles

@@ -482,7 +482,7 @@ double DemEngine::max_radius() { return rmax_; }
 double DemEngine::cutneighmax() const
 {
   double c = 0.0;
-  if (gran_.style) c = 2.0 * rmax_ + (cohe_.enabled ? cohe_.smax : 0.0);
+  if (gran_.style) c = 2.0 * rmax_;   // [3P] PairGranHookeHistory::init_one: maxrad_dynamic[i] + maxrad_dynamic[j]
   if (lub_.enabled && lub_.cut_global > c) c = lub_.cut_global;
   return c + lskin();
 }
@@ -1048,8 +1048,11 @@ void DemEngine::bin_and_build()
     B.M = M_;
     B.Mold = max_neigh_used_;
     B.cap = cap_;
-    B.skin_gran = gran_.style ? lskin() + (cohe_.enabled ? cohe_.smax : 0.0) : -1.0;
+    B.skin_gran = gran_.style ? lskin() : -1.0;
     B.cut_lub = lub_.enabled ? lub_.cut_global + lskin() : 0.0;
+    // fix cohesive walks a regular half list (fix_cohesive.cpp:75-77), whose criterion is the pair cutoff + skin for
+    // every pair, not ri + rj + skin: pairs enter that list exactly when LAMMPS would list them
+    if (cohe_.enabled) B.cut_lub = std::max(B.cut_lub, cutneighmax());
     B.g = grid_;
     B.eoff = lds_active_ ? eoff_ : nullptr;
     B.nloc = nloc_.as<unsigned short>();
@@ -1108,17 +1111,29 @@ void DemEngine::rebuild()
 // ------------------------------------------------------------------------------------------------
 // stepping
 // ------------------------------------------------------------------------------------------------
+double DemEngine::local_particle_volume()
+{
+  // sum over the owned atoms of 4/3 pi r^3 (pair_lubricate_poly.cpp:540-542), in index order on the host: setup-time only
+  std::vector<double4> hx(nlocal_);
+  if (nlocal_)
+    SF_HIP(hipMemcpyAsync(hx.data(), xr_[cur_].ptr, sizeof(double4) * nlocal_, hipMemcpyDeviceToHost, stream_));
+  sync();
+  double volP = 0.0;
+  for (int i = 0; i < nlocal_; i++) volP += (4.0 / 3.0) * kPi * std::pow(hx[i].w, 3.0);
+  return volP;
+}
+
 void DemEngine::setup()
 {
   if (!have_nve_ && nlocal_) { /* allowed: static atoms */ }
   if (lub_.enabled) {
-    // PairLubricatePoly::init_style pair_lubricate_poly.cpp:514-559: volume fraction constants
-    std::vector<double4> hx(nlocal_);
-    if (nlocal_)
-      SF_HIP(hipMemcpyAsync(hx.data(), xr_[cur_].ptr, sizeof(double4) * nlocal_, hipMemcpyDeviceToHost, stream_));
-    sync();
-    double volP = 0.0;
-    for (int i = 0; i < nlocal_; i++) volP += (4.0 / 3.0) * kPi * std::pow(hx[i].w, 3.0);
+    // PairLubricatePoly::init_style pair_lubricate_poly.cpp:514-559: volume fraction constants.  volP is the volume of
+    // ALL particles (MPI_Allreduce, :540-543): on a decomposed domain the driver sums local_particle_volume() over the
+    // ranks and hands the total back through set_global_particle_volume() before setup
+    if (have_subdomain_ && nranks_ > 1 && !(global_volP_ >= 0.0))
+      fail("pair lubricate/poly on a decomposed domain: sum sf_dem_local_particle_volume over the ranks and pass it "
+           "to sf_dem_set_global_particle_volume before sf_dem_setup (pair_lubricate_poly.cpp:540-543)");
+    const double volP = global_volP_ >= 0.0 ? global_volP_ : local_particle_volume();
     const double vol_T = (boxhi_[0] - boxlo_[0]) * (boxhi_[1] - boxlo_[1]) * (boxhi_[2] - boxlo_[2]);
     double vol_f = volP / vol_T;
     if (!lub_.flagVF) vol_f = 0;

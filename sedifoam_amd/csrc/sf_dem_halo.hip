@@ -530,7 +530,14 @@ void DemEngine::create_particles(int np, const double* pos, const double* tag, d
   // library.cpp:460 -- the reference's mistyped pi literal is kept
   const double m = 4.0 * kPiTypo / 3.0 * r * r * r * rho;
   std::vector<double4> hx(np), hv(np), hw(np, double4{0, 0, 0, 0}), hz(np, double4{0, 0, 0, 0});
-  std::vector<int> ht(np), hty(np, type), hm(np, 1), h0(np, 0);
+  // library.cpp:452-455: mask = 1 | bitmask of group "active" (the reference indexes bitmask[-1] when the group does
+  // not exist; here the new atoms are then in `all` only)
+  int newmask = 1;
+  {
+    auto it = groups_.find("active");
+    if (it != groups_.end()) newmask |= it->second;
+  }
+  std::vector<int> ht(np), hty(np, type), hm(np, newmask), h0(np, 0);
   for (int k = 0; k < np; k++) {
     hx[k] = {pos[3 * k], pos[3 * k + 1], pos[3 * k + 2], r};
     hv[k] = {vel[0], vel[1], vel[2], m};

@@ -865,8 +865,8 @@ __global__ __launch_bounds__(256) void k_cell_bounds(const K* keys, int n, int s
 struct BuildParams {
   int nlocal, M, Mold;
   size_t cap;
-  double skin_gran;   // skin (+ smax when cohesion is on) added to ri + rj ; < 0: no granular criterion
-  double cut_lub;     // lubrication cutoff + skin ; 0: off
+  double skin_gran;   // skin added to ri + rj (granular list) ; < 0: no granular criterion
+  double cut_lub;     // absolute cutoff: lubrication cutoff + skin, the regular list of fix cohesive ; 0: off
   BinGrid g;
   const int* eoff;    // LDS staging: [tile][(T+2)^3] offsets (nullptr: no staging tables)
   unsigned short* nloc;

@@ -730,6 +730,36 @@ long long sf_dem_migrate_pack(void* ptr, int side, double xshift, double* dev_bu
   SF_API_END(n)
 }
 
+int sf_dem_local_particle_volume(void* ptr, double* volP)
+{
+  SF_API_BEGIN
+  if (!volP) sf::fail("sf_dem_local_particle_volume: null argument");
+  *volP = H(ptr)->eng.local_particle_volume();
+  SF_API_END(0)
+}
+
+int sf_dem_set_global_particle_volume(void* ptr, double volP)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_global_particle_volume(volP);
+  SF_API_END(0)
+}
+
+int sf_dem_local_max_radius(void* ptr, double* rmax)
+{
+  SF_API_BEGIN
+  if (!rmax) sf::fail("sf_dem_local_max_radius: null argument");
+  *rmax = H(ptr)->eng.local_max_radius();
+  SF_API_END(0)
+}
+
+int sf_dem_set_global_max_radius(void* ptr, double rmax)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.set_global_max_radius(rmax);
+  SF_API_END(0)
+}
+
 long long sf_dem_migrate_count(void* ptr)
 {
   SF_API_BEGIN

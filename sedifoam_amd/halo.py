@@ -89,6 +89,22 @@ class HipSlabEngine:
     def migrate_count(self):
         return self.check(self.L.sf_dem_migrate_count(self.lmp.ptr))
 
+    def local_particle_volume(self):
+        v = C.c_double()
+        self.check(self.L.sf_dem_local_particle_volume(self.lmp.ptr, C.byref(v)))
+        return v.value
+
+    def set_global_particle_volume(self, v):
+        self.check(self.L.sf_dem_set_global_particle_volume(self.lmp.ptr, float(v)))
+
+    def local_max_radius(self):
+        v = C.c_double()
+        self.check(self.L.sf_dem_local_max_radius(self.lmp.ptr, C.byref(v)))
+        return v.value
+
+    def set_global_max_radius(self, r):
+        self.check(self.L.sf_dem_set_global_max_radius(self.lmp.ptr, float(r)))
+
     def migrate_pack(self, side, xshift, buf):
         return self.check(self.L.sf_dem_migrate_pack(self.lmp.ptr, side, xshift, buf.data_ptr(), buf.numel()))
 
@@ -538,8 +554,30 @@ class SlabDriver:
             e.ghost_forward_local()
 
     # ---- lammps_* surface ----
+    def _allreduce_sum_f64(self, v):
+        if self.world == 1 and not self.self_comm:
+            return float(v)
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64,
+                              device=self.e.device if self.transport != "host" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def _allreduce_max_f64(self, v):
+        if self.world == 1 and not self.self_comm:
+            return float(v)
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64,
+                              device=self.e.device if self.transport != "host" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
     def setup(self):
+        # list / ghost cutoff 2 r_max + skin: r_max over ALL ranks ([3P] MPI_Allreduce of maxrad_dynamic)
+        if hasattr(self.e, "local_max_radius"):
+            self.e.set_global_max_radius(self._allreduce_max_f64(self.e.local_max_radius()))
         self.rebuild()
+        # pair lubricate/poly: volume fraction of ALL particles (MPI_Allreduce, pair_lubricate_poly.cpp:540-543)
+        if hasattr(self.e, "local_particle_volume"):
+            self.e.set_global_particle_volume(self._allreduce_sum_f64(self.e.local_particle_volume()))
         self.e.setup()
         self.is_setup = True
 

@@ -5,11 +5,28 @@ import numpy as np
 from oracle import binding as ob
 
 
+def subset(bed, mine):
+    """the atoms of `bed` selected by the boolean mask `mine` (one slab of a decomposed run); tags = global index + 1"""
+    sub = dict(bed)
+    for k in ("x", "v", "diameter", "density", "omega", "type"):
+        if bed.get(k) is not None:
+            sub[k] = np.asarray(bed[k])[mine]
+    sub["tag"] = (np.nonzero(mine)[0] + 1).astype(np.int32)
+    sub["n"] = int(np.count_nonzero(mine))
+    return sub
+
+
+def slab_mask(bed, rank, world):
+    lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
+    w = (hi - lo) / world
+    return (bed["x"][:, 0] >= lo + rank * w) & ((bed["x"][:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
+
+
 def make_oracle(bed, cfg):
     r = 0.5 * bed["diameter"]
     m = 4.0 * np.pi / 3.0 * r ** 3 * bed["density"]
     dem = ob.OracleDem(bed["x"], r, m, bed["boxlo"], bed["boxhi"], periodic=bed["periodic"], v=bed["v"],
-                       omega=bed.get("omega"))
+                       omega=bed.get("omega"), tag=bed.get("tag"))
     style = cfg.get("pair", "hertz")
     dem.pair_gran(style, cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], cfg.get("dampflag", 1))
     if cfg.get("lub"):
@@ -90,7 +107,7 @@ def make_hip(bed, cfg):
     lmp = Lammps()
     lmp.set_box(bed["boxlo"], bed["boxhi"])
     lmp.create_atoms(bed["x"], bed["diameter"], bed["density"], v=bed["v"], omega=bed.get("omega"),
-                     type_=bed.get("type"))
+                     type_=bed.get("type"), tag=bed.get("tag"))
     for line in script_lines(bed, cfg):
         lmp.command(line)
     return lmp

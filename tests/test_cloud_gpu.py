@@ -69,13 +69,18 @@ def test_cell_owner_bit_exact_1m():
     assert (ref == -1).sum() > 1000 and np.array_equal(got, ref)
 
 
-def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=50e-6):
-    """10k-class bed in a 32^3-style mesh (BASELINE config C2 scaled to test size): HIP cloud+DEM vs oracle."""
+def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=50e-6, bed=None, mesh_n=(4, 5, 4),
+                  walls=None, cfg_extra=None):
+    """Coupled cloud + DEM, HIP vs oracle.  Default: a 1 792-grain bed on a 4x5x4 mesh (the small case every force
+    switch runs on); BASELINE configs C2 (10 k grains, 32^3 mesh) and C3 (100 k grains, 50 sub-steps per CFD step)
+    pass their own bed / mesh."""
     from sedifoam_amd import synthetic, enhancedCloud
-    bed = synthetic.fcc_bed((8, 7, 8), seed=21, vmax=0.05)
+    if bed is None:
+        bed = synthetic.fcc_bed((8, 7, 8), seed=21, vmax=0.05)
     cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
-               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
-    mesh_n = np.array([4, 5, 4], np.int32)   # cells ~2.8 d wide: centre-counted alpha stays < 0.8
+               walls=walls if walls is not None else [(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    cfg.update(cfg_extra or {})
+    mesh_n = np.array(mesh_n, np.int32)   # default: cells ~2.8 d wide: centre-counted alpha stays < 0.8
     origin = bed["boxlo"].copy(); dxm = (bed["boxhi"] - bed["boxlo"]) / mesh_n
     ncells = int(np.prod(mesh_n))
     rng = np.random.default_rng(3)
@@ -437,6 +442,51 @@ def test_cell_label_map_of_multi_block_meshes():
 
 def test_coupled_ergun_wenyu_default_forces():
     _coupled_case("ErgunWenYu", {})
+
+
+def _c2_bed():
+    """BASELINE.json configs[1] / SURVEY.md 8d "C2": 10 k monodisperse spheres (FCC, 2 % overlap) standing free on the
+    floor of a closed (32 dx)^3 box, dx = 3.5 d so that the centre-counted void fraction stays below 0.8"""
+    from sedifoam_amd import synthetic
+    nc = synthetic.fcc_cells_for(10000)
+    bed = synthetic.fcc_bed(nc, seed=12345 + 1, vmax=0.01)
+    box = 32 * 3.5e-3
+    bed["x"][:, 0] += 0.5 * (box - nc[0] * bed["edge"])
+    bed["x"][:, 2] += 0.5 * (box - nc[2] * bed["edge"])
+    bed["periodic"] = (0, 0, 0)
+    bed["boxhi"] = np.array([box, box, box])
+    walls = [(1, 0.0, box), (0, 0.0, box), (2, 0.0, box)]
+    return bed, walls
+
+
+@pytest.mark.parametrize("smooth", [None, dict(diffusionBandWidth=0.006, diffusionSteps=6)])
+def test_config_c2_as_named_10k_grains_32cubed_mesh(smooth):
+    """Config C2 AS NAMED: 10 080 monodisperse grains, Hertz-history contact + ErgunWenYu drag, 32 x 32 x 32 = 32 768-cell
+    mesh, coupled (drag closure + assembly, 2 x 50 DEM sub-steps, cell owner bit-exact, void fraction / Ue scatter, Asrc),
+    HIP vs oracle; once unsmoothed (1e-12) and once with the reference's default diffusion smoothing (b = 6 mm, 6 steps)."""
+    bed, walls = _c2_bed()
+    assert bed["n"] >= 10000
+    cloud = _coupled_case("ErgunWenYu", {}, sub_cycles=1, n_cfd=2, deltaT=50e-6, smooth=smooth, bed=bed,
+                          mesh_n=(32, 32, 32), walls=walls)
+    assert cloud.gamma().shape[0] == 32768
+
+
+def test_config_c3_100k_coupled_50_substeps():
+    """Config C3: 100 k-grain bed, 50 DEM sub-steps per CFD step, COUPLED (the DEM leg alone is
+    test_mid_size_100k_bed_with_rebuilds): fluid -> particle drag (ErgunWenYu), sub-steps, cell owner, scatter, Asrc
+    against the oracle over two CFD steps."""
+    from sedifoam_amd import synthetic
+    bed = synthetic.fcc_bed(synthetic.fcc_cells_for(100000), seed=12345 + 2, vmax=0.01)
+    assert bed["n"] >= 100000
+    _coupled_case("ErgunWenYu", dict(particleBuoyancy=True), sub_cycles=1, n_cfd=2, deltaT=50e-6, bed=bed,
+                  mesh_n=(11, 16, 13))
+
+
+def test_coupled_with_carrier_rho_fdrag_sees_zero_DuDt():
+    """`fix fdrag 1000` (in-LAMMPS added mass, fix_fluid_drag.cpp:152-156) under the coupled cloud: the reference's
+    lammps_put_local_info drops the DuDt the cloud computes (library.cpp:314-367), so the fix uses DuDt = 0 -- the
+    device-resident cloud path must do the same as the oracle's put path, with a non-zero DDtUf field present."""
+    _coupled_case("ErgunWenYu", dict(particleAddedMass=True), sub_cycles=2, n_cfd=2, cfg_extra=dict(carrier_rho=1000.0))
 
 
 def test_coupled_syamlal_all_forces():

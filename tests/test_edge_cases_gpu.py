@@ -159,6 +159,27 @@ def test_create_and_delete_particles():
     assert all(t not in dead for pair in lmp.history() for t in pair)
 
 
+def test_created_particles_join_group_active():
+    """library.cpp:452-455: lammps_create_particle puts new atoms into `all` AND group "active" -- in the reference's
+    bed scripts nve/sphere, gravity and fdrag act on `active`, so an injected particle must be integrated and fall."""
+    bed = T._bed((4, 4, 4), periodic=True, seed=6)
+    bed["type"] = np.where(bed["x"][:, 1] < 0.9e-3, 2, 1).astype(np.int32)
+    bed["v"][bed["type"] == 2] = 0.0
+    cfg = dict(T.BASE, walls=T._walls(bed), frozen_types=[2])
+    lmp = dc.make_hip(bed, cfg)
+    lmp.setup()
+    lmp.step(5)
+    n0 = lmp.get_local_n()
+    top = float(bed["x"][:, 1].max())
+    pos = np.array([[1.0e-3, top + 3.0e-3, 1.0e-3]])
+    lmp.create_particle(pos, [n0 + 1], 0.8e-3, 2000.0, 1, [0.0, 0.0, 0.0])
+    lmp.step(100)
+    st = lmp.get_state()
+    k = int(np.nonzero(st["tag"] == n0 + 1)[0][0])
+    # free fall over 100 sub-steps of 1 us: v = -g t (to the half-kick bookkeeping), y below the start
+    assert st["v"][k, 1] == pytest.approx(-9.81 * 100e-6, rel=0.02) and st["x"][k, 1] < pos[0, 1]
+
+
 def test_bed_script_with_groups_read_data_and_comments(tmp_path):
     """The command set of the reference's bed cases through the parser end to end: `read_data` of a sphere data file
     with two atom types, `boundary pp ff pp`, `group .. type`, `group .. subtract`, fixes on a group, trailing `#`

@@ -151,3 +151,97 @@ def test_full_size_disordered_bed_through_many_rebuilds():
     assert len(ha) > 100000 and set(ha) == set(hb)
     ka = sorted(ha)[:50000]
     assert all(np.array_equal(ha[k], hb[k]) for k in ka)
+
+
+# ---- BASELINE config C5 at its named size: 500 k polydisperse grains, fix cohesive + pair lubricate/poly ----
+N_C5 = 500000
+C5_COHESIVE = "fix coh all cohesive 1e-13 1e-7 1e-7 1e-4 1"
+C5_LUB = "lubricate/poly 1e-3 1 1 1.001e-3 1.1e-3 1 1"
+
+
+def _c5_bed(seed=15):
+    nc = synthetic.fcc_cells_for(N_C5)
+    bed = synthetic.fcc_bed(nc, seed=seed, vmax=0.05, poly=(0.85e-3, 1.0e-3), spacing=0.95)
+    bed["boxhi"][1] = nc[1] * bed["edge"]
+    bed["x"][:, 1] %= bed["boxhi"][1]
+    bed["periodic"] = (1, 1, 1)
+    return bed
+
+
+def _c5_engine(bed, pair, fixes=(), order=None, vscale=1.0):
+    from sedifoam_amd import Lammps
+    lmp = Lammps()
+    lmp.set_box(bed["boxlo"], bed["boxhi"])
+    o = np.arange(bed["n"]) if order is None else order
+    lmp.create_atoms(bed["x"][o], bed["diameter"][o], bed["density"][o], v=vscale * bed["v"][o],
+                     tag=(o + 1).astype(np.int64))
+    for line in ["atom_style sphere", "boundary p p p", "newton off", "communicate single vel yes",
+                 "neighbor 0.06e-3 bin", "neigh_modify delay 0", "pair_style " + pair, "pair_coeff * *",
+                 "timestep 1e-6", "fix 1 all nve/sphere", "fix 3 all fdrag"] + list(fixes):
+        lmp.command(line)
+    lmp.setup()
+    return lmp
+
+
+@pytest.fixture(scope="module")
+def c5bed():
+    return _c5_bed()
+
+
+def test_c5_500k_cohesive_obeys_newtons_third_law(c5bed):
+    """fix cohesive adds F to i and -F to j (fix_cohesive.cpp:201-209, :250-258): with Hertz contacts + cohesion and
+    nothing else, the total force and the momentum change vanish; cohesion really acts (forces differ from the
+    contact-only run)."""
+    bed = c5bed
+    assert bed["n"] >= N_C5
+    gran = "gran/hertzFix/history 1e7 NULL 0.5 NULL 0.4 1"
+    a = _c5_engine(bed, gran, fixes=[C5_COHESIVE])
+    b = _c5_engine(bed, gran)
+    m = (np.pi / 6.0) * bed["diameter"] ** 3 * bed["density"]
+    p0 = (m[:, None] * a.get_state()["v"]).sum(axis=0)
+    a.step(20); b.step(20)          # (FixCohe::setup never runs: cohesion acts from the first sub-step on)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.isfinite(sa["f"]).all()
+    assert np.abs(sa["f"].sum(axis=0)).max() <= 1e-10 * np.abs(sa["f"]).sum()
+    p1 = (m[:, None] * sa["v"]).sum(axis=0)
+    assert np.abs(p1 - p0).max() <= 1e-10 * (m[:, None] * np.abs(sa["v"])).sum()
+    assert np.abs(sa["f"] - sb["f"]).max() > 1e-9 * np.abs(sb["f"]).max()
+
+
+def test_c5_500k_lubrication_is_linear_in_velocity_and_acts_on_i_only(c5bed):
+    """pair lubricate/poly alone (setup forces, positions fixed): (i) every term is linear in (v, omega), so doubling
+    the velocities doubles force and torque EXACTLY (a power-of-two scaling commutes with every rounding); (ii) with
+    flagHI = 0 only the isotropic FLD terms remain and act on i alone: f_i = -R0 r_i v_i with R0 from the volume
+    fraction of ALL grains (pair_lubricate_poly.cpp:213-220, :540-559) -- checked against the closed form."""
+    bed = c5bed
+    a = _c5_engine(bed, C5_LUB)
+    b = _c5_engine(bed, C5_LUB, vscale=2.0)
+    fa, fb = a.get_state(), b.get_state()
+    assert np.abs(fa["f"]).max() > 0.0
+    assert np.array_equal(2.0 * fa["f"], fb["f"]) and np.array_equal(2.0 * fa["torque"], fb["torque"])
+    c = _c5_engine(bed, "lubricate/poly 1e-3 1 1 1.001e-3 1.1e-3 0 1")
+    fc = c.get_state()
+    r = 0.5 * bed["diameter"]
+    vol_f = np.sum(4.0 / 3.0 * np.pi * r ** 3) / np.prod(bed["boxhi"] - bed["boxlo"])
+    R0 = 6.0 * np.pi * 1e-3 * (1.0 + 2.725 * vol_f - 6.583 * vol_f ** 2)
+    want = -(R0 * r)[:, None] * bed["v"]
+    o = np.argsort(fc["tag"])
+    assert np.abs(fc["f"][o] - want).max() <= 1e-12 * np.abs(want).max()
+    # the pairwise part (a - c) is NOT antisymmetric for unequal radii: only i is updated from its own beta0 = rj/ri
+    pair = fa["f"] - fc["f"]
+    assert np.abs(pair.sum(axis=0)).max() > 1e-6 * np.abs(pair).sum() / np.sqrt(bed["n"])
+
+
+def test_c5_500k_full_physics_is_bitwise_reproducible_and_order_independent(c5bed):
+    bed = c5bed
+    pair = "hybrid/overlay gran/hertzFix/history 1e7 NULL 0.5 NULL 0.4 1 " + C5_LUB
+    rng = np.random.default_rng(21)
+    a = _c5_engine(bed, pair, fixes=[C5_COHESIVE])
+    b = _c5_engine(bed, pair, fixes=[C5_COHESIVE], order=rng.permutation(bed["n"]))
+    builds0 = a.info().nbuilds
+    for n in (25, 25):
+        a.step(n); b.step(n)
+    sa, sb = a.get_state(), b.get_state()
+    assert a.info().nbuilds == b.info().nbuilds and a.info().nbuilds - builds0 >= 1
+    for k in ("x", "v", "omega", "f", "torque"):
+        assert np.isfinite(sa[k]).all() and np.array_equal(sa[k], sb[k]), k

@@ -21,9 +21,17 @@ def _free_port():
     return p
 
 
-def _case(periodic_x=True, vmax=0.5, skin=0.05e-3, seed=31):
+def _case(periodic_x=True, vmax=0.5, skin=0.05e-3, seed=31, physics="hertz"):
     sys.path.insert(0, ROOT)
     from sedifoam_amd import synthetic
+    if physics == "c5":
+        # BASELINE config C5's physics: polydisperse grains, fix cohesive + hybrid/overlay lubricate/poly with the
+        # volume-fraction (flagVF 1) and isotropic FLD terms (flagfld 1) that need the particle volume of ALL ranks
+        bed = synthetic.fcc_bed((8, 4, 4), seed=seed, vmax=vmax, poly=(0.85e-3, 1.0e-3), spacing=0.95)
+        cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=skin,
+                   cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1), lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1),
+                   walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+        return bed, cfg
     bed = synthetic.fcc_bed((8, 4, 4), seed=seed, vmax=vmax)
     if not periodic_x:
         bed["periodic"] = (0, 0, 1)
@@ -36,7 +44,7 @@ def _case(periodic_x=True, vmax=0.5, skin=0.05e-3, seed=31):
     return bed, cfg
 
 
-def _worker(rank, world, port, outdir, periodic_x, steps, mode):
+def _worker(rank, world, port, outdir, periodic_x, steps, mode, physics="hertz"):
     sys.path.insert(0, ROOT)
     os.environ["SF_HALO_FUSED"] = "0" if mode == "p2p+allreduce" else "1"
     os.environ["SF_HALO_OVERLAP"] = "1" if mode == "overlap" else "0"
@@ -45,24 +53,9 @@ def _worker(rank, world, port, outdir, periodic_x, steps, mode):
     from sedifoam_amd.halo import SlabDriver
     from tests import dem_cases as dc
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    bed, cfg = _case(periodic_x)
+    bed, cfg = _case(periodic_x, physics=physics)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
-    w = (hi - lo) / world
-    mine = (bed["x"][:, 0] >= lo + rank * w) & ((bed["x"][:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
-    sub = dict(bed)
-    for k in ("x", "v", "diameter", "density"):
-        sub[k] = bed[k][mine]
-    tags = (np.nonzero(mine)[0] + 1).astype(np.int32)
-    r = 0.5 * sub["diameter"]
-    m = 4.0 * np.pi / 3.0 * r ** 3 * sub["density"]
-    dem = ob.OracleDem(sub["x"], r, m, bed["boxlo"], bed["boxhi"], periodic=bed["periodic"], v=sub["v"], tag=tags)
-    dem.pair_gran("hertz", cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], 1)
-    dem.fix_gravity(cfg["g"], 0.0, -1.0, 0.0)
-    dem.fix_fdrag(0.0)
-    for (dim, wlo, whi) in cfg["walls"]:
-        dem.fix_wall(dim, wlo, whi, cfg["kn"], None, cfg["gamman"], None, cfg["xmu"], 1)
-    dem.neighbor(cfg["skin"])
-    dem.timestep(cfg["dt"])
+    dem = dc.make_oracle(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
     drv = SlabDriver(ob.OracleSlabEngine(dem), dist, rank, world, lo, hi, periodic_x=periodic_x,
                      transport="host" if mode == "fused-p2p" else "direct")
     assert drv.fused == (mode != "p2p+allreduce") and drv.overlap == (mode == "overlap")
@@ -122,3 +115,42 @@ def test_decomposed_run_matches_single_domain(world, periodic_x, mode):
     assert set(hb) == set(ha)
     sa = np.array([ha[k] for k in sorted(ha)]); sb = np.array([hb[k] for k in sorted(ha)])
     assert dc.rel_err(sb, sa) <= 1e-9
+
+
+def test_decomposed_cohesive_lubricate_matches_single_domain():
+    """Config C5's physics on two slabs: polydisperse grains, fix cohesive, hybrid/overlay lubricate/poly with
+    flagVF = flagfld = 1.  The FLD resistances R0 / RT0 need the particle volume of ALL ranks
+    (MPI_Allreduce, pair_lubricate_poly.cpp:540-543), the ghost cutoff the largest radius of all ranks and the
+    lubrication cutoff; the decomposed run must reproduce the single-domain oracle through rebuilds + migration."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from tests import dem_cases as dc
+    steps = (40, 40)
+    bed, cfg = _case(True, physics="c5")
+    ref = dc.make_oracle(bed, cfg)
+    ref.setup()
+    for n in steps:
+        ref.run(n)
+    a = ref.get()
+    assert ref.nbuilds >= 3
+    # the FLD drag really acts (otherwise a wrong volume fraction would go unnoticed): compare with flagVF = 0
+    novf = dc.make_oracle(bed, dict(cfg, lub=cfg["lub"][:6] + (0,)))
+    withvf = dc.make_oracle(bed, cfg)
+    novf.setup(); withvf.setup()
+    assert dc.rel_err(novf.get()["f"], withvf.get()["f"]) > 1e-6
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_worker, args=(2, _free_port(), out, True, steps, "fused", "c5"), nprocs=2, join=True)
+        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    tag = np.concatenate([p["tag"] for p in parts])
+    assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
+    order = np.argsort(tag)
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    for k in ("x", "v", "omega", "f", "torque"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        want = a[k].copy()
+        if k == "x":
+            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            assert np.max(np.abs(got - want)) <= 1e-12
+        else:
+            assert dc.rel_err(got, want) <= 1e-9, k
+    assert all(int(p["rebuilds"]) >= 3 for p in parts)

@@ -68,7 +68,17 @@ def test_self_halo_with_frozen_bottom_layer():
     assert np.array_equal(a["x"][bottom], bed["x"][a["tag"] - 1][bottom])
 
 
-def _two_rank_worker(rank, world, port, outdir, steps, overlap=False):
+def _c5_case():
+    """BASELINE config C5's physics at test size: polydisperse grains, fix cohesive, hybrid/overlay lubricate/poly
+    with flagVF = flagfld = 1 (the FLD terms need the particle volume of ALL ranks)"""
+    bed = T._bed((8, 5, 5), periodic=True, seed=43, vmax=0.5, poly=(0.85e-3, 1.0e-3), spacing=0.95)
+    cfg = dict(T.BASE, skin=0.06e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
+               lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1))
+    cfg["walls"] = T._walls(bed)
+    return bed, cfg
+
+
+def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="hertz"):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import numpy as np
@@ -80,18 +90,14 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False):
     import tests.test_dem_gpu as T
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.5)
-    cfg = dict(T.BASE, skin=0.05e-3)
-    cfg["walls"] = T._walls(bed)
+    if physics == "c5":
+        bed, cfg = _c5_case()
+    else:
+        bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.5)
+        cfg = dict(T.BASE, skin=0.05e-3)
+        cfg["walls"] = T._walls(bed)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
-    w = (hi - lo) / world
-    mine = (bed["x"][:, 0] >= lo + rank * w) & ((bed["x"][:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
-    lmp = Lammps()
-    lmp.set_box(bed["boxlo"], bed["boxhi"])
-    lmp.create_atoms(bed["x"][mine], bed["diameter"][mine], bed["density"][mine], v=bed["v"][mine],
-                     tag=(np.nonzero(mine)[0] + 1))
-    for line in dc.script_lines(bed, cfg):
-        lmp.command(line)
+    lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
     drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host",
                      overlap=overlap)
     assert drv.overlap == overlap
@@ -143,6 +149,48 @@ def test_two_ranks_sharing_one_gpu_match_single_domain(overlap):
             assert np.max(np.abs(got - want)) <= 1e-12
         else:
             assert dc.rel_err(got, want) <= 1e-9, k
+    assert all(int(p["rebuilds"]) >= 3 for p in parts)
+    hb = {}
+    for p in parts:
+        for (i, j), sv in zip(p["hk"], p["hv"]):
+            hb.setdefault((int(i), int(j)), sv)
+    assert set(hb) == set(ha)
+
+
+def test_two_ranks_cohesive_lubricate_match_single_domain_and_oracle():
+    """Config C5 as BASELINE.json names it -- polydisperse + fix cohesive + lubricate/poly on a DECOMPOSED domain --
+    with the real kernels: two HIP engines on one GPU against the single-domain HIP run and the single-domain oracle.
+    Checks the global volume fraction (pair_lubricate_poly.cpp:540-543), the ghost cutoff max(2 r_max, lubrication
+    cutoff) + skin across the slab face and the migration of polydisperse atoms with their history."""
+    import os, socket, tempfile
+    import torch.multiprocessing as mp
+    steps = (40, 40)
+    bed, cfg = _c5_case()
+    ref = dc.make_hip(bed, cfg)
+    orc = dc.make_oracle(bed, cfg)
+    ref.setup(); orc.setup()
+    for n in steps:
+        ref.step(n); orc.run(n)
+    a = ref.get_state(); ha = ref.history(); c = orc.get()
+    assert ref.info().nbuilds >= 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_two_rank_worker, args=(2, port, out, steps, False, "c5"), nprocs=2, join=True)
+        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    tag = np.concatenate([p["tag"] for p in parts])
+    assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
+    order = np.argsort(tag)
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    oa = np.argsort(a["tag"]); oc = np.argsort(c["tag"])
+    for k in ("x", "v", "omega", "f", "torque"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        for want in (a[k][oa].copy(), c[k][oc].copy()):
+            if k == "x":
+                g2 = got.copy()
+                g2[:, 0] = np.mod(g2[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+                assert np.max(np.abs(g2 - want)) <= 1e-12
+            else:
+                assert dc.rel_err(got, want) <= 1e-9, k
     assert all(int(p["rebuilds"]) >= 3 for p in parts)
     hb = {}
     for p in parts:
