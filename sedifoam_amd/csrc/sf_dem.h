@@ -8,12 +8,17 @@
 //   neigh   [M][cap] int32 : full neighbour list, slot-major (lane i reads consecutive addresses);
 //                            bit 30 of an entry = "touching" flag (LAMMPS keeps it in a separate
 //                            touch[] array, pair_gran_hertzFix_history.cpp:135,212)
-//   shear   [M][3][cap] f64: per-slot shear history, same slot-major layout
+//   shear[2][M][3][cap] f64: per-slot shear history, same slot-major layout, ONE copy per contact (see kOwnBit),
+//                            ping-pong like the records: the partner side gathers the owner's previous value
 //   fdrag/DuDt/vOld [3][cap], wall shear [nwall][3][cap], xhold [3][cap], force/torque double4.
 // The list is FULL (every owned atom lists all its neighbours; each contact is evaluated from both
 // sides, bit-for-bit antisymmetric) so no atomics are needed and results are run-to-run
 // deterministic.  This is the reference's own `newton off` semantics for owned-ghost pairs
-// (pair_gran_hertzFix_history.cpp:273) applied to every pair.
+// (pair_gran_hertzFix_history.cpp:273) applied to every pair.  The shear HISTORY of a pair of two
+// atoms of this GPU is nevertheless kept once, like the reference's half list does: by the atom with the
+// lower index (the "owner" of the pair; its list word carries kOwnBit).  The other side ("partner") reads
+// the owner's previous value, negates it and repeats the same update in registers without storing it.
+// Pairs with a periodic image or with a ghost of another GPU keep a copy on each side, as in the reference.
 #pragma once
 #include <map>
 #include <string>
@@ -27,13 +32,15 @@
 
 namespace sf {
 
-// neighbour word: bit 30 = the reference's touch[] flag.  Root mode (default): bits 0-24 = index of the ROOT atom (an
+// neighbour word: bit 30 = the reference's touch[] flag, bit 31 = this side stores the pair's history (kOwnBit; a
+// partner-side word carries the owner's slot in bits 25-29 instead of an image code).  Root mode (default): bits 0-24 = index of the ROOT atom (an
 // owned atom, or a ghost owned by another GPU), bits 25-29 = periodic image code (sx+1) + 3(sy+1) + 9(sz+1) of the
 // neighbour relative to its root, 13 = the root itself: the kernel gathers the root's record and adds the shift, so
 // periodic images are never materialised between rebuilds (no forward copy per sub-step).  Index mode (LDS-staged
 // kernel): bits 0-29 = index of the owned or ghost atom.
 constexpr int kNeighMask = 0x3FFFFFFF;
 constexpr int kTouchBit = 0x40000000;
+constexpr int kOwnBit = (int)0x80000000;   // this side stores the pair's shear history
 constexpr int kIdxBits = 25;
 constexpr int kIdxMask = (1 << kIdxBits) - 1;
 constexpr int kNoShift = 13;
@@ -90,7 +97,8 @@ struct DemPtrs {
   double4* torque;
   int* neigh;
   int* numneigh;
-  double* shear;
+  const double* shear_in;        // history written by the previous sub-step (or the list build)
+  double* shear_out;             // history after this sub-step (owner slots only)
   double* fdrag;
   double* DuDt;
   double* vOld;
@@ -399,8 +407,12 @@ private:
   DevArray fdrag_, DuDt_, vOld_, xhold_;
   DevArray wshear_, wtouch_;
   DevArray gsrc_, gshift_;
-  DevArray neigh_, numneigh_, shear_;
-  DevArray neigh_old_, numneigh_old_, shear_old_, ptag_;   // B-side buffers swapped in by permute/build
+  DevArray neigh_, numneigh_, shear_[2];
+  DevArray neigh_old_, numneigh_old_, ptag_;   // B-side buffers swapped in by permute/build
+  // During a rebuild shear_[hist_buf_] holds the OLD list's history expanded to a copy per side (what partner tags
+  // address: migration, re-injection); the new list's history is built into the other buffer, which then becomes
+  // shear_[cur_]
+  int hist_buf_ = 0;
   DevArray nloc_;                      // [M][cap] uint16 (see DemPtrs::nloc)
   int* tile_tab_ = nullptr;            // [2][ntiles] tile_first / tile_last, then [ntiles+1] counts, starts
   size_t tile_alloc_ = 0;

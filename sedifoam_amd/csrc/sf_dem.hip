@@ -104,7 +104,7 @@ DemEngine::DemEngine()
   memset(&lub_, 0, sizeof(lub_));
   per_atom_ = {&xr_[0], &xr_[1], &vm_[0], &vm_[1], &om_[0], &om_[1], &force_, &torque_, &tag_, &type_,
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
-               &neigh_, &numneigh_, &shear_, &neigh_old_, &numneigh_old_, &shear_old_, &ptag_, &tmp4_,
+               &neigh_, &numneigh_, &shear_[0], &shear_[1], &neigh_old_, &numneigh_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
                &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_};
 }
@@ -165,10 +165,10 @@ void DemEngine::alloc_all(size_t cap)
   gshift_.alloc(sizeof(double), 3, cap, s);
   neigh_.alloc(sizeof(int), M_, cap, s);
   numneigh_.alloc(sizeof(int), 1, cap, s);
-  shear_.alloc(sizeof(double), 3 * M_, cap, s);
+  shear_[0].alloc(sizeof(double), 3 * M_, cap, s);
+  shear_[1].alloc(sizeof(double), 3 * M_, cap, s);
   neigh_old_.alloc(sizeof(int), M_, cap, s);
   numneigh_old_.alloc(sizeof(int), 1, cap, s);
-  shear_old_.alloc(sizeof(double), 3 * M_, cap, s);
   ptag_.alloc(sizeof(int), M_, cap, s);
   tmp4_.alloc(sizeof(double4), 1, cap, s);
   tmpd_.alloc(sizeof(double), 3 * kMaxWalls, cap, s);
@@ -192,6 +192,7 @@ void DemEngine::ensure_capacity(size_t need)
 {
   if (need <= cap_) return;
   size_t newcap = need + need / 4 + 1024;
+  newcap = (newcap + 63) & ~(size_t)63;   // rows of the [rows][cap] arrays start on 512-byte boundaries
   if (cap_ == 0) {
     alloc_all(newcap);
     return;
@@ -212,9 +213,9 @@ void DemEngine::grow_neigh(int newM)
     a = n;
   };
   regrow(neigh_, 1);
-  regrow(shear_, 3);
+  regrow(shear_[0], 3);
+  regrow(shear_[1], 3);
   regrow(neigh_old_, 1);
-  regrow(shear_old_, 3);
   regrow(ptag_, 1);
   regrow(nloc_, 1);
   M_ = newM;
@@ -513,7 +514,11 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.torque = torque_.as<double4>();
   P.neigh = neigh_.as<int>();
   P.numneigh = numneigh_.as<int>();
-  P.shear = shear_.as<double>();
+  P.shear_in = shear_[in_buf].as<double>();
+  P.shear_out = shear_[ob].as<double>();
+#ifdef SF_EXP_INPLACE   // (WRONG results: racy) history written back in place: prices the ping-pong buffer
+  P.shear_out = shear_[in_buf].as<double>();
+#endif
   P.fdrag = fdrag_.as<double>();
   P.DuDt = DuDt_.as<double>();
   P.vOld = vOld_.as<double>();
@@ -795,10 +800,13 @@ void DemEngine::compute_grid()
 
 void DemEngine::compute_partner_tags()
 {
+  // the old list's history by partner tag, a copy per SIDE of every contact, in the ping-pong buffer the sub-steps
+  // are not using: what migration packs and what the list build re-injects
+  hist_buf_ = cur_ ^ 1;
   if (have_list_ && nlocal_ && max_neigh_used_ > 0)
-    k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
-                                                              tag_.as<int>(), ptag_.as<int>(), nlocal_, cap_,
-                                                              max_neigh_used_, roots_ ? 1 : 0);
+    k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(
+        neigh_.as<int>(), numneigh_.as<int>(), tag_.as<int>(), ptag_.as<int>(), shear_[cur_].as<double>(),
+        shear_[hist_buf_].as<double>(), nlocal_, cap_, max_neigh_used_, roots_ ? 1 : 0);
 }
 
 void DemEngine::rebuild_begin()
@@ -860,11 +868,11 @@ void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
     k_gather_rows<int><<<nb, 256, 0, stream_>>>(numneigh_old_.as<int>(), numneigh_.as<int>(), perm, n_new, 1, cap_);
     k_gather_rows<int><<<nb, 256, 0, stream_>>>(neigh_old_.as<int>(), ptag_.as<int>(), perm, n_new,
                                                 max_neigh_used_, cap_);
-    k_gather_rows<double><<<nb, 256, 0, stream_>>>(shear_old_.as<double>(), shear_.as<double>(), perm, n_new,
-                                                   3 * max_neigh_used_, cap_);
+    k_gather_rows<double><<<nb, 256, 0, stream_>>>(shear_[hist_buf_ ^ 1].as<double>(), shear_[hist_buf_].as<double>(),
+                                                   perm, n_new, 3 * max_neigh_used_, cap_);
     std::swap(numneigh_, numneigh_old_);
     std::swap(ptag_, neigh_old_);
-    std::swap(shear_, shear_old_);
+    hist_buf_ ^= 1;
   }
 }
 
@@ -1066,8 +1074,8 @@ void DemEngine::bin_and_build()
     if (roots_ && cap_ > (size_t)kIdxMask) fail("more than %d atom slots per GPU: not addressable by the neighbour word", kIdxMask);
     k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
-        have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_.as<double>(), neigh_.as<int>(),
-        numneigh_old_.as<int>(), shear_old_.as<double>(), d_flags_);
+        have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), neigh_.as<int>(),
+        numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_);
     k_max_int<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_old_.as<int>(), nlocal_, d_flags_ + F_MAXNEIGH);
     read_flags();
     if (h_flags_[F_NEIGH_OVER] > M_) {
@@ -1084,8 +1092,12 @@ void DemEngine::bin_and_build()
     fail("Lost atoms: an atom left the (non-periodic) simulation box");  // thermo_modify lost error
   }
   std::swap(numneigh_, numneigh_old_);
-  std::swap(shear_, shear_old_);
+  // the new list's history was built into shear_[hist_buf_ ^ 1]: that buffer is the one the next sub-step reads
+  if ((hist_buf_ ^ 1) != cur_) std::swap(shear_[0].ptr, shear_[1].ptr);
   hist_indirect_ = false;   // the old rows are gone with the old list
+  // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
+  k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_, cap_,
+                                                          roots_ ? 1 : 0);
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
                                                            cap_);
@@ -1126,6 +1138,12 @@ double DemEngine::local_particle_volume()
 void DemEngine::setup()
 {
   if (!have_nve_ && nlocal_) { /* allowed: static atoms */ }
+  if (!have_subdomain_) {
+    have_list_ = false;
+    rebuild();
+  } else if (!have_list_)
+    fail("sf_dem_setup on a decomposed domain: run the rebuild protocol (sf_dem_rebuild_*) first");
+  // (after the first sort: the sum then runs over the atoms in (cell, tag) order, the same bits for any input order)
   if (lub_.enabled) {
     // PairLubricatePoly::init_style pair_lubricate_poly.cpp:514-559: volume fraction constants.  volP is the volume of
     // ALL particles (MPI_Allreduce, :540-543): on a decomposed domain the driver sums local_particle_volume() over the
@@ -1148,11 +1166,6 @@ void DemEngine::setup()
       lub_.RS0 = 20.0 / 3.0 * kPi * mu * (1.0 + 3.64 * vol_f - 6.95 * vol_f * vol_f);
     }
   }
-  if (!have_subdomain_) {
-    have_list_ = false;
-    rebuild();
-  } else if (!have_list_)
-    fail("sf_dem_setup on a decomposed domain: run the rebuild protocol (sf_dem_rebuild_*) first");
   // (multi-rank: the driver has already run rebuild_begin / migrate / sort / borders / finish)
   reset_flag(F_TRIGGER, INT_MAX);
   wall_time_origin_ = nsteps_;   // FixWallGranFix::init, fix_wall_granFix.cpp:181
@@ -1487,7 +1500,7 @@ long long DemEngine::get_history(long long max, int* tag_i, int* tag_j, double* 
   ScratchI ti(max), tj(max);
   ScratchD sh(3 * (size_t)max);
   k_collect_history<<<div_up(nlocal_, 256), 256, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(),
-                                                               shear_.as<double>(), tag_.as<int>(), nlocal_, cap_,
+                                                               shear_[cur_].as<double>(), tag_.as<int>(), nlocal_, cap_,
                                                                d, max, ti.p, tj.p, sh.p, roots_ ? 1 : 0);
   unsigned long long h = 0;
   SF_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream_));

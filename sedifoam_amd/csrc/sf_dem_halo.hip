@@ -469,7 +469,7 @@ long long DemEngine::migrate_pack(int side, double xshift, double* buf, long lon
     fail("migrate_pack: %d atoms x %d doubles do not fit the %lld-double buffer", n, rec, max_doubles);
   if (n) {
     MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_,
-                             fdrag_, DuDt_, vOld_, wshear_, shear_, wtouch_);
+                             fdrag_, DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_);
     k_migrate_pack<<<div_up(n, 128), 128, 0, stream_>>>(list.as<int>(), n, xshift, P, cap_, nwalls_, mrec_,
                                                         have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1);
   }
@@ -505,7 +505,7 @@ void DemEngine::migrate_unpack(const double* buf, long long ndoubles)
   if (!n) return;
   ensure_capacity((size_t)nlocal_ + n + 1024);
   MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_, fdrag_,
-                           DuDt_, vOld_, wshear_, shear_, wtouch_);
+                           DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_);
   k_migrate_unpack<<<div_up(n, 128), 128, 0, stream_>>>(buf, n, nlocal_, P, cap_, nwalls_, mrec_, rec);
   nlocal_ += n;
   // tags of immigrants may exceed what this rank has seen

@@ -33,6 +33,15 @@
 #ifndef SF_TOUCH_PREFETCH
 #define SF_TOUCH_PREFETCH 1   // v, omega of a neighbour are prefetched only when the pair touched in the last sub-step
 #endif
+#ifndef SF_HIST_NT_OWN
+#define SF_HIST_NT_OWN 1      // owner-side history loads non-temporal
+#endif
+#ifndef SF_HIST_NT_PARTNER
+#define SF_HIST_NT_PARTNER 1  // partner-side history gathers non-temporal
+#endif
+#ifndef SF_EXP_PARTNER_OWNROW
+#define SF_EXP_PARTNER_OWNROW 0   // (WRONG results) partner reads its own row instead of the owner's: prices the gather
+#endif
 // Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md)
 #ifndef SF_EXP_NOSHLD
 #define SF_EXP_NOSHLD 0       // skip the shear-history loads
@@ -149,6 +158,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   };
   int jraw_n1 = nn > 0 ? ld_stream(&P.neigh[(size_t)q * cap + i]) : 0;
   int jraw_n2 = nn > 1 ? ld_stream(&P.neigh[(size_t)(q + LPA) * cap + i]) : 0;
+  // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
+  // owner's slot; the five image-code bits of a partner-side word hold that slot (a partner-side neighbour is never
+  // a periodic image, see k_back_slots).
   Rec RA, RB;
   RA.x = RA.v = RA.w = RB.x = RB.v = RB.w = double4{0, 0, 0, 0};
   RA.l = RB.l = 0;
@@ -161,11 +173,20 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const size_t slot = (size_t)sl * cap + i;
     const size_t sbase = (size_t)(3 * sl) * cap + i;
     const int jraw = jraw_n1;
+    const bool own = (jraw & kOwnBit) != 0;
     Vec3 sh = {0.0, 0.0, 0.0};
     if (STYLE != 0 && (jraw & kTouchBit) && !(SF_EXP_NOSHLD && S.kstep >= 0)) {
-      sh.x = ld_stream(&P.shear[sbase]);
-      sh.y = ld_stream(&P.shear[sbase + cap]);
-      sh.z = ld_stream(&P.shear[sbase + 2 * cap]);
+      // owner: this atom's own row (coalesced) ; partner: the owner's row, the pair seen from the other side
+      const size_t src = (own || SF_EXP_PARTNER_OWNROW)
+                             ? sbase : (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + (size_t)(jraw & kIdxMask);
+      const double sg = own ? 1.0 : -1.0;
+      auto ldh = [&](const double* p) {
+        if (own ? SF_HIST_NT_OWN : SF_HIST_NT_PARTNER) return ld_stream(p);
+        return *p;
+      };
+      sh.x = sg * ldh(&P.shear_in[src]);
+      sh.y = sg * ldh(&P.shear_in[src + cap]);
+      sh.z = sg * ldh(&P.shear_in[src + 2 * cap]);
     }
     jraw_n1 = jraw_n2;
     if (s + 2 < nn) jraw_n2 = ld_stream(&P.neigh[slot + (size_t)(2 * LPA) * cap]);
@@ -213,8 +234,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         wj4 = {lw[3 * cur.l], lw[3 * cur.l + 1], lw[3 * cur.l + 2], 0.0};
       }
     }
-    if (S.roots) {
+    if (S.roots && own) {
       // periodic image of the root: the same x_root + shift the reference's forward_comm would have stored
+      // (a partner-side word never refers to an image: its code bits hold the owner's slot)
       const int code = (jraw >> kIdxBits) & 31;
       if (code != kNoShift) {
         const int cz = code / 9, cy = (code - 9 * cz) / 3, cx = code - 9 * cz - 3 * cy;
@@ -262,11 +284,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         ContactOut o;
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
 #if !SF_EXP_NOSHST
-        st_stream(&P.shear[sbase], sh.x);
-        st_stream(&P.shear[sbase + cap], sh.y);
-        st_stream(&P.shear[sbase + 2 * cap], sh.z);
+        if (own) {
+          st_stream(&P.shear_out[sbase], sh.x);
+          st_stream(&P.shear_out[sbase + cap], sh.y);
+          st_stream(&P.shear_out[sbase + 2 * cap], sh.z);
+        }
 #else
-        if (sh.x == 1.2345) P.shear[sbase] = sh.y + sh.z;
+        if (sh.x == 1.2345) P.shear_out[sbase] = sh.y + sh.z;
 #endif
         if (!(jraw & kTouchBit)) P.neigh[slot] = jraw | kTouchBit;
         F = F + o.F;
@@ -453,10 +477,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
 }
 
+// Registers: the plain contact kernel needs 169 VGPRs when left alone -- one more than three waves per SIMD allow
+// (512 / 3, granule 8 = 168), and at two waves per SIMD it is 30 % slower (latency bound).  Asked for three waves the
+// compiler finds 167 without spilling.  The cohesive / lubrication variants would spill at three waves: left alone.
 #ifdef SF_WAVES_PER_EU
 #define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu(SF_WAVES_PER_EU, SF_WAVES_PER_EU)))
 #else
-#define SF_SUBSTEP_ATTR
+#define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu((COHE || LUB) ? 1 : 3)))
 #endif
 template <int STYLE, bool COHE, bool LUB, int LPA>
 __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, StepParams S)
@@ -611,9 +638,12 @@ __global__ __launch_bounds__(256) void k_mark_boundary(const int* neigh, const i
 // ------------------------------------------------------------------------------------------------
 // neighbour rebuild
 // ------------------------------------------------------------------------------------------------
-// FixShearHistory::pre_exchange [3P]: remember each touching partner by tag
+// FixShearHistory::pre_exchange [3P]: remember each touching partner by tag, and give BOTH sides of every contact a
+// copy of its shear history (the partner side: the owner's value, negated -- what FixShearHistory's "sign-flipped
+// copy for j" is).  hist_out is the ping-pong buffer the sub-steps are not using.
 __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const int* numneigh, const int* tag,
-                                                      int* ptag, int nlocal, size_t cap, int M, int roots)
+                                                      int* ptag, const double* shear, double* hist_out, int nlocal,
+                                                      size_t cap, int M, int roots)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
@@ -622,9 +652,55 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
     int t = -1;
     if (s < nn) {
       const int jraw = neigh[(size_t)s * cap + i];
-      if (jraw & kTouchBit) t = tag[neigh_index(jraw, roots)];
+      if (jraw & kTouchBit) {
+        const int j = neigh_index(jraw, roots);
+        t = tag[j];
+        size_t src = (size_t)(3 * s) * cap + i;
+        double sign = 1.0;
+        if (!(jraw & kOwnBit)) {
+          src = (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + j;   // (partner sides exist in root mode only)
+          sign = -1.0;
+        }
+        const size_t dst = (size_t)(3 * s) * cap + i;
+        hist_out[dst] = sign * shear[src];
+        hist_out[dst + cap] = sign * shear[src + cap];
+        hist_out[dst + 2 * cap] = sign * shear[src + 2 * cap];
+      }
     }
     ptag[(size_t)s * cap + i] = t;
+  }
+}
+
+// After the list build: a partner-side slot (kOwnBit clear; root mode, the neighbour is an atom of this GPU itself,
+// image code 13) needs the slot of this atom in the owner's list.  It goes into the word's five image-code bits --
+// the kernel knows a partner-side neighbour is not an image.  The list criterion is symmetric for two atoms of this
+// GPU, so the owner lists the partner back; should it not (a list cut short), or should the slot not fit five bits
+// (> 32 neighbours), this side keeps a copy of its own (kOwnBit): a copy on each side is always valid, both evolve
+// to bitwise opposite values.  Index mode (LDS-staged kernel) has no spare bits: every slot owns its copy.
+__global__ __launch_bounds__(128) void k_back_slots(int* neigh, const int* numneigh, int nlocal, size_t cap, int roots)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int nn = numneigh[i];
+  const int codemask = 31 << kIdxBits;
+  const int want = (kNoShift << kIdxBits) | i;   // "atom i itself, not an image", as an owner-side word reads
+  for (int s = 0; s < nn; s++) {
+    const int w = neigh[(size_t)s * cap + i];
+    if (w & kOwnBit) continue;
+    int t = -1;
+    if (roots) {
+      const int r = w & kIdxMask;
+      const int nr = numneigh[r];
+      // owner-side words of r are never rewritten by this kernel (only partner-side ones are, and those point below r)
+      for (int u = 0; u < nr && u < 32; u++) {
+        const int wu = neigh[(size_t)u * cap + r];
+        if ((wu & kOwnBit) && (wu & (codemask | kIdxMask)) == want) {
+          t = u;
+          break;
+        }
+      }
+    }
+    neigh[(size_t)s * cap + i] = t < 0 ? (w | kOwnBit) : ((w & ~codemask) | (t << kIdxBits));
   }
 }
 
@@ -963,6 +1039,9 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   auto accept = [&](const int j, const int tj, const int pos) {
     if (n < B.M) {
       int entry = j;
+      // history owner of the pair: the lower index of two atoms of this GPU; pairs with a periodic image or with a
+      // ghost of another GPU keep a copy on each side (the reference's newton-off treatment of owned-ghost pairs)
+      bool own = j > i;
       if (B.roots) {
         int code = kNoShift;
         if (j >= B.nlocal) {
@@ -973,10 +1052,12 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
             const int iy = (int)rint(B.gshift[B.cap + j] * B.inv_prd[1]);
             const int iz = (int)rint(B.gshift[2 * B.cap + j] * B.inv_prd[2]);
             code = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
+            own = true;
           }
         }
         entry |= code << kIdxBits;
       }
+      if (own) entry |= kOwnBit;
       double sx = 0.0, sy = 0.0, sz = 0.0;
       int found = -1;
 #pragma unroll
@@ -1297,7 +1378,9 @@ __global__ __launch_bounds__(1024) void k_count_pairs(const int* numneigh, int n
   if (threadIdx.x == 0 && t) atomicAdd(out, (unsigned long long)t);
 }
 
-// touching pairs (i-side copy) -> (tag_i, tag_j, shear) compacted with an atomic cursor
+// touching pairs -> (tag_i < tag_j, shear as tag_i sees it) compacted with an atomic cursor.  A pair of two atoms of
+// this GPU has one copy (the owner's slot); pairs with a periodic image or a ghost of another GPU have a copy on
+// each side, of which the lower tag's is reported.
 __global__ __launch_bounds__(256) void k_collect_history(const int* neigh, const int* numneigh, const double* shear,
                                                          const int* tag, int nlocal, size_t cap,
                                                          unsigned long long* cursor, long long max, int* ti,
@@ -1309,17 +1392,21 @@ __global__ __launch_bounds__(256) void k_collect_history(const int* neigh, const
   const int tagi = tag[i];
   for (int s = 0; s < nn; s++) {
     const int jraw = neigh[(size_t)s * cap + i];
-    if (!(jraw & kTouchBit)) continue;
-    const int tagj = tag[neigh_index(jraw, roots)];
-    if (tagi >= tagj) continue;  // the j side holds the bitwise-negated copy
+    if (!(jraw & kTouchBit) || !(jraw & kOwnBit)) continue;
+    const int j = neigh_index(jraw, roots);
+    const int tagj = tag[j];
+    const bool single = j < nlocal && (!roots || ((jraw >> kIdxBits) & 31) == kNoShift);
+    if (!single && tagi >= tagj) continue;   // the other side's own copy is the one reported
+    const bool flip = tagi > tagj;
     const long long k = (long long)atomicAdd(cursor, 1ull);
     if (k < max) {
-      ti[k] = tagi;
-      tj[k] = tagj;
+      ti[k] = flip ? tagj : tagi;
+      tj[k] = flip ? tagi : tagj;
       const size_t b = (size_t)(3 * s) * cap + i;
-      sh[3 * k] = shear[b];
-      sh[3 * k + 1] = shear[b + cap];
-      sh[3 * k + 2] = shear[b + 2 * cap];
+      const double sg = flip ? -1.0 : 1.0;
+      sh[3 * k] = sg * shear[b];
+      sh[3 * k + 1] = sg * shear[b + cap];
+      sh[3 * k + 2] = sg * shear[b + 2 * cap];
     }
   }
 }
