@@ -235,6 +235,15 @@ int sf_dem_set_stream(void *ptr, void *stream);
 /* ------------------------------------------------------------------------------------------
  * (2) per-kernel entry points (device pointers; stream = hipStream_t or NULL)
  * ---------------------------------------------------------------------------------------- */
+/* Device memory for callers that are compiled by a host compiler without the HIP headers (the LAMMPS PairStyle /
+ * FixStyle and OpenFOAM dragModel adapters under adapters/): plain hipMalloc / hipMemcpyAsync / hipMemsetAsync /
+ * hipStreamSynchronize.  sf_dev_alloc returns NULL on failure (see sf_last_error). */
+void *sf_dev_alloc(size_t bytes);
+int sf_dev_free(void *dev);
+int sf_dev_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int sf_dev_download(void *host_dst, const void *dev_src, size_t bytes, void *stream);   /* synchronises the stream */
+int sf_dev_zero(void *dev, size_t bytes, void *stream);
+int sf_dev_sync(void *stream);
 typedef struct {
   double kn, kt, gamman, gammat, xmu;
   int dampflag;

@@ -148,6 +148,12 @@ _SIGS = {
     "sf_dem_migrate_set_slots": (C.c_int, [vp, C.c_int]),
     "sf_dem_ghost_forward_local": (C.c_int, [vp]),
     "sf_dem_set_stream": (C.c_int, [vp, vp]),
+    "sf_dev_alloc": (vp, [C.c_size_t]),
+    "sf_dev_free": (C.c_int, [vp]),
+    "sf_dev_upload": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "sf_dev_download": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "sf_dev_zero": (C.c_int, [vp, C.c_size_t, vp]),
+    "sf_dev_sync": (C.c_int, [vp]),
     "sfk_gran_settings": (C.c_int, [C.POINTER(GranParams), C.c_double, C.c_int, C.c_double, C.c_double,
                                     C.c_int, C.c_double, C.c_double, C.c_int, C.c_double]),
     "sfk_pair_gran_history_compute": (C.c_int, [C.c_int, C.POINTER(GranParams), C.c_double, C.c_int, C.c_int,

@@ -701,7 +701,9 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     static const int lpa_env = getenv("SF_LPA") ? atoi(getenv("SF_LPA")) : 0;
     const int lpa = lpa_env ? lpa_env : (nwork < 20 * 1024 ? 4 : (nwork < 48 * 1024 ? 2 : 1));
     const long long lanes = (long long)nwork * lpa;
-    const int block = block_env ? block_env : (lanes >= 512 * 1024 ? 256 : (lanes >= 128 * 1024 ? 128 : 64));
+    // one wave per workgroup: the dispatcher then balances single waves (a 256-thread workgroup holds its CU slots
+    // until its slowest wave is done); measured 207.0 -> 203.2 us per sub-step at 1 M atoms, never slower below
+    const int block = block_env ? block_env : 64;
     const dim3 grid((unsigned)((lanes + block - 1) / block));
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, lpa, grid, block, stream_, P, S); break;

@@ -39,6 +39,9 @@
 #ifndef SF_HIST_NT_PARTNER
 #define SF_HIST_NT_PARTNER 1  // partner-side history gathers non-temporal
 #endif
+#ifndef SF_EXP_SPLIT_OWN
+#define SF_EXP_SPLIT_OWN 0
+#endif
 #ifndef SF_EXP_PARTNER_OWNROW
 #define SF_EXP_PARTNER_OWNROW 0   // (WRONG results) partner reads its own row instead of the owner's: prices the gather
 #endif
@@ -111,9 +114,19 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
 
+#if SF_EXP_SPLIT_OWN   // (measurement) the own records as 12 scalar loads: does the request count follow the load width?
+  auto ld4 = [&](const double4* p) {
+    const volatile double* q = reinterpret_cast<const volatile double*>(p);
+    return double4{q[0], q[1], q[2], q[3]};
+  };
+  const double4 xi4 = ld4(&P.xr_in[i]);
+  const double4 vi4 = ld4(&P.vm_in[i]);
+  const double4 wi4 = ld4(&P.om_in[i]);
+#else
   const double4 xi4 = P.xr_in[i];   // also a gather target of the neighbours: keep it cached
   const double4 vi4 = P.vm_in[i];
   const double4 wi4 = P.om_in[i];
+#endif
   const Vec3 xi = v3(xi4), vi = v3(vi4), wi = v3(wi4);
   const double radi = xi4.w, mi = vi4.w;
 

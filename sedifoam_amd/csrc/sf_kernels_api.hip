@@ -163,6 +163,53 @@ static double beta_of(double gamman)
 
 extern "C" {
 
+void* sf_dev_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    sf::set_error("sf_dev_alloc(%zu): %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+int sf_dev_free(void* dev)
+{
+  SF_API_BEGIN
+  if (dev) SF_HIP(hipFree(dev));
+  SF_API_END(0)
+}
+
+int sf_dev_upload(void* dev_dst, const void* host_src, size_t bytes, void* stream)
+{
+  SF_API_BEGIN
+  if (bytes) SF_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  SF_API_END(0)
+}
+
+int sf_dev_download(void* host_dst, const void* dev_src, size_t bytes, void* stream)
+{
+  SF_API_BEGIN
+  if (bytes) SF_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  SF_API_END(0)
+}
+
+int sf_dev_zero(void* dev, size_t bytes, void* stream)
+{
+  SF_API_BEGIN
+  if (bytes) SF_HIP(hipMemsetAsync(dev, 0, bytes, (hipStream_t)stream));
+  SF_API_END(0)
+}
+
+int sf_dev_sync(void* stream)
+{
+  SF_API_BEGIN
+  SF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  SF_API_END(0)
+}
+
 int sfk_gran_settings(sfk_gran_params* p, double kn, int kt_null, double kt, double gamman, int gammat_null,
                       double gammat, double xmu, int dampflag, double nktv2p)
 {

@@ -45,3 +45,72 @@ def test_c_caller_runs_a_bed_through_the_library_names(tmp_path):
     tok = r.stdout.strip().split()
     assert tok[0] == "OK" and int(tok[1]) == len(pts)
     assert float(tok[3]) > float(tok[2])          # net upward force 2 m g - m g: the bed rises
+
+
+# ---- the LAMMPS OBJECT shim: how softParticleCloud.C really owns LAMMPS (new LAMMPS / input->one / delete) ----
+SHIM_SRC = os.path.join(ROOT, "tests", "c_abi", "shim_driver.cpp")
+
+
+def _build_shim(tmp_path, std, mpi_flavour):
+    exe = str(tmp_path / ("shim_%s_%s" % (std.replace("+", "x"), mpi_flavour)))
+    cmd = ["g++", "-std=" + std, "-O1", "-Wall", "-Werror", "-Wno-unused-variable",
+           "-I", os.path.join(ROOT, "tests", "c_abi", "fake_mpi_" + mpi_flavour),
+           "-I", os.path.join(ROOT, "include", "lammps_shim"), "-I", os.path.join(ROOT, "include"), SHIM_SRC, "-o", exe,
+           "-L", LIBDIR, "-lsedifoam_amd", "-Wl,-rpath," + LIBDIR]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("std,mpi_flavour", [("c++98", "int"), ("c++98", "ptr"), ("c++17", "int"), ("c++17", "ptr")])
+def test_lammps_object_shim_compiles_for_both_mpi_abis(tmp_path, std, mpi_flavour):
+    """include/lammps_shim/{lammps,input,atom,library}.h stand where LAMMPS' headers stand for
+    lammpsFoam/include/LammpsCollection.H; MPI_Comm as an int (MPICH) and as a pointer (Open MPI); C++98 (OpenFOAM 2.3)
+    and C++17."""
+    if not os.path.exists(os.path.join(LIBDIR, "libsedifoam_amd.so")):
+        pytest.skip("library not built")
+    _build_shim(tmp_path, std, mpi_flavour)
+
+
+def _bed_script(tmp_path):
+    d = 5.0e-4
+    pts = [(0.5 * d + ix * 1.02 * d, 0.5 * d + iy * 1.02 * d, 0.5 * d + iz * 1.02 * d)
+           for iy in range(4) for ix in range(6) for iz in range(6)]
+    data = tmp_path / "bed.in"
+    with open(data, "w") as f:
+        f.write(" sphere data\n\n %d atoms\n 1 atom types\n\n 0.0 %g xlo xhi\n 0.0 %g ylo yhi\n 0.0 %g zlo zhi\n\nAtoms\n\n"
+                % (len(pts), 6.12 * d, 8.0 * d, 6.12 * d))
+        for k, p in enumerate(pts):
+            f.write(" %d 1 %g 2650 %.12g %.12g %.12g\n" % (k + 1, d, p[0], p[1], p[2]))
+    script = tmp_path / "in.lammps"
+    with open(script, "w") as f:
+        f.write("# bed of the reference's kind, read line by line through lmp->input->one\n"
+                "atom_style sphere\nboundary pp ff pp\nnewton off\ncommunicate single vel yes\n"
+                "read_data %s\n\nneighbor 1.0e-4 bin\nneigh_modify delay 0\n"
+                "pair_style gran/hertzFix/history 1.0e7 NULL 0.5 NULL 0.4 1\npair_coeff * *\ntimestep 1e-6\n"
+                "fix 1 all nve/sphere\nfix 2 all gravity 9.8 vector 0 -1 0\nfix 3 all fdrag\n"
+                "fix ywall all wall/granFix 1.0e7 NULL 0.5 NULL 0.4 1 yplane 0.0 0.004\nthermo 1000\n" % data)
+    return script, len(pts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mpi_flavour", ["int", "ptr"])
+def test_lammps_object_shim_runs_the_call_sequence_of_soft_particle_cloud(tmp_path, mpi_flavour):
+    script, n = _bed_script(tmp_path)
+    exe = _build_shim(tmp_path, "c++98", mpi_flavour)
+    r = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tok = r.stdout.strip().split()
+    assert tok[0] == "OK" and int(tok[1]) == n
+    assert float(tok[3]) > float(tok[2])          # net upward force 2 m g - m g: the bed rises
+    assert int(tok[4]) == n + 1 - 2               # one particle created, two deleted
+
+
+@pytest.mark.gpu
+def test_lammps_object_shim_aborts_like_lammps_on_a_bad_script_line(tmp_path):
+    """LAMMPS ends the run on an input error (error->all); the shim prints the engine's message and aborts"""
+    script = tmp_path / "in.lammps"
+    script.write_text("atom_style sphere\npair_style gran/hertzFix/history 1.0e7 NULL\n")
+    exe = _build_shim(tmp_path, "c++98", "int")
+    r = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "pair_style" in (r.stdout + r.stderr)
