@@ -208,6 +208,29 @@ typedef struct {
 int sf_dem_comm_unique_id(char *id128);
 int sf_dem_comm_init(void *ptr, const char *id128, int rank, int world);
 int sf_dem_halo_run(void *ptr, int first_k, int n, const sf_halo_layout *lay, int *trigger);
+/* The whole slab driver in C++ over RCCL -- what an MPI / C++ host (lammpsFoam under mpirun, one rank per GPU) calls
+ * instead of lammps_step on a decomposed domain; Comm::exchange / Comm::borders / Comm::forward_comm and the
+ * MPI_Allreduce's of Neighbor::decide, PairGranHookeHistory::init_one (max radius) and PairLubricatePoly::init_style
+ * (particle volume, pair_lubricate_poly.cpp:540-543) of the reference's LAMMPS [3P].  1-D slabs along x:
+ *   sf_dem_comm_unique_id on rank 0 -> the 128 bytes to every rank (MPI_Bcast) ->
+ *   sf_slab_init(ptr, id, rank, world, xlo, xhi, periodic_x)   collective: communicator, sub-domain of this rank
+ *   sf_slab_setup(ptr)      collective: global max radius, first rebuild (migration, borders, list), global particle
+ *                           volume, setup forces
+ *   sf_slab_step(ptr, n)    collective: "run n pre no post no"; every sub-step = fused pack, ONE grouped
+ *                           ncclSend/ncclRecv (ghost records to the two face neighbours + the rebuild vote to every
+ *                           rank), fused unpack, fused sub-step kernel; one host synchronisation per batch; on a
+ *                           voted trigger: sf_slab_rebuild and the remaining sub-steps
+ *   sf_slab_rebuild(ptr)    collective: migration of leavers with all per-atom state (fix fdrag arrays,
+ *                           fix_fluid_drag.cpp:211-243, wall and pair history), size pre-exchange, border exchange,
+ *                           device list build
+ * Particles are handed over per rank with sf_dem_create_atoms / read_data before sf_slab_setup (every rank its own
+ * slab's atoms).  The rebuild-time exchanges use ncclSend/ncclRecv on device buffers; nothing goes through Python. */
+int sf_slab_init(void *ptr, const char *id128, int rank, int world, double xlo, double xhi, int periodic_x);
+int sf_slab_setup(void *ptr);
+int sf_slab_rebuild(void *ptr);
+int sf_slab_step(void *ptr, int n);
+long long sf_slab_rebuild_count(void *ptr);
+int sf_slab_layout_get(void *ptr, sf_halo_layout *out);   /* the forward-halo layout of the current list (tests) */
 /* owned atoms that left the slab through either face (>= 0; < 0: error): when it is 0 on every rank the migration
  * exchange of this rebuild can be skipped */
 long long sf_dem_migrate_count(void *ptr);

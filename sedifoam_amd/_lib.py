@@ -137,6 +137,12 @@ _SIGS = {
     "sf_dem_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sf_dem_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
     "sf_dem_halo_run": (C.c_int, [vp, C.c_int, C.c_int, vp, ip]),
+    "sf_slab_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "sf_slab_setup": (C.c_int, [vp]),
+    "sf_slab_rebuild": (C.c_int, [vp]),
+    "sf_slab_step": (C.c_int, [vp, C.c_int]),
+    "sf_slab_rebuild_count": (C.c_longlong, [vp]),
+    "sf_slab_layout_get": (C.c_int, [vp, vp]),
     "sf_dem_local_particle_volume": (C.c_int, [vp, dp]),
     "sf_dem_set_global_particle_volume": (C.c_int, [vp, C.c_double]),
     "sf_dem_local_max_radius": (C.c_int, [vp, dp]),

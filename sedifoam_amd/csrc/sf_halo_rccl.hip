@@ -9,8 +9,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/sedifoam_amd.h"
 #include "sf_handles.h"
@@ -26,6 +28,7 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -50,6 +53,7 @@ static RcclApi& rccl()
   api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
   api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
   api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
   return api;
 }
@@ -68,15 +72,55 @@ __global__ void k_fake_link_delay(long long ticks)
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// a device buffer of doubles that only grows
+struct GrowBuf {
+  double* p = nullptr;
+  size_t n = 0;
+  double* need(size_t count)
+  {
+    if (count > n) {
+      if (p) (void)hipFree(p);
+      n = count + count / 4 + 1024;
+      SF_HIP(hipMalloc(&p, sizeof(double) * n));
+    }
+    return p;
+  }
+  ~GrowBuf()
+  {
+    if (p) (void)hipFree(p);
+  }
+};
+
 struct HaloComm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
+  // ---- the slab driver (sf_slab_*): what sedifoam_amd/halo.py SlabDriver does, in C++ ----
+  bool slab = false, periodic_x = true, is_setup = false;
+  double box_lo = 0.0, box_len = 1.0;
+  int left = -1, right = -1;                 // face neighbours (-1: none, a non-periodic box end)
+  double shift_left = 0.0, shift_right = 0.0;
+  long long nsend[2] = {0, 0}, nrecv[2] = {0, 0};   // border atoms to / from the left, right neighbour
+  long long n_rebuilds = 0;
+  GrowBuf mig[2], bor[2], rx[2], a2a_tx, a2a_rx;
+  long long* d_counts = nullptr;             // [4] device: counts to left, to right ; from left, from right
+  long long* h_counts = nullptr;             // pinned twin
+  double* d_red = nullptr;                   // [2] all-reduce scratch
+  double* h_red = nullptr;
+  int* d_hdr = nullptr;                      // [2 * world] header offsets: send, receive
+  std::vector<long long> send_off, send_cnt, recv_off, recv_cnt;
+  sf_halo_layout lay{};
+  bool lay_valid = false;
   ~HaloComm()
   {
     if (comm) (void)rccl().CommDestroy(comm);
     if (ev_boundary) (void)hipEventDestroy(ev_boundary);
     if (ev_halo) (void)hipEventDestroy(ev_halo);
+    if (d_counts) (void)hipFree(d_counts);
+    if (h_counts) (void)hipHostFree(h_counts);
+    if (d_red) (void)hipFree(d_red);
+    if (h_red) (void)hipHostFree(h_red);
+    if (d_hdr) (void)hipFree(d_hdr);
   }
   // rx[chunk p] <- what rank p put into its chunk for this rank (an all-to-all with per-peer counts)
   void all_to_all(const sf_halo_layout& L, hipStream_t st)
@@ -96,6 +140,242 @@ struct HaloComm {
 };
 
 static void halo_deleter(void* p) { delete static_cast<HaloComm*>(p); }
+
+// ------------------------------------------------------------------------------------------------
+// The slab driver in C++: rebuild-time exchanges ([3P] Comm::exchange / Comm::borders, the migration payload of
+// fix_fluid_drag.cpp:211-243 + wall and pair history) and the lammps_step loop over RCCL, so that an MPI / C++ host
+// (lammpsFoam) drives N GPUs through sf_slab_* alone.  Same protocol as sedifoam_amd/halo.py (which the gloo tests
+// run against the oracle twin).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBorderDoublesC = 14, kForwardDoublesC = 9;
+
+static void slab_scratch(HaloComm& hc)
+{
+  if (hc.d_counts) return;
+  SF_HIP(hipMalloc(&hc.d_counts, sizeof(long long) * 4));
+  SF_HIP(hipHostMalloc(&hc.h_counts, sizeof(long long) * 4));
+  SF_HIP(hipMalloc(&hc.d_red, sizeof(double) * 2));
+  SF_HIP(hipHostMalloc(&hc.h_red, sizeof(double) * 2));
+  SF_HIP(hipMalloc(&hc.d_hdr, sizeof(int) * 2 * hc.world));
+}
+
+// one value reduced over the ranks (rebuild / setup time only: synchronises)
+static double slab_allreduce(HaloComm& hc, hipStream_t st, double v, ncclRedOp_t op)
+{
+  if (hc.world == 1) return v;
+  hc.h_red[0] = v;
+  SF_HIP(hipMemcpyAsync(hc.d_red, hc.h_red, sizeof(double), hipMemcpyHostToDevice, st));
+  SF_NCCL(rccl().AllReduce(hc.d_red, hc.d_red + 1, 1, ncclDouble, op, hc.comm, st));
+  SF_HIP(hipMemcpyAsync(hc.h_red + 1, hc.d_red + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+  SF_HIP(hipStreamSynchronize(st));
+  return hc.h_red[1];
+}
+
+// send[0][:n0] goes to the left neighbour, send[1][:n1] to the right one (doubles); returns what arrived from the
+// left / right in hc.rx[0] / hc.rx[1] and their sizes.  known = receive sizes when both sides already know them.
+// Message order with one peer on both sides (2 ranks, periodic): sends left then right, receives from-right then
+// from-left -- what I sent leftwards reaches my left neighbour from its right.
+static void slab_exchange(HaloComm& hc, hipStream_t st, const double* s0, long long n0, const double* s1, long long n1,
+                          long long& m0, long long& m1)
+{
+  RcclApi& a = rccl();
+  if (hc.left < 0) n0 = 0;
+  if (hc.right < 0) n1 = 0;
+  hc.h_counts[0] = n0;
+  hc.h_counts[1] = n1;
+  hc.h_counts[2] = hc.h_counts[3] = 0;
+  SF_HIP(hipMemcpyAsync(hc.d_counts, hc.h_counts, sizeof(long long) * 4, hipMemcpyHostToDevice, st));
+  SF_NCCL(a.GroupStart());
+  if (hc.left >= 0) SF_NCCL(a.Send(hc.d_counts + 0, 1, ncclInt64, hc.left, hc.comm, st));
+  if (hc.right >= 0) SF_NCCL(a.Send(hc.d_counts + 1, 1, ncclInt64, hc.right, hc.comm, st));
+  if (hc.right >= 0) SF_NCCL(a.Recv(hc.d_counts + 3, 1, ncclInt64, hc.right, hc.comm, st));   // leftward traffic comes from my right
+  if (hc.left >= 0) SF_NCCL(a.Recv(hc.d_counts + 2, 1, ncclInt64, hc.left, hc.comm, st));
+  SF_NCCL(a.GroupEnd());
+  SF_HIP(hipMemcpyAsync(hc.h_counts, hc.d_counts, sizeof(long long) * 4, hipMemcpyDeviceToHost, st));
+  SF_HIP(hipStreamSynchronize(st));
+  m0 = hc.h_counts[2];
+  m1 = hc.h_counts[3];
+  double* r0 = hc.rx[0].need((size_t)m0 + 1);
+  double* r1 = hc.rx[1].need((size_t)m1 + 1);
+  SF_NCCL(a.GroupStart());
+  if (hc.left >= 0 && n0) SF_NCCL(a.Send(s0, (size_t)n0, ncclDouble, hc.left, hc.comm, st));
+  if (hc.right >= 0 && n1) SF_NCCL(a.Send(s1, (size_t)n1, ncclDouble, hc.right, hc.comm, st));
+  if (hc.right >= 0 && m1) SF_NCCL(a.Recv(r1, (size_t)m1, ncclDouble, hc.right, hc.comm, st));
+  if (hc.left >= 0 && m0) SF_NCCL(a.Recv(r0, (size_t)m0, ncclDouble, hc.left, hc.comm, st));
+  SF_NCCL(a.GroupEnd());
+}
+
+// send / receive layout of the one-collective forward halo (valid until the next rebuild): per peer rank one header
+// double (rebuild trigger) + the forward records for / from that peer
+static void slab_layout(HaloComm& hc, hipStream_t st)
+{
+  const int W = hc.world, F = kForwardDoublesC;
+  hc.send_cnt.assign(W, 1);
+  hc.recv_cnt.assign(W, 1);
+  hc.send_off.assign(W, 0);
+  hc.recv_off.assign(W, 0);
+  if (hc.left >= 0) {
+    hc.send_cnt[hc.left] += hc.nsend[0] * F;
+    hc.recv_cnt[hc.left] += hc.nrecv[0] * F;
+  }
+  if (hc.right >= 0) {
+    hc.send_cnt[hc.right] += hc.nsend[1] * F;
+    hc.recv_cnt[hc.right] += hc.nrecv[1] * F;
+  }
+  for (int p = 1; p < W; p++) {
+    hc.send_off[p] = hc.send_off[p - 1] + hc.send_cnt[p - 1];
+    hc.recv_off[p] = hc.recv_off[p - 1] + hc.recv_cnt[p - 1];
+  }
+  const long long ntx = hc.send_off[W - 1] + hc.send_cnt[W - 1], nrx = hc.recv_off[W - 1] + hc.recv_cnt[W - 1];
+  const bool same = hc.left >= 0 && hc.left == hc.right;
+  // records selected at a face without a neighbour (non-periodic box end) go to scratch behind the chunks
+  long long scratch = 0;
+  sf_halo_layout& L = hc.lay;
+  L.world = W;
+  L.shift_left = hc.shift_left;
+  L.shift_right = hc.shift_right;
+  if (hc.left >= 0) L.soff_l = hc.send_off[hc.left] + 1;
+  else {
+    L.soff_l = ntx + scratch;
+    scratch += hc.nsend[0] * F;
+  }
+  if (hc.right >= 0) L.soff_r = hc.send_off[hc.right] + 1 + (same ? hc.nsend[0] * F : 0);
+  else {
+    L.soff_r = ntx + scratch;
+    scratch += hc.nsend[1] * F;
+  }
+  L.roff_r = hc.right >= 0 ? hc.recv_off[hc.right] + 1 : 0;
+  L.roff_l = hc.left >= 0 ? hc.recv_off[hc.left] + 1 + (same ? hc.nrecv[1] * F : 0) : 0;
+  L.n_from_left = hc.nrecv[0];
+  L.n_from_right = hc.nrecv[1];
+  L.send_off = hc.send_off.data();
+  L.send_cnt = hc.send_cnt.data();
+  L.recv_off = hc.recv_off.data();
+  L.recv_cnt = hc.recv_cnt.data();
+  std::vector<int> hdr(2 * W);
+  for (int p = 0; p < W; p++) {
+    hdr[p] = (int)hc.send_off[p];
+    hdr[W + p] = (int)hc.recv_off[p];
+  }
+  SF_HIP(hipMemcpyAsync(hc.d_hdr, hdr.data(), sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
+  SF_HIP(hipStreamSynchronize(st));   // (hdr is a local)
+  L.dev_shdr = hc.d_hdr;
+  L.dev_rhdr = hc.d_hdr + W;
+  L.dev_tx = hc.a2a_tx.need((size_t)(ntx + scratch) + 1);
+  L.dev_rx = hc.a2a_rx.need((size_t)nrx + 1);
+  hc.lay_valid = true;
+}
+
+static void slab_rebuild(SfLammps& S, HaloComm& hc)
+{
+  DemEngine& e = S.eng;
+  hipStream_t st = e.stream();
+  e.rebuild_begin();
+  // one all-reduce carries the history slots a migrating atom needs (max over ranks of max_neigh_used) and, above
+  // them, whether any rank has an atom outside its slab: the usual rebuild migrates nothing and skips that round
+  const long long crossed = e.migrate_count();
+  const double v = slab_allreduce(hc, st, (double)e.max_neigh_used() + (crossed ? 1048576.0 : 0.0), ncclMax);
+  const long long vi = (long long)v;
+  e.migrate_set_slots((int)(vi & 1048575));
+  if (vi >> 20) {
+    const int rec = e.migrate_record_doubles();
+    const size_t cap = (size_t)(crossed + 1) * rec;
+    double* b0 = hc.mig[0].need(cap);
+    double* b1 = hc.mig[1].need(cap);
+    const long long n0 = e.migrate_pack(0, hc.shift_left, b0, (long long)cap);
+    const long long n1 = e.migrate_pack(1, hc.shift_right, b1, (long long)cap);
+    if ((hc.left < 0 && n0) || (hc.right < 0 && n1)) fail("Lost atoms: an atom left the non-periodic box in x");
+    long long m0 = 0, m1 = 0;
+    slab_exchange(hc, st, b0, n0, b1, n1, m0, m1);
+    e.migrate_unpack(hc.rx[0].p, m0);
+    e.migrate_unpack(hc.rx[1].p, m1);
+  }
+  e.rebuild_sort();
+  const size_t bcap = (size_t)e.nlocal() + 1;
+  double* s0 = hc.bor[0].need(bcap * kBorderDoublesC);
+  double* s1 = hc.bor[1].need(bcap * kBorderDoublesC);
+  const long long a0 = e.border_pack(0, hc.shift_left, s0, (long long)bcap);
+  const long long a1 = e.border_pack(1, hc.shift_right, s1, (long long)bcap);
+  hc.nsend[0] = a0;
+  hc.nsend[1] = a1;
+  long long m0 = 0, m1 = 0;
+  slab_exchange(hc, st, s0, a0 * kBorderDoublesC, s1, a1 * kBorderDoublesC, m0, m1);
+  hc.nrecv[0] = m0 / kBorderDoublesC;
+  hc.nrecv[1] = m1 / kBorderDoublesC;
+  e.border_unpack(0, hc.rx[0].p, hc.nrecv[0]);
+  e.border_unpack(1, hc.rx[1].p, hc.nrecv[1]);
+  e.rebuild_finish();
+  hc.n_rebuilds++;
+  slab_layout(hc, st);
+}
+
+static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n);
+
+static void slab_step(SfLammps& S, HaloComm& hc, int n)
+{
+  DemEngine& e = S.eng;
+  e.run_begin();
+  int k = 0;
+  while (k < n) {
+    const int trig = slab_halo_run(S, hc, k, n);
+    if (trig >= n) break;
+    k = trig + 1;   // sub-steps k..trig ran (trig = -1: the list was stale for sub-step 0)
+    slab_rebuild(S, hc);
+    if (e.overlap()) e.overlap_begin();
+  }
+}
+
+// queue sub-steps first_k .. n-1 (fused pack, one grouped ncclSend/ncclRecv, fused unpack, kernel; overlapped if
+// sf_dem_set_overlap is on), synchronise once, return the voted rebuild trigger
+static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const sf_halo_layout& layr)
+{
+  HaloComm* hc = &hcr;
+  const sf_halo_layout* lay = &layr;
+  DemEngine& e = S.eng;
+  hipStream_t main = e.stream();
+  int trigger = 0;
+  auto exchange = [&](int kstep, hipStream_t st) {
+    e.forward_pack_fused(lay->shift_left, lay->soff_l, lay->shift_right, lay->soff_r, lay->dev_shdr, lay->world,
+                         lay->dev_tx);
+    hc->all_to_all(*lay, st);
+    e.forward_unpack_fused(lay->dev_rx, lay->roff_l, lay->n_from_left, lay->roff_r, lay->n_from_right, lay->dev_rhdr,
+                           lay->world, kstep);
+  };
+  const int launched = n - first_k;
+  if (!e.overlap()) {
+    for (int s = first_k; s < n; s++) {
+      exchange(-1, main);
+      e.substep_k(s == n - 1, s);
+    }
+    trigger = e.batch_end(first_k, launched);
+  } else {
+    hipStream_t cs = e.comm_stream();
+    SF_HIP(hipEventRecord(hc->ev_boundary, main));
+    SF_HIP(hipStreamWaitEvent(cs, hc->ev_boundary, 0));
+    exchange(first_k - 1, cs);                       // ghosts + vote before sub-step first_k
+    SF_HIP(hipEventRecord(hc->ev_halo, cs));
+    for (int s = first_k; s < n; s++) {
+      const bool last = s == n - 1;
+      SF_HIP(hipStreamWaitEvent(main, hc->ev_halo, 0));
+      e.substep_part(2, last, s);                    // boundary atoms: need the ghosts of exchange s-1
+      SF_HIP(hipEventRecord(hc->ev_boundary, main));
+      e.substep_part(1, last, s);                    // interior atoms, under the exchange of sub-step s
+      e.substep_flip(s);
+      SF_HIP(hipStreamWaitEvent(cs, hc->ev_boundary, 0));
+      exchange(s, cs);
+      SF_HIP(hipEventRecord(hc->ev_halo, cs));
+    }
+    SF_HIP(hipStreamWaitEvent(main, hc->ev_halo, 0));
+    trigger = e.overlap_batch_end(first_k, launched, n - 1);
+  }
+  return trigger;
+}
+
+static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n)
+{
+  if (!hc.lay_valid) fail("sf_slab_step: no halo layout (rebuild first)");
+  return halo_run_layout(S, hc, first_k, n, hc.lay);
+}
 
 }  // namespace sf
 
@@ -144,42 +424,89 @@ int sf_dem_halo_run(void* ptr, int first_k, int n, const sf_halo_layout* lay, in
   if (!hc || !hc->comm) sf::fail("sf_dem_halo_run: call sf_dem_comm_init first");
   if (!lay || !trigger) sf::fail("sf_dem_halo_run: null argument");
   if (lay->world != hc->world) sf::fail("sf_dem_halo_run: layout for %d ranks, communicator has %d", lay->world, hc->world);
+  *trigger = sf::halo_run_layout(*L, *hc, first_k, n, *lay);
+  SF_API_END(0)
+}
+
+int sf_slab_init(void* ptr, const char* id128, int rank, int world, double xlo, double xhi, int periodic_x)
+{
+  SF_API_BEGIN
+  SfLammps* L = H(ptr);
+  if (sf_dem_comm_init(ptr, id128, rank, world) != 0) sf::fail("%s", sf::last_error().c_str());
+  auto* hc = static_cast<sf::HaloComm*>(L->halo);
+  hc->slab = true;
+  hc->periodic_x = periodic_x != 0;
+  hc->box_lo = xlo;
+  hc->box_len = xhi - xlo;
+  hc->left = rank > 0 ? rank - 1 : (periodic_x ? world - 1 : -1);
+  hc->right = rank < world - 1 ? rank + 1 : (periodic_x ? 0 : -1);
+  // shift applied to what goes out through the global box faces
+  hc->shift_left = (rank == 0 && periodic_x) ? hc->box_len : 0.0;
+  hc->shift_right = (rank == world - 1 && periodic_x) ? -hc->box_len : 0.0;
+  const double w = hc->box_len / world;
+  const double sublo = xlo + rank * w, subhi = rank == world - 1 ? xhi : xlo + (rank + 1) * w;
+  L->eng.set_subdomain(rank, world, sublo, subhi);
+  sf::slab_scratch(*hc);
+  SF_API_END(0)
+}
+
+static sf::HaloComm* slab_of(SfLammps* L)
+{
+  auto* hc = static_cast<sf::HaloComm*>(L->halo);
+  if (!hc || !hc->slab) sf::fail("sf_slab_*: call sf_slab_init first");
+  return hc;
+}
+
+int sf_slab_setup(void* ptr)
+{
+  SF_API_BEGIN
+  SfLammps* L = H(ptr);
+  sf::HaloComm* hc = slab_of(L);
   sf::DemEngine& e = L->eng;
-  hipStream_t main = e.stream();
-  auto exchange = [&](int kstep, hipStream_t st) {
-    e.forward_pack_fused(lay->shift_left, lay->soff_l, lay->shift_right, lay->soff_r, lay->dev_shdr, lay->world,
-                         lay->dev_tx);
-    hc->all_to_all(*lay, st);
-    e.forward_unpack_fused(lay->dev_rx, lay->roff_l, lay->n_from_left, lay->roff_r, lay->n_from_right, lay->dev_rhdr,
-                           lay->world, kstep);
-  };
-  const int launched = n - first_k;
-  if (!e.overlap()) {
-    for (int s = first_k; s < n; s++) {
-      exchange(-1, main);
-      e.substep_k(s == n - 1, s);
-    }
-    *trigger = e.batch_end(first_k, launched);
-  } else {
-    hipStream_t cs = e.comm_stream();
-    SF_HIP(hipEventRecord(hc->ev_boundary, main));
-    SF_HIP(hipStreamWaitEvent(cs, hc->ev_boundary, 0));
-    exchange(first_k - 1, cs);                       // ghosts + vote before sub-step first_k
-    SF_HIP(hipEventRecord(hc->ev_halo, cs));
-    for (int s = first_k; s < n; s++) {
-      const bool last = s == n - 1;
-      SF_HIP(hipStreamWaitEvent(main, hc->ev_halo, 0));
-      e.substep_part(2, last, s);                    // boundary atoms: need the ghosts of exchange s-1
-      SF_HIP(hipEventRecord(hc->ev_boundary, main));
-      e.substep_part(1, last, s);                    // interior atoms, under the exchange of sub-step s
-      e.substep_flip(s);
-      SF_HIP(hipStreamWaitEvent(cs, hc->ev_boundary, 0));
-      exchange(s, cs);
-      SF_HIP(hipEventRecord(hc->ev_halo, cs));
-    }
-    SF_HIP(hipStreamWaitEvent(main, hc->ev_halo, 0));
-    *trigger = e.overlap_batch_end(first_k, launched, n - 1);
+  hipStream_t st = e.stream();
+  // list / ghost cutoff 2 r_max + skin: r_max over ALL ranks ([3P] MPI_Allreduce of maxrad_dynamic)
+  e.set_global_max_radius(sf::slab_allreduce(*hc, st, e.local_max_radius(), ncclMax));
+  sf::slab_rebuild(*L, *hc);
+  // pair lubricate/poly: volume fraction of ALL particles (MPI_Allreduce, pair_lubricate_poly.cpp:540-543)
+  e.set_global_particle_volume(sf::slab_allreduce(*hc, st, e.local_particle_volume(), ncclSum));
+  e.setup();
+  hc->is_setup = true;
+  SF_API_END(0)
+}
+
+int sf_slab_rebuild(void* ptr)
+{
+  SF_API_BEGIN
+  SfLammps* L = H(ptr);
+  sf::slab_rebuild(*L, *slab_of(L));
+  SF_API_END(0)
+}
+
+int sf_slab_step(void* ptr, int n)
+{
+  SF_API_BEGIN
+  SfLammps* L = H(ptr);
+  sf::HaloComm* hc = slab_of(L);
+  if (!hc->is_setup) {
+    if (sf_slab_setup(ptr) != 0) sf::fail("%s", sf::last_error().c_str());
   }
+  if (n > 0) sf::slab_step(*L, *hc, n);
+  SF_API_END(0)
+}
+
+long long sf_slab_rebuild_count(void* ptr)
+{
+  SF_API_BEGIN
+  const long long n = slab_of(H(ptr))->n_rebuilds;
+  SF_API_END(n)
+}
+
+int sf_slab_layout_get(void* ptr, sf_halo_layout* out)
+{
+  SF_API_BEGIN
+  sf::HaloComm* hc = slab_of(H(ptr));
+  if (!hc->lay_valid) sf::fail("sf_slab_layout_get: no rebuild yet");
+  *out = hc->lay;
   SF_API_END(0)
 }
 

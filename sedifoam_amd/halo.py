@@ -160,6 +160,30 @@ class HipSlabEngine:
             dist.broadcast_object_list(ident, src=0)
         self.check(self.L.sf_dem_comm_init(self.lmp.ptr, ident[0], int(rank), int(world)))
 
+    # ---- the whole driver in C++ (sf_slab_*): Python only forwards ----
+    def slab_init(self, dist, rank, world, xlo, xhi, periodic_x):
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            self.check(self.L.sf_dem_comm_unique_id(buf))
+            ident[0] = buf.raw
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self.check(self.L.sf_slab_init(self.lmp.ptr, ident[0], int(rank), int(world), float(xlo), float(xhi),
+                                       int(bool(periodic_x))))
+
+    def slab_setup(self):
+        self.check(self.L.sf_slab_setup(self.lmp.ptr))
+
+    def slab_rebuild(self):
+        self.check(self.L.sf_slab_rebuild(self.lmp.ptr))
+
+    def slab_step(self, n):
+        self.check(self.L.sf_slab_step(self.lmp.ptr, int(n)))
+
+    def slab_rebuild_count(self):
+        return self.check(self.L.sf_slab_rebuild_count(self.lmp.ptr))
+
     def halo_run(self, first_k, n, lay):
         from . import _lib
         t = C.c_int()
@@ -257,24 +281,39 @@ class SlabDriver:
         self.overlap = bool(overlap) and self.fused and hasattr(eng, "enable_overlap") and (world > 1 or self.self_comm)
         if self.overlap:
             eng.enable_overlap()
-        # transport "rccl": the per-sub-step loop runs in C++ on its own RCCL communicator (rebuild-time exchanges
-        # stay on torch.distributed, they are rare)
+        # transport "rccl": the WHOLE driver runs in C++ on the engine's own RCCL communicator (sf_slab_*: sub-step
+        # loop, rebuild-time migration / border exchanges, global reductions); this class only forwards.  A failure
+        # to bring RCCL up is an error -- a silent fall-back would benchmark the Python loop -- unless
+        # SF_HALO_ALLOW_FALLBACK=1
+        self._cxx = False
         if self.transport == "rccl":
-            if not (self.fused and hasattr(eng, "comm_init") and (world > 1 or self.self_comm)):
-                self.transport = "direct"
+            if not (self.fused and hasattr(eng, "slab_init") and (world > 1 or self.self_comm)):
+                self.transport = "direct"      # (single slab without self-communication: nothing to exchange)
             else:
                 try:
-                    eng.comm_init(dist, rank, world)
+                    eng.slab_init(dist, rank, world, xlo, xhi, periodic_x)
+                    self._cxx = True
                 except Exception as ex:      # e.g. librccl not loadable: the same on every rank
+                    if os.environ.get("SF_HALO_ALLOW_FALLBACK", "0") != "1":
+                        raise RuntimeError("transport='rccl': the C++ RCCL driver is unavailable (%s); set "
+                                           "SF_HALO_ALLOW_FALLBACK=1 to run the torch.distributed loop instead" % ex)
                     import warnings
-                    warnings.warn("RCCL sub-step loop unavailable (%s); using torch.distributed from Python" % ex)
+                    warnings.warn("RCCL driver unavailable (%s); using torch.distributed from Python" % ex)
                     self.transport = "direct"
         self._cap_atoms = int(halo_atoms) if halo_atoms else max(eng.info().nlocal, 4096)
         self._bufs = {}
         self._nrecv = [0, 0]
-        self.n_rebuilds = 0
+        self._n_rebuilds = 0
         self._lay, self._lay_key = None, -1
         self.is_setup = False
+
+    @property
+    def n_rebuilds(self):
+        return self.e.slab_rebuild_count() if self._cxx else self._n_rebuilds
+
+    @n_rebuilds.setter
+    def n_rebuilds(self, v):
+        self._n_rebuilds = v
 
     # ---- plumbing ----
     def _buf(self, name, ndoubles):
@@ -356,6 +395,9 @@ class SlabDriver:
     # ---- the three halo operations ----
     def rebuild(self):
         e = self.e
+        if self._cxx:
+            e.slab_rebuild()
+            return
         e.rebuild_begin()
         # one all-reduce carries the history slots a migrating atom needs (max over ranks of max_neigh_used) and, in
         # the bits above, whether any rank has an atom outside its slab: the usual rebuild migrates nothing and then
@@ -387,7 +429,7 @@ class SlabDriver:
         e.border_unpack(0, rl, self._nrecv[0])
         e.border_unpack(1, rr, self._nrecv[1])
         e.rebuild_finish()
-        self.n_rebuilds += 1
+        self._n_rebuilds += 1
 
     def _fused_layout(self):
         """Send / receive layout of the one-collective forward halo (valid until the next rebuild, cached): per peer
@@ -571,6 +613,10 @@ class SlabDriver:
         return float(t.item())
 
     def setup(self):
+        if self._cxx:
+            self.e.slab_setup()
+            self.is_setup = True
+            return
         # list / ghost cutoff 2 r_max + skin: r_max over ALL ranks ([3P] MPI_Allreduce of maxrad_dynamic)
         if hasattr(self.e, "local_max_radius"):
             self.e.set_global_max_radius(self._allreduce_max_f64(self.e.local_max_radius()))
@@ -603,17 +649,8 @@ class SlabDriver:
             self.setup()
         n = int(n)
         e = self.e
-        if self.transport == "rccl":
-            e.run_begin()
-            k = 0
-            while k < n:
-                trig = e.halo_run(k, n, self._fused_layout())
-                if trig >= n:
-                    break
-                k = trig + 1
-                self.rebuild()
-                if self.overlap:
-                    e.overlap_begin()
+        if self._cxx:
+            e.slab_step(n)
             return
         if self.overlap:
             self._step_overlapped(n)
