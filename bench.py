@@ -135,6 +135,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
     ap.add_argument("--cpu-all-particles", type=int, default=100000,
                     help="particles per process of the all-cores CPU leg (one oracle process per host core), 0 = skip")
+    ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
+                    help="N > 1: weak = every rank owns one --particles slab (the `value` of the JSON line); strong = "
+                         "--particles in total, split into N x-slabs (BASELINE config C4), reported as "
+                         "`strong_scaling` next to it; both (default) measures one after the other.  N = 1: identical")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="development: all ranks share GPU 0, halo over gloo through host memory (RCCL refuses two "
+                         "ranks on one device); exercises the N > 1 code on a 1-GPU box")
     ap.add_argument("--coupled-multi", action="store_true",
                     help="with --gpus N > 1 also time coupled steps: enhancedCloud over the decomposed particles, "
                          "whole mesh on every rank, per-cell sums all-reduced")
@@ -151,8 +158,11 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    transport = "host" if args.one_gpu else None
     if world > 1 or os.environ.get("SF_HALO_SELF_COMM", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -160,7 +170,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sedifoam_amd import synthetic
     kw = KW
@@ -174,40 +187,66 @@ def main():
     script = synthetic.hertz_script(bed, **kw)
     N = bed["n"]
 
-    if world > 1 or args.slab_driver:
-        from sedifoam_amd.halo import SlabDriver
-        lmp = SlabDriver.from_bed(bed, script, dist, rank, world)
-    else:
-        lmp = build_engine(bed, script)
-    lmp.setup()
-    info = lmp.info()
-    k_half = info.npairs_full / 2.0 / max(info.nlocal, 1)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        lmp.step(args.substeps)
-    lmp.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lmp.step(args.substeps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches, kernel_ms = lmp.get_profile()
-    lmp.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        ntot = torch.tensor([float(N)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ntot)
-        n_total = float(ntot.item())
+    def timed_run(lmp):
+        """W warm-up + K timed steps of `lammps_step(S)`; returns (elapsed max over ranks, total particles, launches,
+        kernel ms, info before, info after)"""
+        lmp.setup()
+        info0 = lmp.info()
+        for _ in range(args.warmup):
+            lmp.step(args.substeps)
+        lmp.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lmp.step(args.substeps)
+        barrier()
+        el = time.perf_counter() - t0
+        launches, kernel_ms = lmp.get_profile()
+        lmp.set_profiling(False)
+        n_own = float(lmp.info().nlocal)
+        if dist is not None:
+            rdev = "cpu" if args.one_gpu else "cuda"
+            t = torch.tensor([el], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            nt = torch.tensor([n_own], dtype=torch.float64, device=rdev)
+            dist.all_reduce(nt)
+            n_own = float(nt.item())
+        return el, n_own, launches, kernel_ms, info0, lmp.info()
+
+    strong = None
+    if world > 1 and args.scaling in ("both", "strong"):
+        # BASELINE config C4: ONE --particles bed, split into `world` x-slabs (strong scaling)
+        from sedifoam_amd.halo import SlabDriver
+        gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
+        sdrv = SlabDriver.from_global_bed(gbed, script, dist, rank, world, transport=transport)
+        el_s, n_s, _l, _k, _i0, _i1 = timed_run(sdrv)
+        strong = {"value": n_s * args.substeps * args.steps / el_s, "unit": "particle-substeps/s",
+                  "ms_per_step": 1e3 * el_s / args.steps, "particles_total": int(n_s), "scaling": "strong",
+                  "workload": "the SAME %d-particle bed split into %d x-slabs (BASELINE config C4)" % (int(n_s), world)}
+        if args.scaling == "strong":
+            elapsed, n_total, launches, kernel_ms, info = el_s, n_s, _l, _k, _i0
+            lmp = sdrv
+            N = info.nlocal
+        else:
+            del sdrv
+        del gbed
+
+    if world > 1 and args.scaling == "strong":
+        pass
+    elif world > 1 or args.slab_driver:
+        from sedifoam_amd.halo import SlabDriver
+        lmp = SlabDriver.from_bed(bed, script, dist, rank, world, transport=transport)
+        elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
     else:
-        n_total = float(N)
+        lmp = build_engine(bed, script)
+        elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
+    k_half = info.npairs_full / 2.0 / max(info.nlocal, 1)
 
     value = n_total * args.substeps * args.steps / elapsed
     b_alg = 284.0 + 52.0 * k_half
@@ -223,7 +262,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (world > 1 and args.scaling == "strong") else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -233,9 +272,11 @@ def main():
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
             **({"bed_override": bed_kw} if bed_kw else {}),
-            "decomposition": "x-slabs, ghost halo over RCCL" if world > 1 else
+            "decomposition": ("x-slabs, ghost halo over gloo through host memory (--one-gpu)" if args.one_gpu else
+                              "x-slabs, ghost halo over RCCL") if world > 1 else
                              ("single slab through the halo driver" if args.slab_driver else "single domain"),
         },
+        **({"strong_scaling": strong} if strong else {}),
         "roofline": {
             "bound": "hbm", "kernel": "k_substep<hertz>", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -279,6 +320,15 @@ def main():
                 cloud.evolve(); cloud.calcTcFields()
             barrier()
             out["config"][key] = ncpl / (time.perf_counter() - t1)
+            if band:
+                # the reference's timer buckets (writeCPUTime.H:1-19), per coupled step; the same names are roctx ranges
+                tm = cloud.cpuTimeSplit()
+                nrun = ncpl + 3
+                out["config"]["coupled_buckets_ms"] = {
+                    "evolve": 1e3 * tm["evolve"] / nrun, "calcTcField": 1e3 * tm["calcTc"] / nrun,
+                    "foam->lammps (drag closure + assembly)": 1e3 * tm["dragOnParticles"] / nrun,
+                    "lammps (%d sub-steps)" % args.substeps: 1e3 * tm["lammps"] / nrun,
+                    "particle move (cell owner + scatter + smoothing)": 1e3 * tm["scatter"] / nrun}
             cloud.close()
         out["config"]["coupled_step"] = ("ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc + diffusion smoothing "
                                          "(b = 6 mm, 6 steps), %dx%dx%d mesh" % (args.substeps, mesh_n[0], mesh_n[1],
@@ -333,6 +383,7 @@ def main():
         sub = 50
         v, n_s, secs = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub)
         out["cpu_baseline"] = {"value": v, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
+                               "buckets_ms_per_step": {"lammps (%d sub-steps)" % sub: 1e3 * secs},
                                "sample": "%d-particle bed of the same packing, %d sub-steps, %.1f s, "
                                          "oracle/ (C, gcc -O2) single thread" % (n_s, sub, secs)}
         allc = cpu_baseline_all_cores(args.cpu_all_particles, 20) if args.cpu_all_particles > 0 else None

@@ -17,6 +17,7 @@
 
 #include "../../include/sedifoam_amd.h"
 #include "sf_handles.h"
+#include "sf_roctx.h"
 #include "sf_smooth.h"
 
 namespace sf {
@@ -649,19 +650,27 @@ class Cloud {
 
   void evolve()
   {
+    Range r_evolve("evolve");   // roctx ranges carry the bucket names of writeCPUTime.H:1-19
     const double t0 = now();
     DemEngine& e = lmp_->eng;
     advance_time();
     update_uf_smoothed();   // :675-690
     for (int k = 0; k < subCycles_; k++) {
       double t1 = now();
-      drag_on_particles();
-      t_.dragOnParticles += sync_now() - t1;
+      {
+        Range r("foam->lammps");   // updateDragOnParticles + what lammps_put_local_info would copy
+        drag_on_particles();
+        t_.dragOnParticles += sync_now() - t1;
+      }
       t1 = now();
-      e.run(subSteps_);  // lammpsEvolveForward without the host round trip
-      t_.lammps += sync_now() - t1;
+      {
+        Range r("lammps");
+        e.run(subSteps_);  // lammpsEvolveForward without the host round trip
+        t_.lammps += sync_now() - t1;
+      }
       // Cloud::move: the new cell owner is recomputed from the DEM positions wherever it is used
       if (k == 0) {
+        Range r("particle move");   // cell owner + particleToEulerianField (enhancedCloud.C:749-776)
         t1 = now();
         particle_to_eulerian();
         t_.scatter += sync_now() - t1;
@@ -672,6 +681,7 @@ class Cloud {
 
   void calc_tc_fields()
   {
+    Range r_tc("calcTcField");
     const double t0 = now();
     calc_tc_local();
     calc_tc_finish();

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "sf_dem_kernels.h"
+#include "sf_roctx.h"
 
 namespace sf {
 
@@ -1117,6 +1118,7 @@ void DemEngine::rebuild_finish()
 
 void DemEngine::rebuild()
 {
+  Range r("neighbor rebuild");   // (inside the reference's "lammps" bucket)
   rebuild_begin();
   rebuild_sort();
   rebuild_finish();

@@ -16,6 +16,7 @@
 
 #include "../../include/sedifoam_amd.h"
 #include "sf_handles.h"
+#include "sf_roctx.h"
 
 namespace sf {
 
@@ -268,6 +269,7 @@ static void slab_layout(HaloComm& hc, hipStream_t st)
 
 static void slab_rebuild(SfLammps& S, HaloComm& hc)
 {
+  Range r("neighbor rebuild");
   DemEngine& e = S.eng;
   hipStream_t st = e.stream();
   e.rebuild_begin();
@@ -313,6 +315,7 @@ static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n);
 
 static void slab_step(SfLammps& S, HaloComm& hc, int n)
 {
+  Range r("lammps");
   DemEngine& e = S.eng;
   e.run_begin();
   int k = 0;

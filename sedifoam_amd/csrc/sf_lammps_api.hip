@@ -14,6 +14,7 @@
 
 #include "../../include/sedifoam_amd.h"
 #include "sf_handles.h"
+#include "sf_roctx.h"
 
 using sf::DemEngine;
 using sf::SfLammps;
@@ -391,6 +392,7 @@ int sf_lammps_get_local_domain(void* ptr, double* domain_)
 int sf_lammps_get_local_info(void* ptr, double* coords, double* velos_, int* foamCpuId_, int* lmpCpuId_, int* tag_)
 {
   SF_API_BEGIN
+  sf::Range r("lammps->foam");   // writeCPUTime.H bucket
   DemEngine& e = H(ptr)->eng;
   e.get_local_info(coords, velos_, foamCpuId_, tag_);
   if (lmpCpuId_)
@@ -402,6 +404,7 @@ int sf_lammps_put_local_info(void* ptr, int nLocalIn, const double* fdrag, const
                              const int* foamCpuIdIn, const int* tagIn)
 {
   SF_API_BEGIN
+  sf::Range r("foam->lammps");
   H(ptr)->eng.put_local_info(nLocalIn, fdrag, foamCpuIdIn, tagIn);
   SF_API_END(0)
 }
@@ -409,6 +412,7 @@ int sf_lammps_put_local_info(void* ptr, int nLocalIn, const double* fdrag, const
 int sf_lammps_step(void* ptr, int n)
 {
   SF_API_BEGIN
+  sf::Range r("lammps");
   H(ptr)->eng.run(n);
   SF_API_END(0)
 }

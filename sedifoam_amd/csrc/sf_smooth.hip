@@ -1,5 +1,6 @@
 // sf_smooth.hip -- see sf_smooth.h (enhancedCloud::smoothField, lammpsFoam/enhancedCloud.C:790-907).
 #include "sf_smooth.h"
+#include "sf_roctx.h"
 
 #include <algorithm>
 #include <cmath>
@@ -426,6 +427,7 @@ void DiffusionSmoother::smooth_spectral(double* fa, int na, double* fb, int nb)
 
 void DiffusionSmoother::smooth2(double* fa, int na, double* fb, int nb)
 {
+  Range r("diffusion");
   if (!enabled_) return;
   if (use_cg_ || na + nb > kMaxCheb) {
     smooth(fa, na);
@@ -500,6 +502,7 @@ void DiffusionSmoother::solve_component(double* x, int stride)
 
 void DiffusionSmoother::smooth(double* field, int ncomp)
 {
+  Range r("diffusion");   // writeCPUTime.H bucket (enhancedCloud::smoothField)
   if (!enabled_) return;
   if (!use_cg_ && ncomp <= kMaxCheb) {
     smooth2(field, ncomp, nullptr, 0);

@@ -685,6 +685,26 @@ class SlabDriver:
         return self.e.lmp.get_profile()
 
     @classmethod
+    def from_global_bed(cls, bed, script, dist, rank, world, transport=None):
+        """bench.py, strong scaling (BASELINE config C4): ONE bed for all ranks, every rank owns the atoms of its
+        x slab (tags = global index + 1)."""
+        from . import Lammps
+        if transport is None:
+            transport = os.environ.get("SF_HALO_TRANSPORT", "rccl")
+        lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
+        w = (hi - lo) / world
+        x = np.asarray(bed["x"])
+        mine = (x[:, 0] >= lo + rank * w) & ((x[:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
+        lmp = Lammps()
+        lmp.set_box(bed["boxlo"], bed["boxhi"])
+        lmp.create_atoms(x[mine], np.asarray(bed["diameter"])[mine], np.asarray(bed["density"])[mine],
+                         v=np.asarray(bed["v"])[mine], tag=(np.nonzero(mine)[0] + 1).astype(np.int64))
+        for line in script:
+            lmp.command(line)
+        return cls(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=bool(bed["periodic"][0]),
+                   transport=transport)
+
+    @classmethod
     def from_bed(cls, bed, script, dist, rank, world, transport=None):
         """bench.py: every rank owns one copy of `bed` (its own seed), laid side by side along x."""
         from . import Lammps
