@@ -432,6 +432,14 @@ private:
   bool row_tables_ = false;   // cell_start_ holds the reversed lower-bound tables (plain keys) instead of cell ranges
   int* tagmap_ = nullptr;
   size_t tagmap_alloc_ = 0;
+  long long order_version_ = 0, tagmap_builds_ = -1;   // the tag -> index table is rebuilt when the atom order changed
+  struct IoBuf {
+    void* p = nullptr;
+    size_t n = 0;
+  };
+  IoBuf io_d_[3], io_i_[2];            // staging of the lammps_put/get_local_info boundary (persistent, grown)
+  double* io_doubles(int which, size_t n);
+  int* io_ints(int which, size_t n);
   void* sort_tmp_ = nullptr;
   size_t sort_tmp_bytes_ = 0;
   int* d_flags_ = nullptr;

@@ -119,6 +119,10 @@ DemEngine::~DemEngine()
   if (stage_idx_) (void)hipFree(stage_idx_);
   if (eoff_) (void)hipFree(eoff_);
   if (tagmap_) (void)hipFree(tagmap_);
+  for (IoBuf& b : io_d_)
+    if (b.p) (void)hipFree(b.p);
+  for (IoBuf& b : io_i_)
+    if (b.p) (void)hipFree(b.p);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (own_flags_) (void)hipFree(own_flags_);
   if (h_flags_) (void)hipHostFree(h_flags_);
@@ -298,6 +302,7 @@ void DemEngine::create_atoms(int n, const double* x, const double* v, const doub
   up(mask_, hm.data(), sizeof(int) * n, sizeof(int) * n0);
   sync();
   nlocal_ = n0 + n;
+  order_version_++;
 }
 
 void DemEngine::set_pair_gran(int style, double kn, bool kt_null, double kt, double gamman, bool gammat_null,
@@ -827,6 +832,7 @@ void DemEngine::rebuild_begin()
 // The old-list rows (partner tags, slot counts, shear) travel with their atom through the B-side buffers.
 void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
 {
+  order_version_++;
   hist_indirect_ = false;
   if (n_new <= 0) return;
   const int nb = div_up(n_new, 256);
@@ -1394,6 +1400,7 @@ void DemEngine::run(int nsteps)
 // data exchange (lammps_* surface)
 // ------------------------------------------------------------------------------------------------
 namespace {
+// one-off scratch of the rarely used accessors (history, pair count)
 struct ScratchD {
   double* p = nullptr;
   explicit ScratchD(size_t n) { SF_HIP(hipMalloc(&p, sizeof(double) * (n ? n : 1))); }
@@ -1406,15 +1413,39 @@ struct ScratchI {
 };
 }  // namespace
 
+// Staging buffers of the per-CFD-step boundary calls (lammps_put_local_info / lammps_get_local_info / get_forces):
+// persistent, grown geometrically -- a hipMalloc / hipFree pair per call is a device-wide synchronisation each.
+double* DemEngine::io_doubles(int which, size_t n)
+{
+  IoBuf& b = io_d_[which];
+  if (n > b.n) {
+    if (b.p) SF_HIP(hipFree(b.p));
+    b.n = n + n / 2 + 1024;
+    SF_HIP(hipMalloc(&b.p, sizeof(double) * b.n));
+  }
+  return static_cast<double*>(b.p);
+}
+
+int* DemEngine::io_ints(int which, size_t n)
+{
+  IoBuf& b = io_i_[which];
+  if (n > b.n) {
+    if (b.p) SF_HIP(hipFree(b.p));
+    b.n = n + n / 2 + 1024;
+    SF_HIP(hipMalloc(&b.p, sizeof(int) * b.n));
+  }
+  return static_cast<int*>(b.p);
+}
+
 void DemEngine::get_local_info(double* x, double* v, int* foamCpuId, int* tag)
 {
   const int n = nlocal_;
   if (!n) return;
-  ScratchD dx(3 * (size_t)n), dv(3 * (size_t)n);
-  k_pack_info<<<div_up(n, 256), 256, 0, stream_>>>(d_xr(), d_vm(), d_om(), d_force(), d_torque(), n, dx.p, dv.p,
+  double *dx = io_doubles(0, 3 * (size_t)n), *dv = io_doubles(1, 3 * (size_t)n);
+  k_pack_info<<<div_up(n, 256), 256, 0, stream_>>>(d_xr(), d_vm(), d_om(), d_force(), d_torque(), n, dx, dv,
                                                    nullptr, nullptr, nullptr, nullptr, nullptr);
-  if (x) SF_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
-  if (v) SF_HIP(hipMemcpyAsync(v, dv.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (x) SF_HIP(hipMemcpyAsync(x, dx, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (v) SF_HIP(hipMemcpyAsync(v, dv, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
   if (foamCpuId)
     SF_HIP(hipMemcpyAsync(foamCpuId, foamCpuId_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
   if (tag) SF_HIP(hipMemcpyAsync(tag, tag_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
@@ -1441,12 +1472,12 @@ void DemEngine::get_forces(double* f, double* torque, double* omega, int* tag)
 {
   const int n = nlocal_;
   if (!n) return;
-  ScratchD df(3 * (size_t)n), dt(3 * (size_t)n), dw(3 * (size_t)n);
+  double *df = io_doubles(0, 3 * (size_t)n), *dt = io_doubles(1, 3 * (size_t)n), *dw = io_doubles(2, 3 * (size_t)n);
   k_pack_info<<<div_up(n, 256), 256, 0, stream_>>>(d_xr(), d_vm(), d_om(), d_force(), d_torque(), n, nullptr,
-                                                   nullptr, dw.p, df.p, dt.p, nullptr, nullptr);
-  if (f) SF_HIP(hipMemcpyAsync(f, df.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
-  if (torque) SF_HIP(hipMemcpyAsync(torque, dt.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
-  if (omega) SF_HIP(hipMemcpyAsync(omega, dw.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+                                                   nullptr, dw, df, dt, nullptr, nullptr);
+  if (f) SF_HIP(hipMemcpyAsync(f, df, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (torque) SF_HIP(hipMemcpyAsync(torque, dt, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
+  if (omega) SF_HIP(hipMemcpyAsync(omega, dw, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
   if (tag) SF_HIP(hipMemcpyAsync(tag, tag_.ptr, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
   sync();
 }
@@ -1459,19 +1490,24 @@ void DemEngine::put_local_info(int n, const double* fdrag, const int* foamCpuId,
                     "particle number is: %5d.\n", n, nlocal_);  // library.cpp:335-341 (prints, continues)
   const int m = std::min(n, nlocal_);
   if (!m) return;
+  // tag -> index table: indices only change when the atoms are re-sorted (a rebuild) or created / deleted / migrated
   if ((size_t)max_tag_ > tagmap_alloc_) {
     if (tagmap_) SF_HIP(hipFree(tagmap_));
     tagmap_alloc_ = (size_t)max_tag_ + max_tag_ / 4 + 16;
     SF_HIP(hipMalloc(&tagmap_, sizeof(int) * tagmap_alloc_));
+    tagmap_builds_ = -1;
   }
-  SF_HIP(hipMemsetAsync(tagmap_, 0xff, sizeof(int) * tagmap_alloc_, stream_));
-  k_tag_map<<<div_up(nlocal_, 256), 256, 0, stream_>>>(tag_.as<int>(), nlocal_, tagmap_, max_tag_);
-  ScratchD din(3 * (size_t)m);
-  ScratchI dtag(m), dcpu(m);
-  SF_HIP(hipMemcpyAsync(din.p, fdrag, sizeof(double) * 3 * m, hipMemcpyHostToDevice, stream_));
-  SF_HIP(hipMemcpyAsync(dtag.p, tagIn, sizeof(int) * m, hipMemcpyHostToDevice, stream_));
-  if (foamCpuId) SF_HIP(hipMemcpyAsync(dcpu.p, foamCpuId, sizeof(int) * m, hipMemcpyHostToDevice, stream_));
-  k_put_fdrag<<<div_up(m, 256), 256, 0, stream_>>>(din.p, dtag.p, foamCpuId ? dcpu.p : nullptr, m, tagmap_,
+  if (tagmap_builds_ != order_version_) {
+    SF_HIP(hipMemsetAsync(tagmap_, 0xff, sizeof(int) * tagmap_alloc_, stream_));
+    k_tag_map<<<div_up(nlocal_, 256), 256, 0, stream_>>>(tag_.as<int>(), nlocal_, tagmap_, max_tag_);
+    tagmap_builds_ = order_version_;
+  }
+  double* din = io_doubles(0, 3 * (size_t)m);
+  int *dtag = io_ints(0, m), *dcpu = io_ints(1, m);
+  SF_HIP(hipMemcpyAsync(din, fdrag, sizeof(double) * 3 * m, hipMemcpyHostToDevice, stream_));
+  SF_HIP(hipMemcpyAsync(dtag, tagIn, sizeof(int) * m, hipMemcpyHostToDevice, stream_));
+  if (foamCpuId) SF_HIP(hipMemcpyAsync(dcpu, foamCpuId, sizeof(int) * m, hipMemcpyHostToDevice, stream_));
+  k_put_fdrag<<<div_up(m, 256), 256, 0, stream_>>>(din, dtag, foamCpuId ? dcpu : nullptr, m, tagmap_,
                                                    max_tag_, fdrag_.as<double>(), foamCpuId_.as<int>(), cap_,
                                                    d_flags_);
   read_flags();

@@ -508,6 +508,7 @@ void DemEngine::migrate_unpack(const double* buf, long long ndoubles)
                            DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_);
   k_migrate_unpack<<<div_up(n, 128), 128, 0, stream_>>>(buf, n, nlocal_, P, cap_, nwalls_, mrec_, rec);
   nlocal_ += n;
+  order_version_++;
   // tags of immigrants may exceed what this rank has seen
   std::vector<double> hb((size_t)n * rec);
   SF_HIP(hipMemcpyAsync(hb.data(), buf, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, stream_));
@@ -570,6 +571,7 @@ void DemEngine::create_particles(int np, const double* pos, const double* tag, d
   up(wtouch_, zb.data(), np, nlocal_);
   sync();
   nlocal_ += np;
+  order_version_++;
   nghost_ = 0;
   // next_reneighbor = ntimestep + 1 for every fix (library.cpp:482-486): rebuild before the next force
   if (setup_done_ && !have_subdomain_) rebuild();

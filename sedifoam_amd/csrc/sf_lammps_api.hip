@@ -137,6 +137,17 @@ void cmd_fix(SfLammps& L, const std::vector<std::string>& w)
   const int gb = L.eng.group_bit(w[2]);   // "Could not find fix group ID" in LAMMPS
   const std::string& st = w[3];
   const int narg = (int)w.size() - 1;  // LAMMPS narg counts ID group style ...
+  // LAMMPS runs the post_force fixes in script order; the fused kernel adds gravity, fdrag, walls and cohesion in a
+  // fixed order (sums only: order-free up to rounding) and applies fix freeze LAST, as every script of the reference
+  // has it.  A force fix that follows `fix freeze` would act on the frozen atoms in LAMMPS and cannot here: refuse.
+  const bool force_fix = st == "gravity" || st == "fdrag" || st == "cohesive" || st == "wall/gran" || st == "wall/granFix";
+  if (force_fix && L.freeze_seen)
+    sf::fail("fix %s after fix freeze: this engine applies fix freeze after every other force fix (as the reference's "
+             "input scripts order them); move the fix freeze line to the end of the fix list", st.c_str());
+  if (st == "freeze") L.freeze_seen = true;
+  if (st == "cohesive" && gb != 1)
+    sf::fail("fix cohesive on a group other than `all` is not supported (the full-list evaluation would differ from "
+             "the reference's half-list ownership of a pair, fix_cohesive.cpp:167)");
   if (st == "nve/sphere") {
     L.eng.set_nve_sphere(gb);
   } else if (st == "gravity") {
@@ -255,16 +266,26 @@ void command(SfLammps& L, const std::string& line)
     if (w.size() < 2) sf::fail("Illegal neighbor command");
     L.eng.set_skin(num(w[1]));
   } else if (c == "neigh_modify") {
-    for (size_t k = 1; k + 1 < w.size(); k += 2)
+    // the engine decides like `delay 0 every 1 check yes` (every case of the reference): refuse anything else
+    // instead of silently rebuilding at other times than LAMMPS would
+    for (size_t k = 1; k + 1 < w.size(); k += 2) {
       if (w[k] == "one") L.eng.set_max_neigh(inum(w[k + 1]));
+      else if (w[k] == "delay" && inum(w[k + 1]) != 0) sf::fail("neigh_modify delay %s: only delay 0 is supported", w[k + 1].c_str());
+      else if (w[k] == "every" && inum(w[k + 1]) != 1) sf::fail("neigh_modify every %s: only every 1 is supported", w[k + 1].c_str());
+      else if (w[k] == "check" && w[k + 1] != "yes") sf::fail("neigh_modify check %s: only check yes is supported", w[k + 1].c_str());
+    }
   } else if (c == "pair_style") {
     cmd_pair_style(L, w, 1);
   } else if (c == "timestep") {
     if (w.size() != 2) sf::fail("Illegal timestep command");
     L.eng.set_timestep(num(w[1]));
   } else if (c == "velocity") {
-    if (w.size() >= 6 && w[2] == "set") L.eng.set_velocity_group(L.eng.group_bit(w[1]), num(w[3]), num(w[4]), num(w[5]));
-    else sf::fail("velocity: only `velocity all set vx vy vz` is supported");
+    if (w.size() >= 6 && w[2] == "set") {
+      for (int k = 3; k < 6; k++)
+        if (w[k] == "NULL") sf::fail("velocity set: NULL components are not supported");
+      L.eng.set_velocity_group(L.eng.group_bit(w[1]), num(w[3]), num(w[4]), num(w[5]));
+    } else
+      sf::fail("velocity: only `velocity GROUP set vx vy vz` is supported");
   } else if (c == "group") {
     cmd_group(L, w);
   } else if (c == "fix") {
