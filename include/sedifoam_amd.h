@@ -352,6 +352,10 @@ typedef struct {
    * NULL = identity.  Every host array that crosses this interface (set_fluid, get_fields, get_particles' cell,
    * smooth_field) is then in label order; sf_cloud_device_fields stays in grid order. */
   const int *cell_label;
+  /* cyclic patch pairs of the diffusion mesh: periodic[k] != 0 couples the first and the last cell layer along axis k
+   * in smoothField (the reference's channel cases: blockMeshDict `cyclic` patches, in.lammps `boundary pp ff pp`);
+   * 0 = zeroGradient at both ends (enhancedCloud.C:800-815 default patch type) */
+  int periodic[3];
 } sf_cloud_mesh;
 
 int sf_cloud_create(void *lmp, const sf_cloud_mesh *mesh, const sf_cloud_props *props,

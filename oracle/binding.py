@@ -66,7 +66,7 @@ class CloudFlags(C.Structure):
 class Smooth(C.Structure):
     _fields_ = [("n", C.c_int * 3), ("dx", C.c_double * 3), ("D", C.c_double * 3), ("band", C.c_double),
                 ("steps", C.c_int), ("UfSmooth", C.c_int), ("UpSmooth", C.c_int), ("dragSmooth", C.c_int),
-                ("alphaSmooth", C.c_int), ("w", C.POINTER(C.c_double) * 3)]
+                ("alphaSmooth", C.c_int), ("w", C.POINTER(C.c_double) * 3), ("periodic", C.c_int * 3)]
 
 
 def _declare(L):
@@ -167,6 +167,8 @@ def _declare(L):
     L.orc_calc_tc_fields.argtypes = [C.c_int, ip, dp, dp, dp, C.c_int, dp, dp, dp, dp, dp]
     L.orc_smooth_field.argtypes = [ip, dp, dp, C.c_double, C.c_int, C.c_int, dp]
     L.orc_smooth_field_graded.argtypes = [ip, dp, C.POINTER(dp), dp, C.c_double, C.c_int, C.c_int, dp]
+    L.orc_smooth_field_periodic.argtypes = [ip, dp, dp, C.c_double, C.c_int, C.c_int, dp, ip]
+    L.orc_smooth_field_graded_periodic.argtypes = [ip, dp, C.POINTER(dp), dp, C.c_double, C.c_int, C.c_int, dp, ip]
     L.orc_particle_to_eulerian_smooth.argtypes = [C.c_int, ip, dp, dp, C.c_int, dp, C.POINTER(Smooth), dp, dp]
     L.orc_uf_smoothed.argtypes = [C.c_int, dp, dp, C.POINTER(Smooth), dp]
     L.orc_calc_tc_fields_smooth.argtypes = [C.c_int, ip, dp, dp, dp, C.c_int, dp, dp, dp, C.POINTER(Smooth), dp, dp]

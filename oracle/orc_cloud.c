@@ -332,6 +332,7 @@ int orc_adjust_timestep(double deltaT, double dtLampIn, int subCycles_in, double
 typedef struct {
   int n[3];
   double c[3];
+  int per[3];   /* cyclic patch pair along this axis ([3P] cyclicFvPatch: the first and the last cell are neighbours) */
 } orc_stencil;
 
 static void apply_A(const orc_stencil *st, const double *v, double *out)
@@ -344,17 +345,32 @@ static void apply_A(const orc_stencil *st, const double *v, double *out)
         int c = i + st->n[0] * (j + st->n[1] * k);
         double vc = v[c], acc = vc;
         if (i > 0) acc += st->c[0] * (vc - v[c - sx]);
+        else if (st->per[0]) acc += st->c[0] * (vc - v[c + (st->n[0] - 1) * sx]);
         if (i < st->n[0] - 1) acc += st->c[0] * (vc - v[c + sx]);
+        else if (st->per[0]) acc += st->c[0] * (vc - v[c - (st->n[0] - 1) * sx]);
         if (j > 0) acc += st->c[1] * (vc - v[c - sy]);
+        else if (st->per[1]) acc += st->c[1] * (vc - v[c + (st->n[1] - 1) * sy]);
         if (j < st->n[1] - 1) acc += st->c[1] * (vc - v[c + sy]);
+        else if (st->per[1]) acc += st->c[1] * (vc - v[c - (st->n[1] - 1) * sy]);
         if (k > 0) acc += st->c[2] * (vc - v[c - sz]);
+        else if (st->per[2]) acc += st->c[2] * (vc - v[c + (st->n[2] - 1) * sz]);
         if (k < st->n[2] - 1) acc += st->c[2] * (vc - v[c + sz]);
+        else if (st->per[2]) acc += st->c[2] * (vc - v[c - (st->n[2] - 1) * sz]);
         out[c] = acc;
       }
 }
 
 void orc_smooth_field(const int n[3], const double dx[3], const double D[3], double band, int steps, int ncomp,
                       double *field)
+{
+  orc_smooth_field_periodic(n, dx, D, band, steps, ncomp, field, NULL);
+}
+
+/* the same with cyclic patch pairs: the diffusion mesh of the reference's channel cases (blockMeshDict `cyclic`
+ * patches, in.lammps `boundary pp ff pp`) couples the first and the last cell of a periodic axis instead of closing
+ * them with zeroGradient */
+void orc_smooth_field_periodic(const int n[3], const double dx[3], const double D[3], double band, int steps,
+                               int ncomp, double *field, const int *periodic)
 {
   int nc = n[0] * n[1] * n[2], s, comp, c, it;
   orc_stencil st;
@@ -363,6 +379,7 @@ void orc_smooth_field(const int n[3], const double dx[3], const double D[3], dou
   for (c = 0; c < 3; c++) {
     st.n[c] = n[c];
     st.c[c] = dtau * D[c] / (dx[c] * dx[c]);
+    st.per[c] = (periodic && periodic[c] && n[c] > 1) ? 1 : 0;
   }
   double *x = malloc(sizeof(double) * nc), *r = malloc(sizeof(double) * nc), *p = malloc(sizeof(double) * nc),
          *ap = malloc(sizeof(double) * nc);
@@ -405,6 +422,7 @@ typedef struct {
   int n[3];
   const double *w[3];
   double dx[3], D[3], dtau;
+  int per[3];
 } orc_gstencil;
 
 static double gwidth(const orc_gstencil *st, int k, int i) { return st->w[k] ? st->w[k][i] : st->dx[k]; }
@@ -424,10 +442,16 @@ static void apply_G(const orc_gstencil *st, const double *v, double *out)
           if (idx[k] > 0) {
             double d = 0.5 * (h[k] + gwidth(st, k, idx[k] - 1));
             acc += st->dtau * st->D[k] * area / d * (vc - v[c - stride[k]]);
+          } else if (st->per[k]) {
+            double d = 0.5 * (h[k] + gwidth(st, k, st->n[k] - 1));
+            acc += st->dtau * st->D[k] * area / d * (vc - v[c + (st->n[k] - 1) * stride[k]]);
           }
           if (idx[k] < st->n[k] - 1) {
             double d = 0.5 * (h[k] + gwidth(st, k, idx[k] + 1));
             acc += st->dtau * st->D[k] * area / d * (vc - v[c + stride[k]]);
+          } else if (st->per[k]) {
+            double d = 0.5 * (h[k] + gwidth(st, k, 0));
+            acc += st->dtau * st->D[k] * area / d * (vc - v[c - (st->n[k] - 1) * stride[k]]);
           }
         }
         out[c] = acc;
@@ -437,11 +461,19 @@ static void apply_G(const orc_gstencil *st, const double *v, double *out)
 void orc_smooth_field_graded(const int n[3], const double dx[3], const double *const w[3], const double D[3],
                              double band, int steps, int ncomp, double *field)
 {
+  orc_smooth_field_graded_periodic(n, dx, w, D, band, steps, ncomp, field, NULL);
+}
+
+void orc_smooth_field_graded_periodic(const int n[3], const double dx[3], const double *const w[3],
+                                      const double D[3], double band, int steps, int ncomp, double *field,
+                                      const int *periodic)
+{
   int nc = n[0] * n[1] * n[2], s, comp, c, it, k;
   orc_gstencil st;
   if (!(band > 0.0) || steps <= 0) return;
   st.dtau = (band * band / 4.0) / (steps + 1.0e-150);             /* :564-565 */
   for (k = 0; k < 3; k++) {
+    st.per[k] = (periodic && periodic[k] && n[k] > 1) ? 1 : 0;
     st.n[k] = n[k];
     st.w[k] = w ? w[k] : NULL;
     st.dx[k] = dx[k];
@@ -489,8 +521,9 @@ void orc_smooth_field_graded(const int n[3], const double dx[3], const double *c
 /* smoothField as the cloud functions below call it: uniform block or graded block (sm->w) */
 static void smooth_any(const orc_smooth *sm, int ncomp, double *field)
 {
-  if (sm->w[0] || sm->w[1] || sm->w[2]) orc_smooth_field_graded(sm->n, sm->dx, sm->w, sm->D, sm->band, sm->steps, ncomp, field);
-  else orc_smooth_field(sm->n, sm->dx, sm->D, sm->band, sm->steps, ncomp, field);
+  if (sm->w[0] || sm->w[1] || sm->w[2])
+    orc_smooth_field_graded_periodic(sm->n, sm->dx, sm->w, sm->D, sm->band, sm->steps, ncomp, field, sm->periodic);
+  else orc_smooth_field_periodic(sm->n, sm->dx, sm->D, sm->band, sm->steps, ncomp, field, sm->periodic);
 }
 
 /* particleToEulerianField with the smoothing branches (:944-962) */

@@ -265,7 +265,13 @@ typedef struct {
   int steps;
   int UfSmooth, UpSmooth, dragSmooth, alphaSmooth;
   const double *w[3];   /* graded block: cell widths along each axis (NULL = uniform dx) */
+  int periodic[3];      /* cyclic patch pair along this axis (the reference's channel cases) instead of zeroGradient */
 } orc_smooth;
+void orc_smooth_field_periodic(const int n[3], const double dx[3], const double D[3], double band, int steps,
+                               int ncomp, double *field, const int *periodic);
+void orc_smooth_field_graded_periodic(const int n[3], const double dx[3], const double *const w[3],
+                                      const double D[3], double band, int steps, int ncomp, double *field,
+                                      const int *periodic);
 void orc_smooth_field_graded(const int n[3], const double dx[3], const double *const w[3], const double D[3],
                              double band, int steps, int ncomp, double *field);
 void orc_smooth_field(const int n[3], const double dx[3], const double D[3], double band, int steps, int ncomp,

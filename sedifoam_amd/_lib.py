@@ -69,7 +69,8 @@ class CloudProps(C.Structure):
 
 class CloudMesh(C.Structure):
     _fields_ = [("origin", C.c_double * 3), ("dx", C.c_double * 3), ("n", C.c_int * 3),
-                ("faces", C.POINTER(C.c_double) * 3), ("cell_label", C.POINTER(C.c_int))]
+                ("faces", C.POINTER(C.c_double) * 3), ("cell_label", C.POINTER(C.c_int)),
+                ("periodic", C.c_int * 3)]
 
 
 class CloudTimers(C.Structure):

@@ -64,11 +64,13 @@ class enhancedCloud:
     transDict keys (constant/transportProperties): rhob, nub."""
 
     def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT, driver=None,
-                 mesh_faces=None, mesh_labels=None):
+                 mesh_faces=None, mesh_labels=None, mesh_periodic=None):
         """mesh_faces: (xf, yf, zf) face coordinates of a graded (blockMesh simpleGrading) block, n+1 ascending values
         per axis or None for a uniform axis (then mesh_origin / mesh_dx apply along it).
         mesh_labels: OpenFOAM cell label of every cell of the grid, in grid order ix + nx*(iy + ny*iz) (multi-block
         blockMesh cases number their cells block by block); every field array is then in label order.
+        mesh_periodic: (px, py, pz) cyclic patch pairs of the (diffusion) mesh: smoothField couples the first and the
+        last cell layer along such an axis instead of closing them with zeroGradient (the reference's channel cases).
         driver: a sedifoam_amd.halo.SlabDriver when the particles are decomposed over several GPUs (lammps is
         then the driver's engine).  Every rank holds the whole mesh; the per-cell sums of gamma, Ue and Asrc are
         added over the ranks (torch.distributed all_reduce on the device arrays) inside evolve()/calcTcFields()."""
@@ -110,6 +112,7 @@ class enhancedCloud:
         m.origin = (C.c_double * 3)(*mesh_origin)
         m.dx = (C.c_double * 3)(*mesh_dx)
         m.n = (C.c_int * 3)(*mesh_n)
+        m.periodic = (C.c_int * 3)(*[int(bool(q)) for q in ((0, 0, 0) if mesh_periodic is None else mesh_periodic)])
         keep_faces = []
         for k in range(3):
             fk = None if mesh_faces is None else mesh_faces[k]

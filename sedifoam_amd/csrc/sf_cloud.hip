@@ -584,7 +584,7 @@ class Cloud {
     const double* wptr[3] = {mesh.faces[0] ? width[0].data() : nullptr, mesh.faces[1] ? width[1].data() : nullptr,
                              mesh.faces[2] ? width[2].data() : nullptr};
     smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_,
-                        wptr);
+                        wptr, mesh.periodic);
     SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
     std::vector<double> hV(nc);
     for (int iz = 0; iz < mesh.n[2]; iz++)

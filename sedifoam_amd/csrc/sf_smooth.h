@@ -20,8 +20,9 @@ class DiffusionSmoother {
   ~DiffusionSmoother();
   // n, dx: the hex block; D: diagonal of smoothDirection; band: diffusionBandWidth; steps: diffusionSteps
   // widths[k]: the n[k] cell widths of a graded axis (blockMesh simpleGrading), or nullptr = uniform dx[k]
+  // periodic[k] != 0: cyclic patch pair along axis k (first and last cell are neighbours) instead of zero gradient
   void configure(const int n[3], const double dx[3], const double D[3], double band, int steps, hipStream_t s,
-                 const double* const widths[3] = nullptr);
+                 const double* const widths[3] = nullptr, const int* periodic = nullptr);
   bool enabled() const { return enabled_; }
   // field: ncells*ncomp doubles, component-interleaved (AoS); smoothed in place
   void smooth(double* field, int ncomp);
@@ -33,6 +34,7 @@ class DiffusionSmoother {
   void solve_component(double* x, int stride);
   bool enabled_ = false;
   int n_[3] = {0, 0, 0};
+  int per_[3] = {0, 0, 0};
   int ncells_ = 0, steps_ = 0, nblocks_ = 0;
   double c_[3] = {0, 0, 0};   // dtau * D_d / dx_d^2
   hipStream_t s_ = nullptr;

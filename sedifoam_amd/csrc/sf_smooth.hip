@@ -13,6 +13,7 @@ struct Stencil {
   int n[3];
   double c[3];
   int ncells;
+  int per[3];   // cyclic patch pair along this axis: the first and the last cell are neighbours
 };
 
 // scalars on the device: [0] rr, [1] pAp, [2] alpha, [3] beta, [4] bb (rhs norm^2), [5] rr_new
@@ -26,11 +27,17 @@ __device__ __forceinline__ double apply_A(const Stencil& st, const double* v, in
   double acc = vc;
   const int sx = 1, sy = st.n[0], sz = st.n[0] * st.n[1];
   if (i > 0) acc += st.c[0] * (vc - v[(size_t)(c - sx) * stride]);
+  else if (st.per[0]) acc += st.c[0] * (vc - v[(size_t)(c + (st.n[0] - 1) * sx) * stride]);
   if (i < st.n[0] - 1) acc += st.c[0] * (vc - v[(size_t)(c + sx) * stride]);
+  else if (st.per[0]) acc += st.c[0] * (vc - v[(size_t)(c - (st.n[0] - 1) * sx) * stride]);
   if (j > 0) acc += st.c[1] * (vc - v[(size_t)(c - sy) * stride]);
+  else if (st.per[1]) acc += st.c[1] * (vc - v[(size_t)(c + (st.n[1] - 1) * sy) * stride]);
   if (j < st.n[1] - 1) acc += st.c[1] * (vc - v[(size_t)(c + sy) * stride]);
+  else if (st.per[1]) acc += st.c[1] * (vc - v[(size_t)(c - (st.n[1] - 1) * sy) * stride]);
   if (k > 0) acc += st.c[2] * (vc - v[(size_t)(c - sz) * stride]);
+  else if (st.per[2]) acc += st.c[2] * (vc - v[(size_t)(c + (st.n[2] - 1) * sz) * stride]);
   if (k < st.n[2] - 1) acc += st.c[2] * (vc - v[(size_t)(c + sz) * stride]);
+  else if (st.per[2]) acc += st.c[2] * (vc - v[(size_t)(c - (st.n[2] - 1) * sz) * stride]);
   return acc;
 }
 
@@ -303,9 +310,10 @@ static void jacobi_eigen(int n, std::vector<double>& a, std::vector<double>& q)
 }
 
 void DiffusionSmoother::configure(const int n[3], const double dx[3], const double D[3], double band, int steps,
-                                  hipStream_t s, const double* const widths[3])
+                                  hipStream_t s, const double* const widths[3], const int* periodic)
 {
   s_ = s;
+  for (int k = 0; k < 3; k++) per_[k] = (periodic && periodic[k] && n[k] > 1) ? 1 : 0;
   enabled_ = band > 0.0 && steps > 0;
   if (!enabled_) return;
   const bool graded = widths && (widths[0] || widths[1] || widths[2]);
@@ -351,6 +359,26 @@ void DiffusionSmoother::configure(const int n[3], const double dx[3], const doub
     for (int d = 0; d < 3; d++) {
       const int nd = n_[d];
       specC_off_[d] = off;
+      if (!(widths && widths[d]) && per_[d]) {
+        // cyclic axis: the operator is circulant, diagonal in the real Fourier basis -- mode 0 constant, modes
+        // 2k-1 / 2k = cos / sin of frequency k, and for even n the alternating mode; eigenvalue 2 - 2 cos(2 pi k / n)
+        for (int m = 0; m < nd; m++) {
+          const int kf = (m + 1) / 2;
+          const bool alt = (nd % 2 == 0) && m == nd - 1;
+          for (int i = 0; i < nd; i++) {
+            double v;
+            if (m == 0) v = std::sqrt(1.0 / nd);
+            else if (alt) v = std::sqrt(1.0 / nd) * ((i & 1) ? -1.0 : 1.0);
+            else if (m & 1) v = std::sqrt(2.0 / nd) * std::cos(2.0 * M_PI * kf * i / nd);
+            else v = std::sqrt(2.0 / nd) * std::sin(2.0 * M_PI * kf * i / nd);
+            h.push_back(v);
+          }
+          lam[d].push_back(c_[d] * (2.0 - 2.0 * std::cos(2.0 * M_PI * kf / nd)));
+        }
+        off += (size_t)nd * nd;
+        specB_off_[d] = specC_off_[d];
+        continue;
+      }
       if (!(widths && widths[d])) {
         for (int m = 0; m < nd; m++)
           for (int i = 0; i < nd; i++)
@@ -372,6 +400,14 @@ void DiffusionSmoother::configure(const int n[3], const double dx[3], const doub
         S[(size_t)i * nd + i] += 1.0 / (w[i] * dist);
         S[(size_t)(i + 1) * nd + i + 1] += 1.0 / (w[i + 1] * dist);
         S[(size_t)i * nd + i + 1] = S[(size_t)(i + 1) * nd + i] = -1.0 / (std::sqrt(w[i] * w[i + 1]) * dist);
+      }
+      if (per_[d]) {   // cyclic pair: the last and the first cell are neighbours (nd = 2: the same pair twice)
+        const int a = nd - 1, b = 0;
+        const double dist = 0.5 * (w[a] + w[b]);
+        S[(size_t)a * nd + a] += 1.0 / (w[a] * dist);
+        S[(size_t)b * nd + b] += 1.0 / (w[b] * dist);
+        S[(size_t)a * nd + b] += -1.0 / (std::sqrt(w[a] * w[b]) * dist);
+        S[(size_t)b * nd + a] = S[(size_t)a * nd + b];
       }
       jacobi_eigen(nd, S, Q);
       for (int m = 0; m < nd; m++)          // forward [mode m][cell i] = Q[i][m] sqrt(h_i)
@@ -442,6 +478,7 @@ void DiffusionSmoother::smooth2(double* fa, int na, double* fb, int nb)
   for (int k = 0; k < 3; k++) {
     A.st.n[k] = n_[k];
     A.st.c[k] = c_[k];
+    A.st.per[k] = per_[k];
   }
   A.st.ncells = ncells_;
   A.a = {fa, na};
@@ -478,6 +515,7 @@ void DiffusionSmoother::solve_component(double* x, int stride)
   for (int k = 0; k < 3; k++) {
     st.n[k] = n_[k];
     st.c[k] = c_[k];
+    st.per[k] = per_[k];
   }
   st.ncells = ncells_;
   const dim3 grid(nblocks_);

@@ -602,6 +602,59 @@ def test_smooth_field_vs_oracle_and_conservation(ncomp):
     assert not np.array_equal(got, f)
 
 
+@pytest.mark.parametrize("solver", ["spectral", "chebyshev", "cg"])
+@pytest.mark.parametrize("graded", [False, True])
+def test_smooth_field_with_cyclic_patches(solver, graded, monkeypatch):
+    """smoothField on the diffusion mesh of the reference's channel cases (cyclic patch pairs along x and z, walls in
+    y: blockMeshDict of transport-bedload, `boundary pp ff pp`): every solver of the product (direct solve in the real
+    Fourier / eigen basis, Chebyshev, CG) against the oracle's CG on the wrapped stencil; uniform and graded in y."""
+    from sedifoam_amd import Lammps, enhancedCloud
+    if graded and solver != "spectral":
+        pytest.skip("graded blocks use the dense-transform solver only")
+    if solver == "chebyshev":
+        monkeypatch.setenv("SF_SMOOTH_SPECTRAL", "0")
+    if solver == "cg":
+        monkeypatch.setenv("SF_SMOOTH_CG", "1")
+    lmp = Lammps()
+    lmp.set_box([0, 0, 0], [1e-2, 1e-2, 1e-2])
+    lmp.create_atoms([[5e-3, 5e-3, 5e-3]], [1e-3], [2650.0])
+    lmp.commands("atom_style sphere\nboundary p f p\npair_style gran/hertzFix/history 1e7 NULL 0.5 NULL 0.4 1\n"
+                 "pair_coeff * *\nneighbor 1e-4 bin\ntimestep 1e-6\nfix 1 all nve/sphere\nfix 2 all fdrag")
+    mesh_n = np.array([12, 9, 8], np.int32); dx = np.array([5e-4, 6e-4, 1.1e-3])
+    faces = None
+    if graded:
+        faces = [None, _graded_faces(0.0, mesh_n[1] * dx[1], int(mesh_n[1]), 4.0), None]
+    band, steps, per = 3.0e-3, 4, np.array([1, 0, 1], np.int32)
+    cloud = enhancedCloud(lmp, np.zeros(3), dx, mesh_n,
+                          dict(dragModel="ErgunWenYu", subCycles=1, g=(0, 0, 0), diffusionBandWidth=band,
+                               diffusionSteps=steps), dict(rhob=1000.0, nub=1e-6), 1e-5, mesh_faces=faces,
+                          mesh_periodic=per)
+    rng = np.random.default_rng(6)
+    nc = int(mesh_n.prod())
+    f = rng.uniform(size=(nc, 3)) * (rng.uniform(size=(nc, 1)) < 0.1)
+    f[0] = 1.0                                  # a spike in the corner cell: it must spread across both cyclic faces
+    got = cloud.smoothField(f)
+    ref = np.ascontiguousarray(f).copy()
+    D = np.ones(3)
+    if graded:
+        w = [np.full(mesh_n[0], dx[0]), np.diff(faces[1]), np.full(mesh_n[2], dx[2])]
+        wp = (ob.dp * 3)(ob.P(w[0]), ob.P(w[1]), ob.P(w[2]))
+        ob.lib().orc_smooth_field_graded_periodic(ob.P(mesh_n), ob.P(dx), wp, ob.P(D), band, steps, 3,
+                                                  ob.P(ref.reshape(-1)), ob.P(per))
+        V = (w[0][:, None, None] * w[1][None, :, None] * w[2][None, None, :]).transpose(2, 1, 0).reshape(-1)
+    else:
+        ob.lib().orc_smooth_field_periodic(ob.P(mesh_n), ob.P(dx), ob.P(D), band, steps, 3, ob.P(ref.reshape(-1)),
+                                           ob.P(per))
+        V = np.ones(nc)
+    assert dc.rel_err(got, ref) <= 1e-10
+    assert np.sum(V[:, None] * got, axis=0) == pytest.approx(np.sum(V[:, None] * f, axis=0), rel=1e-11)
+    # the wrapped neighbours of the corner cell received what a zero-gradient block would have kept inside
+    noper = np.ascontiguousarray(f).copy()
+    if not graded:
+        ob.lib().orc_smooth_field(ob.P(mesh_n), ob.P(dx), ob.P(D), band, steps, 3, ob.P(noper.reshape(-1)))
+        assert dc.rel_err(got, noper) > 1e-3
+
+
 def test_xiaocase3_golden_through_hip_path():
     """cases/auto-testing/test-cases/xiaocase3 driven through the product path: in.lammps commands ->
     enhancedCloud.evolve() (SyamlalOBrien drag + fix fdrag + nve/sphere on the GPU), frozen uniform fluid."""

@@ -108,11 +108,11 @@ def test_script_errors_use_reference_wording():
             lmp.command(bad)
     lmp.command("neigh_modify delay 0 every 1 check yes one 40")
     lmp.command("group bottom type 2")
+    with pytest.raises(SfError, match="fix cohesive on a group"):
+        lmp.command("fix c bottom cohesive 1e-20 1e-7 1e-9 1e-4 1")
     lmp.command("fix 4 bottom freeze")
     with pytest.raises(SfError, match="after fix freeze"):
         lmp.command("fix 2 all gravity 9.8 vector 0 -1 0")
-    with pytest.raises(SfError, match="fix cohesive on a group"):
-        lmp.command("fix c bottom cohesive 1e-20 1e-7 1e-9 1e-4 1")
 
 
 def test_put_local_info_rejects_foreign_tag():

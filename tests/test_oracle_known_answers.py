@@ -216,6 +216,37 @@ def test_smooth_field_neumann_eigenmode():
     assert np.array_equal(g, f0)
 
 
+def test_smooth_field_cyclic_axis_eigenmodes():
+    """Cyclic patch pair along x (the reference's channel cases: blockMeshDict `cyclic`, `boundary pp ff pp`): the
+    operator is circulant there, cos(2 pi k i / n) AND sin(2 pi k i / n) are eigenvectors with eigenvalue
+    (2 - 2 cos(2 pi k / n)) D / dx^2; along the zero-gradient y axis the Neumann cosine still is.  A point source next
+    to the cyclic face spreads across it; with zero-gradient it does not."""
+    n = np.array([12, 6, 1], np.int32); dx = np.array([1e-3, 2e-3, 3e-3]); D = np.array([1.0, 0.5, 2.0])
+    per = np.array([1, 0, 0], np.int32)
+    band, steps, k, m = 4e-3, 3, 2, 1
+    ix = np.arange(n[0]); iy = np.arange(n[1])
+    fx = np.cos(2 * np.pi * k * ix / n[0]) + 0.5 * np.sin(2 * np.pi * k * ix / n[0])
+    fy = np.cos(np.pi * m * (iy + 0.5) / n[1])
+    f0 = (fy[:, None] * fx[None, :]).reshape(-1) + 0.25
+    f = f0.copy()
+    L = ob.lib()
+    L.orc_smooth_field_periodic(ob.P(n), ob.P(dx), ob.P(D), band, steps, 1, ob.P(f), ob.P(per))
+    dtau = band ** 2 / 4.0 / steps
+    lam = (2 - 2 * np.cos(2 * np.pi * k / n[0])) * D[0] / dx[0] ** 2 + (2 - 2 * np.cos(np.pi * m / n[1])) * D[1] / dx[1] ** 2
+    want = 0.25 + (f0 - 0.25) * (1.0 + dtau * lam) ** (-steps)
+    assert np.max(np.abs(f - want)) < 1e-13
+    src = np.zeros(int(n.prod())); src[0] = 1.0                       # cell (0, 0, 0), on the cyclic face
+    a = src.copy(); L.orc_smooth_field_periodic(ob.P(n), ob.P(dx), ob.P(D), band, steps, 1, ob.P(a), ob.P(per))
+    b = src.copy(); L.orc_smooth_field(ob.P(n), ob.P(dx), ob.P(D), band, steps, 1, ob.P(b))
+    assert a[n[0] - 1] == pytest.approx(a[1], rel=1e-12) and a[n[0] - 1] > 10 * b[n[0] - 1]
+    assert a.sum() == pytest.approx(1.0, rel=1e-12) and b.sum() == pytest.approx(1.0, rel=1e-12)
+    # graded solver with uniform widths and the cyclic pair: the same system
+    w = [np.full(n[q], dx[q]) for q in range(3)]
+    wp = (ob.dp * 3)(ob.P(w[0]), ob.P(w[1]), ob.P(w[2]))
+    c = src.copy(); L.orc_smooth_field_graded_periodic(ob.P(n), ob.P(dx), wp, ob.P(D), band, steps, 1, ob.P(c), ob.P(per))
+    assert np.max(np.abs(c - a)) < 1e-13
+
+
 @pytest.mark.parametrize("e", [0.3, 0.5, 0.9])
 def test_hertz_head_on_collision_restitution_equals_gamman(e):
     """Physics-level check of the hertzFix damping (pair_gran_hertzFix_history.cpp:192-200): with
