@@ -133,8 +133,8 @@ struct CloudFlagsDev {
 __global__ __launch_bounds__(256) void k_drag_on_particles(
     int n, size_t cap, const double4* xr, const double4* vm, const int* tag, MeshDev m, CloudFlagsDev fl,
     const double* gamma, const double* UfS, const double* gradp, const double* DDtUf, const double* curlU,
-    double* UOld_bytag, int maxtag, int first_call, int* cell_bytag, double* Jd_bytag, double* pDrag_bytag,
-    double* fdrag, int timeIndex, const double* UfSold, double* sumFb_bytag, double* n0_bytag)
+    double* pstate, int maxtag, int* cell_bytag, double* Jd_bytag, double* pDrag_bytag,
+    double* fdrag, int timeIndex, const double* UfSold)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -144,12 +144,14 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
   double F[3] = {0.0, 0.0, 0.0};
   double jd = 0.0;
   const double U[3] = {v.x, v.y, v.z};
-  double uold[3] = {v.x, v.y, v.z};
-  if (t >= 1 && t <= maxtag) {
-    if (!first_call)
-      for (int k = 0; k < 3; k++) uold[k] = UOld_bytag[(size_t)k * maxtag + (t - 1)];
-    for (int k = 0; k < 3; k++) UOld_bytag[(size_t)k * maxtag + (t - 1)] = U[k];  // setPositionVeloCpuId: UOld = U
-  }
+  // per-particle state that stays with its atom through re-sorts and migration (DemEngine::register_extra):
+  // rows 0-2 UOld (softParticle.H:95), 3-5 sumDeltaFb, 6 n0 (:104-107).  A particle the cloud has not seen yet holds
+  // NaN in UOld: its UOld is its U (softParticle.C:74, UOld_ = U_ at construction)
+  double* const st = pstate + i;
+  double uold[3] = {st[0], st[cap], st[2 * cap]};
+  if (uold[0] != uold[0])
+    for (int k = 0; k < 3; k++) uold[k] = U[k];
+  for (int k = 0; k < 3; k++) st[(size_t)k * cap] = U[k];   // setPositionVeloCpuId: UOld = U
   // pDuDt = DDtUf[c] (enhancedCloud.C:155) is handed to lammps_put_local_info, which drops it (library.cpp:314-367):
   // fix fdrag's DuDt array stays at the 0 it was created with (fix_fluid_drag.cpp:91), so the in-LAMMPS added-mass
   // term of `fix fdrag <carrier_rho>` sees DuDt = 0 on this path exactly as through sf_lammps_put_local_info
@@ -185,9 +187,9 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
       for (int k = 0; k < 3; k++)
         F[k] += 1.6 * fl.rhob * sqrt(fl.nub) * (d * d) * cr[k] / sqrt(magw + kRootVSmall);
     }
-    if (timeIndex >= 0 && t >= 1 && t <= maxtag) {
+    if (timeIndex >= 0) {
       // reduced-order history (Basset) force, Elghannay & Tafti 2016 -- enhancedCloud.C:197-233; per-particle state
-      // sumDeltaFb / n0 (softParticle.H:104-107) kept by tag
+      // sumDeltaFb / n0 (softParticle.H:104-107)
       const double tau_d = d * d / fl.nub;
       double m1 = 0.0, m2 = 0.0;
       for (int k = 0; k < 3; k++) {
@@ -199,11 +201,11 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
       const double a1 = 0.632 / (ReP + kRootVSmall) + 0.087, a2 = 0.632 / (RePOld + kRootVSmall) + 0.087;
       const double tau_h = tau_d * (a1 * a1), tau_h_old = tau_d * (a2 * a2);
       const double Cb = -1.5 * (d * d) * fl.rhob * pow(3.1416 * fl.nub, 0.5);
-      const double n0 = n0_bytag[t - 1];
+      const double n0 = st[6 * cap];
       const double tau_t = fl.deltaT * (timeIndex - n0);
       double sfb[3], dfb[3];
       for (int k = 0; k < 3; k++) {
-        sfb[k] = sumFb_bytag[(size_t)k * maxtag + (t - 1)];
+        sfb[k] = st[(size_t)(3 + k) * cap];
         dfb[k] = Cb * ((U[k] - uold[k]) / fl.deltaT) / sqrt(fl.deltaT);
       }
       double dnh;
@@ -217,11 +219,11 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
           sfb[k] = (dnh - 1) / dnh * sfb[k];
           sfb[k] = sfb[k] + dfb[k];
         }
-        n0_bytag[t - 1] = timeIndex - dnh;
+        st[6 * cap] = timeIndex - dnh;
       }
       const double g1 = dnh < 1 ? 0.9279 : 0.9279 * (2 * dnh - 1) / dnh * pow(dnh, -dnh / (2 * dnh - 1)) + 0.001531;
       for (int k = 0; k < 3; k++) {
-        sumFb_bytag[(size_t)k * maxtag + (t - 1)] = sfb[k];
+        st[(size_t)(3 + k) * cap] = sfb[k];
         F[k] += (g1 * sfb[k]) * fl.deltaT;
       }
     }
@@ -531,6 +533,13 @@ class Cloud {
     }
     mesh_.ncells = mesh.n[0] * mesh.n[1] * mesh.n[2];
     if (mesh_.ncells <= 0) fail("cloud mesh has no cells");
+    {
+      // UOld (NaN = "not seen yet": UOld = U, softParticle.C:74), sumDeltaFb, n0: they live in the engine so that
+      // they follow their atom through re-sorts and, on a decomposed domain, in the migrate record
+      const double nan = std::nan("");
+      const double init[7] = {nan, nan, nan, 0.0, 0.0, 0.0, 0.0};
+      xrow_ = lmp->eng.register_extra(7, init);
+    }
     if (mesh.cell_label) {
       label_.assign(mesh.cell_label, mesh.cell_label + mesh_.ncells);
       std::vector<char> seen(mesh_.ncells, 0);
@@ -601,7 +610,8 @@ class Cloud {
 
   ~Cloud()
   {
-    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, UOld_, pDragT_, UfS_, UfSold_, sumFb_, n0_})
+    if (xrow_ >= 0) lmp_->eng.unregister_extra(xrow_, 7);
+    for (double* p : {V_, gamma_, Ue_, Asrc_, Omega_, Uf_, DDtUf_, gradp_, curlU_, Jd_, pDragT_, UfS_, UfSold_})
       if (p) (void)hipFree(p);
     for (void* p : {(void*)cstart_, (void*)cell_, (void*)keys_, (void*)keys2_, (void*)idx_, (void*)idx2_, sort_tmp_,
                     (void*)faces_dev_[0], (void*)faces_dev_[1], (void*)faces_dev_[2]})
@@ -841,18 +851,7 @@ class Cloud {
     }
     const int mt = e.max_tag();
     if (mt > maxtag_) {
-      double* nu = nullptr;
       const int newmax = mt + mt / 4 + 16;
-      SF_HIP(hipMalloc(&nu, sizeof(double) * 3 * (size_t)newmax));
-      SF_HIP(hipMemsetAsync(nu, 0, sizeof(double) * 3 * (size_t)newmax, s_));
-      if (UOld_) {
-        for (int k = 0; k < 3; k++)
-          SF_HIP(hipMemcpyAsync(nu + (size_t)k * newmax, UOld_ + (size_t)k * maxtag_, sizeof(double) * maxtag_,
-                                hipMemcpyDeviceToDevice, s_));
-        SF_HIP(hipStreamSynchronize(s_));
-        SF_HIP(hipFree(UOld_));
-      }
-      UOld_ = nu;
       auto re2 = [&](void** p, size_t bytes) {
         if (*p) SF_HIP(hipFree(*p));
         SF_HIP(hipMalloc(p, bytes));
@@ -861,25 +860,6 @@ class Cloud {
       re2((void**)&Jd_, sizeof(double) * newmax);
       re2((void**)&cell_, sizeof(int) * newmax);
       re2((void**)&pDragT_, sizeof(double) * 3 * (size_t)newmax);
-      if (props_.particleHistoryForce) {
-        // history state by tag, kept across growth
-        double *ns = nullptr, *nn = nullptr;
-        SF_HIP(hipMalloc(&ns, sizeof(double) * 3 * (size_t)newmax));
-        SF_HIP(hipMalloc(&nn, sizeof(double) * (size_t)newmax));
-        SF_HIP(hipMemsetAsync(ns, 0, sizeof(double) * 3 * (size_t)newmax, s_));
-        SF_HIP(hipMemsetAsync(nn, 0, sizeof(double) * (size_t)newmax, s_));
-        if (sumFb_) {
-          for (int k = 0; k < 3; k++)
-            SF_HIP(hipMemcpyAsync(ns + (size_t)k * newmax, sumFb_ + (size_t)k * maxtag_, sizeof(double) * maxtag_,
-                                  hipMemcpyDeviceToDevice, s_));
-          SF_HIP(hipMemcpyAsync(nn, n0_, sizeof(double) * maxtag_, hipMemcpyDeviceToDevice, s_));
-          SF_HIP(hipStreamSynchronize(s_));
-          SF_HIP(hipFree(sumFb_));
-          SF_HIP(hipFree(n0_));
-        }
-        sumFb_ = ns;
-        n0_ = nn;
-      }
       maxtag_ = newmax;
     }
   }
@@ -908,12 +888,10 @@ class Cloud {
     if (!n) return;
     ensure_particle_arrays();
     k_drag_on_particles<<<div_up(n, 256), 256, 0, s_>>>(n, e.capacity(), e.d_xr(), e.d_vm(), e.d_tag(), mesh_,
-                                                        flags(), gamma_, UfS_, gradp_, DDtUf_, curlU_, UOld_,
-                                                        maxtag_, first_drag_ ? 1 : 0, cell_, Jd_, pDragT_,
-                                                        e.d_fdrag(),
-                                                        props_.particleHistoryForce ? time_index_ : -1, UfSold_,
-                                                        sumFb_, n0_);
-    first_drag_ = false;
+                                                        flags(), gamma_, UfS_, gradp_, DDtUf_, curlU_,
+                                                        e.d_extra() + (size_t)xrow_ * e.capacity(), maxtag_, cell_,
+                                                        Jd_, pDragT_, e.d_fdrag(),
+                                                        props_.particleHistoryForce ? time_index_ : -1, UfSold_);
   }
 
   void sort_by_cell(int n)
@@ -1008,8 +986,8 @@ public:
   double *V_ = nullptr, *gamma_ = nullptr, *Ue_ = nullptr, *Asrc_ = nullptr, *Omega_ = nullptr;
   double *Uf_ = nullptr, *DDtUf_ = nullptr, *gradp_ = nullptr, *curlU_ = nullptr, *UfS_ = nullptr;
   DiffusionSmoother smoother_;
-  double *Jd_ = nullptr, *UOld_ = nullptr, *pDragT_ = nullptr;   // by tag
-  double *sumFb_ = nullptr, *n0_ = nullptr;                      // history-force state by tag
+  double *Jd_ = nullptr, *pDragT_ = nullptr;   // diagnostics by tag
+  int xrow_ = -1;                              // first of the 7 per-atom rows this cloud keeps in the engine
   double* UfSold_ = nullptr;                                     // UfSmoothed_.oldTime()
   int time_index_ = 0;                                           // runTime().timeIndex()
   int *cstart_ = nullptr, *cell_ = nullptr, *idx_ = nullptr, *idx2_ = nullptr;
@@ -1017,7 +995,6 @@ public:
   void* sort_tmp_ = nullptr;
   size_t sort_tmp_bytes_ = 0, pcap_ = 0;
   int maxtag_ = 0;
-  bool first_drag_ = true;
   sf_cloud_timers t_{};
 };
 

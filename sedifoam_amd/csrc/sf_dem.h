@@ -293,6 +293,18 @@ class DemEngine {
   void migrate_set_slots(int mrec);
   void ghost_forward_local();
 
+  // Per-atom state of a client (the cloud's previous velocity and Basset-history sums: softParticle.H:95-107) that must
+  // stay with its atom: up to kMaxExtra rows of doubles that are permuted by every re-sort and travel in the migrate
+  // record, like a LAMMPS fix's per-atom arrays do through copy_arrays / pack_exchange.  init[r] is what a row holds
+  // for an atom that did not exist before (created later).  Returns the first row index.
+  static constexpr int kMaxExtra = 8;
+  int register_extra(int nrows, const double* init);
+  void unregister_extra(int first, int nrows)   // (the client registered last leaves first)
+  {
+    if (first + nrows == nextra_) nextra_ = first;
+  }
+  int nextra() const { return nextra_; }
+  double* d_extra() const { return extra_.as<double>(); }
   // device view for the cloud
   hipStream_t stream() const { return stream_; }
   // run on a caller-owned stream (e.g. torch's current stream, so RCCL traffic orders after the pack
@@ -405,6 +417,9 @@ private:
   DevArray xr_[2], vm_[2], om_[2], force_, torque_;
   DevArray tag_, type_, mask_, foamCpuId_;
   DevArray fdrag_, DuDt_, vOld_, xhold_;
+  DevArray extra_;                 // [kMaxExtra][cap] client rows (register_extra)
+  int nextra_ = 0;
+  double extra_init_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevArray wshear_, wtouch_;
   DevArray gsrc_, gshift_;
   DevArray neigh_, numneigh_, shear_[2];

@@ -104,7 +104,7 @@ DemEngine::DemEngine()
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
   per_atom_ = {&xr_[0], &xr_[1], &vm_[0], &vm_[1], &om_[0], &om_[1], &force_, &torque_, &tag_, &type_,
-               &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &wshear_, &wtouch_, &gsrc_, &gshift_,
+               &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &extra_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_[0], &shear_[1], &neigh_old_, &numneigh_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
                &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_};
@@ -164,6 +164,7 @@ void DemEngine::alloc_all(size_t cap)
   DuDt_.alloc(sizeof(double), 3, cap, s);
   vOld_.alloc(sizeof(double), 3, cap, s);
   xhold_.alloc(sizeof(double), 3, cap, s);
+  extra_.alloc(sizeof(double), kMaxExtra, cap, s);
   wshear_.alloc(sizeof(double), 3 * kMaxWalls, cap, s);
   wtouch_.alloc(sizeof(unsigned char), 1, cap, s);
   gsrc_.alloc(sizeof(int), 1, cap, s);
@@ -224,6 +225,26 @@ void DemEngine::grow_neigh(int newM)
   regrow(ptag_, 1);
   regrow(nloc_, 1);
   M_ = newM;
+}
+
+__global__ __launch_bounds__(256) static void k_fill_row(double* row, int n, double v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) row[i] = v;
+}
+
+int DemEngine::register_extra(int nrows, const double* init)
+{
+  if (nrows < 1 || nextra_ + nrows > kMaxExtra) fail("register_extra: %d rows requested, %d of %d in use", nrows, nextra_, kMaxExtra);
+  if (cap_ == 0) fail("register_extra: create the atoms first");
+  const int first = nextra_;
+  for (int r = 0; r < nrows; r++) {
+    extra_init_[first + r] = init ? init[r] : 0.0;
+    k_fill_row<<<div_up((long long)cap_, 256), 256, 0, stream_>>>(extra_.as<double>() + (size_t)(first + r) * cap_, (int)cap_,
+                                                                 extra_init_[first + r]);
+  }
+  nextra_ += nrows;
+  return first;
 }
 
 void DemEngine::set_max_neigh(int m)
@@ -864,6 +885,7 @@ void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
     gd(DuDt_, 3);
     gd(vOld_, 3);
   }
+  if (nextra_) gd(extra_, nextra_);
   if (nwalls_) {
     gd(wshear_, 3 * nwalls_);
     k_gather_rows<unsigned char><<<nb, 256, 0, stream_>>>((unsigned char*)tmpi_.ptr, wtouch_.as<unsigned char>(),

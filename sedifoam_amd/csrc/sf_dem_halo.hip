@@ -20,7 +20,7 @@ namespace sf {
 
 constexpr int kBorderDoubles = 14;   // x r | v m | omega | tag type mask
 constexpr int kForwardDoubles = 9;
-constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec
+constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec + nextra
 
 // key 0 = selected, 1 = not (a stable compaction then lists the selected atoms, ascending)
 // mode 0: x < bound ; mode 1: x >= bound
@@ -120,6 +120,8 @@ struct MigratePtrs {
   int *tag, *type, *mask, *foamCpuId, *numneigh, *ptag;
   double *fdrag, *DuDt, *vOld, *wshear, *shear;
   unsigned char* wtouch;
+  double* extra;   // client rows (DemEngine::register_extra), nextra of them
+  int nextra;
 };
 
 __global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, double xshift, MigratePtrs P, size_t cap,
@@ -151,6 +153,8 @@ __global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, do
     h[1 + 4 * s] = ok ? (double)P.ptag[(size_t)s * cap + i] : -1.0;
     for (int c = 0; c < 3; c++) h[2 + 4 * s + c] = ok ? P.shear[(size_t)(3 * s + c) * cap + i] : 0.0;
   }
+  double* ex = h + 1 + 4 * mrec;
+  for (int r = 0; r < P.nextra; r++) ex[r] = P.extra[(size_t)r * cap + i];
 }
 
 __global__ __launch_bounds__(128) void k_migrate_unpack(const double* buf, int n, int first, MigratePtrs P, size_t cap,
@@ -177,6 +181,8 @@ __global__ __launch_bounds__(128) void k_migrate_unpack(const double* buf, int n
     P.ptag[(size_t)s * cap + i] = (int)h[1 + 4 * s];
     for (int c = 0; c < 3; c++) P.shear[(size_t)(3 * s + c) * cap + i] = h[2 + 4 * s + c];
   }
+  const double* ex = h + 1 + 4 * mrec;
+  for (int r = 0; r < P.nextra; r++) P.extra[(size_t)r * cap + i] = ex[r];
 }
 
 __global__ __launch_bounds__(256) void k_stay_keys(const int* leave, int n, unsigned* keys, int* idx)
@@ -429,11 +435,12 @@ void DemEngine::migrate_set_slots(int mrec)
   max_neigh_used_ = std::max(max_neigh_used_, mrec_);
 }
 
-int DemEngine::migrate_record_doubles() const { return kMigrateFixed + 3 * nwalls_ + 4 * mrec_; }
+int DemEngine::migrate_record_doubles() const { return kMigrateFixed + 3 * nwalls_ + 4 * mrec_ + nextra_; }
 
 static MigratePtrs mig_ptrs(DevArray& xr, DevArray& vm, DevArray& om, DevArray& tag, DevArray& type, DevArray& mask,
                             DevArray& foam, DevArray& numneigh, DevArray& ptag, DevArray& fdrag, DevArray& DuDt,
-                            DevArray& vOld, DevArray& wshear, DevArray& shear, DevArray& wtouch)
+                            DevArray& vOld, DevArray& wshear, DevArray& shear, DevArray& wtouch, DevArray& extra,
+                            int nextra)
 {
   MigratePtrs P;
   P.xr = xr.as<double4>(); P.vm = vm.as<double4>(); P.om = om.as<double4>();
@@ -442,6 +449,8 @@ static MigratePtrs mig_ptrs(DevArray& xr, DevArray& vm, DevArray& om, DevArray& 
   P.fdrag = fdrag.as<double>(); P.DuDt = DuDt.as<double>(); P.vOld = vOld.as<double>();
   P.wshear = wshear.as<double>(); P.shear = shear.as<double>();
   P.wtouch = wtouch.as<unsigned char>();
+  P.extra = extra.as<double>();
+  P.nextra = nextra;
   return P;
 }
 
@@ -469,7 +478,7 @@ long long DemEngine::migrate_pack(int side, double xshift, double* buf, long lon
     fail("migrate_pack: %d atoms x %d doubles do not fit the %lld-double buffer", n, rec, max_doubles);
   if (n) {
     MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_,
-                             fdrag_, DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_);
+                             fdrag_, DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_, extra_, nextra_);
     k_migrate_pack<<<div_up(n, 128), 128, 0, stream_>>>(list.as<int>(), n, xshift, P, cap_, nwalls_, mrec_,
                                                         have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1);
   }
@@ -505,7 +514,7 @@ void DemEngine::migrate_unpack(const double* buf, long long ndoubles)
   if (!n) return;
   ensure_capacity((size_t)nlocal_ + n + 1024);
   MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_, fdrag_,
-                           DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_);
+                           DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_, extra_, nextra_);
   k_migrate_unpack<<<div_up(n, 128), 128, 0, stream_>>>(buf, n, nlocal_, P, cap_, nwalls_, mrec_, rec);
   nlocal_ += n;
   order_version_++;
@@ -569,6 +578,11 @@ void DemEngine::create_particles(int np, const double* pos, const double* tag, d
   }
   std::vector<unsigned char> zb(np, 0);
   up(wtouch_, zb.data(), np, nlocal_);
+  for (int r = 0; r < nextra_; r++) {   // client rows: the value registered for atoms that did not exist before
+    std::vector<double> iv(np, extra_init_[r]);
+    up(extra_, iv.data(), sizeof(double) * np, sizeof(double) * ((size_t)r * cap_ + nlocal_));
+    sync();
+  }
   sync();
   nlocal_ += np;
   order_version_++;

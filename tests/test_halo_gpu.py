@@ -257,6 +257,19 @@ def test_rccl_transport_self_images(tmp_path, overlap, transport):
         assert dc.rel_err(a[k], b[k]) <= 1e-11, k
 
 
+def _coupled_bed():
+    """the (8, 5, 5) bed shifted along x so that one plane of grains sits ON the face between the two slabs (within the
+    +-5 um jitter): grains rattling in the dense packing cross it back and forth, and with the small skin of
+    _COUPLED_SKIN the list is rebuilt (atoms migrate, with the cloud's per-particle state) every few sub-steps"""
+    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.3)
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    bed["x"][:, 0] = bed["boxlo"][0] + np.mod(bed["x"][:, 0] + 0.3462e-3 - bed["boxlo"][0], L)
+    return bed
+
+
+_COUPLED_SKIN = 0.012e-3
+
+
 def _coupled_setup(bed):
     mesh_n = np.maximum(((bed["boxhi"] - bed["boxlo"]) / 3.0e-3).astype(np.int32), 1)
     dx = (bed["boxhi"] - bed["boxlo"]) / mesh_n
@@ -266,8 +279,11 @@ def _coupled_setup(bed):
                  DDtUf=rng.normal(scale=0.5, size=(nc, 3)),
                  gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)) + rng.normal(scale=50.0, size=(nc, 3)),
                  curlU=rng.normal(scale=5.0, size=(nc, 3)))
+    # added mass + Basset history: both need the particle's PREVIOUS velocity / history sums, which must follow a
+    # particle that migrates to the other rank (they travel in the migrate record)
     cloudDict = dict(dragModel="ErgunWenYu", subCycles=2, g=(0.0, -9.81, 0.0), maxPossibleAlpha=0.65,
-                     particleLift=True, diffusionBandWidth=4.0e-3, diffusionSteps=2)
+                     particleLift=True, particleAddedMass=True, particleHistoryForce=True,
+                     diffusionBandWidth=4.0e-3, diffusionSteps=2)
     return mesh_n, dx, fluid, cloudDict, dict(rhob=1000.0, nub=1.0e-6)
 
 
@@ -283,18 +299,11 @@ def _coupled_worker(rank, world, port, outdir, ncfd):
     import tests.test_dem_gpu as T
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.3)
-    cfg = dict(T.BASE, skin=0.05e-3)
+    bed = _coupled_bed()
+    cfg = dict(T.BASE, skin=_COUPLED_SKIN)
     cfg["walls"] = T._walls(bed)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
-    w = (hi - lo) / world
-    mine = (bed["x"][:, 0] >= lo + rank * w) & ((bed["x"][:, 0] < lo + (rank + 1) * w) | (rank == world - 1))
-    lmp = Lammps()
-    lmp.set_box(bed["boxlo"], bed["boxhi"])
-    lmp.create_atoms(bed["x"][mine], bed["diameter"][mine], bed["density"][mine], v=bed["v"][mine],
-                     tag=(np.nonzero(mine)[0] + 1))
-    for line in dc.script_lines(bed, cfg):
-        lmp.command(line)
+    lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
     drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
     mesh_n, dx, fluid, cloudDict, transDict = _coupled_setup(bed)
     cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, driver=drv)
@@ -304,7 +313,7 @@ def _coupled_worker(rank, world, port, outdir, ncfd):
         cloud.evolve()
         cloud.calcTcFields()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), g0=g0, gamma=cloud.gamma(), Ue=cloud.Ue(), Asrc=cloud.Asrc(),
-             **lmp.get_state())
+             rebuilds=drv.n_rebuilds, tag0=(np.nonzero(dc.slab_mask(bed, rank, world))[0] + 1), **lmp.get_state())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -317,8 +326,8 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain():
     import torch.multiprocessing as mp
     from sedifoam_amd import enhancedCloud
     ncfd = 3
-    bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.3)
-    cfg = dict(T.BASE, skin=0.05e-3)
+    bed = _coupled_bed()
+    cfg = dict(T.BASE, skin=_COUPLED_SKIN)
     cfg["walls"] = T._walls(bed)
     ref = dc.make_hip(bed, cfg)
     mesh_n, dx, fluid, cloudDict, transDict = _coupled_setup(bed)
@@ -343,6 +352,8 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain():
     tag = np.concatenate([p["tag"] for p in parts])
     order = np.argsort(tag)
     assert len(np.unique(tag)) == bed["n"]
+    # particles really changed rank during the run (their previous velocity / history sums travelled with them)
+    assert any(set(p["tag"].tolist()) != set(p["tag0"].tolist()) for p in parts)
     L = bed["boxhi"][0] - bed["boxlo"][0]
     for k in ("x", "v", "omega"):
         got = np.concatenate([p[k] for p in parts])[order]
