@@ -66,6 +66,8 @@ enum Flag {
   F_VOTE0,
   F_VOTE1,
   F_MARGIN_FAIL,    // an atom moved more than half the list margin in one sub-step (overlap mode)
+  F_PART_SLOTS,     // would-be partner sides of the last list build ...
+  F_PART_COAL,      // ... and how many of them gather coalesced (k_partner_coalescing)
   F_NFLAGS = 16
 };
 
@@ -428,6 +430,10 @@ private:
   // address: migration, re-injection); the new list's history is built into the other buffer, which then becomes
   // shear_[cur_]
   int hist_buf_ = 0;
+  // one history copy per contact (true) or one per side (false): chosen per list build from the measured coalescing
+  // of the previous list (SF_HIST_COPIES=1 / 2 pins it)
+  bool hist_single_ = true;
+  int hist_mode_env_ = 0;
   DevArray nloc_;                      // [M][cap] uint16 (see DemPtrs::nloc)
   int* tile_tab_ = nullptr;            // [2][ntiles] tile_first / tile_last, then [ntiles+1] counts, starts
   size_t tile_alloc_ = 0;

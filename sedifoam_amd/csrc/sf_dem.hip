@@ -100,6 +100,7 @@ DemEngine::DemEngine()
   roots_ = !opt_lds_;
   if (const char* e = getenv("SF_ROOTS")) roots_ = atoi(e) != 0 && !opt_lds_;
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
+  if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -726,7 +727,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     // lanes per atom: small systems are latency bound (one lane walks all ~12 neighbours).  Measured: 10 k atoms
     // 17.3 -> 10.5 us per sub-step with 4 lanes, while at 100 k (1.5 waves per SIMD already) more lanes are slower
     static const int lpa_env = getenv("SF_LPA") ? atoi(getenv("SF_LPA")) : 0;
-    const int lpa = lpa_env ? lpa_env : (nwork < 20 * 1024 ? 4 : (nwork < 48 * 1024 ? 2 : 1));
+    const int lpa = lpa_env ? lpa_env : (nwork < 20 * 1024 ? 4 : (nwork < 150 * 1024 ? 2 : 1));
     const long long lanes = (long long)nwork * lpa;
     // one wave per workgroup: the dispatcher then balances single waves (a 256-thread workgroup holds its CU slots
     // until its slowest wave is done); measured 207.0 -> 203.2 us per sub-step at 1 M atoms, never slower below
@@ -1055,6 +1056,17 @@ void DemEngine::bin_and_build()
     have_list_ = true;
     return;
   }
+  // history copies of this list: from the coalescing the previous list measured (h_flags_ was refreshed by the
+  // synchronisation that led here), with hysteresis; the first list is built single-copy
+  if (hist_mode_env_ == 1) hist_single_ = true;
+  else if (hist_mode_env_ == 2 || !roots_) hist_single_ = false;
+  else if (have_list_ && h_flags_[F_PART_SLOTS] > 0) {
+    const double frac = (double)h_flags_[F_PART_COAL] / (double)h_flags_[F_PART_SLOTS];
+    if (hist_single_ && frac < 0.45) hist_single_ = false;
+    else if (!hist_single_ && frac > 0.60) hist_single_ = true;
+    static const bool dbg = getenv("SF_DEBUG_HIST") != nullptr;
+    if (dbg) fprintf(stderr, "[sedifoam_amd] partner-side coalescing %.3f -> %s history copy\n", frac, hist_single_ ? "one" : "two");
+  }
   int* cellLS = cell_start_;        // interleaved per cell: {owned start, owned end, ghost start, ghost end}
   int* cellLE = cell_start_ + 1;
   int* cellGS = cell_start_ + 2;
@@ -1096,6 +1108,7 @@ void DemEngine::bin_and_build()
     B.eoff = lds_active_ ? eoff_ : nullptr;
     B.nloc = nloc_.as<unsigned short>();
     B.old_index = hist_indirect_ ? hist_perm_.as<int>() : nullptr;
+    B.two_copies = hist_single_ ? 0 : 1;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
     B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;
     B.roots = roots_ ? 1 : 0;
@@ -1129,6 +1142,15 @@ void DemEngine::bin_and_build()
   // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
   k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_, cap_,
                                                           roots_ ? 1 : 0);
+  // how well would partner-side gathers coalesce on THIS list?  (read with the flags at the next synchronisation;
+  // decides the mode of the next build)
+  if (roots_) {
+    static_assert(F_PART_COAL == F_PART_SLOTS + 1, "adjacent counters");
+    reset_flag(F_PART_SLOTS, 0);
+    reset_flag(F_PART_COAL, 0);
+    k_partner_coalescing<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_,
+                                                                     cap_, d_flags_ + F_PART_SLOTS);
+  }
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
                                                            cap_);

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(128) void k_back_slots(int* neigh, const int* numne
     const int w = neigh[(size_t)s * cap + i];
     if (w & kOwnBit) continue;
     int t = -1;
-    if (roots) {
+    if (roots && s < 32) {   // (the per-atom masks of k_partner_coalesced cover 32 slots)
       const int r = w & kIdxMask;
       const int nr = numneigh[r];
       // owner-side words of r are never rewritten by this kernel (only partner-side ones are, and those point below r)
@@ -714,6 +714,42 @@ __global__ __launch_bounds__(128) void k_back_slots(int* neigh, const int* numne
       }
     }
     neigh[(size_t)s * cap + i] = t < 0 ? (w | kOwnBit) : ((w & ~codemask) | (t << kIdxBits));
+  }
+}
+
+// One history copy per contact pays off when the partner side's gather of the owner's row is coalesced: when the
+// lane next to it (atom i - 1 or i + 1) reads, in the same slot, the row of the NEXT owner (r - 1 / r + 1) -- the rule
+// in an ordered bed, the exception in a disordered one, where three scattered 8-byte gathers per contact cost more
+// requests than the second copy saves (measured, 1 M grains, us per sub-step, two copies / one copy: lattice 214 / 204,
+// jitter 0.15 bed 246 / 219, jitter 0.3 loose bed 249 / 272).  This kernel measures that on the finished list: of the
+// slots that point at a LOWER-indexed atom of this GPU itself (the would-be partner sides, whichever mode the list
+// was built in), how many have such a lane neighbour.  The engine picks the mode of the NEXT list build from the
+// ratio (with hysteresis): the answer depends on the particles only, so runs stay reproducible.
+__global__ __launch_bounds__(1024) void k_partner_coalescing(const int* neigh, const int* numneigh, int nlocal,
+                                                            size_t cap, int* counters)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = 0, coal = 0;
+  if (i < nlocal) {
+    const int nn = numneigh[i];
+    const int codemask = 31 << kIdxBits;
+    for (int s = 0; s < nn; s++) {
+      const int w = neigh[(size_t)s * cap + i];
+      const int r = w & kIdxMask;
+      const bool partner_side = !(w & kOwnBit) || (r < i && (w & codemask) == (kNoShift << kIdxBits));
+      if (!partner_side || r >= nlocal) continue;
+      total++;
+      bool ok = false;
+      if (i + 1 < nlocal && s < numneigh[i + 1]) ok = (neigh[(size_t)s * cap + i + 1] & kIdxMask) == r + 1;
+      if (!ok && i > 0 && s < numneigh[i - 1]) ok = (neigh[(size_t)s * cap + i - 1] & kIdxMask) == r - 1;
+      coal += ok ? 1 : 0;
+    }
+  }
+  const int t = block_sum_int_1024(total);
+  const int c = block_sum_int_1024(coal);
+  if (threadIdx.x == 0 && t) {
+    atomicAdd(&counters[0], t);
+    atomicAdd(&counters[1], c);
   }
 }
 
@@ -968,6 +1004,7 @@ struct BuildParams {
   const int* lb_own;
   const int* lb_ghost;
   const int* old_index;   // new index -> index before the re-sort (history rows not permuted), or nullptr
+  int two_copies;         // every side of every contact keeps its own history copy (see k_partner_coalescing)
 };
 
 // ---- counting sort of the owned atoms by cell key (plain keys): a by-product is first[b], the first sorted position
@@ -1054,7 +1091,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       int entry = j;
       // history owner of the pair: the lower index of two atoms of this GPU; pairs with a periodic image or with a
       // ghost of another GPU keep a copy on each side (the reference's newton-off treatment of owned-ghost pairs)
-      bool own = j > i;
+      bool own = j > i || B.two_copies;
       if (B.roots) {
         int code = kNoShift;
         if (j >= B.nlocal) {
@@ -1408,7 +1445,20 @@ __global__ __launch_bounds__(256) void k_collect_history(const int* neigh, const
     if (!(jraw & kTouchBit) || !(jraw & kOwnBit)) continue;
     const int j = neigh_index(jraw, roots);
     const int tagj = tag[j];
-    const bool single = j < nlocal && (!roots || ((jraw >> kIdxBits) & 31) == kNoShift);
+    // is this the pair's only copy?  Only if the other side is an atom of this GPU itself (no image) whose word for
+    // this atom is a partner-side one; otherwise both sides hold a copy (images, ghosts of another GPU, lists built
+    // with two copies per contact) and the lower tag's is the one reported
+    bool single = false;
+    if (roots && j < nlocal && ((jraw >> kIdxBits) & 31) == kNoShift) {
+      const int nj = numneigh[j];
+      for (int u = 0; u < nj; u++) {
+        const int wu = neigh[(size_t)u * cap + j];
+        if (!(wu & kOwnBit) && (wu & kIdxMask) == i) {
+          single = true;
+          break;
+        }
+      }
+    }
     if (!single && tagi >= tagj) continue;   // the other side's own copy is the one reported
     const bool flip = tagi > tagj;
     const long long k = (long long)atomicAdd(cursor, 1ull);
