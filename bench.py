@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+PMC_SUMMARY = "r02_b_pmc_summary.json"   # the committed PMC passes of the current kernel (tests/profile_round.sh)
 
 
 def build_engine(bed, script):
@@ -130,6 +131,8 @@ def main():
     ap.add_argument("--spacing", type=float, default=None, help="sensitivity runs: lattice spacing / d (default 0.98)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coupled", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true",
+                    help="do not sample per-launch HIP events in the timed region (the roofline leg is then empty)")
     ap.add_argument("--slab-driver", action="store_true",
                     help="drive the sub-steps through the multi-rank SlabDriver even at N=1 (self halo)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle sample size (particles), 0 = auto")
@@ -199,7 +202,7 @@ def main():
         info0 = lmp.info()
         for _ in range(args.warmup):
             lmp.step(args.substeps)
-        lmp.set_profiling(True)
+        lmp.set_profiling(not args.no_kernel_profile)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -286,12 +289,17 @@ def main():
         },
     }
     # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes
-    # (FETCH_SIZE + WRITE_SIZE, separate passes; see profiles/r01_g_pmc_summary.json for the calibration note)
-    pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json")
-    if os.path.exists(pmc) and args.particles == 1000000:
+    # (separate passes; the summary file holds the calibration of FETCH_SIZE on known byte counts)
+    pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if os.path.exists(pmc) and args.particles == 1000000 and not bed_kw:
         try:
-            out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]["total_raw"]
-            out["roofline"]["traffic_source"] = "profiles/r01_g_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+            hb = json.load(open(pmc))["hbm_bytes_per_launch"]
+            out["roofline"]["traffic"] = hb["total_calibrated"]
+            out["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc bytes per launch of this kernel on this "
+                                                 "workload, WRITE_SIZE + calibrated reads (FETCH_SIZE counts every "
+                                                 "coalesced stream at 1/2: calibrated on tests/micro/stream_bench)"
+                                                 % PMC_SUMMARY)
+            out["roofline"]["traffic_raw_counters"] = hb["total_raw"]
         except Exception:
             pass
     # secondary metric of BASELINE.json: coupled CFD-DEM steps/s (drag closure + drag assembly + S sub-steps +

@@ -35,12 +35,32 @@ if durs:
     out["kernel_trace"] = {"launches": len(durs), "executed": len(ex), "avg_us_all": sum(durs) / len(durs),
                            "avg_us_executed": sum(ex) / len(ex)}
 rd, wr = m("FETCH_SIZE") * 1024.0, m("WRITE_SIZE") * 1024.0
+# Calibration on known byte counts (tests/calibrate_traffic.sh -> gpurun_out/cal_<tag>.json, the read / read+write row
+# streams of tests/micro/stream_bench.hip): FETCH_SIZE reports 0.500 of the bytes of EVERY coalesced stream (8, 16 and
+# 32 bytes per lane alike: 128-byte fabric requests tallied at 64), WRITE_SIZE 1.000; scattered 32-byte gathers are
+# counted ~1:1 (r01_c).  k_substep mixes the two kinds of read, so the calibrated read traffic is taken from the L2
+# instead: every 64-byte line the TCC misses is fetched once (TCC_MISS_sum x 64 B); it lies between read_raw and
+# 2 x read_raw as the FETCH_SIZE calibration demands.
+cal = {}
+try:
+    rows = json.load(open(f"gpurun_out/cal_{tag}.json"))
+    st = [r for r in rows if not r["write"]]
+    cal = {"fetch_reported_over_true_streams": sum(r["fetch_reported_over_true"] for r in st) / len(st),
+           "write_reported_over_true": sum(r["write_reported_over_true"] for r in rows if r["write"] and r["load_bytes_per_lane"] < 32)
+                                       / max(1, len([r for r in rows if r["write"] and r["load_bytes_per_lane"] < 32])),
+           "cases": rows}
+except (OSError, KeyError, ZeroDivisionError):
+    pass
+rd_cal = m("TCC_MISS_sum") * 64.0
 out["hbm_bytes_per_launch"] = {
     "read_raw": rd, "write": wr, "total_raw": rd + wr,
-    "note": "FETCH_SIZE/WRITE_SIZE are KiB (separate --pmc passes). Calibration (r01_c): gathers are counted x1.02, "
-            "coalesced double4 streams x0.50 (the under-count MI355X_MICROARCH.md describes), writes within 1 %. "
-            "k_substep mixes both kinds of load: the true read traffic lies between read_raw and 2 x read_raw; "
-            "bench.py reports the raw sum as `traffic`."}
+    "read_calibrated": rd_cal, "total_calibrated": rd_cal + wr,
+    "algorithmic": 594.35 * N,
+    "calibration": cal,
+    "note": "FETCH_SIZE/WRITE_SIZE are KiB (separate --pmc passes). FETCH_SIZE under-counts every coalesced stream by "
+            "exactly 2 (calibration above), scattered gathers not: read_calibrated = TCC_MISS_sum x 64 B (each missed "
+            "line fetched once), read_raw <= read_calibrated <= 2 read_raw. bench.py reports total_calibrated as "
+            "`traffic`."}
 out["l2_hit_rate"] = m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum"))
 wc = m("SQ_WAVE_CYCLES")
 out["wave_cycle_split"] = {"waiting_any": m("SQ_WAIT_ANY") / wc, "issue_stall": m("SQ_WAIT_INST_ANY") / wc,
