@@ -36,11 +36,11 @@ if durs:
                            "avg_us_executed": sum(ex) / len(ex)}
 rd, wr = m("FETCH_SIZE") * 1024.0, m("WRITE_SIZE") * 1024.0
 # Calibration on known byte counts (tests/calibrate_traffic.sh -> gpurun_out/cal_<tag>.json, the read / read+write row
-# streams of tests/micro/stream_bench.hip): FETCH_SIZE reports 0.500 of the bytes of EVERY coalesced stream (8, 16 and
-# 32 bytes per lane alike: 128-byte fabric requests tallied at 64), WRITE_SIZE 1.000; scattered 32-byte gathers are
-# counted ~1:1 (r01_c).  k_substep mixes the two kinds of read, so the calibrated read traffic is taken from the L2
-# instead: every 64-byte line the TCC misses is fetched once (TCC_MISS_sum x 64 B); it lies between read_raw and
-# 2 x read_raw as the FETCH_SIZE calibration demands.
+# streams of tests/micro/stream_bench.hip): FETCH_SIZE reports 0.500 of the bytes read, for 8, 16 and 32 bytes per lane
+# alike (128-byte fabric requests tallied at 64), WRITE_SIZE 1.000, and TCC_MISS_sum counts 128-byte lines for reads
+# AND writes (TCC_MISS_sum x 128 B = bytes read + written).  For k_substep the two agree: 2 x FETCH_SIZE + WRITE_SIZE =
+# TCC_MISS_sum x 128 B within 1 % -- so the gathers' misses are 128-byte fetches tallied at 64 as well, and
+#   read_calibrated = 2 x FETCH_SIZE.
 cal = {}
 try:
     rows = json.load(open(f"gpurun_out/cal_{tag}.json"))
@@ -51,16 +51,17 @@ try:
            "cases": rows}
 except (OSError, KeyError, ZeroDivisionError):
     pass
-rd_cal = m("TCC_MISS_sum") * 64.0
+rd_cal = 2.0 * rd
 out["hbm_bytes_per_launch"] = {
     "read_raw": rd, "write": wr, "total_raw": rd + wr,
     "read_calibrated": rd_cal, "total_calibrated": rd_cal + wr,
+    "tcc_miss_x_128B": m("TCC_MISS_sum") * 128.0,
     "algorithmic": 594.35 * N,
     "calibration": cal,
-    "note": "FETCH_SIZE/WRITE_SIZE are KiB (separate --pmc passes). FETCH_SIZE under-counts every coalesced stream by "
-            "exactly 2 (calibration above), scattered gathers not: read_calibrated = TCC_MISS_sum x 64 B (each missed "
-            "line fetched once), read_raw <= read_calibrated <= 2 read_raw. bench.py reports total_calibrated as "
-            "`traffic`."}
+    "note": "FETCH_SIZE/WRITE_SIZE are KiB (separate --pmc passes). On known byte counts FETCH_SIZE reports exactly 1/2 "
+            "of the bytes read (every load width), WRITE_SIZE all of the bytes written, TCC_MISS_sum 128-byte lines "
+            "read + written: read_calibrated = 2 x read_raw, cross-checked by tcc_miss_x_128B ~ total_calibrated. "
+            "bench.py reports total_calibrated as `traffic`."}
 out["l2_hit_rate"] = m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum"))
 wc = m("SQ_WAVE_CYCLES")
 out["wave_cycle_split"] = {"waiting_any": m("SQ_WAIT_ANY") / wc, "issue_stall": m("SQ_WAIT_INST_ANY") / wc,
