@@ -157,7 +157,8 @@ def test_rebuild_with_history_carry_over():
 
 
 def test_mid_size_100k_bed_with_rebuilds():
-    """BASELINE config C2's size (100 k grains): the launch shapes of the large-N path (256-thread blocks, XCD remap,
+    """BASELINE config C3's size (100 k grains), the DEM leg; the coupled step at this size is
+    tests/test_cloud_gpu.py::test_config_c3_100k_coupled_50_substeps.  The launch shapes of the large-N path (XCD remap,
     several rebuilds with history carry-over) against the oracle, which still finishes in seconds here."""
     bed = _bed((29, 29, 30), periodic=True, seed=23, vmax=0.5)
     assert bed["n"] >= 100000
@@ -236,7 +237,7 @@ def test_polydisperse_cohesive_lubricate():
 
 
 def test_mid_size_polydisperse_cohesive_lubricate_32k():
-    """BASELINE config C4's physics (polydisperse grains, fix cohesive + pair lubricate/poly overlay) at 32 k grains,
+    """BASELINE config C5's physics (polydisperse grains, fix cohesive + pair lubricate/poly overlay) at 32 k grains,
     through a rebuild"""
     bed = _bed((20, 20, 20), periodic=True, seed=13, poly=(0.85e-3, 1.0e-3), spacing=0.95, vmax=0.5)
     cfg = dict(BASE, skin=0.06e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
