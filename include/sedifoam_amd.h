@@ -134,13 +134,13 @@ int sf_dem_substep(void *ptr, int last);    /* fused force + final [+ next initi
 int sf_dem_need_rebuild(void *ptr);         /* 1 if any owned atom moved > skin/2 (synchronises) */
 /* Batch mode (no host synchronisation per sub-step).  The engine keeps an int32 "trigger" word on the device:
  * the smallest sub-step index whose new positions left the skin/2 sphere (INT_MAX: none); a sub-step whose
- * index is larger than the trigger exits immediately.  sf_dem_set_flag_buffer places the 16-int flag block
+ * index is larger than the trigger exits immediately.  sf_dem_set_flag_buffer places the 32-int flag block
  * (trigger = word 0) in caller-owned device memory so the driver can all-reduce(MIN) it over the ranks with RCCL
  * on the same stream between two sub-steps; sf_dem_batch_end synchronises once, returns the trigger and repairs
  * the ping-pong parity for the sub-steps that exited early. */
 int sf_dem_substep_k(void *ptr, int last, int kstep);
 int sf_dem_batch_end(void *ptr, int first_k, int launched, int *trigger);
-int sf_dem_set_flag_buffer(void *ptr, void *dev_ints16);
+int sf_dem_set_flag_buffer(void *ptr, void *dev_ints32);
 int sf_dem_setup(void *ptr);                /* first run's setup: forces with shearupdate = 0 */
 int sf_dem_rebuild_begin(void *ptr);        /* shear history -> partner tags; forget ghosts */
 int sf_dem_rebuild_sort(void *ptr);         /* pbc + sort owned atoms by bin (after migration) */

@@ -68,7 +68,9 @@ enum Flag {
   F_MARGIN_FAIL,    // an atom moved more than half the list margin in one sub-step (overlap mode)
   F_PART_SLOTS,     // would-be partner sides of the last list build ...
   F_PART_COAL,      // ... and how many of them gather coalesced (k_partner_coalescing)
-  F_NFLAGS = 16
+  F_LIST_SLOTS,     // listed neighbours of the owned atoms (same kernel) ...
+  F_LIST_TOUCH,     // ... and how many of them touch
+  F_NFLAGS = 32
 };
 
 struct WallParams {
@@ -434,6 +436,12 @@ private:
   // of the previous list (SF_HIST_COPIES=1 / 2 pins it)
   bool hist_single_ = true;
   int hist_mode_env_ = 0;
+  // v / omega of a neighbour prefetched by touch bit (true) or always (false): template parameter TP of k_substep,
+  // from the measured fraction of listed neighbours that touch (SF_TOUCH_PREFETCH=0 / 1 pins it)
+  bool touch_prefetch_ = true;
+  int touch_prefetch_env_ = -1;
+  void measure_list();     // queue k_partner_coalescing on the current list (results with the next flag read)
+  void choose_kernel();    // pick touch_prefetch_ from the last measurement
   DevArray nloc_;                      // [M][cap] uint16 (see DemPtrs::nloc)
   int* tile_tab_ = nullptr;            // [2][ntiles] tile_first / tile_last, then [ntiles+1] counts, starts
   size_t tile_alloc_ = 0;

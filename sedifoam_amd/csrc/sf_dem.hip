@@ -101,6 +101,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_ROOTS")) roots_ = atoi(e) != 0 && !opt_lds_;
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
+  if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -621,23 +622,27 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   return S;
 }
 
-template <int STYLE, int LPA>
+template <int STYLE, int LPA, bool TP>
 static void launch_substep_lpa(bool cohe, bool lub, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
                                const StepParams& S)
 {
-  if (cohe && lub) k_substep<STYLE, true, true, LPA><<<grid, block, 0, s>>>(P, S);
-  else if (cohe) k_substep<STYLE, true, false, LPA><<<grid, block, 0, s>>>(P, S);
-  else if (lub) k_substep<STYLE, false, true, LPA><<<grid, block, 0, s>>>(P, S);
-  else k_substep<STYLE, false, false, LPA><<<grid, block, 0, s>>>(P, S);
+  if (cohe && lub) k_substep<STYLE, true, true, LPA, TP><<<grid, block, 0, s>>>(P, S);
+  else if (cohe) k_substep<STYLE, true, false, LPA, TP><<<grid, block, 0, s>>>(P, S);
+  else if (lub) k_substep<STYLE, false, true, LPA, true><<<grid, block, 0, s>>>(P, S);   // (lubrication needs v, omega
+  else k_substep<STYLE, false, false, LPA, TP><<<grid, block, 0, s>>>(P, S);            //  of every neighbour anyway)
 }
 
 template <int STYLE>
-static void launch_substep_style(bool cohe, bool lub, int lpa, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
-                                 const StepParams& S)
+static void launch_substep_style(bool cohe, bool lub, int lpa, bool tp, dim3 grid, int block, hipStream_t s,
+                                 const DemPtrs& P, const StepParams& S)
 {
-  if (lpa == 4) launch_substep_lpa<STYLE, 4>(cohe, lub, grid, block, s, P, S);
-  else if (lpa == 2) launch_substep_lpa<STYLE, 2>(cohe, lub, grid, block, s, P, S);
-  else launch_substep_lpa<STYLE, 1>(cohe, lub, grid, block, s, P, S);
+  if (lub) tp = true;   // one instantiation
+  if (lpa == 4) tp ? launch_substep_lpa<STYLE, 4, true>(cohe, lub, grid, block, s, P, S)
+                   : launch_substep_lpa<STYLE, 4, false>(cohe, lub, grid, block, s, P, S);
+  else if (lpa == 2) tp ? launch_substep_lpa<STYLE, 2, true>(cohe, lub, grid, block, s, P, S)
+                        : launch_substep_lpa<STYLE, 2, false>(cohe, lub, grid, block, s, P, S);
+  else tp ? launch_substep_lpa<STYLE, 1, true>(cohe, lub, grid, block, s, P, S)
+          : launch_substep_lpa<STYLE, 1, false>(cohe, lub, grid, block, s, P, S);
 }
 
 template <int STYLE, bool COHE, bool LUB>
@@ -734,9 +739,9 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     const int block = block_env ? block_env : 64;
     const dim3 grid((unsigned)((lanes + block - 1) / block));
     switch (gran_.style) {
-      case 2: launch_substep_style<2>(cohe, lub, lpa, grid, block, stream_, P, S); break;
-      case 1: launch_substep_style<1>(cohe, lub, lpa, grid, block, stream_, P, S); break;
-      default: launch_substep_style<0>(cohe, lub, lpa, grid, block, stream_, P, S); break;
+      case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, grid, block, stream_, P, S); break;
+      case 1: launch_substep_style<1>(cohe, lub, lpa, touch_prefetch_, grid, block, stream_, P, S); break;
+      default: launch_substep_style<0>(cohe, lub, lpa, touch_prefetch_, grid, block, stream_, P, S); break;
     }
   }
   SF_HIP(hipGetLastError());
@@ -1142,20 +1147,42 @@ void DemEngine::bin_and_build()
   // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
   k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_, cap_,
                                                           roots_ ? 1 : 0);
-  // how well would partner-side gathers coalesce on THIS list?  (read with the flags at the next synchronisation;
-  // decides the mode of the next build)
-  if (roots_) {
-    static_assert(F_PART_COAL == F_PART_SLOTS + 1, "adjacent counters");
-    reset_flag(F_PART_SLOTS, 0);
-    reset_flag(F_PART_COAL, 0);
-    k_partner_coalescing<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_,
-                                                                     cap_, d_flags_ + F_PART_SLOTS);
-  }
+  measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
                                                            cap_);
   have_list_ = true;
   nbuilds_++;
+}
+
+// List statistics that pick the kernel variant and the history layout (read back with the flags at the next
+// synchronisation): coalescing of the would-be partner-side gathers, listed and touching neighbours.
+void DemEngine::measure_list()
+{
+  if (!nlocal_ || !roots_) return;
+  static_assert(F_PART_COAL == F_PART_SLOTS + 1 && F_LIST_SLOTS == F_PART_SLOTS + 2 && F_LIST_TOUCH == F_PART_SLOTS + 3,
+                "adjacent counters");
+  for (int k = 0; k < 4; k++) reset_flag(F_PART_SLOTS + k, 0);
+  k_partner_coalescing<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_,
+                                                                   cap_, d_flags_ + F_PART_SLOTS);
+}
+
+void DemEngine::choose_kernel()
+{
+  if (touch_prefetch_env_ >= 0) {
+    touch_prefetch_ = touch_prefetch_env_ != 0;
+    return;
+  }
+  if (h_flags_[F_LIST_SLOTS] <= 0) return;
+  const double frac = (double)h_flags_[F_LIST_TOUCH] / (double)h_flags_[F_LIST_SLOTS];
+  // hysteresis: prefetch by touch bit below 0.70, always above 0.85
+  const bool before = touch_prefetch_;
+  if (touch_prefetch_ && frac > 0.85) touch_prefetch_ = false;
+  else if (!touch_prefetch_ && frac < 0.70) touch_prefetch_ = true;
+  static const bool dbg = getenv("SF_DEBUG_HIST") != nullptr;
+  if (dbg && before != touch_prefetch_)
+    fprintf(stderr, "[sedifoam_amd] %.3f of the listed neighbours touch -> v, omega %s\n", frac,
+            touch_prefetch_ ? "prefetched by touch bit" : "always prefetched");
 }
 
 void DemEngine::rebuild_finish()
@@ -1226,13 +1253,16 @@ void DemEngine::setup()
   launch_substep(cur_, 2, 0);
   launch_ghost_forward(cur_ ^ 1, 0);
   cur_ ^= 1;
-  sync();
+  measure_list();   // (the setup evaluation has set the touch bits of the first list)
+  read_flags();
+  choose_kernel();
   setup_done_ = true;
 }
 
 void DemEngine::run_begin()
 {
   run_base_step_ = nsteps_;
+  choose_kernel();
   if (overlap_) overlap_begin();
   reset_flag(F_TRIGGER, INT_MAX);
   launch_initial_integrate();
@@ -1402,6 +1432,7 @@ void DemEngine::run(int nsteps)
   if (nsteps <= 0) return;
   if (have_subdomain_) fail("sf_lammps_step on a decomposed domain: drive the sub-steps through sf_dem_*");
   run_base_step_ = nsteps_;
+  choose_kernel();
   reset_flag(F_TRIGGER, INT_MAX);
   launch_initial_integrate();
   launch_ghost_forward(cur_, 0);

@@ -28,11 +28,12 @@
 #define SF_ST_SHUFFLE 1       // output records exchanged between lanes so that every store covers whole cache lines
 #endif
 #ifndef SF_GATHER_SHUFFLE
-#define SF_GATHER_SHUFFLE 1   // neighbour records taken from the next lane's registers when it holds them
+#define SF_GATHER_SHUFFLE 0   // neighbour records taken from the next lane's registers when it holds them: -20 % L2 read
+                              // requests, +50 shuffle / select instructions per slot -- a gain while the kernel ran four
+                              // waves per SIMD (round 1), a loss of 1-3 % since it is as much issue- as memory-bound
 #endif
-#ifndef SF_TOUCH_PREFETCH
-#define SF_TOUCH_PREFETCH 1   // v, omega of a neighbour are prefetched only when the pair touched in the last sub-step
-#endif
+// (whether v, omega of a neighbour are prefetched always or only when the pair touched one sub-step ago is the template
+// parameter TP of k_substep, chosen per list from the fraction of listed neighbours that touch)
 #ifndef SF_HIST_NT_OWN
 #define SF_HIST_NT_OWN 1      // owner-side history loads non-temporal
 #endif
@@ -107,7 +108,7 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // LPA lanes per atom (1, 2 or 4): lane q of an atom's group handles the slots q, q + LPA, ...; the partial force and
 // torque sums are combined with a fixed shuffle tree and lane 0 integrates.  Small systems (< ~3 waves per SIMD at
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
-template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA>
+template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP>
 __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw)
 {
@@ -152,7 +153,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // always touched one sub-step ago (its touch bit): for the others only x is gathered, and the rare new contact loads
   // v and omega on demand.  A settled bed lists about twice as many neighbours as it has contacts.
   auto wants_vw = [&](const int jraw) {
-    return NEED_VW && (LUB || !SF_TOUCH_PREFETCH || (jraw & kTouchBit) != 0);
+    return NEED_VW && (LUB || !TP || (jraw & kTouchBit) != 0);
   };
   // request the records of the neighbour in `slot` (global gather), or its LDS position
   auto fetch = [&](int jraw, size_t slot, Rec& R) {
@@ -498,7 +499,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 #else
 #define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu((COHE || LUB) ? 1 : 3)))
 #endif
-template <int STYLE, bool COHE, bool LUB, int LPA>
+// TP: v and omega of a neighbour are requested with its x only when the pair touched one sub-step ago (a bed that
+// lists many more neighbours than it touches: -11 % in the loose disordered bed), or always (a bed whose listed
+// neighbours nearly all touch: the bookkeeping of the former costs 4 % there)
+template <int STYLE, bool COHE, bool LUB, int LPA, bool TP>
 __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   } else if (i >= S.nlocal) {
     return;
   }
-  substep_particle<STYLE, COHE, LUB, false, LPA>(P, S, i, q, nullptr, nullptr, nullptr);
+  substep_particle<STYLE, COHE, LUB, false, LPA, TP>(P, S, i, q, nullptr, nullptr, nullptr);
 }
 
 // LDS-staged cell bins: one workgroup per tile of T x T x T bins.  The x/v/omega records of every atom in
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
   }
   __syncthreads();
   for (int i = first + threadIdx.x; i < last; i += blockDim.x)
-    substep_particle<STYLE, COHE, LUB, true, 1>(P, S, i, 0, lx, lv, lw);
+    substep_particle<STYLE, COHE, LUB, true, 1, true>(P, S, i, 0, lx, lv, lw);
 }
 
 // first half-kick of a run with the forces stored by the previous run's last sub-step
@@ -729,12 +733,14 @@ __global__ __launch_bounds__(1024) void k_partner_coalescing(const int* neigh, c
                                                             size_t cap, int* counters)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int total = 0, coal = 0;
+  int total = 0, coal = 0, listed = 0, touching = 0;
   if (i < nlocal) {
     const int nn = numneigh[i];
     const int codemask = 31 << kIdxBits;
+    listed = nn;
     for (int s = 0; s < nn; s++) {
       const int w = neigh[(size_t)s * cap + i];
+      touching += (w & kTouchBit) ? 1 : 0;
       const int r = w & kIdxMask;
       const bool partner_side = !(w & kOwnBit) || (r < i && (w & codemask) == (kNoShift << kIdxBits));
       if (!partner_side || r >= nlocal) continue;
@@ -747,9 +753,13 @@ __global__ __launch_bounds__(1024) void k_partner_coalescing(const int* neigh, c
   }
   const int t = block_sum_int_1024(total);
   const int c = block_sum_int_1024(coal);
-  if (threadIdx.x == 0 && t) {
+  const int l = block_sum_int_1024(listed);
+  const int u = block_sum_int_1024(touching);
+  if (threadIdx.x == 0 && l) {
     atomicAdd(&counters[0], t);
     atomicAdd(&counters[1], c);
+    atomicAdd(&counters[2], l);
+    atomicAdd(&counters[3], u);
   }
 }
 

@@ -38,7 +38,7 @@ class HipSlabEngine:
         self.check(self.L.sf_dem_set_stream(lmp.ptr, torch.cuda.current_stream().cuda_stream))
         # the engine's flag block lives in a torch tensor so that word 0 (the rebuild trigger) can be
         # all-reduced over the ranks on the stream, between two sub-steps, without the host looking at it
-        self.flags = torch.zeros(16, dtype=torch.int32, device=self.device)
+        self.flags = torch.zeros(32, dtype=torch.int32, device=self.device)
         self.check(self.L.sf_dem_set_flag_buffer(lmp.ptr, self.flags.data_ptr()))
         self.trigger = self.flags[0:1]
 
