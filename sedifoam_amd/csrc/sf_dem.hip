@@ -98,7 +98,6 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
   roots_ = !opt_lds_;
-  if (const char* e = getenv("SF_ROOTS")) roots_ = atoi(e) != 0 && !opt_lds_;
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
   if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);

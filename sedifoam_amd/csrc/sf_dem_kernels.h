@@ -114,6 +114,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 {
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
+  // the gathering kernel always runs on (root, image code) words, the LDS-staged one on plain indices: a compile-time
+  // fact lets the compiler see that a gathered index has 25 bits, i.e. that record offsets fit 32 bits (scalar base +
+  // 32-bit offset addressing instead of 64-bit address arithmetic in vector registers)
+  constexpr int ROOTS = LDS ? 0 : 1;
+  __builtin_assume(i >= 0 && i < (1 << kIdxBits));
 
 #if SF_EXP_SPLIT_OWN   // (measurement) the own records as 12 scalar loads: does the request count follow the load width?
   auto ld4 = [&](const double4* p) {
@@ -156,11 +161,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     return NEED_VW && (LUB || !TP || (jraw & kTouchBit) != 0);
   };
   // request the records of the neighbour in `slot` (global gather), or its LDS position
-  auto fetch = [&](int jraw, size_t slot, Rec& R) {
+  auto fetch = [&](int jraw, int slotrow, Rec& R) {
     if (LDS) {
-      R.l = P.nloc[slot];
+      R.l = (P.nloc + (size_t)slotrow * cap)[i];
     } else {
-      const int j = neigh_index(jraw, S.roots);
+      const int j = neigh_index(jraw, ROOTS);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.x = P.xr_in[j];
       R.vw = wants_vw(jraw);
@@ -170,8 +175,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       }
     }
   };
-  int jraw_n1 = nn > 0 ? ld_stream(&P.neigh[(size_t)q * cap + i]) : 0;
-  int jraw_n2 = nn > 1 ? ld_stream(&P.neigh[(size_t)(q + LPA) * cap + i]) : 0;
+  // rows of the slot-major arrays are addressed as (row pointer)[i]: with one lane per atom the slot -- hence the row
+  // pointer -- is wave-uniform (scalar registers), the element offset 32 bits
+  int jraw_n1 = nn > 0 ? ld_stream(&(P.neigh + (size_t)q * cap)[i]) : 0;
+  int jraw_n2 = nn > 1 ? ld_stream(&(P.neigh + (size_t)(q + LPA) * cap)[i]) : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
   // owner's slot; the five image-code bits of a partner-side word hold that slot (a partner-side neighbour is never
   // a periodic image, see k_back_slots).
@@ -179,31 +186,37 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   RA.x = RA.v = RA.w = RB.x = RB.v = RB.w = double4{0, 0, 0, 0};
   RA.l = RB.l = 0;
   RA.vw = RB.vw = false;
-  if (nn > 0) fetch(jraw_n1, (size_t)q * cap + i, RA);
+  if (nn > 0) fetch(jraw_n1, q, RA);
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
   auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more) {
-    const int sl = q + LPA * s;   // the list slot this iteration works on
-    const size_t slot = (size_t)sl * cap + i;
-    const size_t sbase = (size_t)(3 * sl) * cap + i;
+    // the list slot this iteration works on; with one lane per atom it is the same in every active lane of the wave
+    const int sl = LPA == 1 ? __builtin_amdgcn_readfirstlane(s) : q + LPA * s;
+    int* const nrow = P.neigh + (size_t)sl * cap;                       // this slot's row of the list
+    const double* const hin = P.shear_in + (size_t)(3 * sl) * cap;       // ... and of the history (x, y, z rows)
+    double* const hout = P.shear_out + (size_t)(3 * sl) * cap;
     const int jraw = jraw_n1;
     const bool own = (jraw & kOwnBit) != 0;
     Vec3 sh = {0.0, 0.0, 0.0};
     if (STYLE != 0 && (jraw & kTouchBit) && !(SF_EXP_NOSHLD && S.kstep >= 0)) {
       // owner: this atom's own row (coalesced) ; partner: the owner's row, the pair seen from the other side
-      const size_t src = (own || SF_EXP_PARTNER_OWNROW)
-                             ? sbase : (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + (size_t)(jraw & kIdxMask);
-      const double sg = own ? 1.0 : -1.0;
       auto ldh = [&](const double* p) {
         if (own ? SF_HIST_NT_OWN : SF_HIST_NT_PARTNER) return ld_stream(p);
         return *p;
       };
-      sh.x = sg * ldh(&P.shear_in[src]);
-      sh.y = sg * ldh(&P.shear_in[src + cap]);
-      sh.z = sg * ldh(&P.shear_in[src + 2 * cap]);
+      if (own || SF_EXP_PARTNER_OWNROW) {
+        sh.x = ldh(&hin[i]);
+        sh.y = ldh(&(hin + cap)[i]);
+        sh.z = ldh(&(hin + 2 * cap)[i]);
+      } else {
+        const double* src = P.shear_in + (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + (size_t)(jraw & kIdxMask);
+        sh.x = -ldh(src);
+        sh.y = -ldh(src + cap);
+        sh.z = -ldh(src + 2 * cap);
+      }
     }
     jraw_n1 = jraw_n2;
-    if (s + 2 < nn) jraw_n2 = ld_stream(&P.neigh[slot + (size_t)(2 * LPA) * cap]);
+    if (s + 2 < nn) jraw_n2 = ld_stream(&(nrow + (size_t)(2 * LPA) * cap)[i]);
     if (more) {
       bool reuse = false;
 #if SF_GATHER_SHUFFLE
@@ -212,7 +225,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       // in lane l+1's registers: take them by shuffle instead of gathering them from L2 again.  Checked per lane on
       // the root index, so it is only a shortcut, never a different result.
       if (!LDS && LPA == 1) {
-        const int jn = neigh_index(jraw_n1, S.roots);
+        const int jn = neigh_index(jraw_n1, ROOTS);
         const unsigned long long act = __ballot(1);
         const int lane = threadIdx.x & 63;
         const int jdn = __shfl_down(cur.l, 1, 64);
@@ -238,7 +251,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         }
       }
 #endif
-      if (!reuse) fetch(jraw_n1, slot + (size_t)LPA * cap, nxt);
+      if (!reuse) fetch(jraw_n1, sl + LPA, nxt);
     }
     double4 xj4 = cur.x, vj4 = cur.v, wj4 = cur.w;
     if (LDS) {
@@ -248,7 +261,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         wj4 = {lw[3 * cur.l], lw[3 * cur.l + 1], lw[3 * cur.l + 2], 0.0};
       }
     }
-    if (S.roots && own) {
+    if (ROOTS && own) {
       // periodic image of the root: the same x_root + shift the reference's forward_comm would have stored
       // (a partner-side word never refers to an image: its code bits hold the owner's slot)
       const int code = (jraw >> kIdxBits) & 31;
@@ -267,7 +280,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (STYLE != 0) {
       if (rsq >= radsum * radsum) {
         // unset non-touching neighbours (:131-139); the stale shear is ignored once the bit is clear
-        if (jraw & kTouchBit) P.neigh[slot] = jraw & ~kTouchBit;
+        if (jraw & kTouchBit) nrow[i] = jraw & ~kTouchBit;
       } else {
         if (!LDS && !cur.vw) {   // a contact that did not exist one sub-step ago
           vj4 = P.vm_in[cur.l];
@@ -299,14 +312,14 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
 #if !SF_EXP_NOSHST
         if (own) {
-          st_stream(&P.shear_out[sbase], sh.x);
-          st_stream(&P.shear_out[sbase + cap], sh.y);
-          st_stream(&P.shear_out[sbase + 2 * cap], sh.z);
+          st_stream(&hout[i], sh.x);
+          st_stream(&(hout + cap)[i], sh.y);
+          st_stream(&(hout + 2 * cap)[i], sh.z);
         }
 #else
-        if (sh.x == 1.2345) P.shear_out[sbase] = sh.y + sh.z;
+        if (sh.x == 1.2345) hout[i] = sh.y + sh.z;
 #endif
-        if (!(jraw & kTouchBit)) P.neigh[slot] = jraw | kTouchBit;
+        if (!(jraw & kTouchBit)) nrow[i] = jraw | kTouchBit;
         F = F + o.F;
         T = T - radi * o.tor;
       }
