@@ -34,6 +34,9 @@
 #endif
 // (whether v, omega of a neighbour are prefetched always or only when the pair touched one sub-step ago is the template
 // parameter TP of k_substep, chosen per list from the fraction of listed neighbours that touch)
+#ifndef SF_HIST_PREFETCH
+#define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
+#endif
 #ifndef SF_HIST_NT_OWN
 #define SF_HIST_NT_OWN 1      // owner-side history loads non-temporal
 #endif
@@ -151,8 +154,31 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   constexpr bool NEED_VW = (STYLE != 0) || LUB;
   struct Rec {
     double4 x, v, w;
+    Vec3 sh; // the pair's history as THIS side sees it (SF_HIST_PREFETCH)
     int l;   // LDS: position of the neighbour in the staged tile
     bool vw; // v and w were requested
+  };
+  // history of the pair in list slot `slotrow` whose word is jraw: the owner reads its own row (coalesced), the
+  // partner the owner's row, the pair seen from the other side
+  auto load_history = [&](const int jraw, const int slotrow, Vec3& sh) {
+    sh = {0.0, 0.0, 0.0};
+    if (STYLE == 0 || !(jraw & kTouchBit) || (SF_EXP_NOSHLD && S.kstep >= 0)) return;
+    const bool own = (jraw & kOwnBit) != 0;
+    auto ldh = [&](const double* p) {
+      if (own ? SF_HIST_NT_OWN : SF_HIST_NT_PARTNER) return ld_stream(p);
+      return *p;
+    };
+    if (own || SF_EXP_PARTNER_OWNROW) {
+      const double* const hin = P.shear_in + (size_t)(3 * slotrow) * cap;
+      sh.x = ldh(&hin[i]);
+      sh.y = ldh(&(hin + cap)[i]);
+      sh.z = ldh(&(hin + 2 * cap)[i]);
+    } else {
+      const double* src = P.shear_in + (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + (size_t)(jraw & kIdxMask);
+      sh.x = -ldh(src);
+      sh.y = -ldh(src + cap);
+      sh.z = -ldh(src + 2 * cap);
+    }
   };
   // The contact law needs the neighbour's v and omega only if the pair touches, and a pair that touches now almost
   // always touched one sub-step ago (its touch bit): for the others only x is gathered, and the rare new contact loads
@@ -174,6 +200,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         R.w = P.om_in[j];
       }
     }
+    if (SF_HIST_PREFETCH) load_history(jraw, slotrow, R.sh);
   };
   // rows of the slot-major arrays are addressed as (row pointer)[i]: with one lane per atom the slot -- hence the row
   // pointer -- is wave-uniform (scalar registers), the element offset 32 bits
@@ -184,6 +211,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // a periodic image, see k_back_slots).
   Rec RA, RB;
   RA.x = RA.v = RA.w = RB.x = RB.v = RB.w = double4{0, 0, 0, 0};
+  RA.sh = RB.sh = Vec3{0.0, 0.0, 0.0};
   RA.l = RB.l = 0;
   RA.vw = RB.vw = false;
   if (nn > 0) fetch(jraw_n1, q, RA);
@@ -193,28 +221,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     // the list slot this iteration works on; with one lane per atom it is the same in every active lane of the wave
     const int sl = LPA == 1 ? __builtin_amdgcn_readfirstlane(s) : q + LPA * s;
     int* const nrow = P.neigh + (size_t)sl * cap;                       // this slot's row of the list
-    const double* const hin = P.shear_in + (size_t)(3 * sl) * cap;       // ... and of the history (x, y, z rows)
     double* const hout = P.shear_out + (size_t)(3 * sl) * cap;
     const int jraw = jraw_n1;
     const bool own = (jraw & kOwnBit) != 0;
-    Vec3 sh = {0.0, 0.0, 0.0};
-    if (STYLE != 0 && (jraw & kTouchBit) && !(SF_EXP_NOSHLD && S.kstep >= 0)) {
-      // owner: this atom's own row (coalesced) ; partner: the owner's row, the pair seen from the other side
-      auto ldh = [&](const double* p) {
-        if (own ? SF_HIST_NT_OWN : SF_HIST_NT_PARTNER) return ld_stream(p);
-        return *p;
-      };
-      if (own || SF_EXP_PARTNER_OWNROW) {
-        sh.x = ldh(&hin[i]);
-        sh.y = ldh(&(hin + cap)[i]);
-        sh.z = ldh(&(hin + 2 * cap)[i]);
-      } else {
-        const double* src = P.shear_in + (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + (size_t)(jraw & kIdxMask);
-        sh.x = -ldh(src);
-        sh.y = -ldh(src + cap);
-        sh.z = -ldh(src + 2 * cap);
-      }
-    }
+    Vec3 sh = cur.sh;
+    if (!SF_HIST_PREFETCH) load_history(jraw, sl, sh);
     jraw_n1 = jraw_n2;
     if (s + 2 < nn) jraw_n2 = ld_stream(&(nrow + (size_t)(2 * LPA) * cap)[i]);
     if (more) {
@@ -248,6 +259,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
           }
           nxt.l = jn;
           nxt.vw = donor_vw;
+          if (SF_HIST_PREFETCH) load_history(jraw_n1, sl + LPA, nxt.sh);
         }
       }
 #endif
