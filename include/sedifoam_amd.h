@@ -356,6 +356,13 @@ typedef struct {
    * in smoothField (the reference's channel cases: blockMeshDict `cyclic` patches, in.lammps `boundary pp ff pp`);
    * 0 = zeroGradient at both ends (enhancedCloud.C:800-815 default patch type) */
   int periodic[3];
+  /* Mesh partitioned into x-slabs by the planes of the particle decomposition (one slab per GPU): this block is then
+   * ONE slab -- n[0] = its owned cell layers + one ghost layer on each side, origin[0] = the low face of the low ghost
+   * layer, uniform along x -- and slab_nx_global (> 0) is the number of cell layers of the WHOLE mesh along x
+   * (periodic[0] its cyclic pair).  0: the block is the whole mesh.  Ghost layers receive what this rank's particles
+   * deposit just outside its slab (they drift by up to skin/2 between rebuilds); the caller adds them to the neighbour's
+   * edge layers and refreshes them (sedifoam_amd/cloud.py: SlabCloud). */
+  int slab_nx_global;
 } sf_cloud_mesh;
 
 int sf_cloud_create(void *lmp, const sf_cloud_mesh *mesh, const sf_cloud_props *props,
@@ -377,7 +384,15 @@ int sf_cloud_smooth_field(void *cloud, double *field, int ncomp);
  *   caller adds gamma [ncells] and Ue [ncells][3] over the ranks in place -> phase 3 smoothing + Ue/gamma.
  *   calcTcFields: phase 4 (alpha cap, local Asrc sums) -> add Asrc [ncells][3] over the ranks -> phase 5.
  * sf_cloud_device_fields returns the device arrays to reduce (MPI_Allreduce / ncclAllReduce / torch.distributed). */
-int sf_cloud_phase(void *cloud, int phase);
+int sf_cloud_phase(void *cloud, int phase);   /* 0: done ; 1 (slab mesh): paused for the x solve, see below */
+/* Slab mesh: the implicit diffusion solve of smoothField is global along x.  A smoothing phase (0 / 6, 3, 5) does the
+ * local half (transforms along y and z) and returns 1; the caller transposes the planar work array
+ * [nfields][nz][ny][n[0]] (owned columns 1 .. n[0]-2) to complete x-lines -- line number = (field * nz + iz) * ny + iy,
+ * an all-to-all of local size -- runs sf_cloud_smooth_xsolve on its share of the lines ([nlines][slab_nx_global],
+ * first_line = the number of its first line), transposes back so that every rank also gets the two columns next to
+ * its slab (its ghost layers), and calls the same phase again. */
+int sf_cloud_smooth_work(void *cloud, double **dev_work, int *nfields);
+int sf_cloud_smooth_xsolve(void *cloud, double *dev_lines, long long nlines, long long first_line);
 int sf_cloud_sub_cycling(void *cloud, int *subCycles, int *subSteps);
 int sf_cloud_device_fields(void *cloud, double **gamma, double **Ue, double **Asrc, int *ncells);
 /* accessors: gamma (alpha) [ncells], Ue [ncells][3], Asrc [ncells][3], Omega [ncells] to host */

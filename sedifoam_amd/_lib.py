@@ -70,7 +70,7 @@ class CloudProps(C.Structure):
 class CloudMesh(C.Structure):
     _fields_ = [("origin", C.c_double * 3), ("dx", C.c_double * 3), ("n", C.c_int * 3),
                 ("faces", C.POINTER(C.c_double) * 3), ("cell_label", C.POINTER(C.c_int)),
-                ("periodic", C.c_int * 3)]
+                ("periodic", C.c_int * 3), ("slab_nx_global", C.c_int)]
 
 
 class CloudTimers(C.Structure):
@@ -180,6 +180,8 @@ _SIGS = {
     "sf_cloud_calc_tc_fields": (C.c_int, [vp]),
     "sf_cloud_smooth_field": (C.c_int, [vp, dp, C.c_int]),
     "sf_cloud_phase": (C.c_int, [vp, C.c_int]),
+    "sf_cloud_smooth_work": (C.c_int, [vp, C.POINTER(dp), ip]),
+    "sf_cloud_smooth_xsolve": (C.c_int, [vp, vp, C.c_longlong, C.c_longlong]),
     "sf_cloud_sub_cycling": (C.c_int, [vp, ip, ip]),
     "sf_cloud_device_fields": (C.c_int, [vp, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp), ip]),
     "sf_cloud_get_fields": (C.c_int, [vp, dp, dp, dp, dp]),

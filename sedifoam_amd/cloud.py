@@ -64,13 +64,18 @@ class enhancedCloud:
     transDict keys (constant/transportProperties): rhob, nub."""
 
     def __init__(self, lammps, mesh_origin, mesh_dx, mesh_n, cloudDict, transDict, deltaT, driver=None,
-                 mesh_faces=None, mesh_labels=None, mesh_periodic=None):
+                 mesh_faces=None, mesh_labels=None, mesh_periodic=None, mesh_partition=False):
         """mesh_faces: (xf, yf, zf) face coordinates of a graded (blockMesh simpleGrading) block, n+1 ascending values
         per axis or None for a uniform axis (then mesh_origin / mesh_dx apply along it).
         mesh_labels: OpenFOAM cell label of every cell of the grid, in grid order ix + nx*(iy + ny*iz) (multi-block
         blockMesh cases number their cells block by block); every field array is then in label order.
         mesh_periodic: (px, py, pz) cyclic patch pairs of the (diffusion) mesh: smoothField couples the first and the
         last cell layer along such an axis instead of closing them with zeroGradient (the reference's channel cases).
+        mesh_partition (with driver): the mesh is PARTITIONED by the slab planes of the particle decomposition instead
+        of replicated: this rank keeps its nx/world cell layers plus a ghost layer on each side, scatters locally, moves
+        the ghost-layer sums to its face neighbours and takes part in a distributed smoothing solve (see _slab_*);
+        no collective is as large as the mesh.  mesh_origin / mesh_dx / mesh_n still describe the WHOLE mesh, setFluid
+        takes whole-mesh arrays (it keeps this rank's part) and gamma() / Ue() / Asrc() return this rank's owned cells.
         driver: a sedifoam_amd.halo.SlabDriver when the particles are decomposed over several GPUs (lammps is
         then the driver's engine).  Every rank holds the whole mesh; the per-cell sums of gamma, Ue and Asrc are
         added over the ranks (torch.distributed all_reduce on the device arrays) inside evolve()/calcTcFields()."""
@@ -108,10 +113,28 @@ class enhancedCloud:
                 raise SfError("smoothDirection: only diagonal tensors are supported")
             sd = (sd[0], sd[4], sd[8])
         pr.smoothDirection = (C.c_double * 3)(*sd)
+        self.partition = bool(mesh_partition) and driver is not None
+        self.mesh_n_global = tuple(int(k) for k in mesh_n)
+        if self.partition:
+            W, r = driver.world, driver.rank
+            if mesh_faces is not None and mesh_faces[0] is not None:
+                raise SfError("mesh_partition: the mesh must be uniform along x")
+            if mesh_labels is not None:
+                raise SfError("mesh_partition: cell labels are not supported")
+            if int(mesh_n[0]) % W:
+                raise SfError("mesh_partition: %d cell layers along x do not divide into %d slabs" % (mesh_n[0], W))
+            self.nxl = int(mesh_n[0]) // W
+            x0 = float(mesh_origin[0]) + r * self.nxl * float(mesh_dx[0])
+            if abs(x0 - driver.sublo) > 1e-9 * abs(float(mesh_dx[0])):
+                raise SfError("mesh_partition: the slab planes of the mesh (%g) and of the particles (%g) differ"
+                              % (x0, driver.sublo))
+            mesh_origin = (x0 - float(mesh_dx[0]), float(mesh_origin[1]), float(mesh_origin[2]))
+            mesh_n = (self.nxl + 2, int(mesh_n[1]), int(mesh_n[2]))
         m = _lib.CloudMesh()
         m.origin = (C.c_double * 3)(*mesh_origin)
         m.dx = (C.c_double * 3)(*mesh_dx)
         m.n = (C.c_int * 3)(*mesh_n)
+        m.slab_nx_global = self.mesh_n_global[0] if self.partition else 0
         m.periodic = (C.c_int * 3)(*[int(bool(q)) for q in ((0, 0, 0) if mesh_periodic is None else mesh_periodic)])
         keep_faces = []
         for k in range(3):
@@ -145,8 +168,13 @@ class enhancedCloud:
             self._dev = dict(gamma=(C.cast(g, C.c_void_p).value, nc.value),
                              Ue=(C.cast(u, C.c_void_p).value, 3 * nc.value),
                              Asrc=(C.cast(a, C.c_void_p).value, 3 * nc.value))
-            # the constructor scattered this rank's particles only: redo it over all ranks
-            self._phase(2); self._sum_over_ranks("gamma", "Ue"); self._phase(3); self._phase(6)
+            if self.partition:
+                self._slab_init(mesh_periodic)
+                # the constructor scattered this rank's particles into its slab + ghost layers
+                self._slab_halo_add("gamma", "Ue"); self._slab_phase(3); self._slab_phase(6)
+            else:
+                # the constructor scattered this rank's particles only: redo it over all ranks
+                self._phase(2); self._sum_over_ranks("gamma", "Ue"); self._phase(3); self._phase(6)
 
     def close(self):
         if getattr(self, "ptr", None):
@@ -160,6 +188,12 @@ class enhancedCloud:
             pass
 
     def setFluid(self, Uf=None, DDtUf=None, gradp=None, curlU=None):
+        if self.partition:
+            arrs = [None if a is None else self._slab_take(_f64(a).reshape(-1, 3)) for a in (Uf, DDtUf, gradp, curlU)]
+            check(self.L.sf_cloud_set_fluid(self.ptr, *[_p(a) for a in arrs]))
+            if Uf is not None and not self._slab_started:
+                self._slab_phase(6)          # UfSmoothed of the initial condition (enhancedCloud.C:641-655)
+            return
         arrs = [None if a is None else _f64(a).reshape(self.ncells, 3) for a in (Uf, DDtUf, gradp, curlU)]
         check(self.L.sf_cloud_set_fluid(self.ptr, *[_p(a) for a in arrs]))
 
@@ -175,6 +209,18 @@ class enhancedCloud:
             check(self.L.sf_cloud_evolve(self.ptr))
             return
         # enhancedCloud::evolve (enhancedCloud.C:669-787) on a decomposed domain
+        if self.partition:
+            self._slab_started = True
+            self._slab_phase(0)
+            sub_cycles, sub_steps = self._sub
+            for k in range(sub_cycles):
+                self._phase(1)
+                self.driver.step(sub_steps)
+                if k == 0:
+                    self._phase(2)
+                    self._slab_halo_add("gamma", "Ue")
+                    self._slab_phase(3)
+            return
         self._phase(0)
         sub_cycles, sub_steps = self._sub
         for k in range(sub_cycles):
@@ -189,12 +235,159 @@ class enhancedCloud:
         if self.driver is None:
             check(self.L.sf_cloud_calc_tc_fields(self.ptr))
             return
+        if self.partition:
+            self._phase(4)
+            self._slab_halo_add("Asrc")
+            self._slab_phase(5)
+            return
         self._phase(4)
         self._sum_over_ranks("Asrc")
         self._phase(5)
 
     def _phase(self, ph):
-        check(self.L.sf_cloud_phase(self.ptr, int(ph)))
+        return check(self.L.sf_cloud_phase(self.ptr, int(ph)))
+
+    # ---- mesh partitioned into x-slabs (mesh_partition=True): everything below moves data of LOCAL size only ----
+    def _slab_init(self, mesh_periodic):
+        import torch
+        d = self.driver
+        self._slab_started = False
+        self._torch = torch
+        self._per_x = bool(mesh_periodic[0]) if mesh_periodic is not None else False
+        W, r = d.world, d.rank
+        self._left = r - 1 if r > 0 else (W - 1 if self._per_x else None)
+        self._right = r + 1 if r < W - 1 else (0 if self._per_x else None)
+        nxg, ny, nz = self.mesh_n_global
+        self._shape = (nz, ny, self.nxl + 2)
+
+    def _dev_tensor(self, ptr, shape):
+        torch = self._torch
+        n = int(np.prod(shape))
+
+        class _View:
+            def __init__(self, p, k):
+                self.__cuda_array_interface__ = dict(shape=(k,), typestr="<f8", data=(p, False), version=2)
+        return torch.as_tensor(_View(ptr, n), device=self.driver.e.device).view(*shape)
+
+    def _field(self, name):
+        ptr, n = self._dev[name]
+        ncomp = n // int(np.prod(self._shape))
+        return self._dev_tensor(ptr, self._shape + ((ncomp,) if ncomp > 1 else ()))
+
+    def _slab_take(self, a):
+        """this rank's cells (ghost layers included, wrapped or clamped at the box ends) of a whole-mesh array"""
+        nxg, ny, nz = self.mesh_n_global
+        g = a.reshape(nz, ny, nxg, -1)
+        r = self.driver.rank
+        ix = np.arange(r * self.nxl - 1, (r + 1) * self.nxl + 1)
+        ix = np.mod(ix, nxg) if self._per_x else np.clip(ix, 0, nxg - 1)
+        return np.ascontiguousarray(g[:, :, ix, :]).reshape(-1, a.shape[1])
+
+    def _sendrecv(self, to_left, to_right):
+        """two face messages: returns (from_left, from_right); None where there is no neighbour"""
+        torch, d = self._torch, self.driver
+        dist = d.dist
+        if d.world == 1:
+            return (to_right if self._left is not None else None, to_left if self._right is not None else None)
+        host = d.transport == "host"
+        dev = "cpu" if host else d.e.device
+        sl, sr = to_left.to(dev).contiguous(), to_right.to(dev).contiguous()
+        rl, rr = torch.empty_like(sl), torch.empty_like(sr)
+        ops = []
+        if self._left is not None:
+            ops.append(dist.P2POp(dist.isend, sl, self._left, tag=31))
+        if self._right is not None:
+            ops.append(dist.P2POp(dist.isend, sr, self._right, tag=32))
+        if self._right is not None:
+            ops.append(dist.P2POp(dist.irecv, rr, self._right, tag=31))
+        if self._left is not None:
+            ops.append(dist.P2POp(dist.irecv, rl, self._left, tag=32))
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+        odev = d.e.device
+        return (rl.to(odev) if self._left is not None else None, rr.to(odev) if self._right is not None else None)
+
+    def _slab_halo_add(self, *names):
+        """what this rank's particles deposited in its ghost layers belongs to the neighbours' edge layers: send it,
+        add what arrives, then refresh the ghost layers with the neighbours' edge values"""
+        for nm in names:
+            f = self._field(nm)                      # [nz, ny, nxs(, 3)]
+            gl, gr = f[:, :, 0].clone(), f[:, :, -1].clone()
+            fl, fr = self._sendrecv(gl, gr)
+            if fl is not None:
+                f[:, :, 1] += fl
+            if fr is not None:
+                f[:, :, -2] += fr
+            self._slab_refresh(f)
+
+    def _slab_refresh(self, f):
+        el, er = f[:, :, 1].clone(), f[:, :, -2].clone()
+        fl, fr = self._sendrecv(el, er)
+        # from the left neighbour comes ITS right edge = my left ghost layer
+        f[:, :, 0] = fl if fl is not None else f[:, :, 1]
+        f[:, :, -1] = fr if fr is not None else f[:, :, -2]
+
+    def _a2a(self, send):
+        """send[q] -> rank q ; returns recv[p] = what rank p sent to me (equal shapes)"""
+        torch, d = self._torch, self.driver
+        if d.world == 1:
+            return send.clone()
+        if d.transport != "host":
+            recv = torch.empty_like(send)
+            d.dist.all_to_all_single(recv, send.contiguous())
+            return recv
+        h = send.cpu().contiguous()                  # gloo has no all-to-all: point-to-point messages through the host
+        out = torch.empty_like(h)
+        ops = []
+        for q in range(d.world):
+            if q == d.rank:
+                out[q] = h[q]
+            else:
+                ops.append(d.dist.P2POp(d.dist.isend, h[q], q, tag=40))
+                ops.append(d.dist.P2POp(d.dist.irecv, out[q], q, tag=40))
+        for w in d.dist.batch_isend_irecv(ops):
+            w.wait()
+        return out.to(send.device)
+
+    def _slab_xsolve(self):
+        """the x direction of the implicit diffusion solve: transpose the smoother's work array to complete x-lines
+        (each rank a share of the lines), solve, transpose back -- with the two columns next to every slab"""
+        torch, d = self._torch, self.driver
+        W, r = d.world, d.rank
+        wp = _lib.dp(); nf = C.c_int()
+        check(self.L.sf_cloud_smooth_work(self.ptr, C.byref(wp), C.byref(nf)))
+        nz, ny, nxs = self._shape
+        nxg = self.mesh_n_global[0]
+        NL = nf.value * nz * ny
+        work = self._dev_tensor(C.cast(wp, C.c_void_p).value, (NL, nxs))
+        nlq = (NL + W - 1) // W
+        send = torch.zeros((W * nlq, self.nxl), dtype=torch.float64, device=work.device)
+        send[:NL] = work[:, 1:-1]
+        recv = self._a2a(send.view(W, nlq, self.nxl))             # recv[p] = my lines, columns of rank p
+        lines = recv.permute(1, 0, 2).reshape(nlq, nxg).contiguous()
+        nvalid = max(0, min(nlq, NL - r * nlq))
+        check(self.L.sf_cloud_smooth_xsolve(self.ptr, lines.data_ptr(), nvalid, r * nlq))
+        cols = []
+        for p in range(W):
+            ix = np.arange(p * self.nxl - 1, (p + 1) * self.nxl + 1)
+            ix = np.mod(ix, nxg) if self._per_x else np.clip(ix, 0, nxg - 1)
+            cols.append(lines[:, torch.as_tensor(ix, device=lines.device)])
+        back = self._a2a(torch.stack(cols, 0))                    # back[q] = rows of rank q's lines, my columns
+        work[:, :] = back.reshape(W * nlq, nxs)[:NL]
+
+    def _slab_phase(self, ph):
+        if self._phase(ph) == 1:
+            self._slab_xsolve()
+            if self._phase(ph) != 0:
+                raise SfError("sf_cloud_phase %d did not finish after its x solve" % ph)
+        elif ph in (3, 5):
+            pass    # (no smoothing configured for this field: the ghost layers were refreshed by _slab_halo_add)
+
+    def owned(self, a):
+        """the owned cells [nz*ny*nxl(, 3)] of a local field array returned by gamma() / Ue() / Asrc()"""
+        nz, ny, nxs = self._shape
+        b = np.asarray(a).reshape(nz, ny, nxs, -1)[:, :, 1:-1, :]
+        return b.reshape(nz * ny * self.nxl, -1).squeeze()
 
     def _sum_over_ranks(self, *names):
         """in-place SUM over the ranks of the named device arrays (views through __cuda_array_interface__)"""

@@ -86,6 +86,9 @@ struct MeshDev {
   int n[3];
   int ncells;
   const double* f[3];   // graded axis: n+1 ascending face coordinates (device); nullptr: uniform origin + i dx
+  int per[3];           // cyclic patch pair along a (uniform) axis: a position one period outside is tracked through
+                        // the cyclic face into the cell on the other side ([3P] cyclicPolyPatch; LAMMPS wraps its
+                        // periodic coordinates only when it reneighbours, so positions sit slightly outside in between)
 };
 
 // cell index along one axis, -1 outside: floor((x - origin)/dx) on a uniform axis, the interval [f[i], f[i+1]) that
@@ -95,7 +98,11 @@ __device__ __forceinline__ int axis_cell(const MeshDev& m, int k, double x)
   const int n = m.n[k];
   const double* f = m.f[k];
   if (!f) {
-    const double fl = floor((x - m.origin[k]) / m.dx[k]);
+    double fl = floor((x - m.origin[k]) / m.dx[k]);
+    if (m.per[k]) {
+      if (fl < 0.0 && fl >= -(double)n) fl += (double)n;
+      else if (fl >= (double)n && fl < 2.0 * (double)n) fl -= (double)n;
+    }
     if (fl < 0.0 || fl >= (double)n) return -1;
     return (int)fl;
   }
@@ -530,6 +537,8 @@ class Cloud {
       mesh_.dx[k] = mesh.dx[k];
       mesh_.n[k] = mesh.n[k];
       mesh_.f[k] = nullptr;
+      // (a slab block is not periodic along x itself: its ghost layers are the way through the cyclic face)
+      mesh_.per[k] = (mesh.periodic[k] && !mesh.faces[k] && !(k == 0 && mesh.slab_nx_global > 0)) ? 1 : 0;
     }
     mesh_.ncells = mesh.n[0] * mesh.n[1] * mesh.n[2];
     if (mesh_.ncells <= 0) fail("cloud mesh has no cells");
@@ -594,6 +603,13 @@ class Cloud {
                              mesh.faces[2] ? width[2].data() : nullptr};
     smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_,
                         wptr, mesh.periodic);
+    if (mesh.slab_nx_global > 0) {
+      // this block is one x-slab of a larger mesh plus a ghost layer on each side (the mesh partitioned by
+      // the particle slab planes)
+      if (mesh.faces[0]) fail("a slab mesh must be uniform along x");
+      if (mesh.n[0] < 3) fail("a slab mesh needs at least one owned cell layer between its two ghost layers");
+      smoother_.configure_slab(mesh.slab_nx_global);
+    }
     SF_HIP(hipMalloc(&cstart_, sizeof(int) * 2 * (nc + 1)));
     std::vector<double> hV(nc);
     for (int iz = 0; iz < mesh.n[2]; iz++)
@@ -603,8 +619,12 @@ class Cloud {
     SF_HIP(hipMemcpyAsync(V_, hV.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s_));
     SF_HIP(hipStreamSynchronize(s_));
     if (!e.is_setup()) e.setup();  // lammps_step(0) at construction, softParticleCloud.C:189
-    particle_to_eulerian();        // enhancedCloud.C:635
-    update_uf_smoothed();          // :641-655
+    if (smoother_.slab()) {
+      scatter_local();             // (slab mesh: the caller moves the ghost-layer sums and runs phases 3 and 6)
+    } else {
+      particle_to_eulerian();      // enhancedCloud.C:635
+      update_uf_smoothed();        // :641-655
+    }
     SF_HIP(hipStreamSynchronize(s_));
   }
 
@@ -654,12 +674,13 @@ class Cloud {
     if (curlU) upload_field(curlU_, curlU, 3);
     // before the first step the fields are the initial condition: UfSmoothed_ (whose oldTime() the history force
     // reads in the first step) is built from them, as the reference does at construction (:641-655)
-    if (Uf && time_index_ == 0) update_uf_smoothed();
+    if (Uf && time_index_ == 0 && !smoother_.slab()) update_uf_smoothed();   // (slab mesh: the caller runs phase 6)
     SF_HIP(hipStreamSynchronize(s_));
   }
 
   void evolve()
   {
+    if (smoother_.slab()) fail("sf_cloud_evolve on a slab mesh: drive it through sf_cloud_phase");
     Range r_evolve("evolve");   // roctx ranges carry the bucket names of writeCPUTime.H:1-19
     const double t0 = now();
     DemEngine& e = lmp_->eng;
@@ -691,6 +712,7 @@ class Cloud {
 
   void calc_tc_fields()
   {
+    if (smoother_.slab()) fail("sf_cloud_calc_tc_fields on a slab mesh: drive it through sf_cloud_phase");
     Range r_tc("calcTcField");
     const double t0 = now();
     calc_tc_local();
@@ -731,28 +753,61 @@ class Cloud {
     return per_cell >= 256.0 ? 64 : (per_cell >= 2.0 ? 8 : 1);
   }
 
-  void calc_tc_finish()
+  // smoothing of up to two fields: the whole solve, or -- on a slab mesh -- its first half (returns true: paused)
+  // when `resume` is false and its second half when it is true
+  bool smooth_step(bool resume, double* fa, int na, double* fb, int nb)
   {
-    if (props_.dragSmooth) smoother_.smooth(Asrc_, 3);                                         // :410-413
+    if (!smoother_.enabled()) return false;
+    if (!smoother_.slab()) {
+      if (nb) smoother_.smooth2(fa, na, fb, nb);
+      else smoother_.smooth(fa, na);
+      return false;
+    }
+    if (!resume) {
+      smoother_.begin(fa, na, fb, nb);
+      return true;
+    }
+    smoother_.end();
+    return false;
+  }
+
+  bool calc_tc_finish(bool resume = false)
+  {
+    if (props_.dragSmooth && smooth_step(resume, Asrc_, 3, nullptr, 0)) return true;           // :410-413
     k_weight<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, 1, gamma_, Asrc_, nullptr);   // :415-416
+    return false;
   }
 
   // The pieces of evolve() / calcTcFields() for a decomposed domain (one engine per GPU, the whole mesh replicated on
   // every rank): the caller runs the DEM sub-steps through the halo driver between phase 1 and 2 and sums the
   // per-cell fields over the ranks between the "local" and the "finish" phases.
-  void phase(int ph)
+  // Returns 0 when the phase is complete.  On a mesh partitioned into x-slabs (sf_cloud_mesh.slab_nx_global) the
+  // phases that smooth a field (0 / 6, 3, 5) stop after the local half of the implicit diffusion solve and return 1:
+  // the caller then transposes the smoother's work array to complete x-lines, calls sf_cloud_smooth_xsolve on them,
+  // transposes back (DiffusionSmoother, sf_smooth.h) and calls the SAME phase again to finish it.
+  int phase(int ph)
   {
+    const bool resume = pending_ == ph;
+    if (pending_ >= 0 && !resume) fail("sf_cloud_phase %d: phase %d is waiting for its x solve", ph, pending_);
+    pending_ = -1;
+    bool paused = false;
     switch (ph) {
-      case 0: advance_time(); update_uf_smoothed(); break;
-      case 6: update_uf_smoothed(); break;   // (re-)initialisation, no time advance
+      case 0:
+        if (!resume) advance_time();
+        paused = update_uf_smoothed(resume);
+        break;
+      case 6: paused = update_uf_smoothed(resume); break;   // (re-)initialisation, no time advance
       case 1: drag_on_particles(); break;
       case 2: scatter_local(); break;
-      case 3: scatter_finish(); break;
+      case 3: paused = scatter_finish(resume); break;
       case 4: calc_tc_local(); break;
-      case 5: calc_tc_finish(); break;
+      case 5: paused = calc_tc_finish(resume); break;
       default: fail("sf_cloud_phase: unknown phase %d", ph);
     }
+    if (paused) pending_ = ph;
+    return paused ? 1 : 0;
   }
+  DiffusionSmoother& smoother() { return smoother_; }
   int sub_cycles() const { return subCycles_; }
   int sub_steps() const { return subSteps_; }
   void device_fields(double** gamma, double** Ue, double** Asrc, int* ncells)
@@ -931,13 +986,16 @@ class Cloud {
     else launch(k_particle_to_eulerian<1>);
   }
 
-  void scatter_finish()
+  bool scatter_finish(bool resume = false)
   {
     // gamma (:944-948) and Ue (:950-953): independent solves, batched through the same launches
-    if (props_.alphaSmooth && props_.UpSmooth) smoother_.smooth2(gamma_, 1, Ue_, 3);
-    else if (props_.alphaSmooth) smoother_.smooth(gamma_, 1);
-    else if (props_.UpSmooth) smoother_.smooth(Ue_, 3);
+    bool paused = false;
+    if (props_.alphaSmooth && props_.UpSmooth) paused = smooth_step(resume, gamma_, 1, Ue_, 3);
+    else if (props_.alphaSmooth) paused = smooth_step(resume, gamma_, 1, nullptr, 0);
+    else if (props_.UpSmooth) paused = smooth_step(resume, Ue_, 3, nullptr, 0);
+    if (paused) return true;
     k_divide_ue<<<div_up(mesh_.ncells, 256), 256, 0, s_>>>(mesh_.ncells, gamma_, Ue_);
+    return false;
   }
 
   // UfSmoothed_ = Uf_ [ * (1 - gamma), smoothed, / (1 - gamma) ]   enhancedCloud.C:675-690
@@ -948,15 +1006,16 @@ class Cloud {
     time_index_++;
   }
 
-  void update_uf_smoothed()
+  bool update_uf_smoothed(bool resume = false)
   {
     const int nb = div_up(mesh_.ncells, 256);
-    k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 2, gamma_, UfS_, Uf_);
+    if (!resume) k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 2, gamma_, UfS_, Uf_);
     if (props_.UfSmooth && smoother_.enabled()) {
-      k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 0, gamma_, UfS_, nullptr);
-      smoother_.smooth(UfS_, 3);
+      if (!resume) k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 0, gamma_, UfS_, nullptr);
+      if (smooth_step(resume, UfS_, 3, nullptr, 0)) return true;
       k_weight<<<nb, 256, 0, s_>>>(mesh_.ncells, 1, gamma_, UfS_, nullptr);
     }
+    return false;
   }
 
 public:
@@ -988,6 +1047,7 @@ public:
   DiffusionSmoother smoother_;
   double *Jd_ = nullptr, *pDragT_ = nullptr;   // diagnostics by tag
   int xrow_ = -1;                              // first of the 7 per-atom rows this cloud keeps in the engine
+  int pending_ = -1;                           // phase paused for the x solve of a slab mesh
   double* UfSold_ = nullptr;                                     // UfSmoothed_.oldTime()
   int time_index_ = 0;                                           // runTime().timeIndex()
   int *cstart_ = nullptr, *cell_ = nullptr, *idx_ = nullptr, *idx2_ = nullptr;
@@ -1036,7 +1096,24 @@ int sf_cloud_evolve(void* cloud)
 int sf_cloud_phase(void* cloud, int phase)
 {
   SF_API_BEGIN
-  static_cast<Cloud*>(cloud)->phase(phase);
+  const int rc = static_cast<Cloud*>(cloud)->phase(phase);
+  SF_API_END(rc)
+}
+
+int sf_cloud_smooth_work(void* cloud, double** dev_work, int* nfields)
+{
+  SF_API_BEGIN
+  sf::DiffusionSmoother& sm = static_cast<Cloud*>(cloud)->smoother();
+  if (!sm.slab() || !sm.enabled()) sf::fail("sf_cloud_smooth_work: not a smoothed slab mesh");
+  *dev_work = sm.work();
+  *nfields = sm.work_fields();
+  SF_API_END(0)
+}
+
+int sf_cloud_smooth_xsolve(void* cloud, double* dev_lines, long long nlines, long long first_line)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->smoother().xsolve(dev_lines, nlines, first_line);
   SF_API_END(0)
 }
 
@@ -1140,6 +1217,7 @@ int sfk_cell_owner_graded(int n, const double* x, const double origin[3], const 
     m.dx[k] = dx[k];
     m.n[k] = ncell[k];
     m.f[k] = dev_faces[k];
+    m.per[k] = 0;
   }
   m.ncells = ncell[0] * ncell[1] * ncell[2];
   if (n > 0) {

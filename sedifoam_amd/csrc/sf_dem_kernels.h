@@ -217,9 +217,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   if (nn > 0) fetch(jraw_n1, q, RA);
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
-  auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more) {
-    // the list slot this iteration works on; with one lane per atom it is the same in every active lane of the wave
-    const int sl = LPA == 1 ? __builtin_amdgcn_readfirstlane(s) : q + LPA * s;
+  auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more, const bool uniform_s) {
+    // the list slot this iteration works on; with one lane per atom and inside the (convergent) loop it is the same in
+    // every active lane of the wave -- NOT in the tail call after the loop, where lanes with different neighbour
+    // counts arrive with different s
+    const int sl = (LPA == 1 && uniform_s) ? __builtin_amdgcn_readfirstlane(s) : q + LPA * s;
     int* const nrow = P.neigh + (size_t)sl * cap;                       // this slot's row of the list
     double* const hout = P.shear_out + (size_t)(3 * sl) * cap;
     const int jraw = jraw_n1;
@@ -356,13 +358,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   int s = 0;
 #if SF_UNROLL2
   for (; s + 1 < nn; s += 2) {
-    slot_body(s, RA, RB, true);
-    slot_body(s + 1, RB, RA, s + 2 < nn);
+    slot_body(s, RA, RB, true, true);
+    slot_body(s + 1, RB, RA, s + 2 < nn, true);
   }
-  if (s < nn) slot_body(s, RA, RB, false);
+  if (s < nn) slot_body(s, RA, RB, false, false);
 #else
   for (; s < nn; s++) {
-    slot_body(s, RA, RB, s + 1 < nn);
+    slot_body(s, RA, RB, s + 1 < nn, true);
     RA = RB;
   }
 #endif

@@ -30,6 +30,22 @@ class DiffusionSmoother {
   void smooth2(double* fa, int na, double* fb, int nb);
   long long iterations() const { return iters_; }
 
+  // ---- mesh partitioned into x-slabs (one slab per GPU): the local block holds this rank's nx_local cell layers plus
+  // one ghost layer on each side; the implicit diffusion solve is global, so the direct solver runs as
+  //   begin()  : forward transforms along y and z of the local block (no communication)
+  //   caller   : transposes the planar work array to complete x-lines (an all-to-all of local size), calls
+  //   xsolve() : forward x transform, filter (1 + lx + ly + lz)^-steps, inverse x transform on those lines,
+  //              and transposes back (every rank also receives the two layers next to its slab: the ghost layers)
+  //   end()    : inverse transforms along z and y into the fields
+  // nx_global: cells of the whole mesh along x (uniform dx; periodic[0] = cyclic pair of the WHOLE mesh)
+  void configure_slab(int nx_global);
+  bool slab() const { return nx_global_ > 0; }
+  void begin(double* fa, int na, double* fb, int nb);
+  void end();
+  double* work() const;            // planar [ntot][nz][ny][nx_local + 2]
+  int work_fields() const { return slab_ntot_; }
+  void xsolve(double* lines, long long nlines, long long first_line);   // lines: [nlines][nx_global]
+
  private:
   void solve_component(double* x, int stride);
   bool enabled_ = false;
@@ -53,6 +69,13 @@ class DiffusionSmoother {
   double* spec_ = nullptr;    // DCT matrices, eigenvalues, two planar work arrays
   size_t specC_off_[3] = {0, 0, 0}, specB_off_[3] = {0, 0, 0}, specL_off_[3] = {0, 0, 0}, spec_work_off_ = 0;
   static constexpr int kMaxSpectral = 256;   // cells per direction the dense transforms are used for
+  int nx_global_ = 0;
+  double* slab_x_ = nullptr;      // global x direction: forward matrix, eigenvalues, a line buffer
+  size_t slab_tmp_cap_ = 0;
+  double* slab_tmp_ = nullptr;
+  double *slab_fa_ = nullptr, *slab_fb_ = nullptr;
+  int slab_na_ = 0, slab_nb_ = 0, slab_ntot_ = 0;
+  bool slab_open_ = false;
 };
 
 }  // namespace sf

@@ -265,8 +265,41 @@ __global__ __launch_bounds__(256) void k_spectral_pass(SpecArgs A)
   }
 }
 
+// ---- slab mode: the x direction of the direct solve on complete lines (see sf_smooth.h) ----
+// lines [nlines][nx] (x fastest); line L = first_line + l belongs to field k = L / (ny nz), row iz = (L / ny) % nz,
+// iy = L % ny of the planar work array.  pass 0: tmp[l][m] = filter * sum_i C[m][i] lines[l][i] ; pass 1: lines[l][i] =
+// sum_m C[m][i] tmp[l][m]
+__global__ __launch_bounds__(256) void k_slab_xsolve(int pass, double* lines, double* tmp, long long nlines,
+                                                     long long first_line, int nx, int ny, int nz, const double* C,
+                                                     const double* lamx, const double* lamy, const double* lamz,
+                                                     int steps)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nlines * nx) return;
+  const long long l = t / nx;
+  const int m = (int)(t - l * nx);
+  if (pass == 0) {
+    const double* src = lines + l * nx;
+    double acc = 0.0;
+    for (int i = 0; i < nx; i++) acc += C[m * nx + i] * src[i];
+    const long long L = first_line + l;
+    const int iy = (int)(L % ny), iz = (int)((L / ny) % nz);
+    const double g = 1.0 / (1.0 + lamx[m] + lamy[iy] + lamz[iz]);
+    double w = 1.0;
+    for (int s = 0; s < steps; s++) w *= g;
+    tmp[l * nx + m] = acc * w;
+  } else {
+    const double* src = tmp + l * nx;
+    double acc = 0.0;
+    for (int i = 0; i < nx; i++) acc += C[i * nx + m] * src[i];
+    lines[l * nx + m] = acc;
+  }
+}
+
 DiffusionSmoother::~DiffusionSmoother()
 {
+  if (slab_x_) (void)hipFree(slab_x_);
+  if (slab_tmp_) (void)hipFree(slab_tmp_);
   for (double* q : {r_, p_, ap_, partial_, scal_, cheb_, spec_})
     if (q) (void)hipFree(q);
   if (h_scal_) (void)hipHostFree(h_scal_);
@@ -429,6 +462,132 @@ void DiffusionSmoother::configure(const int n[3], const double dx[3], const doub
     SF_HIP(hipMemcpyAsync(spec_, h.data(), sizeof(double) * off, hipMemcpyHostToDevice, s_));
     SF_HIP(hipStreamSynchronize(s_));
   }
+}
+
+void DiffusionSmoother::configure_slab(int nx_global)
+{
+  if (!enabled_) {
+    nx_global_ = nx_global;
+    return;
+  }
+  if (!use_spectral_) fail("a mesh partitioned into x-slabs needs the dense-transform smoother (no SF_SMOOTH_CG / SF_SMOOTH_SPECTRAL=0)");
+  if (nx_global < 1 || nx_global > kMaxSpectral) fail("slab smoothing: %d cells along x (1..%d)", nx_global, kMaxSpectral);
+  nx_global_ = nx_global;
+  const int nd = nx_global;
+  // orthonormal basis of the WHOLE x direction (the local block only knows its slab): cosine modes, or the real
+  // Fourier modes of a cyclic pair; eigenvalues scaled like c_[0] = dtau D_x / dx^2
+  std::vector<double> h;
+  std::vector<double> lam;
+  for (int m = 0; m < nd; m++) {
+    const int kf = (m + 1) / 2;
+    const bool alt = (nd % 2 == 0) && m == nd - 1;
+    for (int i = 0; i < nd; i++) {
+      double v;
+      if (!per_[0]) v = std::sqrt((m == 0 ? 1.0 : 2.0) / nd) * std::cos(M_PI * m * (i + 0.5) / nd);
+      else if (m == 0) v = std::sqrt(1.0 / nd);
+      else if (alt) v = std::sqrt(1.0 / nd) * ((i & 1) ? -1.0 : 1.0);
+      else if (m & 1) v = std::sqrt(2.0 / nd) * std::cos(2.0 * M_PI * kf * i / nd);
+      else v = std::sqrt(2.0 / nd) * std::sin(2.0 * M_PI * kf * i / nd);
+      h.push_back(v);
+    }
+    lam.push_back(per_[0] ? c_[0] * (2.0 - 2.0 * std::cos(2.0 * M_PI * kf / nd)) : c_[0] * (2.0 - 2.0 * std::cos(M_PI * m / nd)));
+  }
+  h.insert(h.end(), lam.begin(), lam.end());
+  SF_HIP(hipMalloc(&slab_x_, sizeof(double) * h.size()));
+  SF_HIP(hipMemcpyAsync(slab_x_, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, s_));
+  SF_HIP(hipStreamSynchronize(s_));
+}
+
+double* DiffusionSmoother::work() const { return spec_ + spec_work_off_ + (size_t)kMaxCheb * ncells_; }
+
+void DiffusionSmoother::begin(double* fa, int na, double* fb, int nb)
+{
+  if (!enabled_ || !slab()) fail("DiffusionSmoother::begin: not in slab mode");
+  if (slab_open_) fail("DiffusionSmoother::begin: the previous solve was not finished");
+  if (na + nb > kMaxCheb) fail("DiffusionSmoother::begin: at most %d field components per solve", kMaxCheb);
+  slab_fa_ = fa;
+  slab_fb_ = fb;
+  slab_na_ = na;
+  slab_nb_ = nb;
+  slab_ntot_ = na + nb;
+  SpecArgs A;
+  A.a = {fa, na};
+  A.b = {fb, nb};
+  A.ntot = na + nb;
+  for (int d = 0; d < 3; d++) {
+    A.n[d] = n_[d];
+    A.lam[d] = spec_ + specL_off_[d];
+  }
+  A.steps = steps_;
+  A.filter = 0;
+  double* w0 = spec_ + spec_work_off_;
+  double* w1 = w0 + (size_t)kMaxCheb * ncells_;
+  const dim3 grid(div_up(ncells_, 256), A.ntot);
+  // forward y (fields -> w0), forward z (w0 -> w1): the local part of the solve
+  A.inverse = 0;
+  A.dim = 1;
+  A.C = spec_ + specC_off_[1];
+  A.in = nullptr;
+  A.out = w0;
+  k_spectral_pass<<<grid, 256, 0, s_>>>(A);
+  A.dim = 2;
+  A.C = spec_ + specC_off_[2];
+  A.in = w0;
+  A.out = w1;
+  k_spectral_pass<<<grid, 256, 0, s_>>>(A);
+  SF_HIP(hipGetLastError());
+  slab_open_ = true;
+}
+
+void DiffusionSmoother::xsolve(double* lines, long long nlines, long long first_line)
+{
+  if (!slab_open_) fail("DiffusionSmoother::xsolve: no solve in progress");
+  if (nlines <= 0) return;
+  const size_t need = (size_t)nlines * nx_global_;
+  if (need > slab_tmp_cap_) {
+    if (slab_tmp_) SF_HIP(hipFree(slab_tmp_));
+    slab_tmp_cap_ = need + need / 4 + 1024;
+    SF_HIP(hipMalloc(&slab_tmp_, sizeof(double) * slab_tmp_cap_));
+  }
+  const double* C = slab_x_;
+  const double* lamx = slab_x_ + (size_t)nx_global_ * nx_global_;
+  const int nb = div_up((long long)need, 256);
+  for (int pass = 0; pass < 2; pass++)
+    k_slab_xsolve<<<nb, 256, 0, s_>>>(pass, lines, slab_tmp_, nlines, first_line, nx_global_, n_[1], n_[2], C, lamx,
+                                      spec_ + specL_off_[1], spec_ + specL_off_[2], steps_);
+  SF_HIP(hipGetLastError());
+}
+
+void DiffusionSmoother::end()
+{
+  if (!slab_open_) fail("DiffusionSmoother::end: no solve in progress");
+  SpecArgs A;
+  A.a = {slab_fa_, slab_na_};
+  A.b = {slab_fb_, slab_nb_};
+  A.ntot = slab_ntot_;
+  for (int d = 0; d < 3; d++) {
+    A.n[d] = n_[d];
+    A.lam[d] = spec_ + specL_off_[d];
+  }
+  A.steps = steps_;
+  A.filter = 0;
+  double* w0 = spec_ + spec_work_off_;
+  double* w1 = w0 + (size_t)kMaxCheb * ncells_;
+  const dim3 grid(div_up(ncells_, 256), A.ntot);
+  // inverse z (w1 -> w0), inverse y (w0 -> fields)
+  A.inverse = 1;
+  A.dim = 2;
+  A.C = spec_ + specB_off_[2];
+  A.in = w1;
+  A.out = w0;
+  k_spectral_pass<<<grid, 256, 0, s_>>>(A);
+  A.dim = 1;
+  A.C = spec_ + specB_off_[1];
+  A.in = w0;
+  A.out = nullptr;
+  k_spectral_pass<<<grid, 256, 0, s_>>>(A);
+  SF_HIP(hipGetLastError());
+  slab_open_ = false;
 }
 
 void DiffusionSmoother::smooth_spectral(double* fa, int na, double* fb, int nb)

@@ -363,3 +363,105 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain():
             assert np.max(np.abs(got - want)) <= 1e-11
         else:
             assert dc.rel_err(got, want) <= 1e-8, k
+
+
+def _partition_worker(rank, world, port, outdir, ncfd, smooth, per, mesh):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sedifoam_amd import enhancedCloud
+    from sedifoam_amd.halo import SlabDriver, HipSlabEngine
+    from tests import dem_cases as dc
+    import tests.test_dem_gpu as T
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    bed = _coupled_bed()
+    cfg = dict(T.BASE, skin=_COUPLED_SKIN)
+    cfg["walls"] = T._walls(bed)
+    lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
+    lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
+    mesh_n, dx, fluid, cloudDict, transDict = _partition_setup(bed, smooth, mesh)
+    cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, driver=drv,
+                          mesh_periodic=per, mesh_partition=True)
+    cloud.setFluid(**fluid)
+    g0 = cloud.owned(cloud.gamma())
+    for _ in range(ncfd):
+        cloud.evolve()
+        cloud.calcTcFields()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), g0=g0, gamma=cloud.owned(cloud.gamma()),
+             Ue=cloud.owned(cloud.Ue()), Asrc=cloud.owned(cloud.Asrc()), nxl=cloud.nxl, **lmp.get_state())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _partition_setup(bed, smooth, mesh):
+    # x divides into the two slabs; unsmoothed the cells must be wide enough for the void fraction to stay below 0.85
+    mesh_n = np.array(mesh, np.int32)
+    dx = (bed["boxhi"] - bed["boxlo"]) / mesh_n
+    nc = int(np.prod(mesh_n))
+    rng = np.random.default_rng(19)
+    fluid = dict(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)) + 0.01 * rng.normal(size=(nc, 3)),
+                 DDtUf=rng.normal(scale=0.5, size=(nc, 3)),
+                 gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)) + rng.normal(scale=50.0, size=(nc, 3)),
+                 curlU=rng.normal(scale=5.0, size=(nc, 3)))
+    cloudDict = dict(dragModel="ErgunWenYu", subCycles=2, g=(0.0, -9.81, 0.0), maxPossibleAlpha=0.65,
+                     particleLift=True, particleAddedMass=True)
+    if smooth:
+        cloudDict.update(diffusionBandWidth=4.0e-3, diffusionSteps=2)
+    return mesh_n, dx, fluid, cloudDict, dict(rhob=1000.0, nub=1.0e-6)
+
+
+@pytest.mark.parametrize("smooth,per,mesh", [(True, (1, 0, 1), (4, 5, 4)), (False, (1, 0, 1), (2, 3, 2)),
+                                             (True, (1, 0, 0), (4, 5, 4))])
+def test_cloud_mesh_partitioned_by_the_slab_planes(smooth, per, mesh):
+    """the mesh partitioned by the planes of the particle decomposition (mesh_partition=True) instead of
+    replicated -- local scatter, ghost-layer sums moved to the face neighbours, distributed smoothing solve (local y / z
+    transforms, x on transposed lines), no collective of the size of the mesh -- against the single-GPU cloud on the
+    whole (cyclic) mesh; grains cross the slab face and the cyclic box face during the run."""
+    import os, socket, tempfile
+    import torch.multiprocessing as mp
+    from sedifoam_amd import enhancedCloud
+    ncfd = 3
+    bed = _coupled_bed()
+    cfg = dict(T.BASE, skin=_COUPLED_SKIN)
+    cfg["walls"] = T._walls(bed)
+    ref = dc.make_hip(bed, cfg)
+    mesh_n, dx, fluid, cloudDict, transDict = _partition_setup(bed, smooth, mesh)
+    cloud = enhancedCloud(ref, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, mesh_periodic=per)
+    cloud.setFluid(**fluid)
+    g0 = cloud.gamma()
+    assert g0.max() < 0.85
+    for _ in range(ncfd):
+        cloud.evolve()
+        cloud.calcTcFields()
+    a = ref.get_state()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_partition_worker, args=(2, port, out, ncfd, smooth, per, mesh), nprocs=2, join=True)
+        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    nx, ny, nz = [int(k) for k in mesh_n]
+
+    def whole(name, ncomp):
+        nxl = int(parts[0]["nxl"])
+        blocks = [p[name].reshape(nz, ny, nxl, ncomp) for p in parts]
+        return np.concatenate(blocks, axis=2).reshape(nz * ny * nx, ncomp).squeeze()
+    tol = 1e-9 if smooth else 1e-12
+    assert dc.rel_err(whole("g0", 1), g0) <= tol
+    assert dc.rel_err(whole("gamma", 1), cloud.gamma()) <= 1e-9
+    assert dc.rel_err(whole("Ue", 3), cloud.Ue()) <= 1e-8
+    assert dc.rel_err(whole("Asrc", 3), cloud.Asrc()) <= 1e-8
+    tag = np.concatenate([p["tag"] for p in parts])
+    order = np.argsort(tag)
+    assert len(np.unique(tag)) == bed["n"]
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    for k in ("x", "v", "omega"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        want = a[k].copy()
+        if k == "x":
+            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            assert np.max(np.abs(got - want)) <= 1e-11
+        else:
+            assert dc.rel_err(got, want) <= 1e-8, k
