@@ -3,7 +3,8 @@ polydisperse bed, pair hybrid/overlay gran/hertzFix/history + lubricate/poly, fi
 and particle-sub-steps/s"""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sedifoam_amd import synthetic, Lammps
 n_target = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
