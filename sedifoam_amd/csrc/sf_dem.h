@@ -90,6 +90,12 @@ struct WallMotion {
   double lo0 = 0.0, hi0 = 0.0;   // the positions of the fix command
 };
 
+constexpr int kForwardDoubles = 9;   // forward halo record: x | v | omega
+// the rebuild vote in the one-double header of a forward chunk: an int in the slot's first four bytes (so that the
+// kernel that finds an atom beyond skin/2 can lower it with an integer atomicMin)
+__host__ __device__ inline int* header_vote_ptr(double* slot) { return reinterpret_cast<int*>(slot); }
+__host__ __device__ inline int header_vote(const double* slot) { return *reinterpret_cast<const int*>(slot); }
+
 struct DemPtrs {
   const double4* xr_in;
   const double4* vm_in;
@@ -111,7 +117,12 @@ struct DemPtrs {
   const double* xhold;     // [3][cap]
   const int* mask;
   int* flags;
-  // boundary / interior split of the overlapped halo
+  // forward halo written by the sub-step itself (StepParams::tx_fused): position of an atom in the send list of the
+  // left / right face (-1: not sent) and the two send blocks (component-major, see k_forward_pack_fused)
+  const int* sendslot[2];
+  double* tx[2];
+  double* tx_sendbuf;           // vote headers: the 8-byte slot at tx_sendbuf + tx_hdr_off[p] holds an int (header_vote)
+  const int* tx_hdr_off;
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -147,6 +158,11 @@ struct StepParams {
   // LAMMPS groups: every fix acts on the atoms whose mask has the fix's group bit (bit 0 = all).  use_groups = 0:
   // every fix is on `all`, the mask is not even read.  freeze_bit != 0: fix freeze; frozen atoms carry omega.w = 1
   int use_groups, nve_bit, grav_bit, fdrag_bit, cohe_bit, freeze_bit;
+  // mode 0 only: atoms with x < tx_xlo or x >= tx_xhi look their send slots up and write their new x (+ tx_shift of the
+  // face), v, omega into DemPtrs::tx -- the pack kernel of the forward halo, fused
+  int tx_fused, tx_nhdr;   // tx_nhdr > 0 (any part, mode 0): a trigger also lowers the tx_nhdr vote headers
+  int tx_n[2];             // atoms in the left / right send list (a face's block is [kForwardDoubles][tx_n])
+  double tx_xlo, tx_xhi, tx_shift[2];
 };
 
 struct BinGrid {
@@ -291,6 +307,14 @@ class DemEngine {
                           double* sendbuf);
   void forward_unpack_fused(const double* recvbuf, long long off0, long long n0, long long off1, long long n1,
                             const int* hdr_off, int nhdr, int kstep);
+  // The sub-step kernel writes the forward records of the border atoms itself (no pack kernel between a sub-step and
+  // the exchange that follows it): tx0 / tx1 = send buffers of the left / right face in border-list order.  Valid
+  // until the next rebuild.  forward_tx_written(): the last sub-step launched did so.
+  // sendbuf + hdr_off[p] (p < nhdr): the vote header of the chunk for rank p (see header_vote); a kernel whose atom
+  // moves beyond skin/2 lowers the headers together with its trigger word.
+  void set_forward_tx(double* tx0, double shift0, double* tx1, double shift1, double* sendbuf, const int* hdr_off,
+                      int nhdr);
+  bool forward_tx_written() const { return tx_written_; }
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;
@@ -478,6 +502,13 @@ private:
   BinGrid grid_{};
   // halo bookkeeping: send lists for forward comm [side] (device index arrays) and ghost slot ranges
   DevArray sendlist_[2];
+  DevArray sendslot_;                  // [2][cap] inverse of sendlist_ (-1: not sent), for the fused forward pack
+  double* tx_ptr_[2] = {nullptr, nullptr};
+  double tx_shift_[2] = {0.0, 0.0};
+  double* tx_sendbuf_ = nullptr;
+  const int* tx_hdr_off_ = nullptr;
+  int tx_nhdr_ = 0, tx_n_[2] = {0, 0};
+  bool tx_ready_ = false, tx_written_ = false;
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
   int nb_ = 0;                         // boundary atoms = [0, n_lo_) and [n_hi_, nlocal_) of the x-slowest order
   int n_lo_ = 0, n_hi_ = 0;

@@ -557,6 +557,12 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.flags = d_flags_;
   P.nloc = nloc_.as<unsigned short>();
   P.tile_first = tile_tab_;
+  for (int f = 0; f < 2; f++) {
+    P.sendslot[f] = tx_ready_ ? sendslot_.as<int>() + (size_t)f * sendslot_.cap : nullptr;
+    P.tx[f] = tx_ptr_[f];
+  }
+  P.tx_sendbuf = tx_sendbuf_;
+  P.tx_hdr_off = tx_hdr_off_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
   P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
   P.stage_idx = stage_idx_;
@@ -685,6 +691,20 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     S.trig_add = part == 1 ? 1 : 0;
     const double half_margin = 0.5 * (lskin() - skin_);
     S.margin_sq = half_margin * half_margin;
+  }
+  // the forward halo of the exchange that follows: written by the kernel that integrates the border atoms
+  if (part != 1) tx_written_ = false;   // (the interior part sends nothing: what the boundary part wrote stands)
+  if (tx_ready_ && mode == 0 && !lds_active_) S.tx_nhdr = tx_nhdr_;
+  if (tx_ready_ && mode == 0 && part != 1 && !lds_active_) {
+    S.tx_fused = 1;
+    const double cut = cutneighmax() + skin_;   // (an atom is within skin/2 of where the border lists were made)
+    S.tx_xlo = sublo_x_ + cut;
+    S.tx_xhi = subhi_x_ - cut;
+    S.tx_shift[0] = tx_shift_[0];
+    S.tx_shift[1] = tx_shift_[1];
+    S.tx_n[0] = tx_n_[0];
+    S.tx_n[1] = tx_n_[1];
+    tx_written_ = true;
   }
   const bool cohe = cohe_.enabled, lub = lub_.enabled;
   // one event pair per sub-step: around the single kernel, or from the boundary part to the interior part
@@ -852,6 +872,7 @@ void DemEngine::rebuild_begin()
   next_ghost_ = 0;
   nsend_[0] = nsend_[1] = 0;
   recv_count_[0] = recv_count_[1] = 0;
+  tx_ready_ = tx_written_ = false;
 }
 
 // Re-order (and possibly shrink to n_new) every per-atom array of the owned atoms: dst[i] = src[perm[i]].
@@ -1261,6 +1282,7 @@ void DemEngine::setup()
 void DemEngine::run_begin()
 {
   run_base_step_ = nsteps_;
+  tx_written_ = false;
   choose_kernel();
   if (overlap_) overlap_begin();
   reset_flag(F_TRIGGER, INT_MAX);

@@ -19,7 +19,6 @@
 namespace sf {
 
 constexpr int kBorderDoubles = 14;   // x r | v m | omega | tag type mask
-constexpr int kForwardDoubles = 9;
 constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec + nextra
 
 // key 0 = selected, 1 = not (a stable compaction then lists the selected atoms, ascending)
@@ -321,23 +320,30 @@ __global__ __launch_bounds__(256) void k_forward_pack_fused(const int* list0, in
   const int* list = list0;
   double shift = shift0;
   double* buf = buf0;
+  size_t n = (size_t)n0;
   if (k >= n0) {
     k -= n0;
     if (k >= n1) {
       k -= n1;
-      if (k < nhdr) sendbuf[hdr_off[k]] = (double)__atomic_load_n(trig_word, __ATOMIC_RELAXED);
+      if (k < nhdr) {
+        sendbuf[hdr_off[k]] = 0.0;
+        *header_vote_ptr(sendbuf + hdr_off[k]) = __atomic_load_n(trig_word, __ATOMIC_RELAXED);
+      }
       return;
     }
     list = list1;
     shift = shift1;
     buf = buf1;
+    n = (size_t)n1;
   }
+  // a face's block is component-major, [kForwardDoubles][n]: consecutive border atoms write (and the receiver reads)
+  // consecutive doubles -- also what lets the sub-step kernel write these records itself (StepParams::tx_fused)
   const int i = list[k];
   const double4 x = xr[i], v = vm[i], w = om[i];
-  double* b = buf + (size_t)k * kForwardDoubles;
-  b[0] = x.x + shift; b[1] = x.y; b[2] = x.z;
-  b[3] = v.x; b[4] = v.y; b[5] = v.z;
-  b[6] = w.x; b[7] = w.y; b[8] = w.z;
+  double* b = buf + k;
+  b[0] = x.x + shift; b[n] = x.y; b[2 * n] = x.z;
+  b[3 * n] = v.x; b[4 * n] = v.y; b[5 * n] = v.z;
+  b[6 * n] = w.x; b[7 * n] = w.y; b[8 * n] = w.z;
 }
 
 __global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0, int n0, int first0,
@@ -348,24 +354,26 @@ __global__ __launch_bounds__(256) void k_forward_unpack_fused(const double* buf0
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   const double* buf = buf0;
   int first = first0;
+  size_t n = (size_t)n0;
   if (k >= n0) {
     k -= n0;
     if (k >= n1) {
       k -= n1;
-      if (k < nhdr) atomicMin(vote_word, (int)recvbuf[hdr_off[k]]);
+      if (k < nhdr) atomicMin(vote_word, header_vote(recvbuf + hdr_off[k]));
       return;
     }
     buf = buf1;
     first = first1;
+    n = (size_t)n1;
   }
-  const double* b = buf + (size_t)k * kForwardDoubles;
+  const double* b = buf + k;
   const int g = first + k;
   double4 x = xr[g], v = vm[g];
-  x.x = b[0]; x.y = b[1]; x.z = b[2];
-  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  x.x = b[0]; x.y = b[n]; x.z = b[2 * n];
+  v.x = b[3 * n]; v.y = b[4 * n]; v.z = b[5 * n];
   xr[g] = x;
   vm[g] = v;
-  om[g] = {b[6], b[7], b[8], om[g].w};   // .w: frozen mark, set by the border exchange
+  om[g] = {b[6 * n], b[7 * n], b[8 * n], om[g].w};   // .w: frozen mark, set by the border exchange
 }
 
 void DemEngine::forward_pack_fused(double shift0, long long off0, double shift1, long long off1, const int* hdr_off,
@@ -400,6 +408,39 @@ void DemEngine::forward_unpack_fused(const double* recvbuf, long long off0, long
     launch_ghost_forward(cur_, kstep, 2, F_VOTE0 + ((kstep + 1) & 1), comm_stream_);
   else
     launch_ghost_forward(cur_, INT_MIN);   // local y/z images of everything, received ghosts included
+}
+
+__global__ __launch_bounds__(256) void k_fill_sendslot(const int* list0, int n0, int* slot0, const int* list1, int n1,
+                                                       int* slot1)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n0) slot0[list0[k]] = k;
+  else if (k - n0 < n1) slot1[list1[k - n0]] = k - n0;
+}
+
+void DemEngine::set_forward_tx(double* tx0, double shift0, double* tx1, double shift1, double* sendbuf,
+                               const int* hdr_off, int nhdr)
+{
+  static const bool off = getenv("SF_HALO_FUSED_PACK") && !atoi(getenv("SF_HALO_FUSED_PACK"));
+  tx_ready_ = tx_written_ = false;
+  if (off || !nlocal_) return;
+  if (sendslot_.cap < cap_) sendslot_.alloc(sizeof(int), 2, cap_, stream_);
+  SF_HIP(hipMemsetAsync(sendslot_.ptr, 0xFF, sizeof(int) * 2 * sendslot_.cap, stream_));
+  const int tot = (int)(nsend_[0] + nsend_[1]);
+  if (tot)
+    k_fill_sendslot<<<div_up(tot, 256), 256, 0, stream_>>>(sendlist_[0].as<int>(), (int)nsend_[0], sendslot_.as<int>(),
+                                                           sendlist_[1].as<int>(), (int)nsend_[1],
+                                                           sendslot_.as<int>() + sendslot_.cap);
+  tx_ptr_[0] = tx0;
+  tx_ptr_[1] = tx1;
+  tx_shift_[0] = shift0;
+  tx_shift_[1] = shift1;
+  tx_sendbuf_ = sendbuf;
+  tx_hdr_off_ = hdr_off;
+  tx_nhdr_ = nhdr;
+  tx_n_[0] = (int)nsend_[0];
+  tx_n_[1] = (int)nsend_[1];
+  tx_ready_ = true;
 }
 
 void DemEngine::forward_pack2(double shift0, double* buf0, double shift1, double* buf1, long long* n0, long long* n1)

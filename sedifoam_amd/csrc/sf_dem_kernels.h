@@ -385,6 +385,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     }
   }
 
+  // (fused forward pack: the send slots of a border atom, requested here so that they have arrived by the end)
+  int txk0 = -1, txk1 = -1;
+  if (S.tx_fused && (xi.x < S.tx_xlo || xi.x >= S.tx_xhi)) {
+    txk0 = P.sendslot[0][i];
+    txk1 = P.sendslot[1][i];
+  }
+
   // ---- post_force fixes, in script order gravity -> fdrag -> walls ----
   if (S.have_gravity && (mk & S.grav_bit)) F = F + Vec3{mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
   if (S.have_fdrag && (mk & S.fdrag_bit)) {   // fix_fluid_drag.cpp:145
@@ -473,12 +480,27 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       wn = wn + dtirot * T;
       const double dx = xn.x - ld_stream(&P.xhold[i]), dy = xn.y - ld_stream(&P.xhold[cap + i]),
                    dz = xn.z - ld_stream(&P.xhold[2 * cap + i]);
-      if (dx * dx + dy * dy + dz * dz > S.trigger_sq) atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
+      if (dx * dx + dy * dy + dz * dz > S.trigger_sq) {
+        atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
+        // (fused forward pack: no kernel will copy the trigger word into the vote headers before the exchange)
+        for (int p = 0; p < S.tx_nhdr; p++) atomicMin(header_vote_ptr(P.tx_sendbuf + P.tx_hdr_off[p]), S.kstep + S.trig_add);
+      }
       if (S.margin_sq > 0.0) {
         const double sx = xn.x - xi.x, sy = xn.y - xi.y, sz = xn.z - xi.z;
         if (sx * sx + sy * sy + sz * sz > S.margin_sq) P.flags[F_MARGIN_FAIL] = 1;
       }
     }
+  }
+  // the forward halo record of an atom another GPU (or the periodic image of this slab) sees as a ghost: what
+  // k_forward_pack_fused would gather after this kernel
+  if (S.tx_fused) {
+    auto put = [&](double* b, size_t n, double shift) {
+      b[0] = xn.x + shift; b[n] = xn.y; b[2 * n] = xn.z;
+      b[3 * n] = vn.x; b[4 * n] = vn.y; b[5 * n] = vn.z;
+      b[6 * n] = wn.x; b[7 * n] = wn.y; b[8 * n] = wn.z;
+    };
+    if (txk0 >= 0) put(P.tx[0] + txk0, (size_t)S.tx_n[0], S.tx_shift[0]);
+    if (txk1 >= 0) put(P.tx[1] + txk1, (size_t)S.tx_n[1], S.tx_shift[1]);
   }
 #if SF_ST_SHUFFLE
   // A 32-byte record per lane is two 16-byte stores at a 32-byte stride: each store instruction covers only half

@@ -135,6 +135,10 @@ struct HaloComm {
         SF_NCCL(a.Recv(L.dev_rx + L.recv_off[p], (size_t)L.recv_cnt[p], ncclDouble, p, comm, st));
     }
     SF_NCCL(a.GroupEnd());
+    link_delay(st);
+  }
+  static void link_delay(hipStream_t st)
+  {
     static const int fake_us = getenv("SF_HALO_FAKE_DELAY_US") ? atoi(getenv("SF_HALO_FAKE_DELAY_US")) : 0;
     if (fake_us > 0) k_fake_link_delay<<<1, 64, 0, st>>>((long long)fake_us * 100);   // wall_clock64: 100 MHz
   }
@@ -267,6 +271,14 @@ static void slab_layout(HaloComm& hc, hipStream_t st)
   hc.lay_valid = true;
 }
 
+// (after slab_layout: the sub-step kernels write the forward records of the border atoms straight into the chunks)
+static void slab_fused_pack(SfLammps& S, HaloComm& hc)
+{
+  const sf_halo_layout& L = hc.lay;
+  S.eng.set_forward_tx(L.dev_tx + L.soff_l, L.shift_left, L.dev_tx + L.soff_r, L.shift_right, L.dev_tx, L.dev_shdr,
+                       L.world);
+}
+
 static void slab_rebuild(SfLammps& S, HaloComm& hc)
 {
   Range r("neighbor rebuild");
@@ -309,6 +321,7 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   e.rebuild_finish();
   hc.n_rebuilds++;
   slab_layout(hc, st);
+  slab_fused_pack(S, hc);
 }
 
 static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n);
@@ -337,9 +350,12 @@ static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const
   DemEngine& e = S.eng;
   hipStream_t main = e.stream();
   int trigger = 0;
+  // (the slab driver's own layout: the sub-step kernel that integrated the border atoms has written their forward
+  // records and, if one of its atoms moved beyond skin/2, the vote headers -- DemEngine::set_forward_tx)
   auto exchange = [&](int kstep, hipStream_t st) {
-    e.forward_pack_fused(lay->shift_left, lay->soff_l, lay->shift_right, lay->soff_r, lay->dev_shdr, lay->world,
-                         lay->dev_tx);
+    if (!e.forward_tx_written())
+      e.forward_pack_fused(lay->shift_left, lay->soff_l, lay->shift_right, lay->soff_r, lay->dev_shdr, lay->world,
+                           lay->dev_tx);
     hc->all_to_all(*lay, st);
     e.forward_unpack_fused(lay->dev_rx, lay->roff_l, lay->n_from_left, lay->roff_r, lay->n_from_right, lay->dev_rhdr,
                            lay->world, kstep);
