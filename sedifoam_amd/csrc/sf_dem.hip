@@ -101,6 +101,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
   if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);
+  if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -627,27 +628,37 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   return S;
 }
 
-template <int STYLE, int LPA, bool TP>
+template <int STYLE, int LPA, bool TP, int NTP>
 static void launch_substep_lpa(bool cohe, bool lub, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
                                const StepParams& S)
 {
-  if (cohe && lub) k_substep<STYLE, true, true, LPA, TP><<<grid, block, 0, s>>>(P, S);
-  else if (cohe) k_substep<STYLE, true, false, LPA, TP><<<grid, block, 0, s>>>(P, S);
-  else if (lub) k_substep<STYLE, false, true, LPA, true><<<grid, block, 0, s>>>(P, S);   // (lubrication needs v, omega
-  else k_substep<STYLE, false, false, LPA, TP><<<grid, block, 0, s>>>(P, S);            //  of every neighbour anyway)
+  if (cohe && lub) k_substep<STYLE, true, true, LPA, TP, NTP><<<grid, block, 0, s>>>(P, S);
+  else if (cohe) k_substep<STYLE, true, false, LPA, TP, NTP><<<grid, block, 0, s>>>(P, S);
+  else if (lub) k_substep<STYLE, false, true, LPA, true, NTP><<<grid, block, 0, s>>>(P, S);   // (lubrication needs v, omega
+  else k_substep<STYLE, false, false, LPA, TP, NTP><<<grid, block, 0, s>>>(P, S);            //  of every neighbour anyway)
 }
 
-template <int STYLE>
-static void launch_substep_style(bool cohe, bool lub, int lpa, bool tp, dim3 grid, int block, hipStream_t s,
-                                 const DemPtrs& P, const StepParams& S)
+template <int STYLE, int LPA, int NTP>
+static void launch_substep_tp(bool cohe, bool lub, bool tp, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
+                              const StepParams& S)
 {
   if (lub) tp = true;   // one instantiation
-  if (lpa == 4) tp ? launch_substep_lpa<STYLE, 4, true>(cohe, lub, grid, block, s, P, S)
-                   : launch_substep_lpa<STYLE, 4, false>(cohe, lub, grid, block, s, P, S);
-  else if (lpa == 2) tp ? launch_substep_lpa<STYLE, 2, true>(cohe, lub, grid, block, s, P, S)
-                        : launch_substep_lpa<STYLE, 2, false>(cohe, lub, grid, block, s, P, S);
-  else tp ? launch_substep_lpa<STYLE, 1, true>(cohe, lub, grid, block, s, P, S)
-          : launch_substep_lpa<STYLE, 1, false>(cohe, lub, grid, block, s, P, S);
+  tp ? launch_substep_lpa<STYLE, LPA, true, NTP>(cohe, lub, grid, block, s, P, S)
+     : launch_substep_lpa<STYLE, LPA, false, NTP>(cohe, lub, grid, block, s, P, S);
+}
+
+// ntp: non-temporal policy of the row streams (sf_dem_kernels.h); systems small enough for several lanes per atom
+// always fit the memory-side cache (policy 0)
+template <int STYLE>
+static void launch_substep_style(bool cohe, bool lub, int lpa, bool tp, int ntp, dim3 grid, int block, hipStream_t s,
+                                 const DemPtrs& P, const StepParams& S)
+{
+  if (lpa == 4) launch_substep_tp<STYLE, 4, 0>(cohe, lub, tp, grid, block, s, P, S);
+  else if (lpa == 2) launch_substep_tp<STYLE, 2, 0>(cohe, lub, tp, grid, block, s, P, S);
+  else if (ntp == 0) launch_substep_tp<STYLE, 1, 0>(cohe, lub, tp, grid, block, s, P, S);
+  else if (ntp == 1) launch_substep_tp<STYLE, 1, 1>(cohe, lub, tp, grid, block, s, P, S);
+  else if (ntp == 3) launch_substep_tp<STYLE, 1, 3>(cohe, lub, tp, grid, block, s, P, S);
+  else launch_substep_tp<STYLE, 1, 2>(cohe, lub, tp, grid, block, s, P, S);
 }
 
 template <int STYLE, bool COHE, bool LUB>
@@ -758,9 +769,9 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     const int block = block_env ? block_env : 64;
     const dim3 grid((unsigned)((lanes + block - 1) / block));
     switch (gran_.style) {
-      case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, grid, block, stream_, P, S); break;
-      case 1: launch_substep_style<1>(cohe, lub, lpa, touch_prefetch_, grid, block, stream_, P, S); break;
-      default: launch_substep_style<0>(cohe, lub, lpa, touch_prefetch_, grid, block, stream_, P, S); break;
+      case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
+      case 1: launch_substep_style<1>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
+      default: launch_substep_style<0>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
     }
   }
   SF_HIP(hipGetLastError());
@@ -1189,6 +1200,24 @@ void DemEngine::measure_list()
 
 void DemEngine::choose_kernel()
 {
+  static const bool dbg = getenv("SF_DEBUG_HIST") != nullptr;
+  // Non-temporal policy of the row streams (sf_dem_kernels.h, NTP): what one sub-step touches against the 256 MB
+  // memory-side cache.  Records in + out 192 B, history in + out 48 B per stored copy, list words, fix arrays.
+  {
+    const double khalf = (nlocal_ > 0 && h_flags_[F_LIST_SLOTS] > 0)
+                             ? 0.5 * (double)h_flags_[F_LIST_SLOTS] / (double)nlocal_ : 6.0;
+    const double copies = hist_single_ ? 1.0 : 2.0;
+    const double touched = (double)nlocal_ * (252.0 + (8.0 + 48.0 * copies) * khalf);
+    const double mall = 256.0 * 1024.0 * 1024.0;
+    const int before = nt_policy_;
+    if (nt_policy_env_ >= 0) nt_policy_ = nt_policy_env_;
+    else if (touched < mall) nt_policy_ = 0;
+    else if (touched < 1.4 * mall) nt_policy_ = 3;
+    else nt_policy_ = hist_single_ ? 1 : 2;
+    if (dbg && before != nt_policy_)
+      fprintf(stderr, "[sedifoam_amd] a sub-step touches %.0f MB -> non-temporal policy %d\n", touched / 1048576.0,
+              nt_policy_);
+  }
   if (touch_prefetch_env_ >= 0) {
     touch_prefetch_ = touch_prefetch_env_ != 0;
     return;
@@ -1199,7 +1228,6 @@ void DemEngine::choose_kernel()
   const bool before = touch_prefetch_;
   if (touch_prefetch_ && frac > 0.85) touch_prefetch_ = false;
   else if (!touch_prefetch_ && frac < 0.70) touch_prefetch_ = true;
-  static const bool dbg = getenv("SF_DEBUG_HIST") != nullptr;
   if (dbg && before != touch_prefetch_)
     fprintf(stderr, "[sedifoam_amd] %.3f of the listed neighbours touch -> v, omega %s\n", frac,
             touch_prefetch_ ? "prefetched by touch bit" : "always prefetched");

@@ -37,12 +37,6 @@
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
-#ifndef SF_HIST_NT_OWN
-#define SF_HIST_NT_OWN 1      // owner-side history loads non-temporal
-#endif
-#ifndef SF_HIST_NT_PARTNER
-#define SF_HIST_NT_PARTNER 1  // partner-side history gathers non-temporal
-#endif
 #ifndef SF_EXP_SPLIT_OWN
 #define SF_EXP_SPLIT_OWN 0
 #endif
@@ -61,46 +55,40 @@ namespace sf {
 
 __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 
-// Streamed (read-once / write-once per sub-step) rows.  SF_NT=1 marks them non-temporal so that they do not
-// evict the neighbour records the gathers want to find again in the 32 KB vector L1.
-template <class T>
+// Streamed (read-once / write-once per sub-step) rows can be marked non-temporal so that they do not evict the
+// neighbour records the gathers want to find again in the 32 KB vector L1 and the 4 MB L2 of the XCD.  Whether that
+// pays depends on what the 256 MB memory-side cache can keep from one sub-step to the next -- the template parameter
+// NTP of the sub-step kernels, chosen by DemEngine::choose_kernel from the bytes a sub-step touches:
+//   0  nothing non-temporal: the whole state fits the memory-side cache and is found there by the next sub-step
+//      (measured against policy 2: 100 k grains 33 -> 28 us, 200 k 56 -> 44, 300 k 70 -> 55, 400 k 91 -> 81);
+//   3  loads non-temporal except the history, stores plain: the state almost fits (500 k: 103 -> 96 us);
+//   1  rows and stores non-temporal, history loads plain: one history copy per contact, read twice per sub-step (by
+//      the owner and by the partner side) -- the second reader finds the line in L2 (-10 % L2 misses; 1 M grains
+//      201 -> 196 us, 2 M 393 -> 382, the settled disordered bed 215 -> 203);
+//   2  everything non-temporal: two copies per contact, every history row is read once (the loose bed: 232 us, 242
+//      with plain history loads).
+template <bool NT, class T>
 __device__ __forceinline__ T ld_stream(const T* p)
 {
-#if SF_NT
-  return __builtin_nontemporal_load(p);
-#else
+  if (NT && SF_NT) return __builtin_nontemporal_load(p);
   return *p;
-#endif
 }
-template <class T>
+template <bool NT, class T>
 __device__ __forceinline__ void st_stream(T* p, T v)
 {
-#if SF_NT_ST
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+  if (NT && SF_NT_ST) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
-__device__ __forceinline__ double4 ld_stream4(const double4* p)
-{
-#if SF_NT
-  const double* q = reinterpret_cast<const double*>(p);
-  typedef double d4v __attribute__((ext_vector_type(4)));
-  const d4v v = __builtin_nontemporal_load(reinterpret_cast<const d4v*>(q));
-  return {v.x, v.y, v.z, v.w};
-#else
-  return *p;
-#endif
-}
+template <bool NT>
 __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 {
-#if SF_NT
-  typedef double d4v __attribute__((ext_vector_type(4)));
-  d4v t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<d4v*>(p));
-#else
-  *p = v;
-#endif
+  if (NT && SF_NT) {
+    typedef double d4v __attribute__((ext_vector_type(4)));
+    d4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<d4v*>(p));
+  } else {
+    *p = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -111,7 +99,7 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // LPA lanes per atom (1, 2 or 4): lane q of an atom's group handles the slots q, q + LPA, ...; the partial force and
 // torque sums are combined with a fixed shuffle tree and lane 0 integrates.  Small systems (< ~3 waves per SIMD at
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
-template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP>
+template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP>
 __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw)
 {
@@ -121,6 +109,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // fact lets the compiler see that a gathered index has 25 bits, i.e. that record offsets fit 32 bits (scalar base +
   // 32-bit offset addressing instead of 64-bit address arithmetic in vector registers)
   constexpr int ROOTS = LDS ? 0 : 1;
+  constexpr bool NT_LD = NTP != 0, NT_ST = NTP == 1 || NTP == 2, NT_HIST = NTP == 2;
   __builtin_assume(i >= 0 && i < (1 << kIdxBits));
 
 #if SF_EXP_SPLIT_OWN   // (measurement) the own records as 12 scalar loads: does the request count follow the load width?
@@ -140,7 +129,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const double radi = xi4.w, mi = vi4.w;
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
-  const int nn_all = ld_stream(&P.numneigh[i]);
+  const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
   const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
@@ -164,10 +153,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     sh = {0.0, 0.0, 0.0};
     if (STYLE == 0 || !(jraw & kTouchBit) || (SF_EXP_NOSHLD && S.kstep >= 0)) return;
     const bool own = (jraw & kOwnBit) != 0;
-    auto ldh = [&](const double* p) {
-      if (own ? SF_HIST_NT_OWN : SF_HIST_NT_PARTNER) return ld_stream(p);
-      return *p;
-    };
+    auto ldh = [&](const double* p) { return ld_stream<NT_HIST>(p); };
     if (own || SF_EXP_PARTNER_OWNROW) {
       const double* const hin = P.shear_in + (size_t)(3 * slotrow) * cap;
       sh.x = ldh(&hin[i]);
@@ -204,8 +190,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   };
   // rows of the slot-major arrays are addressed as (row pointer)[i]: with one lane per atom the slot -- hence the row
   // pointer -- is wave-uniform (scalar registers), the element offset 32 bits
-  int jraw_n1 = nn > 0 ? ld_stream(&(P.neigh + (size_t)q * cap)[i]) : 0;
-  int jraw_n2 = nn > 1 ? ld_stream(&(P.neigh + (size_t)(q + LPA) * cap)[i]) : 0;
+  int jraw_n1 = nn > 0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
+  int jraw_n2 = nn > 1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)(q + LPA) * cap)[i]) : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
   // owner's slot; the five image-code bits of a partner-side word hold that slot (a partner-side neighbour is never
   // a periodic image, see k_back_slots).
@@ -229,7 +215,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     Vec3 sh = cur.sh;
     if (!SF_HIST_PREFETCH) load_history(jraw, sl, sh);
     jraw_n1 = jraw_n2;
-    if (s + 2 < nn) jraw_n2 = ld_stream(&(nrow + (size_t)(2 * LPA) * cap)[i]);
+    if (s + 2 < nn) jraw_n2 = ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
     if (more) {
       bool reuse = false;
 #if SF_GATHER_SHUFFLE
@@ -326,9 +312,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
 #if !SF_EXP_NOSHST
         if (own) {
-          st_stream(&hout[i], sh.x);
-          st_stream(&(hout + cap)[i], sh.y);
-          st_stream(&(hout + 2 * cap)[i], sh.z);
+          st_stream<NT_ST>(&hout[i], sh.x);
+          st_stream<NT_ST>(&(hout + cap)[i], sh.y);
+          st_stream<NT_ST>(&(hout + 2 * cap)[i], sh.z);
         }
 #else
         if (sh.x == 1.2345) hout[i] = sh.y + sh.z;
@@ -478,8 +464,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       vn = vn + dtfm * F;
       xn = xn + S.dt * vn;
       wn = wn + dtirot * T;
-      const double dx = xn.x - ld_stream(&P.xhold[i]), dy = xn.y - ld_stream(&P.xhold[cap + i]),
-                   dz = xn.z - ld_stream(&P.xhold[2 * cap + i]);
+      const double dx = xn.x - ld_stream<NT_LD>(&P.xhold[i]), dy = xn.y - ld_stream<NT_LD>(&P.xhold[cap + i]),
+                   dz = xn.z - ld_stream<NT_LD>(&P.xhold[2 * cap + i]);
       if (dx * dx + dy * dy + dz * dz > S.trigger_sq) {
         atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
         // (fused forward pack: no kernel will copy the trigger word into the vote headers before the exchange)
@@ -525,9 +511,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 #endif
   {
 #if SF_NT_OUT
-    st_stream4(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
-    st_stream4(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
-    st_stream4(&P.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
+    st_stream4<NT_ST>(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
+    st_stream4<NT_ST>(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
+    st_stream4<NT_ST>(&P.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
 #else
     P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
     P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
@@ -551,7 +537,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 // TP: v and omega of a neighbour are requested with its x only when the pair touched one sub-step ago (a bed that
 // lists many more neighbours than it touches: -11 % in the loose disordered bed), or always (a bed whose listed
 // neighbours nearly all touch: the bookkeeping of the former costs 4 % there)
-template <int STYLE, bool COHE, bool LUB, int LPA, bool TP>
+template <int STYLE, bool COHE, bool LUB, int LPA, bool TP, int NTP>
 __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
@@ -577,7 +563,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   } else if (i >= S.nlocal) {
     return;
   }
-  substep_particle<STYLE, COHE, LUB, false, LPA, TP>(P, S, i, q, nullptr, nullptr, nullptr);
+  substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
 }
 
 // LDS-staged cell bins: one workgroup per tile of T x T x T bins.  The x/v/omega records of every atom in
@@ -613,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
   }
   __syncthreads();
   for (int i = first + threadIdx.x; i < last; i += blockDim.x)
-    substep_particle<STYLE, COHE, LUB, true, 1, true>(P, S, i, 0, lx, lv, lw);
+    substep_particle<STYLE, COHE, LUB, true, 1, true, 2>(P, S, i, 0, lx, lv, lw);
 }
 
 // first half-kick of a run with the forces stored by the previous run's last sub-step
