@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_SUMMARY = "r02_c_pmc_summary.json"   # the committed PMC passes of the current kernel (tests/profile_round.sh)
+PMC_SUMMARY = "r02_d_pmc_summary.json"   # the committed PMC passes of the current kernel (tests/profile_round.sh)
 
 
 def build_engine(bed, script):
