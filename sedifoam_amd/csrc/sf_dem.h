@@ -464,6 +464,7 @@ private:
   // from the measured fraction of listed neighbours that touch (SF_TOUCH_PREFETCH=0 / 1 pins it)
   bool touch_prefetch_ = true;
   int touch_prefetch_env_ = -1;
+  int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
   int nt_policy_ = 2, nt_policy_env_ = -1;   // non-temporal policy of the row streams (sf_dem_kernels.h, NTP)
   void measure_list();     // queue k_partner_coalescing on the current list (results with the next flag read)
   void choose_kernel();    // pick touch_prefetch_ from the last measurement

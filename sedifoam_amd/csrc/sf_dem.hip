@@ -102,6 +102,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
   if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);
   if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
+  if (const char* e = getenv("SF_LPA")) opt_lpa_ = atoi(e);
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -761,8 +762,8 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     if (nwork <= 0) return;
     // lanes per atom: small systems are latency bound (one lane walks all ~12 neighbours).  Measured: 10 k atoms
     // 17.3 -> 10.5 us per sub-step with 4 lanes, while at 100 k (1.5 waves per SIMD already) more lanes are slower
-    static const int lpa_env = getenv("SF_LPA") ? atoi(getenv("SF_LPA")) : 0;
-    const int lpa = lpa_env ? lpa_env : (nwork < 20 * 1024 ? 4 : (nwork < 150 * 1024 ? 2 : 1));
+    const int lpa = (opt_lpa_ == 1 || opt_lpa_ == 2 || opt_lpa_ == 4) ? opt_lpa_
+                                                                      : (nwork < 20 * 1024 ? 4 : (nwork < 150 * 1024 ? 2 : 1));
     const long long lanes = (long long)nwork * lpa;
     // one wave per workgroup: the dispatcher then balances single waves (a 256-thread workgroup holds its CU slots
     // until its slowest wave is done); measured 207.0 -> 203.2 us per sub-step at 1 M atoms, never slower below

@@ -267,10 +267,14 @@ def test_deterministic_rerun():
 
 @pytest.mark.parametrize("env", [{"SF_LDS": "1", "SF_TILE": "4", "SF_SUB": "1"},
                                  {"SF_TILE": "0", "SF_XCD_REMAP": "0", "SF_SUB": "1"},
-                                 {"SF_TILE": "8", "SF_SUB": "2"}, {"SF_TILE": "4", "SF_SUB": "3"}])
+                                 {"SF_TILE": "8", "SF_SUB": "2"}, {"SF_TILE": "4", "SF_SUB": "3"},
+                                 {"SF_LPA": "1", "SF_NT_POLICY": "0"}, {"SF_LPA": "1", "SF_NT_POLICY": "1"},
+                                 {"SF_LPA": "1", "SF_NT_POLICY": "2", "SF_HIST_COPIES": "2"},
+                                 {"SF_LPA": "1", "SF_NT_POLICY": "3"}, {"SF_LPA": "2"}, {"SF_LPA": "4"}])
 def test_kernel_variants_agree_with_oracle(env, monkeypatch):
-    """The LDS-staged tile kernel (k_substep_lds) and the plain / tiled orderings of the gathering kernel are
-    speed options only: every one must reproduce the oracle, through rebuilds too."""
+    """The LDS-staged tile kernel (k_substep_lds), the plain / tiled orderings of the gathering kernel, its cache
+    policies (non-temporal rows or not, chosen by system size in production) and the lanes per atom are speed options
+    only: every one must reproduce the oracle, through rebuilds too."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     bed = _bed((6, 6, 6), periodic=True, seed=99, vmax=0.5)
