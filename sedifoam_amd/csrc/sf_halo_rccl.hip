@@ -37,9 +37,15 @@ static RcclApi& rccl()
 {
   static RcclApi api;
   if (api.lib) return api;
+  // SF_RCCL_LIB: another build of the library -- or the tests' stand-in that moves the messages of several ranks
+  // sharing ONE GPU through host memory (tests/c_abi/standin_rccl.cpp; RCCL itself refuses two ranks on one device)
+  if (const char* over = getenv("SF_RCCL_LIB")) {
+    api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) fail("SF_RCCL_LIB=%s: %s", over, dlerror());
+  }
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (api.lib) break;
+    api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!api.lib) fail("cannot load librccl.so.1 (%s)", dlerror());
   auto sym = [&](const char* n) {

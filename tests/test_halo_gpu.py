@@ -1,6 +1,8 @@
 """The ghost-particle halo kernels (border / forward / migrate pack+unpack, csrc/sf_dem_halo.hip) on one GPU:
 a single slab whose x-halo goes through the SlabDriver protocol (its own periodic images arrive as "external"
 ghosts) must reproduce the engine's internal periodic handling -- and therefore the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,9 +80,12 @@ def _c5_case():
     return bed, cfg
 
 
-def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="hertz"):
+def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="hertz", transport="host", rccl_lib=None,
+                     ncells=(8, 5, 5)):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if rccl_lib:
+        os.environ["SF_RCCL_LIB"] = rccl_lib
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -93,14 +98,14 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
     if physics == "c5":
         bed, cfg = _c5_case()
     else:
-        bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.5)
+        bed = T._bed(tuple(ncells), periodic=True, seed=41, vmax=0.5)
         cfg = dict(T.BASE, skin=0.05e-3)
         cfg["walls"] = T._walls(bed)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
     lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host",
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport=transport,
                      overlap=overlap)
-    assert drv.overlap == overlap
+    assert drv.overlap == overlap and drv.transport == transport
     drv.setup()
     if overlap:
         nb = lmp.L.sf_dem_boundary_count(lmp.ptr)
@@ -144,6 +149,68 @@ def test_two_ranks_sharing_one_gpu_match_single_domain(overlap):
     for k in ("x", "v", "omega", "f", "torque"):
         got = np.concatenate([p[k] for p in parts])[order]
         want = a[k].copy()
+        if k == "x":
+            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            assert np.max(np.abs(got - want)) <= 1e-12
+        else:
+            assert dc.rel_err(got, want) <= 1e-9, k
+    assert all(int(p["rebuilds"]) >= 3 for p in parts)
+    hb = {}
+    for p in parts:
+        for (i, j), sv in zip(p["hk"], p["hv"]):
+            hb.setdefault((int(i), int(j)), sv)
+    assert set(hb) == set(ha)
+
+
+def _standin_rccl(tmp_path):
+    """tests/c_abi/standin_rccl.cpp built for this test: the entry points the C++ slab driver loads from librccl, moving
+    the messages of several ranks that share ONE GPU through host shared memory (RCCL refuses two ranks on one device)"""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi", "standin_rccl.cpp")
+    lib = str(tmp_path / "libstandin_rccl.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", src, "-o", lib, "-lrt"], check=True,
+                   capture_output=True, timeout=300)
+    return lib
+
+
+@pytest.mark.parametrize("world,ncells,physics,overlap", [(2, (8, 5, 5), "hertz", False), (3, (9, 5, 5), "hertz", False),
+                                                          (2, (8, 5, 5), "c5", False), (2, (8, 5, 5), "hertz", True),
+                                                          (3, (9, 5, 5), "hertz", True)])
+def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, overlap):
+    """The C++ driver of a decomposed run (sf_slab_*: size pre-exchange + migration, border exchange, the forward halo
+    written by the sub-step kernel with the rebuild vote in its headers, the setup all-reduces) on 2 and 3 ranks --
+    left and right neighbour the same rank, and different ranks -- against the single-domain run.  The ranks share the
+    one GPU of the box; only the wire is a stand-in (tests/c_abi/standin_rccl.cpp, NCCL's grouped point-to-point
+    semantics through host shared memory), every line of the driver and every kernel is the product's."""
+    import socket
+    import torch.multiprocessing as mp
+    lib = _standin_rccl(tmp_path)
+    steps = (50, 50) if physics == "hertz" else (40, 40)
+    if physics == "c5":
+        bed, cfg = _c5_case()
+    else:
+        bed = T._bed(ncells, periodic=True, seed=41, vmax=0.5)
+        cfg = dict(T.BASE, skin=0.05e-3)
+        cfg["walls"] = T._walls(bed)
+    ref = dc.make_hip(bed, cfg)
+    ref.setup()
+    for n in steps:
+        ref.step(n)
+    a = ref.get_state(); ha = ref.history()
+    assert ref.info().nbuilds >= 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path)
+    mp.spawn(_two_rank_worker, args=(world, port, out, steps, overlap, physics, "rccl", lib, ncells), nprocs=world,
+             join=True)
+    parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+    tag = np.concatenate([p["tag"] for p in parts])
+    assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
+    order = np.argsort(tag)
+    oa = np.argsort(a["tag"])
+    L = bed["boxhi"][0] - bed["boxlo"][0]
+    for k in ("x", "v", "omega", "f", "torque"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        want = a[k][oa].copy()
         if k == "x":
             got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
             assert np.max(np.abs(got - want)) <= 1e-12
