@@ -165,7 +165,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    transport = "host" if args.one_gpu else None
+    # --one-gpu: gloo through host memory from Python, or -- with SF_RCCL_LIB pointing at tests/c_abi/standin_rccl.cpp
+    # built as a library -- the C++ driver of the real N > 1 run over that stand-in for librccl
+    transport = ("rccl" if os.environ.get("SF_RCCL_LIB") else "host") if args.one_gpu else None
     if world > 1 or os.environ.get("SF_HALO_SELF_COMM", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -275,7 +277,9 @@ def main():
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
             **({"bed_override": bed_kw} if bed_kw else {}),
-            "decomposition": ("x-slabs, ghost halo over gloo through host memory (--one-gpu)" if args.one_gpu else
+            "decomposition": (("x-slabs, C++ driver over a stand-in for librccl through host memory (--one-gpu)"
+                               if transport == "rccl" else
+                               "x-slabs, ghost halo over gloo through host memory (--one-gpu)") if args.one_gpu else
                               "x-slabs, ghost halo over RCCL") if world > 1 else
                              ("single slab through the halo driver" if args.slab_driver else "single domain"),
         },

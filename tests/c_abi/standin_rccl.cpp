@@ -5,9 +5,9 @@
 // exchange, fused forward halo + rebuild vote, the setup all-reduces) could only ever talk to itself.  This library
 // exports the nine entry points that driver loads (SF_RCCL_LIB points the loader here) with NCCL's semantics --
 // grouped point-to-point operations, the k-th send to a peer matches that peer's k-th receive from the sender,
-// operations ordered after the work already queued on the stream -- and moves the bytes through a POSIX shared-memory
-// segment: device -> host copy on the sending process, host -> device copy on the receiving one.  Slow, synchronous,
-// and exactly what is needed to run world_size 2 and 3 of the driver against the single-domain result.
+// operations ordered after the work already queued on the stream -- and moves the bytes through a file in /tmp mapped
+// by every rank: device -> host copy on the sending process, host -> device copy on the receiving one.  Slow, synchronous,
+// and exactly what is needed to run world_size 2 to 8 of the driver on a one-GPU box.
 //
 // build: hipcc -shared -fPIC -O2 tests/c_abi/standin_rccl.cpp -o libstandin_rccl.so   (tests/test_halo_gpu.py does it)
 #include <fcntl.h>
@@ -26,9 +26,9 @@
 
 namespace {
 
-constexpr int kMaxRanks = 4;
-constexpr int kSlots = 8;                    // messages in flight per directed pair
-constexpr size_t kSlotBytes = 4u << 20;      // (untouched pages of the segment cost nothing)
+constexpr int kMaxRanks = 8;
+constexpr int kSlots = 2;                    // messages in flight per directed pair (a group of the driver has <= 2)
+constexpr size_t kSlotBytes = 8u << 20;      // (untouched pages of the segment cost nothing)
 constexpr double kTimeoutS = 120.0;
 
 struct Slot {
@@ -111,7 +111,7 @@ ncclResult_t run_ops(ncclComm* c, std::vector<Op>& ops)
   size_t left = ops.size();
   const double t0 = now();
   while (left) {
-    bool blocked_s[kMaxRanks] = {false, false, false, false}, blocked_r[kMaxRanks] = {false, false, false, false};
+    bool blocked_s[kMaxRanks] = {}, blocked_r[kMaxRanks] = {};
     bool progress = false;
     for (Op& o : ops) {
       if (o.done) continue;
@@ -182,7 +182,7 @@ extern "C" {
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id)
 {
   memset(id, 0, sizeof(*id));
-  snprintf(id->internal, sizeof(id->internal), "/sf_standin_rccl_%d_%llx", (int)getpid(),
+  snprintf(id->internal, sizeof(id->internal), "/tmp/sf_standin_rccl_%d_%llx", (int)getpid(),
            (unsigned long long)(now() * 1e6));
   return ncclSuccess;
 }
@@ -195,9 +195,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   c->world = nranks;
   strncpy(c->name, id.internal, sizeof(c->name) - 1);
   c->name[sizeof(c->name) - 1] = 0;
-  const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+  const int fd = open(c->name, O_CREAT | O_RDWR, 0600);   // (sparse: only the pages messages touch exist)
   if (fd < 0 || ftruncate(fd, sizeof(Shared)) != 0) {
-    perror("standin_rccl: shm");
+    perror("standin_rccl: mapping file");
     return ncclSystemError;
   }
   void* p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);   // a new segment reads as zeros
@@ -212,7 +212,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
   if (!c) return ncclSuccess;
-  shm_unlink(c->name);
+  unlink(c->name);
   munmap(c->sh, sizeof(Shared));
   delete c;
   return ncclSuccess;

@@ -168,7 +168,7 @@ def _standin_rccl(tmp_path):
     import subprocess
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi", "standin_rccl.cpp")
     lib = str(tmp_path / "libstandin_rccl.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", src, "-o", lib, "-lrt"], check=True,
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", src, "-o", lib], check=True,
                    capture_output=True, timeout=300)
     return lib
 
