@@ -224,6 +224,34 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
     assert set(hb) == set(ha)
 
 
+@pytest.mark.parametrize("world,ncx", [(2, 8), (3, 9)])
+def test_mpi_cxx_host_drives_the_slabs_through_the_c_abi(tmp_path, world, ncx):
+    """lammpsFoam's side of a decomposed run, stood in for by tests/c_abi/mpi_slab_host.cpp: an MPI program in C++ (the
+    image's MPICH) that opens one engine per rank, hands over the script lines and its slab's atoms, broadcasts the
+    communicator id with MPI_Bcast and then only calls sf_slab_init / setup / step -- no Python, no torch in the loop.
+    Rank 0 runs the whole bed on a second engine and compares (positions 1e-12, velocities 1e-9, >= 3 rebuilds)."""
+    import shutil
+    import subprocess
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    libmpi = "/opt/conda/lib/libmpi.so"
+    if not (os.path.exists(mpirun) and os.path.exists(libmpi)):
+        pytest.skip("no MPI in this image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "sedifoam_amd")
+    exe = str(tmp_path / "mpi_slab_host")
+    # (conda's lib directory also holds an older libstdc++: the system one must come first on the run path)
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                        "-I", "/opt/conda/include", os.path.join(root, "tests", "c_abi", "mpi_slab_host.cpp"), "-o", exe,
+                        "-L", libdir, "-lsedifoam_amd", "-Wl,-rpath," + libdir, libmpi,
+                        "-Wl,-rpath,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,/opt/conda/lib", "-lm"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path))
+    r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "50"], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0 and "OK ranks %d" % world in r.stdout, r.stdout + r.stderr
+
+
 def test_two_ranks_cohesive_lubricate_match_single_domain_and_oracle():
     """Config C5 as BASELINE.json names it -- polydisperse + fix cohesive + lubricate/poly on a DECOMPOSED domain --
     with the real kernels: two HIP engines on one GPU against the single-domain HIP run and the single-domain oracle.
