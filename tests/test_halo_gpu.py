@@ -382,9 +382,11 @@ def _coupled_setup(bed):
     return mesh_n, dx, fluid, cloudDict, dict(rhob=1000.0, nub=1.0e-6)
 
 
-def _coupled_worker(rank, world, port, outdir, ncfd):
+def _coupled_worker(rank, world, port, outdir, ncfd, transport="host", rccl_lib=None):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if rccl_lib:
+        os.environ["SF_RCCL_LIB"] = rccl_lib
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -399,7 +401,8 @@ def _coupled_worker(rank, world, port, outdir, ncfd):
     cfg["walls"] = T._walls(bed)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
     lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport=transport)
+    assert drv.transport == transport
     mesh_n, dx, fluid, cloudDict, transDict = _coupled_setup(bed)
     cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, driver=drv)
     cloud.setFluid(**fluid)
@@ -413,13 +416,16 @@ def _coupled_worker(rank, world, port, outdir, ncfd):
     dist.destroy_process_group()
 
 
-def test_coupled_cloud_on_two_ranks_matches_single_domain():
+@pytest.mark.parametrize("transport", ["host", "rccl"])
+def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
     """enhancedCloud over a decomposed particle set (sf_cloud_phase + all-reduce of the per-cell sums, whole mesh on
     every rank) against the single-GPU cloud: drag closure, 2 sub-cycles of DEM sub-steps through the halo driver,
-    void fraction / Ue scatter, diffusion smoothing, Asrc."""
+    void fraction / Ue scatter, diffusion smoothing, Asrc.  transport="rccl": the DEM side through the C++ driver
+    (sf_slab_*; the cloud's per-particle rows migrate inside its record), over the stand-in for librccl."""
     import os, socket, tempfile
     import torch.multiprocessing as mp
     from sedifoam_amd import enhancedCloud
+    lib = _standin_rccl(tmp_path) if transport == "rccl" else None
     ncfd = 3
     bed = _coupled_bed()
     cfg = dict(T.BASE, skin=_COUPLED_SKIN)
@@ -436,7 +442,7 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain():
     a = ref.get_state()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_coupled_worker, args=(2, port, out, ncfd), nprocs=2, join=True)
+        mp.spawn(_coupled_worker, args=(2, port, out, ncfd, transport, lib), nprocs=2, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
     for p in parts:     # every rank holds the same global fields
         assert dc.rel_err(p["g0"], g0) <= 1e-12
