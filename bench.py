@@ -197,6 +197,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_us = [None]
+
     def timed_run(lmp):
         """W warm-up + K timed steps of `lammps_step(S)`; returns (elapsed max over ranks, total particles, launches,
         kernel ms, info before, info after)"""
@@ -212,6 +214,10 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         launches, kernel_ms = lmp.get_profile()
+        # decomposed run through the C++ driver: what a forward exchange (vote + ghosts over RCCL, unpack) costs on this
+        # rank's stream, HIP events around every 8th one; the slowest rank's mean goes into the line
+        xn, xms = lmp.get_exchange_profile() if hasattr(lmp, "get_exchange_profile") else (0, 0.0)
+        exchange_us[0] = 1e3 * xms / xn if xn else None
         lmp.set_profiling(False)
         n_own = float(lmp.info().nlocal)
         if dist is not None:
@@ -222,6 +228,9 @@ def main():
             nt = torch.tensor([n_own], dtype=torch.float64, device=rdev)
             dist.all_reduce(nt)
             n_own = float(nt.item())
+            xt = torch.tensor([exchange_us[0] if exchange_us[0] is not None else -1.0], dtype=torch.float64, device=rdev)
+            dist.all_reduce(xt, op=dist.ReduceOp.MAX)
+            exchange_us[0] = float(xt.item()) if xt.item() >= 0 else None
         return el, n_own, launches, kernel_ms, info0, lmp.info()
 
     strong = None
@@ -232,6 +241,7 @@ def main():
         sdrv = SlabDriver.from_global_bed(gbed, script, dist, rank, world, transport=transport)
         el_s, n_s, _l, _k, _i0, _i1 = timed_run(sdrv)
         strong = {"value": n_s * args.substeps * args.steps / el_s, "unit": "particle-substeps/s",
+                  "halo_exchange_us_per_substep": exchange_us[0],
                   "ms_per_step": 1e3 * el_s / args.steps, "particles_total": int(n_s), "scaling": "strong",
                   "workload": "the SAME %d-particle bed split into %d x-slabs (BASELINE config C4)" % (int(n_s), world)}
         if args.scaling == "strong":
@@ -276,6 +286,7 @@ def main():
                         "periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step" % args.substeps,
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
+            **({"halo_exchange_us_per_substep": exchange_us[0]} if exchange_us[0] is not None else {}),
             **({"bed_override": bed_kw} if bed_kw else {}),
             "decomposition": (("x-slabs, C++ driver over a stand-in for librccl through host memory (--one-gpu)"
                                if transport == "rccl" else

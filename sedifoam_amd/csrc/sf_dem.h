@@ -315,6 +315,7 @@ class DemEngine {
   void set_forward_tx(double* tx0, double shift0, double* tx1, double shift1, double* sendbuf, const int* hdr_off,
                       int nhdr);
   bool forward_tx_written() const { return tx_written_; }
+  bool profiling() const { return profiling_; }
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;

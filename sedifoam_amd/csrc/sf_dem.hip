@@ -1340,6 +1340,10 @@ int DemEngine::batch_end(int first_k, int launched)
 {
   read_flags();
   const int trig = h_flags_[F_TRIGGER];
+  if (profiling_) {
+    harvest_profile(trig);   // (the launches after a trigger were early exits: not kernel time)
+    prof_used_ = 0;
+  }
   const int executed = trig == INT_MAX ? launched : std::max(0, trig + 1 - first_k);
   // every substep_k flipped the buffer parity; the early-exited ones must not count
   if ((launched - executed) & 1) cur_ ^= 1;
@@ -1453,6 +1457,10 @@ int DemEngine::overlap_batch_end(int first_k, int launched, int last_kstep)
     fail("overlapped halo: an atom moved more than %.3g (5 %% of the skin) in one sub-step; the one-step-late "
          "rebuild vote of interior atoms is not safe at this speed -- run with SF_HALO_OVERLAP=0", 0.05 * skin_);
   const int trig = h_flags_[F_VOTE0 + (last_kstep & 1)];
+  if (profiling_) {
+    harvest_profile(trig);
+    prof_used_ = 0;
+  }
   const int executed = trig >= first_k + launched ? launched : std::max(0, trig + 1 - first_k);
   if ((launched - executed) & 1) cur_ ^= 1;
   nsteps_ += executed;

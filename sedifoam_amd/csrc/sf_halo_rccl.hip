@@ -118,11 +118,29 @@ struct HaloComm {
   std::vector<long long> send_off, send_cnt, recv_off, recv_cnt;
   sf_halo_layout lay{};
   bool lay_valid = false;
+  // what the forward exchange costs on this rank's stream (profiling on: an event pair around every 8th exchange of
+  // the serial loop, from the end of the sub-step kernel before it to the end of the unpack kernel)
+  std::vector<hipEvent_t> xev;
+  size_t xev_used = 0;
+  long long x_count = 0;
+  double x_ms = 0.0;
+  void harvest_exchange_profile()
+  {
+    for (size_t q = 0; 2 * q + 1 < xev_used; q++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, xev[2 * q], xev[2 * q + 1]) == hipSuccess) {
+        x_ms += ms;
+        x_count++;
+      }
+    }
+    xev_used = 0;
+  }
   ~HaloComm()
   {
     if (comm) (void)rccl().CommDestroy(comm);
     if (ev_boundary) (void)hipEventDestroy(ev_boundary);
     if (ev_halo) (void)hipEventDestroy(ev_halo);
+    for (hipEvent_t e : xev) (void)hipEventDestroy(e);
     if (d_counts) (void)hipFree(d_counts);
     if (h_counts) (void)hipHostFree(h_counts);
     if (d_red) (void)hipFree(d_red);
@@ -369,10 +387,25 @@ static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const
   const int launched = n - first_k;
   if (!e.overlap()) {
     for (int s = first_k; s < n; s++) {
+      const bool timed = e.profiling() && s % 8 == 4 && s > first_k;   // (not the sub-steps the kernel profile times)
+      if (timed) {
+        if (hc->xev_used + 2 > hc->xev.size())
+          for (int k = 0; k < 2; k++) {
+            hipEvent_t ev;
+            SF_HIP(hipEventCreate(&ev));
+            hc->xev.push_back(ev);
+          }
+        SF_HIP(hipEventRecord(hc->xev[hc->xev_used], main));
+      }
       exchange(-1, main);
+      if (timed) {
+        SF_HIP(hipEventRecord(hc->xev[hc->xev_used + 1], main));
+        hc->xev_used += 2;
+      }
       e.substep_k(s == n - 1, s);
     }
     trigger = e.batch_end(first_k, launched);
+    hc->harvest_exchange_profile();   // (batch_end has synchronised)
   } else {
     hipStream_t cs = e.comm_stream();
     SF_HIP(hipEventRecord(hc->ev_boundary, main));
@@ -516,6 +549,17 @@ int sf_slab_step(void* ptr, int n)
     if (sf_slab_setup(ptr) != 0) sf::fail("%s", sf::last_error().c_str());
   }
   if (n > 0) sf::slab_step(*L, *hc, n);
+  SF_API_END(0)
+}
+
+int sf_slab_exchange_profile(void* ptr, long long* exchanges, double* ms)
+{
+  SF_API_BEGIN
+  sf::HaloComm* hc = slab_of(H(ptr));
+  *exchanges = hc->x_count;
+  *ms = hc->x_ms;
+  hc->x_count = 0;
+  hc->x_ms = 0.0;
   SF_API_END(0)
 }
 
