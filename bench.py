@@ -198,6 +198,7 @@ def main():
         torch.cuda.synchronize()
 
     exchange_us = [None]
+    rebuild_ms = [None]
 
     def timed_run(lmp):
         """W warm-up + K timed steps of `lammps_step(S)`; returns (elapsed max over ranks, total particles, launches,
@@ -218,6 +219,8 @@ def main():
         # rank's stream, HIP events around every 8th one; the slowest rank's mean goes into the line
         xn, xms = lmp.get_exchange_profile() if hasattr(lmp, "get_exchange_profile") else (0, 0.0)
         exchange_us[0] = 1e3 * xms / xn if xn else None
+        rn, rms = lmp.get_rebuild_profile() if hasattr(lmp, "get_rebuild_profile") else (0, 0.0)
+        rebuild_ms[0] = rms / rn if rn else None
         lmp.set_profiling(False)
         n_own = float(lmp.info().nlocal)
         if dist is not None:
@@ -287,6 +290,7 @@ def main():
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
             **({"halo_exchange_us_per_substep": exchange_us[0]} if exchange_us[0] is not None else {}),
+            **({"decomposed_rebuild_ms_rank0": rebuild_ms[0]} if rebuild_ms[0] is not None else {}),
             **({"bed_override": bed_kw} if bed_kw else {}),
             "decomposition": (("x-slabs, C++ driver over a stand-in for librccl through host memory (--one-gpu)"
                                if transport == "rccl" else

@@ -144,6 +144,7 @@ _SIGS = {
     "sf_slab_step": (C.c_int, [vp, C.c_int]),
     "sf_slab_rebuild_count": (C.c_longlong, [vp]),
     "sf_slab_exchange_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "sf_slab_rebuild_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "sf_slab_layout_get": (C.c_int, [vp, vp]),
     "sf_dem_local_particle_volume": (C.c_int, [vp, dp]),
     "sf_dem_set_global_particle_volume": (C.c_int, [vp, C.c_double]),

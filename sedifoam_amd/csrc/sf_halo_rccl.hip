@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -124,6 +125,7 @@ struct HaloComm {
   size_t xev_used = 0;
   long long x_count = 0;
   double x_ms = 0.0;
+  double rebuild_ms = 0.0;   // host wall time inside slab_rebuild (it ends synchronised), all rebuilds since setup
   void harvest_exchange_profile()
   {
     for (size_t q = 0; 2 * q + 1 < xev_used; q++) {
@@ -306,6 +308,7 @@ static void slab_fused_pack(SfLammps& S, HaloComm& hc)
 static void slab_rebuild(SfLammps& S, HaloComm& hc)
 {
   Range r("neighbor rebuild");
+  const auto t_begin = std::chrono::steady_clock::now();
   DemEngine& e = S.eng;
   hipStream_t st = e.stream();
   e.rebuild_begin();
@@ -346,6 +349,7 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   hc.n_rebuilds++;
   slab_layout(hc, st);
   slab_fused_pack(S, hc);
+  hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
 static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n);
@@ -560,6 +564,15 @@ int sf_slab_exchange_profile(void* ptr, long long* exchanges, double* ms)
   *ms = hc->x_ms;
   hc->x_count = 0;
   hc->x_ms = 0.0;
+  SF_API_END(0)
+}
+
+int sf_slab_rebuild_profile(void* ptr, long long* rebuilds, double* ms)
+{
+  SF_API_BEGIN
+  sf::HaloComm* hc = slab_of(H(ptr));
+  *rebuilds = hc->n_rebuilds;
+  *ms = hc->rebuild_ms;
   SF_API_END(0)
 }
 

@@ -684,6 +684,15 @@ class SlabDriver:
     def get_profile(self):
         return self.e.lmp.get_profile()
 
+    def get_rebuild_profile(self):
+        """(rebuilds since setup, host ms spent in them) -- C++ driver only"""
+        if not getattr(self, "_cxx", False):
+            return 0, 0.0
+        import ctypes as C
+        n, ms = C.c_longlong(0), C.c_double(0.0)
+        self.e.check(self.e.L.sf_slab_rebuild_profile(self.e.lmp.ptr, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
     def get_exchange_profile(self):
         """(sampled forward exchanges, their summed ms) since profiling was switched on -- C++ driver only"""
         if not getattr(self, "_cxx", False):
