@@ -233,7 +233,7 @@ long long sf_slab_rebuild_count(void *ptr);
 /* while sf_dem_set_profiling is on: HIP-event time of the sampled forward exchanges (vote + ghosts: RCCL kernel and
  * unpack, measured on this rank's stream from the end of the sub-step kernel before); returns and resets the sums */
 int sf_slab_exchange_profile(void *ptr, long long *exchanges, double *ms);
-/* rebuilds since sf_slab_init (the one of sf_slab_setup included) and the host wall time spent in them */
+/* rebuilds since sf_slab_setup (its own, which allocates, not counted) and the host wall time spent in them */
 int sf_slab_rebuild_profile(void *ptr, long long *rebuilds, double *ms);
 int sf_slab_layout_get(void *ptr, sf_halo_layout *out);   /* the forward-halo layout of the current list (tests) */
 /* owned atoms that left the slab through either face (>= 0; < 0: error): when it is 0 on every rank the migration

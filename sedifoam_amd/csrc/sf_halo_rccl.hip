@@ -125,7 +125,8 @@ struct HaloComm {
   size_t xev_used = 0;
   long long x_count = 0;
   double x_ms = 0.0;
-  double rebuild_ms = 0.0;   // host wall time inside slab_rebuild (it ends synchronised), all rebuilds since setup
+  double rebuild_ms = 0.0;   // host wall time inside slab_rebuild (it ends synchronised), rebuilds after the setup's
+  long long rebuilds_at_setup = 0;
   void harvest_exchange_profile()
   {
     for (size_t q = 0; 2 * q + 1 < xev_used; q++) {
@@ -533,6 +534,8 @@ int sf_slab_setup(void* ptr)
   e.set_global_particle_volume(sf::slab_allreduce(*hc, st, e.local_particle_volume(), ncclSum));
   e.setup();
   hc->is_setup = true;
+  hc->rebuild_ms = 0.0;   // (the first rebuild allocates)
+  hc->rebuilds_at_setup = hc->n_rebuilds;
   SF_API_END(0)
 }
 
@@ -571,7 +574,7 @@ int sf_slab_rebuild_profile(void* ptr, long long* rebuilds, double* ms)
 {
   SF_API_BEGIN
   sf::HaloComm* hc = slab_of(H(ptr));
-  *rebuilds = hc->n_rebuilds;
+  *rebuilds = hc->n_rebuilds - hc->rebuilds_at_setup;
   *ms = hc->rebuild_ms;
   SF_API_END(0)
 }
