@@ -204,6 +204,40 @@ __device__ __forceinline__ int block_sum_int_1024(int v)
   return t;   // valid in thread 0
 }
 
+// Sub-steps are queued speculatively: the host learns that the list went stale only when it synchronises, and every
+// sub-step queued behind the trigger is a wasted launch (4-5 us; on a decomposed domain a wasted forward exchange
+// too, ~24 us).  Rebuilds come at regular intervals in a bed that does not change its temperature, so the queue is cut
+// short of where the next trigger is expected, then fed in small pieces until it has happened.  Which sub-step
+// triggers is decided on the device as before: only launch counts change, never results.  The same numbers on every
+// rank (rebuilds are global events), so all ranks of a decomposed run queue the same exchanges.
+struct RebuildPredictor {
+  long long last = 0;      // absolute sub-step index of the last rebuild
+  double interval = 0.0;   // sub-steps between rebuilds (mean of the last two estimates); 0: no history yet
+  bool on = true;
+  void rebuilt(long long step)
+  {
+    if (step > last) {
+      const double d = (double)(step - last);
+      interval = interval > 0.0 ? 0.5 * (interval + d) : d;
+    }
+    last = step;
+  }
+  // how many of the `remaining` sub-steps of a run to queue now; `step` = absolute index of the first of them
+  int chunk(long long step, int remaining) const
+  {
+    if (!on || interval <= 0.0 || remaining <= 4) return remaining;
+    int small = (int)(interval / 8.0);
+    small = small < 4 ? 4 : (small > 16 ? 16 : small);
+    const double left = interval - (double)(step - last);   // predicted sub-steps until the trigger
+    int c;
+    if (left >= (double)(remaining + small)) c = remaining;           // not expected within this run
+    else if (left > 2.0 * small) c = (int)left - small;               // stop short of it
+    else if (left >= -(double)small) c = small;                       // around it: small pieces
+    else c = (int)(-left / 2.0) > small ? (int)(-left / 2.0) : small; // overdue (the bed calmed down): lengthen again
+    return c < remaining ? (c < 1 ? 1 : c) : remaining;
+  }
+};
+
 class DemEngine {
  public:
   DemEngine();
@@ -466,6 +500,7 @@ private:
   bool touch_prefetch_ = true;
   int touch_prefetch_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
+  RebuildPredictor predict_;                 // single-domain run(): how far to queue (SF_QUEUE_PREDICT=0: everything)
   int nt_policy_ = 2, nt_policy_env_ = -1;   // non-temporal policy of the row streams (sf_dem_kernels.h, NTP)
   void measure_list();     // queue k_partner_coalescing on the current list (results with the next flag read)
   void choose_kernel();    // pick touch_prefetch_ from the last measurement

@@ -103,6 +103,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);
   if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
   if (const char* e = getenv("SF_LPA")) opt_lpa_ = atoi(e);
+  if (const char* e = getenv("SF_QUEUE_PREDICT")) predict_.on = atoi(e) != 0;
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
   memset(&lub_, 0, sizeof(lub_));
@@ -1499,7 +1500,9 @@ void DemEngine::run(int nsteps)
   while (k < nsteps) {
     const int base = cur_;
     prof_used_ = 0;
-    for (int s = k; s < nsteps; s++) {
+    // queue up to where the next rebuild is expected (RebuildPredictor), not blindly to the end of the run
+    const int end = k + predict_.chunk(run_base_step_ + k, nsteps - k);
+    for (int s = k; s < end; s++) {
       const int in_buf = (base + (s - k)) & 1;
       launch_substep(in_buf, (s == nsteps - 1) ? 1 : 0, s);
       launch_ghost_forward(in_buf ^ 1, s);
@@ -1511,14 +1514,15 @@ void DemEngine::run(int nsteps)
       prof_used_ = 0;
     }
     if (trig == INT_MAX) {
-      cur_ = (base + (nsteps - k)) & 1;
-      k = nsteps;
+      cur_ = (base + (end - k)) & 1;
+      k = end;
     } else {
       // sub-steps k..trig ran; the list went stale for sub-step trig+1 (trig = -1: for sub-step 0)
       const int done = trig + 1 - k;
       cur_ = (base + done) & 1;
       k = trig + 1;
       rebuild();
+      predict_.rebuilt(run_base_step_ + k);
     }
   }
   SF_HIP(hipEventRecord(ev1_, stream_));

@@ -125,6 +125,8 @@ struct HaloComm {
   size_t xev_used = 0;
   long long x_count = 0;
   double x_ms = 0.0;
+  RebuildPredictor predict;  // how far slab_step queues (every sub-step queued behind a trigger is a wasted exchange)
+  bool pre_exchanged = false;   // the exchange in front of the next sub-step has already run (end of the last piece)
   double rebuild_ms = 0.0;   // host wall time inside slab_rebuild (it ends synchronised), rebuilds after the setup's
   long long rebuilds_at_setup = 0;
   void harvest_exchange_profile()
@@ -353,26 +355,35 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
-static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n);
+static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int n);
 
 static void slab_step(SfLammps& S, HaloComm& hc, int n)
 {
   Range r("lammps");
   DemEngine& e = S.eng;
   e.run_begin();
+  hc.pre_exchanged = false;
   int k = 0;
   while (k < n) {
-    const int trig = slab_halo_run(S, hc, k, n);
-    if (trig >= n) break;
+    // (the overlapped schedule opens every call with an exchange of its own: it queues the whole run as before)
+    const int end = e.overlap() ? n : k + hc.predict.chunk(e.nsteps(), n - k);
+    const int trig = slab_halo_run(S, hc, k, end, n);
+    if (trig >= end) {
+      k = end;
+      continue;
+    }
     k = trig + 1;   // sub-steps k..trig ran (trig = -1: the list was stale for sub-step 0)
+    hc.pre_exchanged = false;
     slab_rebuild(S, hc);
+    hc.predict.rebuilt(e.nsteps());
     if (e.overlap()) e.overlap_begin();
   }
 }
 
 // queue sub-steps first_k .. n-1 (fused pack, one grouped ncclSend/ncclRecv, fused unpack, kernel; overlapped if
 // sf_dem_set_overlap is on), synchronise once, return the voted rebuild trigger
-static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const sf_halo_layout& layr)
+// queue sub-steps first_k .. end_k - 1 of a run of n
+static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int end_k, int n, const sf_halo_layout& layr)
 {
   HaloComm* hc = &hcr;
   const sf_halo_layout* lay = &layr;
@@ -389,9 +400,14 @@ static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const
     e.forward_unpack_fused(lay->dev_rx, lay->roff_l, lay->n_from_left, lay->roff_r, lay->n_from_right, lay->dev_rhdr,
                            lay->world, kstep);
   };
-  const int launched = n - first_k;
+  const int launched = end_k - first_k;
   if (!e.overlap()) {
-    for (int s = first_k; s < n; s++) {
+    for (int s = first_k; s < end_k; s++) {
+      if (s == first_k && hc->pre_exchanged) {   // (ghosts and votes in front of this sub-step are in place)
+        hc->pre_exchanged = false;
+        e.substep_k(s == n - 1, s);
+        continue;
+      }
       const bool timed = e.profiling() && s % 8 == 4 && s > first_k;   // (not the sub-steps the kernel profile times)
       if (timed) {
         if (hc->xev_used + 2 > hc->xev.size())
@@ -409,6 +425,13 @@ static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const
       }
       e.substep_k(s == n - 1, s);
     }
+    // A piece that stops before the end of the run closes with the exchange that belongs in front of the next
+    // sub-step: the ranks learn of a trigger in the LAST sub-step of the piece only through its votes, and every rank
+    // must take the same decision here (rebuild or go on) -- found by the 2-rank coupled test over the stand-in wire.
+    if (end_k < n) {
+      exchange(-1, main);
+      hc->pre_exchanged = true;
+    }
     trigger = e.batch_end(first_k, launched);
     hc->harvest_exchange_profile();   // (batch_end has synchronised)
   } else {
@@ -417,7 +440,7 @@ static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const
     SF_HIP(hipStreamWaitEvent(cs, hc->ev_boundary, 0));
     exchange(first_k - 1, cs);                       // ghosts + vote before sub-step first_k
     SF_HIP(hipEventRecord(hc->ev_halo, cs));
-    for (int s = first_k; s < n; s++) {
+    for (int s = first_k; s < end_k; s++) {
       const bool last = s == n - 1;
       SF_HIP(hipStreamWaitEvent(main, hc->ev_halo, 0));
       e.substep_part(2, last, s);                    // boundary atoms: need the ghosts of exchange s-1
@@ -429,15 +452,15 @@ static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int n, const
       SF_HIP(hipEventRecord(hc->ev_halo, cs));
     }
     SF_HIP(hipStreamWaitEvent(main, hc->ev_halo, 0));
-    trigger = e.overlap_batch_end(first_k, launched, n - 1);
+    trigger = e.overlap_batch_end(first_k, launched, end_k - 1);
   }
   return trigger;
 }
 
-static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int n)
+static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int n)
 {
   if (!hc.lay_valid) fail("sf_slab_step: no halo layout (rebuild first)");
-  return halo_run_layout(S, hc, first_k, n, hc.lay);
+  return halo_run_layout(S, hc, first_k, end_k, n, hc.lay);
 }
 
 }  // namespace sf
@@ -487,7 +510,7 @@ int sf_dem_halo_run(void* ptr, int first_k, int n, const sf_halo_layout* lay, in
   if (!hc || !hc->comm) sf::fail("sf_dem_halo_run: call sf_dem_comm_init first");
   if (!lay || !trigger) sf::fail("sf_dem_halo_run: null argument");
   if (lay->world != hc->world) sf::fail("sf_dem_halo_run: layout for %d ranks, communicator has %d", lay->world, hc->world);
-  *trigger = sf::halo_run_layout(*L, *hc, first_k, n, *lay);
+  *trigger = sf::halo_run_layout(*L, *hc, first_k, n, n, *lay);
   SF_API_END(0)
 }
 
@@ -510,6 +533,7 @@ int sf_slab_init(void* ptr, const char* id128, int rank, int world, double xlo, 
   const double sublo = xlo + rank * w, subhi = rank == world - 1 ? xhi : xlo + (rank + 1) * w;
   L->eng.set_subdomain(rank, world, sublo, subhi);
   sf::slab_scratch(*hc);
+  if (const char* q = getenv("SF_QUEUE_PREDICT")) hc->predict.on = atoi(q) != 0;
   SF_API_END(0)
 }
 
