@@ -535,6 +535,7 @@ private:
   size_t sort_tmp_bytes_ = 0;
   int* d_flags_ = nullptr;
   int* own_flags_ = nullptr;
+  unsigned long long* count64_ = nullptr;   // scratch counter of npairs_full()
   int* h_flags_ = nullptr;             // pinned
   std::vector<DevArray*> per_atom_;    // registry for capacity growth
   BinGrid grid_{};

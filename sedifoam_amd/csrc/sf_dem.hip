@@ -90,6 +90,7 @@ DemEngine::DemEngine()
   stream_ = own_stream_;
   SF_HIP(hipMalloc(&own_flags_, sizeof(int) * F_NFLAGS));
   d_flags_ = own_flags_;
+  SF_HIP(hipMalloc(&count64_, sizeof(unsigned long long)));
   SF_HIP(hipHostMalloc(&h_flags_, sizeof(int) * F_NFLAGS));
   SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
   SF_HIP(hipEventCreate(&ev0_));
@@ -129,6 +130,7 @@ DemEngine::~DemEngine()
     if (b.p) (void)hipFree(b.p);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (own_flags_) (void)hipFree(own_flags_);
+  if (count64_) (void)hipFree(count64_);
   if (h_flags_) (void)hipHostFree(h_flags_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -1657,14 +1659,12 @@ void DemEngine::put_local_info(int n, const double* fdrag, const int* foamCpuId,
 long long DemEngine::npairs_full()
 {
   if (!nlocal_ || !have_list_) return 0;
-  unsigned long long* d = nullptr;
-  SF_HIP(hipMalloc(&d, sizeof(unsigned long long)));
+  unsigned long long* d = count64_;   // (persistent: a hipMalloc / hipFree pair per call synchronises the device)
   SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), stream_));
   k_count_pairs<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_.as<int>(), nlocal_, d);
   unsigned long long h = 0;
   SF_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream_));
   sync();
-  (void)hipFree(d);
   return (long long)h;
 }
 
