@@ -549,9 +549,6 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.numneigh = numneigh_.as<int>();
   P.shear_in = shear_[in_buf].as<double>();
   P.shear_out = shear_[ob].as<double>();
-#ifdef SF_EXP_INPLACE   // (WRONG results: racy) history written back in place: prices the ping-pong buffer
-  P.shear_out = shear_[in_buf].as<double>();
-#endif
   P.fdrag = fdrag_.as<double>();
   P.DuDt = DuDt_.as<double>();
   P.vOld = vOld_.as<double>();

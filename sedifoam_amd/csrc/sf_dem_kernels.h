@@ -37,12 +37,6 @@
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
-#ifndef SF_EXP_SPLIT_OWN
-#define SF_EXP_SPLIT_OWN 0
-#endif
-#ifndef SF_EXP_PARTNER_OWNROW
-#define SF_EXP_PARTNER_OWNROW 0   // (WRONG results) partner reads its own row instead of the owner's: prices the gather
-#endif
 // Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md)
 #ifndef SF_EXP_NOSHLD
 #define SF_EXP_NOSHLD 0       // skip the shear-history loads
@@ -112,19 +106,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   constexpr bool NT_LD = NTP != 0, NT_ST = NTP == 1 || NTP == 2, NT_HIST = NTP == 2;
   __builtin_assume(i >= 0 && i < (1 << kIdxBits));
 
-#if SF_EXP_SPLIT_OWN   // (measurement) the own records as 12 scalar loads: does the request count follow the load width?
-  auto ld4 = [&](const double4* p) {
-    const volatile double* q = reinterpret_cast<const volatile double*>(p);
-    return double4{q[0], q[1], q[2], q[3]};
-  };
-  const double4 xi4 = ld4(&P.xr_in[i]);
-  const double4 vi4 = ld4(&P.vm_in[i]);
-  const double4 wi4 = ld4(&P.om_in[i]);
-#else
   const double4 xi4 = P.xr_in[i];   // also a gather target of the neighbours: keep it cached
   const double4 vi4 = P.vm_in[i];
   const double4 wi4 = P.om_in[i];
-#endif
   const Vec3 xi = v3(xi4), vi = v3(vi4), wi = v3(wi4);
   const double radi = xi4.w, mi = vi4.w;
 
@@ -154,7 +138,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (STYLE == 0 || !(jraw & kTouchBit) || (SF_EXP_NOSHLD && S.kstep >= 0)) return;
     const bool own = (jraw & kOwnBit) != 0;
     auto ldh = [&](const double* p) { return ld_stream<NT_HIST>(p); };
-    if (own || SF_EXP_PARTNER_OWNROW) {
+    if (own) {
       const double* const hin = P.shear_in + (size_t)(3 * slotrow) * cap;
       sh.x = ldh(&hin[i]);
       sh.y = ldh(&(hin + cap)[i]);
