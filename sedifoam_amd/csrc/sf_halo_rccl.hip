@@ -314,12 +314,23 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   const auto t_begin = std::chrono::steady_clock::now();
   DemEngine& e = S.eng;
   hipStream_t st = e.stream();
+  static const bool dbgt = getenv("SF_DEBUG_REBUILD_PHASES") != nullptr;
+  auto tprev = t_begin;
+  auto lap = [&](const char* what) {
+    if (!dbgt) return;
+    (void)hipStreamSynchronize(st);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rebuild] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - tprev).count());
+    tprev = t;
+  };
   e.rebuild_begin();
+  lap("rebuild_begin (partner tags)");
   // one all-reduce carries the history slots a migrating atom needs (max over ranks of max_neigh_used) and, above
   // them, whether any rank has an atom outside its slab: the usual rebuild migrates nothing and skips that round
   const long long crossed = e.migrate_count();
   const double v = slab_allreduce(hc, st, (double)e.max_neigh_used() + (crossed ? 1048576.0 : 0.0), ncclMax);
   const long long vi = (long long)v;
+  lap("allreduce");
   e.migrate_set_slots((int)(vi & 1048575));
   if (vi >> 20) {
     const int rec = e.migrate_record_doubles();
@@ -334,7 +345,9 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
     e.migrate_unpack(hc.rx[0].p, m0);
     e.migrate_unpack(hc.rx[1].p, m1);
   }
+  lap("migration");
   e.rebuild_sort();
+  lap("rebuild_sort");
   const size_t bcap = (size_t)e.nlocal() + 1;
   double* s0 = hc.bor[0].need(bcap * kBorderDoublesC);
   double* s1 = hc.bor[1].need(bcap * kBorderDoublesC);
@@ -343,15 +356,20 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   hc.nsend[0] = a0;
   hc.nsend[1] = a1;
   long long m0 = 0, m1 = 0;
+  lap("border_pack x2");
   slab_exchange(hc, st, s0, a0 * kBorderDoublesC, s1, a1 * kBorderDoublesC, m0, m1);
+  lap("border exchange");
   hc.nrecv[0] = m0 / kBorderDoublesC;
   hc.nrecv[1] = m1 / kBorderDoublesC;
   e.border_unpack(0, hc.rx[0].p, hc.nrecv[0]);
   e.border_unpack(1, hc.rx[1].p, hc.nrecv[1]);
+  lap("border_unpack x2");
   e.rebuild_finish();
+  lap("rebuild_finish (ghosts, list)");
   hc.n_rebuilds++;
   slab_layout(hc, st);
   slab_fused_pack(S, hc);
+  lap("layout + send slots");
   hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
