@@ -2,7 +2,8 @@
 then 60 coupled steps with smoothing on the same engine; prints energy, extrema, rebuild count, finiteness"""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sedifoam_amd import synthetic, enhancedCloud
 import bench
 kw = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
