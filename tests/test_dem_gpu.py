@@ -283,3 +283,22 @@ def test_kernel_variants_agree_with_oracle(env, monkeypatch):
     bed = _bed((5, 5, 5), periodic=True, seed=11, poly=(0.85e-3, 1.0e-3), spacing=0.95)
     _run_case(bed, dict(BASE, skin=0.2e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
                         lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)), steps=(1, 30))
+
+
+def test_queueing_up_to_the_predicted_rebuild_changes_nothing(monkeypatch):
+    """Sub-steps are queued up to where the next rebuild is expected instead of to the end of the run
+    (RebuildPredictor): which sub-step triggers is still decided on the device, so a hot bed that rebuilds every few
+    sub-steps must end in bitwise the same state with the prediction on and off, after the same number of rebuilds."""
+    bed = _bed((6, 6, 6), periodic=True, seed=5, vmax=0.8)
+    cfg = dict(BASE, skin=0.04e-3, walls=_walls(bed))
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("SF_QUEUE_PREDICT", on)
+        lmp = dc.make_hip(bed, cfg)
+        lmp.setup()
+        for n in (60, 35, 60):
+            lmp.step(n)
+        outs.append((lmp.get_state(), lmp.info().nbuilds))
+    assert outs[0][1] == outs[1][1] and outs[0][1] >= 6
+    for k in ("x", "v", "omega", "f", "torque"):
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
