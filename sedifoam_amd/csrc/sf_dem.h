@@ -332,6 +332,8 @@ class DemEngine {
 
   // halo (device buffers)
   long long border_pack(int side, double xshift, double* buf, long long max_atoms);
+  void border_pack_both(double xshift0, double* buf0, double xshift1, double* buf1, long long max_atoms, long long* n0,
+                        long long* n1);
   void border_unpack(int side, const double* buf, long long natoms);
   long long forward_pack(int side, double xshift, double* buf);
   void forward_unpack(int side, const double* buf, long long natoms);

@@ -219,6 +219,38 @@ long long DemEngine::border_pack(int side, double xshift, double* buf, long long
   return n;
 }
 
+// both faces with ONE host read of the two counts (the per-side call above synchronises once per side)
+void DemEngine::border_pack_both(double xshift0, double* buf0, double xshift1, double* buf1, long long max_atoms,
+                                 long long* n0, long long* n1)
+{
+  *n0 = *n1 = 0;
+  nsend_[0] = nsend_[1] = 0;
+  if (!nlocal_) return;
+  const double cut = cutneighmax();
+  const double bound[2] = {sublo_x_ + cut, subhi_x_ - cut};
+  for (int side = 0; side < 2; side++) {
+    k_select_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, side, bound[side],
+                                                           keys_.as<unsigned>());
+    select_zero_keys(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), sendlist_[side].as<int>(),
+                     d_flags_ + (side ? F_SEND_COUNT2 : F_SEND_COUNT), nlocal_, stream_);
+  }
+  read_flags();
+  const int n[2] = {h_flags_[F_SEND_COUNT], h_flags_[F_SEND_COUNT2]};
+  double* const buf[2] = {buf0, buf1};
+  const double shift[2] = {xshift0, xshift1};
+  for (int side = 0; side < 2; side++) {
+    if (n[side] > max_atoms) fail("border_pack: %d atoms do not fit the %lld-atom buffer", n[side], max_atoms);
+    nsend_[side] = n[side];
+    if (n[side])
+      k_border_pack<<<div_up(n[side], 256), 256, 0, stream_>>>(sendlist_[side].as<int>(), n[side], shift[side],
+                                                               xr_[cur_].as<double4>(), vm_[cur_].as<double4>(),
+                                                               om_[cur_].as<double4>(), tag_.as<int>(), type_.as<int>(),
+                                                               mask_.as<int>(), buf[side]);
+  }
+  *n0 = n[0];
+  *n1 = n[1];
+}
+
 void DemEngine::border_unpack(int side, const double* buf, long long natoms)
 {
   if (side < 0 || side > 1) fail("border_unpack: side must be 0 or 1");

@@ -116,6 +116,7 @@ struct HaloComm {
   double* d_red = nullptr;                   // [2] all-reduce scratch
   double* h_red = nullptr;
   int* d_hdr = nullptr;                      // [2 * world] header offsets: send, receive
+  int* h_hdr = nullptr;                      // pinned twin
   std::vector<long long> send_off, send_cnt, recv_off, recv_cnt;
   sf_halo_layout lay{};
   bool lay_valid = false;
@@ -151,6 +152,7 @@ struct HaloComm {
     if (d_red) (void)hipFree(d_red);
     if (h_red) (void)hipHostFree(h_red);
     if (d_hdr) (void)hipFree(d_hdr);
+    if (h_hdr) (void)hipHostFree(h_hdr);
   }
   // rx[chunk p] <- what rank p put into its chunk for this rank (an all-to-all with per-peer counts)
   void all_to_all(const sf_halo_layout& L, hipStream_t st)
@@ -191,6 +193,7 @@ static void slab_scratch(HaloComm& hc)
   SF_HIP(hipMalloc(&hc.d_red, sizeof(double) * 2));
   SF_HIP(hipHostMalloc(&hc.h_red, sizeof(double) * 2));
   SF_HIP(hipMalloc(&hc.d_hdr, sizeof(int) * 2 * hc.world));
+  SF_HIP(hipHostMalloc(&hc.h_hdr, sizeof(int) * 2 * hc.world));
 }
 
 // one value reduced over the ranks (rebuild / setup time only: synchronises)
@@ -286,13 +289,13 @@ static void slab_layout(HaloComm& hc, hipStream_t st)
   L.send_cnt = hc.send_cnt.data();
   L.recv_off = hc.recv_off.data();
   L.recv_cnt = hc.recv_cnt.data();
-  std::vector<int> hdr(2 * W);
+  // (h_hdr is pinned and stays: the copy may read it after this function has returned; the stream is synchronised
+  // long before the next layout overwrites it)
   for (int p = 0; p < W; p++) {
-    hdr[p] = (int)hc.send_off[p];
-    hdr[W + p] = (int)hc.recv_off[p];
+    hc.h_hdr[p] = (int)hc.send_off[p];
+    hc.h_hdr[W + p] = (int)hc.recv_off[p];
   }
-  SF_HIP(hipMemcpyAsync(hc.d_hdr, hdr.data(), sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
-  SF_HIP(hipStreamSynchronize(st));   // (hdr is a local)
+  SF_HIP(hipMemcpyAsync(hc.d_hdr, hc.h_hdr, sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
   L.dev_shdr = hc.d_hdr;
   L.dev_rhdr = hc.d_hdr + W;
   L.dev_tx = hc.a2a_tx.need((size_t)(ntx + scratch) + 1);
@@ -351,8 +354,8 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   const size_t bcap = (size_t)e.nlocal() + 1;
   double* s0 = hc.bor[0].need(bcap * kBorderDoublesC);
   double* s1 = hc.bor[1].need(bcap * kBorderDoublesC);
-  const long long a0 = e.border_pack(0, hc.shift_left, s0, (long long)bcap);
-  const long long a1 = e.border_pack(1, hc.shift_right, s1, (long long)bcap);
+  long long a0 = 0, a1 = 0;
+  e.border_pack_both(hc.shift_left, s0, hc.shift_right, s1, (long long)bcap, &a0, &a1);
   hc.nsend[0] = a0;
   hc.nsend[1] = a1;
   long long m0 = 0, m1 = 0;
