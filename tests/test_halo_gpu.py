@@ -80,8 +80,17 @@ def _c5_case():
     return bed, cfg
 
 
+def _walled_x(bed, cfg):
+    """the same bed between two walls in x instead of periodic: the end slabs have no neighbour on one side"""
+    bed["periodic"] = (0, 0, 1)
+    bed["x"][:, 0] += 0.3e-3
+    bed["boxhi"][0] += 0.6e-3
+    cfg["walls"] = list(cfg["walls"]) + [(0, float(bed["boxlo"][0]), float(bed["boxhi"][0]))]
+    return bed, cfg
+
+
 def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="hertz", transport="host", rccl_lib=None,
-                     ncells=(8, 5, 5)):
+                     ncells=(8, 5, 5), periodic_x=True):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if rccl_lib:
@@ -101,9 +110,11 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
         bed = T._bed(tuple(ncells), periodic=True, seed=41, vmax=0.5)
         cfg = dict(T.BASE, skin=0.05e-3)
         cfg["walls"] = T._walls(bed)
+    if not periodic_x:
+        bed, cfg = _walled_x(bed, cfg)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
     lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport=transport,
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=periodic_x, transport=transport,
                      overlap=overlap)
     assert drv.overlap == overlap and drv.transport == transport
     drv.setup()
@@ -173,13 +184,16 @@ def _standin_rccl(tmp_path):
     return lib
 
 
-@pytest.mark.parametrize("world,ncells,physics,overlap", [(2, (8, 5, 5), "hertz", False), (3, (9, 5, 5), "hertz", False),
-                                                          (2, (8, 5, 5), "c5", False), (2, (8, 5, 5), "hertz", True),
-                                                          (3, (9, 5, 5), "hertz", True)])
-def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, overlap):
+@pytest.mark.parametrize("world,ncells,physics,overlap,periodic_x",
+                         [(2, (8, 5, 5), "hertz", False, True), (3, (9, 5, 5), "hertz", False, True),
+                          (2, (8, 5, 5), "c5", False, True), (2, (8, 5, 5), "hertz", True, True),
+                          (3, (9, 5, 5), "hertz", True, True), (2, (8, 5, 5), "hertz", False, False),
+                          (3, (9, 5, 5), "hertz", False, False)])
+def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, overlap, periodic_x):
     """The C++ driver of a decomposed run (sf_slab_*: size pre-exchange + migration, border exchange, the forward halo
     written by the sub-step kernel with the rebuild vote in its headers, the setup all-reduces) on 2 and 3 ranks --
-    left and right neighbour the same rank, and different ranks -- against the single-domain run.  The ranks share the
+    left and right neighbour the same rank, and different ranks; periodic in x, or between two x walls (the end slabs
+    then have a face without a neighbour) -- against the single-domain run.  The ranks share the
     one GPU of the box; only the wire is a stand-in (tests/c_abi/standin_rccl.cpp, NCCL's grouped point-to-point
     semantics through host shared memory), every line of the driver and every kernel is the product's."""
     import socket
@@ -192,6 +206,8 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
         bed = T._bed(ncells, periodic=True, seed=41, vmax=0.5)
         cfg = dict(T.BASE, skin=0.05e-3)
         cfg["walls"] = T._walls(bed)
+    if not periodic_x:
+        bed, cfg = _walled_x(bed, cfg)
     ref = dc.make_hip(bed, cfg)
     ref.setup()
     for n in steps:
@@ -200,8 +216,8 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
     assert ref.info().nbuilds >= 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path)
-    mp.spawn(_two_rank_worker, args=(world, port, out, steps, overlap, physics, "rccl", lib, ncells), nprocs=world,
-             join=True)
+    mp.spawn(_two_rank_worker, args=(world, port, out, steps, overlap, physics, "rccl", lib, ncells, periodic_x),
+             nprocs=world, join=True)
     parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
     tag = np.concatenate([p["tag"] for p in parts])
     assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
@@ -212,7 +228,8 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
         got = np.concatenate([p[k] for p in parts])[order]
         want = a[k][oa].copy()
         if k == "x":
-            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            if periodic_x:
+                got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
             assert np.max(np.abs(got - want)) <= 1e-12
         else:
             assert dc.rel_err(got, want) <= 1e-9, k
