@@ -188,7 +188,7 @@ def _standin_rccl(tmp_path):
                          [(2, (8, 5, 5), "hertz", False, True), (3, (9, 5, 5), "hertz", False, True),
                           (2, (8, 5, 5), "c5", False, True), (2, (8, 5, 5), "hertz", True, True),
                           (3, (9, 5, 5), "hertz", True, True), (2, (8, 5, 5), "hertz", False, False),
-                          (3, (9, 5, 5), "hertz", False, False)])
+                          (3, (9, 5, 5), "hertz", False, False), (4, (16, 6, 6), "hertz", False, True)])
 def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, overlap, periodic_x):
     """The C++ driver of a decomposed run (sf_slab_*: size pre-exchange + migration, border exchange, the forward halo
     written by the sub-step kernel with the rebuild vote in its headers, the setup all-reduces) on 2 and 3 ranks --
