@@ -241,12 +241,9 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
     assert set(hb) == set(ha)
 
 
-@pytest.mark.parametrize("world,ncx", [(2, 8), (3, 9)])
-def test_mpi_cxx_host_drives_the_slabs_through_the_c_abi(tmp_path, world, ncx):
-    """lammpsFoam's side of a decomposed run, stood in for by tests/c_abi/mpi_slab_host.cpp: an MPI program in C++ (the
-    image's MPICH) that opens one engine per rank, hands over the script lines and its slab's atoms, broadcasts the
-    communicator id with MPI_Bcast and then only calls sf_slab_init / setup / step -- no Python, no torch in the loop.
-    Rank 0 runs the whole bed on a second engine and compares (positions 1e-12, velocities 1e-9, >= 3 rebuilds)."""
+def _build_mpi_host(tmp_path, name):
+    """g++ against the image's MPICH (conda's lib directory also holds an older libstdc++: the system one must come
+    first on the run path); returns (mpirun, executable) or skips"""
     import shutil
     import subprocess
     mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
@@ -255,16 +252,41 @@ def test_mpi_cxx_host_drives_the_slabs_through_the_c_abi(tmp_path, world, ncx):
         pytest.skip("no MPI in this image")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libdir = os.path.join(root, "sedifoam_amd")
-    exe = str(tmp_path / "mpi_slab_host")
-    # (conda's lib directory also holds an older libstdc++: the system one must come first on the run path)
+    exe = str(tmp_path / name)
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
-                        "-I", "/opt/conda/include", os.path.join(root, "tests", "c_abi", "mpi_slab_host.cpp"), "-o", exe,
+                        "-I", os.path.join(root, "tests", "c_abi"), "-I", "/opt/conda/include",
+                        os.path.join(root, "tests", "c_abi", name + ".cpp"), "-o", exe,
                         "-L", libdir, "-lsedifoam_amd", "-Wl,-rpath," + libdir, libmpi,
                         "-Wl,-rpath,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,/opt/conda/lib", "-lm"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
+    return mpirun, exe
+
+
+@pytest.mark.parametrize("world,ncx", [(2, 8), (3, 9)])
+def test_mpi_cxx_host_drives_the_slabs_through_the_c_abi(tmp_path, world, ncx):
+    """lammpsFoam's side of a decomposed run, stood in for by tests/c_abi/mpi_slab_host.cpp: an MPI program in C++ (the
+    image's MPICH) that opens one engine per rank, hands over the script lines and its slab's atoms, broadcasts the
+    communicator id with MPI_Bcast and then only calls sf_slab_init / setup / step -- no Python, no torch in the loop.
+    Rank 0 runs the whole bed on a second engine and compares (positions 1e-12, velocities 1e-9, >= 3 rebuilds)."""
+    import subprocess
+    mpirun, exe = _build_mpi_host(tmp_path, "mpi_slab_host")
     env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path))
     r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "50"], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0 and "OK ranks %d" % world in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("world,ncx", [(2, 8), (3, 9)])
+def test_mpi_cxx_host_runs_the_coupled_step_on_slabs(tmp_path, world, ncx):
+    """The coupled CFD-DEM step of a decomposed case from the same kind of host (tests/c_abi/mpi_cloud_host.cpp):
+    sf_cloud_phase pieces, sf_slab_step for the DEM sub-steps, MPI_Allreduce of the per-cell sums of gamma, Ue and Asrc
+    -- ErgunWenYu drag, pressure gradient, buoyancy, added mass and the Basset history force (whose per-particle state
+    migrates with the grains), diffusion smoothing -- against sf_cloud_evolve / sf_cloud_calc_tc_fields on one engine."""
+    import subprocess
+    mpirun, exe = _build_mpi_host(tmp_path, "mpi_cloud_host")
+    env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path))
+    r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "3"], capture_output=True, text=True, timeout=600,
                        env=env)
     assert r.returncode == 0 and "OK ranks %d" % world in r.stdout, r.stdout + r.stderr
 
