@@ -20,6 +20,9 @@ using namespace LAMMPS_NS;
 int main(int argc, char** argv)
 {
   const char* script = argc > 1 ? argv[1] : "in.lammps";
+#ifdef SHIM_DRIVER_REAL_MPI   // built against a real MPI library (the image's MPICH) instead of the stand-in headers
+  MPI_Init(&argc, &argv);
+#endif
   MPI_Comm commLammps;
   MPI_Comm_dup(MPI_COMM_WORLD, &commLammps);
   LAMMPS* lmp = new LAMMPS(0, NULL, commLammps);
@@ -94,6 +97,9 @@ int main(int argc, char** argv)
   lammps_step(lmp, 5);
 
   delete lmp;   // finishLammps, :357
+#ifdef SHIM_DRIVER_REAL_MPI
+  MPI_Finalize();
+#endif
   std::printf("OK %d %.12g %.12g %d\n", n, y0, y1, nAfter);
   return 0;
 }

@@ -72,6 +72,28 @@ def test_lammps_object_shim_compiles_for_both_mpi_abis(tmp_path, std, mpi_flavou
     _build_shim(tmp_path, std, mpi_flavour)
 
 
+def _build_shim_real_mpich(tmp_path):
+    """the same driver against the image's real MPICH (mpi.h + libmpi of /opt/conda) instead of a stand-in header"""
+    if not (os.path.exists("/opt/conda/include/mpi.h") and os.path.exists("/opt/conda/lib/libmpi.so")):
+        pytest.skip("no MPICH in this image")
+    exe = str(tmp_path / "shim_real_mpich")
+    cmd = ["g++", "-std=c++98", "-O1", "-Wall", "-Werror", "-Wno-unused-variable", "-Wno-long-long",
+           "-DSHIM_DRIVER_REAL_MPI", "-I", "/opt/conda/include",
+           "-I", os.path.join(ROOT, "include", "lammps_shim"), "-I", os.path.join(ROOT, "include"), SHIM_SRC, "-o", exe,
+           "-L", LIBDIR, "-lsedifoam_amd", "-Wl,-rpath," + LIBDIR, "/opt/conda/lib/libmpi.so",
+           "-Wl,-rpath,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,/opt/conda/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_lammps_object_shim_compiles_against_a_real_mpi(tmp_path):
+    """MPICH 3.3 of the image: MPI_Comm is its real int handle, mpi.h its real header (C++98, as OpenFOAM 2.3 builds)"""
+    if not os.path.exists(os.path.join(LIBDIR, "libsedifoam_amd.so")):
+        pytest.skip("library not built")
+    _build_shim_real_mpich(tmp_path)
+
+
 def _bed_script(tmp_path):
     d = 5.0e-4
     pts = [(0.5 * d + ix * 1.02 * d, 0.5 * d + iy * 1.02 * d, 0.5 * d + iz * 1.02 * d)
@@ -104,6 +126,17 @@ def test_lammps_object_shim_runs_the_call_sequence_of_soft_particle_cloud(tmp_pa
     assert tok[0] == "OK" and int(tok[1]) == n
     assert float(tok[3]) > float(tok[2])          # net upward force 2 m g - m g: the bed rises
     assert int(tok[4]) == n + 1 - 2               # one particle created, two deleted
+
+
+@pytest.mark.gpu
+def test_lammps_object_shim_runs_on_the_real_mpich(tmp_path):
+    """the same call sequence with MPI_Init / MPI_Comm_dup / MPI_Finalize of a real MPI library (singleton start)"""
+    script, n = _bed_script(tmp_path)
+    exe = _build_shim_real_mpich(tmp_path)
+    r = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tok = r.stdout.strip().split()
+    assert tok[0] == "OK" and int(tok[1]) == n and int(tok[4]) == n + 1 - 2
 
 
 @pytest.mark.gpu
