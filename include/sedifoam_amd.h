@@ -343,6 +343,16 @@ typedef struct {
   int UfSmooth, UpSmooth, dragSmooth, alphaSmooth;
   double smoothDirection[3];
   int particleHistoryForce;   /* reduced-order Basset history force, enhancedCloud.C:197-233 */
+  /* the inlet override of updateDragOnParticles (enhancedCloud.C:249-257; keys read at :600-608 and
+   * softParticleCloud.C:460-486): with addParticleOption 1 (box) or 2 (hollow cylinder) and a non-zero inletForce, a
+   * particle inside inletBox gets pDrag = m (inletForce - U) / deltaT instead of the assembled force.  inletBox holds
+   * the tensor's nine components x1 x2 y1 y2 z1 z2 r1 r2 (unused) as pointInRegion reads them
+   * (softParticleCloud.C:1354-1417); eccentricity shifts the inner cylinder.  The add / delete schedules that
+   * addParticleOption also switches on in the reference are not part of this library. */
+  int addParticleOption;
+  double inletForce[3];
+  double inletBox[9];
+  double eccentricity[3];
 } sf_cloud_props;
 /* uniform hex block mesh (blockMeshDict: hex (...) (nx ny nz) simpleGrading (1 1 1)) */
 typedef struct {

@@ -160,6 +160,8 @@ def _declare(L):
     L.orc_no_correction_jd.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
     L.orc_cell_owner.argtypes = [C.c_int, dp, dp, dp, ip, ip]
     L.orc_cell_owner_graded.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(dp), ip]
+    L.orc_inlet_force_override.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_int, dp, dp, dp, dp]
+    L.orc_inlet_force_override.restype = None
     L.orc_drag_on_particles.argtypes = [C.POINTER(CloudFlags), C.c_int, C.c_int, ip] + [dp] * 14
     L.orc_drag_on_particles_hist.argtypes = ([C.POINTER(CloudFlags), C.c_int, C.c_int, ip] + [dp] * 9 + [C.c_int] +
                                              [dp] * 3 + [dp] * 5)

@@ -254,6 +254,46 @@ void orc_drag_on_particles_hist(const orc_cloud_flags *fl, int dragModel, int n,
   }
 }
 
+/* softParticleCloud::pointInRegion  softParticleCloud.C:1354-1417 (box = the tensor's components 0..7) */
+static int point_in_region(int option, const double *b, const double *ecc, const double *pt)
+{
+  double x1 = b[0], x2 = b[1], y1 = b[2], y2 = b[3], z1 = b[4], z2 = b[5], r1 = b[6], r2 = b[7];
+  if (option == 1) {
+    if ((pt[0] - x1) * (pt[0] - x2) < ROOTVSMALL && (pt[1] - y1) * (pt[1] - y2) < ROOTVSMALL &&
+        (pt[2] - z1) * (pt[2] - z2) < ROOTVSMALL)
+      return 1;
+    return 0;
+  } else if (option == 2) {
+    double p2p1[3] = {x2 - x1, y2 - y1, z2 - z1};
+    double h = sqrt(p2p1[0] * p2p1[0] + p2p1[1] * p2p1[1] + p2p1[2] * p2p1[2]);
+    double pxp1[3] = {pt[0] - x1, pt[1] - y1, pt[2] - z1};
+    double dot = p2p1[0] * pxp1[0] + p2p1[1] * pxp1[1] + p2p1[2] * pxp1[2];
+    double pxp1E[3] = {pxp1[0] - ecc[0], pxp1[1] - ecc[1], pxp1[2] - ecc[2]};
+    if (dot < 0.0 || dot > pow(h, 2)) return 0;
+    {
+      double dsq = (pxp1[0] * pxp1[0] + pxp1[1] * pxp1[1] + pxp1[2] * pxp1[2]) - dot * dot / pow(h, 2);
+      double dsqE = (pxp1E[0] * pxp1E[0] + pxp1E[1] * pxp1E[1] + pxp1E[2] * pxp1E[2]) - dot * dot / pow(h, 2);
+      if (dsqE > r1 * r1 && dsq < r2 * r2) return 1;
+      return 0;
+    }
+  }
+  return 0;
+}
+
+/* the inlet override at the end of the particle loop of updateDragOnParticles, enhancedCloud.C:249-257:
+ * inletForceRatio_ is zero unless addParticleOption_ > 0 (:600-608); mass = softParticle::m() */
+void orc_inlet_force_override(int addParticleOption, const double inletForce[3], const double inletBox[9],
+                              const double eccentricity[3], double deltaT, int n, const double *pos,
+                              const double *mass, const double *U, double *pDrag)
+{
+  int i, k;
+  double magF = sqrt(inletForce[0] * inletForce[0] + inletForce[1] * inletForce[1] + inletForce[2] * inletForce[2]);
+  if (addParticleOption <= 0 || !(magF > 0)) return;
+  for (i = 0; i < n; i++)
+    if (point_in_region(addParticleOption, inletBox, eccentricity, pos + 3 * i))
+      for (k = 0; k < 3; k++) pDrag[3 * i + k] = mass[i] * (inletForce[k] - U[3 * i + k]) / deltaT;
+}
+
 void orc_particle_to_eulerian(int n, const int *cell, const double *d, const double *U,
                               int ncells, const double *V, double *gamma, double *Ue)
 {

@@ -239,6 +239,11 @@ void orc_drag_on_particles(const orc_cloud_flags *fl, int dragModel, int n, cons
                            const double *gradp, const double *DDtUf, const double *curlU,
                            double *Uri, double *magUri, double *Jd, double *pDrag,
                            double *pDuDt);
+/* the inlet override that closes the particle loop of updateDragOnParticles (enhancedCloud.C:249-257) with
+ * softParticleCloud::pointInRegion (softParticleCloud.C:1354-1417): applied to pDrag [n][3] after the assembly above */
+void orc_inlet_force_override(int addParticleOption, const double inletForce[3], const double inletBox[9],
+                              const double eccentricity[3], double deltaT, int n, const double *pos,
+                              const double *mass, const double *U, double *pDrag);
 void orc_drag_on_particles_hist(const orc_cloud_flags *fl, int dragModel, int n, const int *cell,
                                 const double *pos, const double *d, const double *U,
                                 const double *UOld, const double *gamma, const double *UfSmoothed,

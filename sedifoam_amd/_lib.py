@@ -64,7 +64,9 @@ class CloudProps(C.Structure):
                 ("rhob", C.c_double), ("nub", C.c_double), ("maxPossibleAlpha", C.c_double),
                 ("diffusionBandWidth", C.c_double), ("diffusionSteps", C.c_int), ("UfSmooth", C.c_int),
                 ("UpSmooth", C.c_int), ("dragSmooth", C.c_int), ("alphaSmooth", C.c_int),
-                ("smoothDirection", C.c_double * 3), ("particleHistoryForce", C.c_int)]
+                ("smoothDirection", C.c_double * 3), ("particleHistoryForce", C.c_int),
+                ("addParticleOption", C.c_int), ("inletForce", C.c_double * 3), ("inletBox", C.c_double * 9),
+                ("eccentricity", C.c_double * 3)]
 
 
 class CloudMesh(C.Structure):

@@ -59,7 +59,8 @@ class enhancedCloud:
     """enhancedCloud(U, p, Ue, Uf, DDtUf, nu, alpha, cloudDict, transDict, ...) on a uniform hex block.
 
     cloudDict keys (constant/cloudProperties): dragModel, subCycles, particleDrag, particlePressureGrad,
-    particleBuoyancy, particleAddedMass, particleLift, particleHistoryForce, lubricationForce, g, maxPossibleAlpha, diffusionBandWidth,
+    particleBuoyancy, particleAddedMass, particleLift, particleHistoryForce, lubricationForce, addParticleOption +
+    inletForce + inletBox + eccentricity (the inlet override only), g, maxPossibleAlpha, diffusionBandWidth,
     diffusionSteps, UfSmooth, UpSmooth, dragSmooth, alphaSmooth, smoothDirection.
     transDict keys (constant/transportProperties): rhob, nub."""
 
@@ -96,6 +97,12 @@ class enhancedCloud:
         pr.particleLift = int(cloudDict.get("particleLift", False))                   # :593
         pr.lubricationForce = int(cloudDict.get("lubricationForce", False))           # :597
         pr.particleHistoryForce = int(cloudDict.get("particleHistoryForce", False))   # :595-596
+        # the inlet override of updateDragOnParticles (:249-257): addParticleOption 1 | 2, inletForce, inletBox (the
+        # tensor's nine numbers), eccentricity -- softParticleCloud.C:460-486; the add / delete schedules are not built
+        pr.addParticleOption = int(cloudDict.get("addParticleOption", 0))
+        pr.inletForce = (C.c_double * 3)(*cloudDict.get("inletForce", (0.0, 0.0, 0.0)))
+        pr.inletBox = (C.c_double * 9)(*cloudDict.get("inletBox", (0.0,) * 9))
+        pr.eccentricity = (C.c_double * 3)(*cloudDict.get("eccentricity", (0.0, 0.0, 0.0)))
         g = cloudDict.get("g", (0.0, 0.0, 0.0))
         pr.gravity = (C.c_double * 3)(*g)
         pr.rhob = float(transDict["rhob"])

@@ -133,7 +133,31 @@ struct CloudFlagsDev {
   int dragModel, particleDrag, particlePressureGrad, particleBuoyancy, particleAddedMass, particleLift,
       lubricationForce;
   double g[3], rhob, nub, deltaT;
+  int inletOption;   // 0: no inlet override ; 1 box ; 2 hollow cylinder (addParticleOption with a non-zero inletForce)
+  double inletForce[3], inletBox[9], ecc[3];
 };
+
+// softParticleCloud::pointInRegion  softParticleCloud.C:1354-1417 (option 1: box, faces included; option 2: between the
+// cylinders r1 -- shifted by the eccentricity -- and r2 around the axis (x1,y1,z1)-(x2,y2,z2); as there, the inner
+// distance uses the projection of the UNshifted point)
+__device__ __forceinline__ bool point_in_region(int option, const double* b, const double* ecc, double px, double py,
+                                                double pz)
+{
+  const double x1 = b[0], x2 = b[1], y1 = b[2], y2 = b[3], z1 = b[4], z2 = b[5], r1 = b[6], r2 = b[7];
+  if (option == 1)
+    return (px - x1) * (px - x2) < kRootVSmall && (py - y1) * (py - y2) < kRootVSmall && (pz - z1) * (pz - z2) < kRootVSmall;
+  if (option == 2) {
+    const double a[3] = {x2 - x1, y2 - y1, z2 - z1}, q[3] = {px - x1, py - y1, pz - z1};
+    const double h = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const double dot = a[0] * q[0] + a[1] * q[1] + a[2] * q[2];
+    if (dot < 0.0 || dot > pow(h, 2)) return false;
+    const double qe[3] = {q[0] - ecc[0], q[1] - ecc[1], q[2] - ecc[2]};
+    const double dsq = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - dot * dot / pow(h, 2);
+    const double dsqE = (qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]) - dot * dot / pow(h, 2);
+    return dsqE > r1 * r1 && dsq < r2 * r2;
+  }
+  return false;
+}
 
 // updateParticleUr + updateParticleAlpha + Jd + updateDragOnParticles, one owned atom per lane.
 // pDrag goes straight into fix fdrag's [3][cap] array (what lammps_put_local_info would copy).
@@ -240,6 +264,9 @@ __global__ __launch_bounds__(256) void k_drag_on_particles(
       if (distWall < distMax && distWall > distMin)
         F[1] += 6 * 3.1416 * fl.nub * fl.rhob * (-U[1]) / distWall * (d * d) / 4.0 * 1.0;
     }
+    // inlet: the assembled force is replaced by what brings the particle to inletForce within one time step (:249-257)
+    if (fl.inletOption && point_in_region(fl.inletOption, fl.inletBox, fl.ecc, x.x, x.y, x.z))
+      for (int k = 0; k < 3; k++) F[k] = v.w * (fl.inletForce[k] - U[k]) / fl.deltaT;
   }
   for (int k = 0; k < 3; k++) fdrag[(size_t)k * cap + i] = F[k];
   // diagnostics kept by tag (the DEM engine may re-sort its atoms at any neighbour rebuild)
@@ -933,6 +960,15 @@ class Cloud {
     f.rhob = props_.rhob;
     f.nub = props_.nub;
     f.deltaT = deltaT_;
+    // enhancedCloud.C:600-608: inletForce is only read with addParticleOption > 0; :249 mag(inletForceRatio_) > 0
+    const double* iF = props_.inletForce;
+    const bool on = props_.addParticleOption > 0 && (iF[0] != 0.0 || iF[1] != 0.0 || iF[2] != 0.0);
+    f.inletOption = on ? props_.addParticleOption : 0;
+    for (int k = 0; k < 3; k++) {
+      f.inletForce[k] = iF[k];
+      f.ecc[k] = props_.eccentricity[k];
+    }
+    for (int k = 0; k < 9; k++) f.inletBox[k] = props_.inletBox[k];
     return f;
   }
 

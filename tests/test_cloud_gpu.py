@@ -70,7 +70,7 @@ def test_cell_owner_bit_exact_1m():
 
 
 def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=50e-6, bed=None, mesh_n=(4, 5, 4),
-                  walls=None, cfg_extra=None):
+                  walls=None, cfg_extra=None, inlet=None):
     """Coupled cloud + DEM, HIP vs oracle.  Default: a 1 792-grain bed on a 4x5x4 mesh (the small case every force
     switch runs on); BASELINE configs C2 (10 k grains, 32^3 mesh) and C3 (100 k grains, 50 sub-steps per CFD step)
     pass their own bed / mesh."""
@@ -92,6 +92,8 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
     gradp = np.tile([0.0, -9810.0, 0.0], (ncells, 1)) + rng.normal(scale=50.0, size=(ncells, 3))
     curlU = rng.normal(scale=5.0, size=(ncells, 3))
     cloudDict = dict(dragModel=drag_name, subCycles=sub_cycles, g=(0.0, -9.81, 0.0), maxPossibleAlpha=0.65, **flags)
+    if inlet:   # dict(addParticleOption, inletForce, inletBox[, eccentricity]): the inlet override of the drag assembly
+        cloudDict.update(inlet)
     sm = None
     if smooth:
         cloudDict.update(smooth)
@@ -148,6 +150,7 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
     dmodel = 0 if drag_name == "ErgunWenYu" else 1
     Uri = np.zeros((n, 3)); mag = np.zeros(n); Jd = np.zeros(n); pDrag = np.zeros((n, 3)); pDuDt = np.zeros((n, 3))
     UOld = st["v"].copy()
+    ninside = [0]
     for it in range(n_cfd):
         cloud.evolve()
         UfS_old = UfS.copy()                                                  # UfSmoothed_.oldTime()
@@ -158,6 +161,14 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
                                          ob.P(UOld), ob.P(gamma), ob.P(UfS), ob.P(gradp), ob.P(DDtUf), ob.P(curlU),
                                          (it + 1) if hist else -1, ob.P(UfS_old), ob.P(sumFb), ob.P(n0),
                                          ob.P(Uri), ob.P(mag), ob.P(Jd), ob.P(pDrag), ob.P(pDuDt))
+            if inlet:
+                mass = np.pi / 6.0 * d ** 3 * bed["density"]
+                before = pDrag.copy()
+                L.orc_inlet_force_override(int(inlet["addParticleOption"]), ob.P(np.array(inlet["inletForce"], float)),
+                                           ob.P(np.array(inlet["inletBox"], float)),
+                                           ob.P(np.array(inlet.get("eccentricity", (0.0, 0.0, 0.0)), float)), deltaT, n,
+                                           ob.P(st["x"]), ob.P(mass), ob.P(st["v"]), ob.P(pDrag))
+                ninside[0] = int(np.any(before != pDrag, axis=1).sum())
             cell_before, pDrag_before, Jd_before = cell.copy(), pDrag.copy(), Jd.copy()
             orc.put_fdrag(pDrag, st["tag"])
             orc.run(ss.value)
@@ -197,7 +208,27 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
                                 ob.P(UfS), smp, ob.P(Asrc), ob.P(Omega))
     assert dc.rel_err(cloud.Asrc(), Asrc) <= max(tol_s, 1e-11)
     assert np.all(cloud.Omega() == 0.0) and np.all(Omega == 0.0)     # enhancedCloud.C:391
+    if inlet:
+        assert 0 < ninside[0] < n     # some particles are driven by the inlet, most are not
     return cloud
+
+
+@pytest.mark.parametrize("option", [1, 2])
+def test_inlet_force_override_box_and_hollow_cylinder(option):
+    """updateDragOnParticles' inlet override (enhancedCloud.C:249-257): inside inletBox -- a box, or the space between
+    two cylinders, the inner one shifted by the eccentricity (softParticleCloud::pointInRegion) -- a particle's force is
+    replaced by m (inletForce - U) / deltaT.  HIP against the oracle through sub-cycled coupled steps."""
+    from sedifoam_amd import synthetic
+    bed = synthetic.fcc_bed((8, 7, 8), seed=21, vmax=0.05)
+    lo, hi = bed["boxlo"], bed["boxhi"]
+    if option == 1:      # the upstream quarter of the bed in x, its lower half in y
+        box = (lo[0], lo[0] + 0.25 * (hi[0] - lo[0]), lo[1], lo[1] + 0.3 * (hi[1] - lo[1]), lo[2], hi[2], 0.0, 0.0, 0.0)
+        inlet = dict(addParticleOption=1, inletForce=(0.02, 0.0, 0.0), inletBox=box)
+    else:                # a hollow cylinder along z through the middle of the bed
+        cx, cy = 0.5 * (lo[0] + hi[0]), lo[1] + 0.3 * (hi[1] - lo[1])
+        box = (cx, cx, cy, cy, lo[2], hi[2], 1.0e-3, 3.5e-3, 0.0)
+        inlet = dict(addParticleOption=2, inletForce=(0.0, 0.03, 0.01), inletBox=box, eccentricity=(2.0e-4, -1.0e-4, 0.0))
+    _coupled_case("ErgunWenYu", dict(particleBuoyancy=True), sub_cycles=2, n_cfd=2, bed=bed, inlet=inlet)
 
 
 @pytest.mark.parametrize("mesh_n", [(1, 2, 2), (2, 2, 2), (12, 12, 12)])

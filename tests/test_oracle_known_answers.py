@@ -375,3 +375,38 @@ def test_graded_block_cell_owner_and_smoothing():
     one = np.full(int(n.prod()), 3.25)
     L.orc_smooth_field_graded(ob.P(n), ob.P(dx), wp, ob.P(D), 3e-3, 3, 1, ob.P(one))
     assert np.allclose(one, 3.25, rtol=1e-14)
+
+
+def test_inlet_override_known_answers():
+    """enhancedCloud.C:249-257 with softParticleCloud::pointInRegion (:1354-1417): inside the region the force becomes
+    m (inletForce - U) / deltaT, outside it stays; option 1 = box with its faces, option 2 = between two cylinders around
+    the axis (x1,y1,z1)-(x2,y2,z2); off (option 0 or zero inletForce) nothing changes."""
+    import ctypes as C
+    L = ob.lib()
+    pos = np.array([[0.5, 0.5, 0.5], [1.0, 0.2, 0.3], [1.5, 0.5, 0.5], [0.5, 0.5, 2.0]])   # inside, on a face, outside x, outside z
+    U = np.array([[0.1, 0.0, 0.0], [0.0, 0.2, 0.0], [0.0, 0.0, 0.3], [0.1, 0.1, 0.1]])
+    m = np.array([2.0, 3.0, 4.0, 5.0])
+    F = np.array([0.5, -0.25, 0.125]); dT = 1.0e-3
+    box = np.array([0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0]); ecc = np.zeros(3)
+    base = np.arange(12, dtype=float).reshape(4, 3) + 1.0
+    p = base.copy()
+    L.orc_inlet_force_override(1, ob.P(F), ob.P(box), ob.P(ecc), dT, 4, ob.P(pos), ob.P(m), ob.P(U), ob.P(p))
+    for i in (0, 1):
+        assert np.allclose(p[i], m[i] * (F - U[i]) / dT, rtol=1e-15)
+    assert np.array_equal(p[2:], base[2:])
+    for opt, f in ((0, F), (1, np.zeros(3))):     # switched off
+        p = base.copy()
+        L.orc_inlet_force_override(opt, ob.P(f), ob.P(box), ob.P(ecc), dT, 4, ob.P(pos), ob.P(m), ob.P(U), ob.P(p))
+        assert np.array_equal(p, base)
+    # hollow cylinder along z from z = 0 to 1 around (0.5, 0.5): r1 = 0.1, r2 = 0.4
+    cyl = np.array([0.5, 0.5, 0.5, 0.5, 0.0, 1.0, 0.1, 0.4, 0.0])
+    pts = np.array([[0.5, 0.5, 0.5], [0.7, 0.5, 0.5], [0.95, 0.5, 0.5], [0.7, 0.5, 1.2]])   # on the axis, in the shell, beyond r2, beyond the end
+    p = base.copy()
+    L.orc_inlet_force_override(2, ob.P(F), ob.P(cyl), ob.P(ecc), dT, 4, ob.P(pts), ob.P(m), ob.P(U), ob.P(p))
+    assert np.allclose(p[1], m[1] * (F - U[1]) / dT, rtol=1e-15)
+    assert np.array_equal(p[[0, 2, 3]], base[[0, 2, 3]])
+    # the eccentricity shifts the inner cylinder only: with it at (0.2, 0, 0) the point at x = 0.7 sits on its axis
+    p = base.copy()
+    L.orc_inlet_force_override(2, ob.P(F), ob.P(cyl), ob.P(np.array([0.2, 0.0, 0.0])), dT, 4, ob.P(pts), ob.P(m), ob.P(U),
+                               ob.P(p))
+    assert np.array_equal(p[1], base[1]) and not np.array_equal(p[0], base[0])
