@@ -236,12 +236,39 @@ def main():
             exchange_us[0] = float(xt.item()) if xt.item() >= 0 else None
         return el, n_own, launches, kernel_ms, info0, lmp.info()
 
+    fallback_note = [None]
+
+    def make_driver(factory, the_bed):
+        """the C++ driver over RCCL; if it cannot come up on EVERY rank alike (an exception, not a hang), say so loudly
+        and measure the same protocol driven from Python over torch.distributed instead of measuring nothing"""
+        from sedifoam_amd.halo import SlabDriver
+        err = None
+        try:
+            drv = getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport=transport)
+        except Exception as ex:   # noqa: BLE001
+            drv, err = None, ex
+        if dist is not None and world > 1:
+            rdev = "cpu" if args.one_gpu else "cuda"
+            flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64, device=rdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = flag.item() > 0
+        else:
+            failed = err is not None
+        if not failed:
+            return drv
+        if args.one_gpu or transport not in (None, "rccl"):
+            raise err if err is not None else RuntimeError("another rank could not create its halo driver")
+        sys.stderr.write("bench.py: the C++ RCCL halo driver did not come up (%s) -- FALLING BACK to the Python loop over "
+                         "torch.distributed (slower; config.decomposition says so)\n" % (err,))
+        fallback_note[0] = "x-slabs, ghost halo driven from Python over torch.distributed (the C++ RCCL driver failed: %s)" % (err,)
+        return getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport="direct")
+
     strong = None
     if world > 1 and args.scaling in ("both", "strong"):
         # BASELINE config C4: ONE --particles bed, split into `world` x-slabs (strong scaling)
         from sedifoam_amd.halo import SlabDriver
         gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
-        sdrv = SlabDriver.from_global_bed(gbed, script, dist, rank, world, transport=transport)
+        sdrv = make_driver("from_global_bed", gbed)
         el_s, n_s, _l, _k, _i0, _i1 = timed_run(sdrv)
         strong = {"value": n_s * args.substeps * args.steps / el_s, "unit": "particle-substeps/s",
                   "halo_exchange_us_per_substep": exchange_us[0],
@@ -259,7 +286,7 @@ def main():
         pass
     elif world > 1 or args.slab_driver:
         from sedifoam_amd.halo import SlabDriver
-        lmp = SlabDriver.from_bed(bed, script, dist, rank, world, transport=transport)
+        lmp = make_driver("from_bed", bed)
         elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
     else:
         lmp = build_engine(bed, script)
@@ -295,7 +322,7 @@ def main():
             "decomposition": (("x-slabs, C++ driver over a stand-in for librccl through host memory (--one-gpu)"
                                if transport == "rccl" else
                                "x-slabs, ghost halo over gloo through host memory (--one-gpu)") if args.one_gpu else
-                              "x-slabs, ghost halo over RCCL") if world > 1 else
+                              (fallback_note[0] or "x-slabs, C++ driver (sf_slab_*), ghost halo over RCCL")) if world > 1 else
                              ("single slab through the halo driver" if args.slab_driver else "single domain"),
         },
         **({"strong_scaling": strong} if strong else {}),
