@@ -401,9 +401,9 @@ static void slab_step(SfLammps& S, HaloComm& hc, int n)
   }
 }
 
-// queue sub-steps first_k .. n-1 (fused pack, one grouped ncclSend/ncclRecv, fused unpack, kernel; overlapped if
-// sf_dem_set_overlap is on), synchronise once, return the voted rebuild trigger
-// queue sub-steps first_k .. end_k - 1 of a run of n
+// queue sub-steps first_k .. end_k - 1 of a run of n (per sub-step: one grouped ncclSend/ncclRecv, fused unpack, the
+// kernel that also writes the next exchange's records; overlapped if sf_dem_set_overlap is on), synchronise once,
+// return the voted rebuild trigger
 static int halo_run_layout(SfLammps& S, HaloComm& hcr, int first_k, int end_k, int n, const sf_halo_layout& layr)
 {
   HaloComm* hc = &hcr;
