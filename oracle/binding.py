@@ -80,6 +80,7 @@ def _declare(L):
     L.orc_dem_fix_cohesive.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_int]
     L.orc_dem_fix_gravity.argtypes = [C.c_void_p] + [C.c_double] * 4
     L.orc_dem_fix_fdrag.argtypes = [C.c_void_p, C.c_double]
+    L.orc_dem_fix_freeze.argtypes = [C.c_void_p, C.c_int]
     L.orc_dem_fix_wall.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                    C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                    C.c_double, C.c_double, C.c_int]
@@ -238,6 +239,10 @@ class OracleDem:
 
     def fix_fdrag(self, carrier_rho=0.0):
         self.L.orc_dem_fix_fdrag(self.h, carrier_rho)
+
+    def fix_freeze(self, groupbit):
+        """fix freeze at this place of the fix list (the fixes registered later still act on the frozen atoms)"""
+        self.L.orc_dem_fix_freeze(self.h, int(groupbit))
 
     def fix_wall(self, dim, lo, hi, kn, kt, gamman, gammat, xmu, dampflag):
         self.L.orc_dem_fix_wall(self.h, dim, lo is None, lo or 0.0, hi is None, hi or 0.0, kn,

@@ -153,6 +153,16 @@ void orc_dem_fix_gravity(orc_dem *d, double magnitude, double gx, double gy, dou
   fx->gdir[0] = gx; fx->gdir[1] = gy; fx->gdir[2] = gz;
 }
 
+/* [3P] fix freeze at ITS PLACE in the fix list: Modify::post_force runs the fixes in script order, so the fixes
+ * registered after this call still act on the frozen atoms (cases/example-cases/transport-bedload/in.lammps:28-31:
+ * `fix 4 bottom freeze`, then `fix ywall all wall/gran ...`) */
+void orc_dem_fix_freeze(orc_dem *d, int groupbit)
+{
+  orc_fix *fx = new_fix(d, FIX_FREEZE);
+  fx->groupbit = groupbit;
+  d->freeze_bit = groupbit;
+}
+
 void orc_dem_fix_fdrag(orc_dem *d, double carrier_rho)
 {
   orc_fix *fx = new_fix(d, FIX_FDRAG);
@@ -205,7 +215,7 @@ void orc_dem_set_groups(orc_dem *d, int nve_bit, int gravity_bit, int fdrag_bit,
 {
   int w;
   d->nve_bit = nve_bit;
-  d->freeze_bit = freeze_bit;
+  if (freeze_bit || !d->freeze_bit) d->freeze_bit = freeze_bit;   /* (0 keeps what orc_dem_fix_freeze registered) */
   for (w = 0; w < d->nfix; w++) {
     orc_fix *fx = &d->fix[w];
     if (fx->kind == FIX_GRAVITY) fx->groupbit = gravity_bit;
@@ -518,7 +528,7 @@ void orc__compute_forces(orc_dem *d, int setupflag)
     int k;
     for (k = 0; k < d->nfix; k++) d->fix[k].time_origin = d->ntimestep;   /* FixWallGranFix::init, :181 */
   }
-  int nall = d->nlocal + d->nghost, i, w;
+  int nall = d->nlocal + d->nghost, i, w, freeze_in_list = 0;
   int shearupdate = setupflag ? 0 : 1; /* pair_gran_hertzFix_history.cpp:65-66 */
   for (i = 0; i < 3 * nall; i++) d->f[i] = d->torque[i] = 0.0;
 
@@ -568,10 +578,14 @@ void orc__compute_forces(orc_dem *d, int setupflag)
                            d->radius, d->mask, fx->groupbit, &hl, d->f);
         }
         break;
+      case FIX_FREEZE:
+        orc_fix_freeze(d->nlocal, d->mask, fx->groupbit, d->f, d->torque);
+        freeze_in_list = 1;
+        break;
     }
   }
-  /* fix freeze comes last in every input script of the reference (cases/example-cases in.lammps: "fix 4 bottom freeze") */
-  if (d->freeze_bit) orc_fix_freeze(d->nlocal, d->mask, d->freeze_bit, d->f, d->torque);
+  /* a freeze group given through orc_dem_set_groups only (no place in the list): applied after every other fix */
+  if (d->freeze_bit && !freeze_in_list) orc_fix_freeze(d->nlocal, d->mask, d->freeze_bit, d->f, d->torque);
 }
 
 void orc_dem_setup(orc_dem *d)

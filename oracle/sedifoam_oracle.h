@@ -147,6 +147,8 @@ void orc_dem_pair_lubricate(orc_dem *d, double mu, int flaglog, int flagfld, dou
 void orc_dem_fix_cohesive(orc_dem *d, double ah, double lam, double smin, double smax, int opt);
 void orc_dem_fix_gravity(orc_dem *d, double magnitude, double gx, double gy, double gz);
 void orc_dem_fix_fdrag(orc_dem *d, double carrier_rho);
+/* [3P] fix freeze at its place in the fix list: the fixes registered after it still act on the frozen atoms */
+void orc_dem_fix_freeze(orc_dem *d, int groupbit);
 /* wallstyle 0/1/2 ; lo_null/hi_null mark NULL bounds */
 void orc_dem_fix_wall(orc_dem *d, int wallstyle, int lo_null, double lo, int hi_null, double hi,
                       double kn, int kt_null, double kt, double gamman, int gammat_null,

@@ -76,6 +76,8 @@ enum Flag {
 struct WallParams {
   int dim;         // 0/1/2: plane normal ; 3: z cylinder (fix_wall_granFix.cpp:107-112)
   int bit;         // group of the fix (mask bit, 1 = all)
+  int post_freeze; // the fix line follows `fix freeze` in the script: it still acts on frozen atoms ([3P] Modify runs
+                   // post_force in script order; cases/example-cases/transport-*/in.lammps: freeze, then wall/gran)
   double lo, hi;   // planes: the positions for THIS sub-step (a wiggling wall moves them, :259-262)
   double cylradius;
   double vwall[3]; // wall velocity for this sub-step (wiggle :263, shear :264)
@@ -158,6 +160,7 @@ struct StepParams {
   // LAMMPS groups: every fix acts on the atoms whose mask has the fix's group bit (bit 0 = all).  use_groups = 0:
   // every fix is on `all`, the mask is not even read.  freeze_bit != 0: fix freeze; frozen atoms carry omega.w = 1
   int use_groups, nve_bit, grav_bit, fdrag_bit, cohe_bit, freeze_bit;
+  int post_freeze;   // bit 0: fix gravity, bit 1: fix fdrag come AFTER fix freeze in the script (walls: WallParams)
   // mode 0 only: atoms with x < tx_xlo or x >= tx_xhi look their send slots up and write their new x (+ tx_shift of the
   // face), v, omega into DemPtrs::tx -- the pack kernel of the forward halo, fused
   int tx_fused, tx_nhdr;   // tx_nhdr > 0 (any part, mode 0): a trigger also lowers the tx_nhdr vote headers
@@ -473,6 +476,7 @@ private:
   std::map<std::string, int> groups_{{"all", 1}};
   bool use_groups_ = false;
   int nve_bit_ = 1, grav_bit_ = 1, fdrag_bit_ = 1, cohe_bit_ = 1, freeze_bit_ = 0;
+  int post_freeze_ = 0;   // StepParams::post_freeze
   int new_group_bit(const std::string& name);
   void mark_frozen();
   double gacc_[3] = {0, 0, 0};

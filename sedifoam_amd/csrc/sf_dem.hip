@@ -361,6 +361,9 @@ void DemEngine::set_pair_lubricate(double mu, int flaglog, int flagfld, double c
 void DemEngine::set_cohesive(double ah, double lam, double smin, double smax, int opt, int groupbit)
 {
   if (opt != 0 && opt != 1) fail("invalid option for cohesive force model");  // fix_cohesive.cpp:262
+  if (freeze_bit_)
+    fail("fix cohesive after fix freeze: the pair loop adds cohesion before every post_force fix; put the fix "
+         "cohesive line before fix freeze (no input script of the reference has the two together)");
   cohe_ = {ah, lam, smin, smax, opt, 1};
   cohe_bit_ = groupbit;
   use_groups_ = use_groups_ || groupbit != 1;
@@ -371,6 +374,7 @@ void DemEngine::set_gravity(double mag, double gx, double gy, double gz, int gro
   const double len = std::sqrt(gx * gx + gy * gy + gz * gz);
   have_gravity_ = true;
   grav_bit_ = groupbit;
+  post_freeze_ = (post_freeze_ & ~1) | (freeze_bit_ ? 1 : 0);
   use_groups_ = use_groups_ || groupbit != 1;
   gacc_[0] = len > 0 ? mag * (gx / len) : 0.0;
   gacc_[1] = len > 0 ? mag * (gy / len) : 0.0;
@@ -380,6 +384,7 @@ void DemEngine::set_gravity(double mag, double gx, double gy, double gz, int gro
 void DemEngine::set_fdrag(double carrier_rho, int groupbit)
 {
   have_fdrag_ = true;
+  post_freeze_ = (post_freeze_ & ~2) | (freeze_bit_ ? 2 : 0);
   carrier_rho_ = carrier_rho;
   fdrag_bit_ = groupbit;
   use_groups_ = use_groups_ || groupbit != 1;
@@ -463,6 +468,7 @@ void DemEngine::add_wall(int dim, bool lo_null, double lo, bool hi_null, double 
   WallMotion& M = wall_motion_[nwalls_++];
   W.dim = dim;
   W.bit = groupbit;
+  W.post_freeze = freeze_bit_ ? 1 : 0;
   use_groups_ = use_groups_ || groupbit != 1;
   W.lo = M.lo0 = lo_null ? -1.0e20 : lo;
   W.hi = M.hi0 = hi_null ? 1.0e20 : hi;
@@ -626,6 +632,7 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.fdrag_bit = fdrag_bit_;
   S.cohe_bit = cohe_bit_;
   S.freeze_bit = freeze_bit_;
+  S.post_freeze = post_freeze_;
   return S;
 }
 

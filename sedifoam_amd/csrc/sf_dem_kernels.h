@@ -362,8 +362,17 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     txk1 = P.sendslot[1][i];
   }
 
-  // ---- post_force fixes, in script order gravity -> fdrag -> walls ----
-  if (S.have_gravity && (mk & S.grav_bit)) F = F + Vec3{mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
+  // ---- post_force fixes: gravity -> fdrag -> walls; fix freeze zeroes what the fixes BEFORE it in the script (and
+  // the pair styles) gave a frozen atom, the fixes after it still act ([3P] Modify::post_force runs them in script
+  // order; the reference's bed cases have `fix 4 bottom freeze` followed by `fix ywall all wall/gran`).  Fa, Ta: what
+  // the fixes after fix freeze add, in their order; a free atom sums everything in F, T as before ----
+  Vec3 Fa = {0.0, 0.0, 0.0}, Ta = {0.0, 0.0, 0.0};
+  const bool any_post = S.freeze_bit != 0;   // (wave-uniform: no fix freeze, nothing to keep apart)
+  if (S.have_gravity && (mk & S.grav_bit)) {
+    const Vec3 g = {mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
+    F = F + g;
+    if (any_post && (S.post_freeze & 1)) Fa = Fa + g;
+  }
   if (S.have_fdrag && (mk & S.fdrag_bit)) {   // fix_fluid_drag.cpp:145
     Vec3 fd = {P.fdrag[i], P.fdrag[cap + i], P.fdrag[2 * cap + i]};
     if (S.carrier_rho != 0.0) {
@@ -379,6 +388,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       P.vOld[2 * cap + i] = vi.z;
     }
     F = F + fd;
+    if (any_post && (S.post_freeze & 2)) Fa = Fa + fd;
   }
   if (S.nwalls) {
     unsigned wt = P.wtouch[i], wt_new = 0;
@@ -427,15 +437,19 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       wt_new |= (1u << w);
       F = F + o.F;
       T = T - radi * o.tor;
+      if (any_post && W.post_freeze) {
+        Fa = Fa + o.F;
+        Ta = Ta - radi * o.tor;
+      }
     }
     if (wt_new != wt) P.wtouch[i] = (unsigned char)wt_new;
   }
 
   // ---- integrate: final(k) [+ initial(k+1)]  ([3P] FixNVESphere, dtf = dt/2, INERTIA = 0.4) ----
-  // [3P] fix freeze (last post_force fix in every script of the reference): no force, no torque
+  // [3P] fix freeze: force and torque of the group's atoms are zeroed where the fix stands in the script
   if (mk & S.freeze_bit) {
-    F = {0.0, 0.0, 0.0};
-    T = {0.0, 0.0, 0.0};
+    F = Fa;
+    T = Ta;
   }
   Vec3 vn = vi, wn = wi, xn = xi;
   if (S.mode != 2 && S.have_nve && (mk & S.nve_bit)) {

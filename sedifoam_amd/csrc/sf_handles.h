@@ -9,7 +9,6 @@ namespace sf {
 struct SfLammps {
   DemEngine eng;
   bool pair_hybrid = false;
-  bool freeze_seen = false;   // a `fix freeze` line has been read (must stay the last force fix)
   intptr_t comm = 0;
   // RCCL communicator + events of the C++ halo loop (sf_halo_rccl.hip); opaque here so that only that file
   // sees the RCCL headers

@@ -137,14 +137,10 @@ void cmd_fix(SfLammps& L, const std::vector<std::string>& w)
   const int gb = L.eng.group_bit(w[2]);   // "Could not find fix group ID" in LAMMPS
   const std::string& st = w[3];
   const int narg = (int)w.size() - 1;  // LAMMPS narg counts ID group style ...
-  // LAMMPS runs the post_force fixes in script order; the fused kernel adds gravity, fdrag, walls and cohesion in a
-  // fixed order (sums only: order-free up to rounding) and applies fix freeze LAST, as every script of the reference
-  // has it.  A force fix that follows `fix freeze` would act on the frozen atoms in LAMMPS and cannot here: refuse.
-  const bool force_fix = st == "gravity" || st == "fdrag" || st == "cohesive" || st == "wall/gran" || st == "wall/granFix";
-  if (force_fix && L.freeze_seen)
-    sf::fail("fix %s after fix freeze: this engine applies fix freeze after every other force fix (as the reference's "
-             "input scripts order them); move the fix freeze line to the end of the fix list", st.c_str());
-  if (st == "freeze") L.freeze_seen = true;
+  // LAMMPS runs the post_force fixes in script order.  The fused kernel adds gravity, fdrag and the walls in that
+  // fixed order (sums only: order-free up to rounding); what matters is on which side of `fix freeze` a fix stands --
+  // the reference's bed cases put `fix ywall all wall/gran` AFTER `fix 4 bottom freeze`, so the wall still pushes
+  // frozen grains -- and the engine keeps that per fix (DemEngine::set_freeze and the setters called after it).
   if (st == "cohesive" && gb != 1)
     sf::fail("fix cohesive on a group other than `all` is not supported (the full-list evaluation would differ from "
              "the reference's half-list ownership of a pair, fix_cohesive.cpp:167)");

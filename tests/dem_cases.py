@@ -33,6 +33,9 @@ def make_oracle(bed, cfg):
         dem.pair_lubricate(*cfg["lub"])
     dem.fix_gravity(cfg["g"], 0.0, -1.0, 0.0)
     dem.fix_fdrag(cfg.get("carrier_rho", 0.0))
+    frozen = cfg.get("frozen_types") is not None
+    if frozen and cfg.get("freeze_first"):
+        dem.fix_freeze(2)   # the reference's order: fix 4 bottom freeze, THEN fix ywall all wall/gran
     for wall in cfg["walls"]:
         dim, lo, hi = wall[:3]
         extra = wall[3] if len(wall) > 3 else {}
@@ -50,8 +53,9 @@ def make_oracle(bed, cfg):
         t = np.asarray(bed["type"])
         bottom = np.isin(t, cfg["frozen_types"])
         dem.set_mask(1 + 2 * bottom + 4 * (~bottom))
-        dem.set_groups(nve=4, gravity=4, fdrag=1 if cfg.get("fdrag_group", "all") == "all" else 4, wall=1,
-                       cohesive=1, freeze=2)
+        nve = 1 if cfg.get("nve_all") else 4   # the reference's bed cases: fix 1 all nve/sphere
+        dem.set_groups(nve=nve, gravity=nve, fdrag=1 if cfg.get("fdrag_group", "all") == "all" else 4, wall=1,
+                       cohesive=1, freeze=0 if cfg.get("freeze_first") else 2)
     dem.neighbor(cfg["skin"])
     dem.timestep(cfg["dt"])
     return dem
@@ -70,7 +74,7 @@ def script_lines(bed, cfg):
         pair = "pair_style " + gran
     p = bed["periodic"]
     frozen = cfg.get("frozen_types") is not None
-    act = "active" if frozen else "all"
+    act = "active" if frozen and not cfg.get("nve_all") else "all"
     lines = ["atom_style sphere", "boundary %s %s %s" % tuple("p" if q else "f" for q in p), "newton off",
              "communicate single vel yes", "neighbor %.17g bin" % cfg["skin"], "neigh_modify delay 0", pair,
              "pair_coeff * *", "timestep %.17g" % cfg["dt"]]
@@ -81,6 +85,8 @@ def script_lines(bed, cfg):
     cr = cfg.get("carrier_rho", 0.0)
     lines.append("fix 3 %s fdrag" % (act if cfg.get("fdrag_group", "all") != "all" else "all")
                  + (" %d" % int(cr) if cr else ""))
+    if frozen and cfg.get("freeze_first"):
+        lines.append("fix 4 bottom freeze")
     for k, wl in enumerate(cfg["walls"]):
         dim, lo, hi = wl[:3]
         extra = wl[3] if len(wl) > 3 else {}
@@ -97,7 +103,7 @@ def script_lines(bed, cfg):
         lines.append(line)
     if cfg.get("cohesive"):
         lines.append("fix coh all cohesive %.17g %.17g %.17g %.17g %d" % tuple(cfg["cohesive"]))
-    if frozen:
+    if frozen and not cfg.get("freeze_first"):
         lines.append("fix 4 bottom freeze")
     return lines
 

@@ -190,6 +190,33 @@ def test_frozen_bottom_layer_groups(pair, fdrag_group):
     assert lmp.info().nbuilds >= 2
 
 
+def test_reference_bed_script_order_wall_after_freeze():
+    """cases/example-cases/transport-bedload/in.lammps:25-31 verbatim in their own order: `fix 1 all nve/sphere`,
+    `fix 2 all gravity`, `fix 3 all fdrag`, `fix 4 bottom freeze`, THEN `fix ywall all wall/gran ... yplane`.  [3P]
+    Modify::post_force runs the fixes in script order, so the wall still pushes frozen grains (and nve/sphere, on
+    `all`, moves them): the bottom layer overlaps the wall here and must lift off exactly as in the oracle."""
+    bed = _bed((6, 5, 6), periodic=True, seed=31, vmax=0.2)
+    bed["type"] = np.where(bed["x"][:, 1] < 0.9e-3, 2, 1).astype(np.int32)
+    bed["v"][bed["type"] == 2] = 0.0
+    lowest = bed["x"][:, 1].min()
+    walls = [(1, float(lowest - 0.45e-3), float(bed["boxhi"][1]))]     # lowest grains overlap the wall by ~0.05 mm
+    cfg = dict(BASE, pair="hooke", kn=2.0e3, gamman=50.0, skin=0.08e-3, frozen_types=[2], freeze_first=True,
+               nve_all=True, walls=walls)
+    lines = dc.script_lines(bed, cfg)
+    k = [i for i, l in enumerate(lines) if l.startswith("fix")]
+    assert [lines[i].split()[3] for i in k] == ["nve/sphere", "gravity", "fdrag", "freeze", "wall/gran"]
+    lmp, orc = _run_case(bed, cfg, steps=(1, 60), tol_f=5e-12, walls=walls)
+    a = lmp.get_state()
+    bottom = bed["type"][a["tag"] - 1] == 2
+    touching = bottom & (bed["x"][a["tag"] - 1][:, 1] < lowest + 1e-9 + 0.02e-3)
+    assert touching.any()
+    # frozen grains in contact with the wall: only the wall force is left, and it moves them
+    assert np.all(a["f"][touching][:, 1] > 0.0) and np.all(a["x"][touching][:, 1] > bed["x"][a["tag"] - 1][touching][:, 1])
+    # frozen grains that do not reach the wall: no force at all
+    free_frozen = bottom & ~touching & (bed["x"][a["tag"] - 1][:, 1] > lowest + 0.3e-3)
+    assert free_frozen.any() and np.all(a["f"][free_frozen] == 0.0)
+
+
 def test_random_dilute_gas_collisions():
     """Not a lattice: 1500 spheres at random non-overlapping positions (volume fraction ~0.2) with 1 m/s random
     velocities in a periodic box with y walls -- neighbour counts from 0 to ~8, contacts that open and close

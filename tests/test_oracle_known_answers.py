@@ -410,3 +410,26 @@ def test_inlet_override_known_answers():
     L.orc_inlet_force_override(2, ob.P(F), ob.P(cyl), ob.P(np.array([0.2, 0.0, 0.0])), dT, 4, ob.P(pts), ob.P(m), ob.P(U),
                                ob.P(p))
     assert np.array_equal(p[1], base[1]) and not np.array_equal(p[0], base[0])
+
+
+def test_fix_freeze_acts_where_it_stands_in_the_fix_list():
+    """[3P] Modify::post_force runs the fixes in script order: a wall registered AFTER fix freeze still pushes a frozen
+    grain (cases/example-cases/transport-bedload/in.lammps:28-31), one registered before it does not."""
+    from tests import dem_cases as dc
+    d = 1.0e-3
+    bed = dict(x=np.array([[1.5e-3, 0.45e-3, 1.5e-3], [1.5e-3, 2.0e-3, 1.5e-3]]), v=np.zeros((2, 3)),
+               diameter=np.full(2, d), density=np.full(2, 2650.0), boxlo=np.zeros(3), boxhi=np.full(3, 3.0e-3),
+               periodic=(1, 0, 1), n=2, type=np.array([2, 1], dtype=np.int32))
+    base = dict(pair="hooke", kn=2.0e3, gamman=0.0, xmu=0.0, g=9.81, dt=1.0e-6, skin=0.25e-3,
+                walls=[(1, 0.0, 3.0e-3)], frozen_types=[2], nve_all=True)
+    f = {}
+    for first in (False, True):
+        orc = dc.make_oracle(bed, dict(base, freeze_first=first))
+        orc.setup()
+        f[first] = orc.get()["f"]
+    m = 4.0 * np.pi / 3.0 * (0.5 * d) ** 3 * 2650.0
+    assert np.all(f[False][0] == 0.0)                                        # freeze last: nothing left
+    assert f[True][0][1] == pytest.approx(2.0e3 * 0.05e-3, rel=1e-12)        # freeze first: the wall spring kn * overlap only
+    assert f[True][0][0] == 0.0 and f[True][0][2] == 0.0                     # (no gravity: it came before the freeze)
+    for k in (False, True):
+        assert f[k][1][1] == pytest.approx(-m * 9.81, rel=1e-12)             # the free grain just falls
