@@ -55,7 +55,9 @@ void PairGranHertzFixHistoryAmd::flatten_list()
   shear_.resize(3 * (size_t)(npairs_ ? npairs_ : 1));
   for (int ii = 0; ii < inum; ii++) {
     const int i = il[ii], n = numneigh[i], o = first_[ii];
-    std::memcpy(&jlist_[o], firstneigh[i], sizeof(int) * n);
+    // j &= NEIGHMASK as the reference does with every list entry (pair_gran_hertzFix_history.cpp:122): the two top
+    // bits of a LAMMPS neighbour word carry special-bond flags
+    for (int jj = 0; jj < n; jj++) jlist_[o + jj] = firstneigh[i][jj] & NEIGHMASK;
     std::memcpy(&touch_[o], firsttouch[i], sizeof(int) * n);
     std::memcpy(&shear_[3 * (size_t)o], firstshear[i], sizeof(double) * 3 * n);
   }

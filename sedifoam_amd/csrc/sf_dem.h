@@ -70,6 +70,7 @@ enum Flag {
   F_PART_COAL,      // ... and how many of them gather coalesced (k_partner_coalescing)
   F_LIST_SLOTS,     // listed neighbours of the owned atoms (same kernel) ...
   F_LIST_TOUCH,     // ... and how many of them touch
+  F_MIG_TRUNC,      // a migrating atom had more history slots than the migrate record carries (an error, never truncated)
   F_NFLAGS = 32
 };
 
@@ -225,6 +226,9 @@ struct RebuildPredictor {
     }
     last = step;
   }
+  // a rebuild outside the stepping loop (particles created / deleted, an external sf_slab_rebuild, setup): the
+  // displacements start from zero again, the interval estimate stands
+  void external(long long step) { last = step; }
   // how many of the `remaining` sub-steps of a run to queue now; `step` = absolute index of the first of them
   int chunk(long long step, int remaining) const
   {
@@ -367,10 +371,7 @@ class DemEngine {
   // for an atom that did not exist before (created later).  Returns the first row index.
   static constexpr int kMaxExtra = 8;
   int register_extra(int nrows, const double* init);
-  void unregister_extra(int first, int nrows)   // (the client registered last leaves first)
-  {
-    if (first + nrows == nextra_) nextra_ = first;
-  }
+  void unregister_extra(int first, int nrows);   // any order: the rows are tracked in a bitmap
   int nextra() const { return nextra_; }
   double* d_extra() const { return extra_.as<double>(); }
   // device view for the cloud
@@ -487,7 +488,8 @@ private:
   DevArray tag_, type_, mask_, foamCpuId_;
   DevArray fdrag_, DuDt_, vOld_, xhold_;
   DevArray extra_;                 // [kMaxExtra][cap] client rows (register_extra)
-  int nextra_ = 0;
+  int nextra_ = 0;                 // 1 + highest row in use
+  unsigned extra_used_ = 0;        // bit r: row r belongs to a client
   double extra_init_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevArray wshear_, wtouch_;
   DevArray gsrc_, gshift_;
@@ -506,6 +508,7 @@ private:
   bool touch_prefetch_ = true;
   int touch_prefetch_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
+  bool in_run_ = false;                      // rebuild() called from the stepping loop of run()
   RebuildPredictor predict_;                 // single-domain run(): how far to queue (SF_QUEUE_PREDICT=0: everything)
   int nt_policy_ = 2, nt_policy_env_ = -1;   // non-temporal policy of the row streams (sf_dem_kernels.h, NTP)
   void measure_list();     // queue k_partner_coalescing on the current list (results with the next flag read)

@@ -152,6 +152,12 @@ void DemEngine::set_stream(hipStream_t s)
   }
 }
 
+__global__ __launch_bounds__(256) static void k_fill_row(double* row, int n, double v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) row[i] = v;
+}
+
 void DemEngine::alloc_all(size_t cap)
 {
   hipStream_t s = stream_;
@@ -233,24 +239,34 @@ void DemEngine::grow_neigh(int newM)
   M_ = newM;
 }
 
-__global__ __launch_bounds__(256) static void k_fill_row(double* row, int n, double v)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) row[i] = v;
-}
-
 int DemEngine::register_extra(int nrows, const double* init)
 {
-  if (nrows < 1 || nextra_ + nrows > kMaxExtra) fail("register_extra: %d rows requested, %d of %d in use", nrows, nextra_, kMaxExtra);
-  if (cap_ == 0) fail("register_extra: create the atoms first");
-  const int first = nextra_;
+  if (nrows < 1 || nrows > kMaxExtra) fail("register_extra: %d rows requested (at most %d)", nrows, kMaxExtra);
+  // first fit: a client that leaves out of order gives its rows back (ownership bitmap, not a stack)
+  int first = -1;
+  for (int f = 0; f + nrows <= kMaxExtra && first < 0; f++) {
+    const unsigned want = ((1u << nrows) - 1u) << f;
+    if (!(extra_used_ & want)) first = f;
+  }
+  if (first < 0) fail("register_extra: %d rows requested, rows in use 0x%x of %d", nrows, extra_used_, kMaxExtra);
+  // an engine without atoms yet (an empty slab rank, a case that starts empty and injects particles): the rows live in
+  // a small capacity that grows with the first atoms
+  if (cap_ == 0) ensure_capacity(4096);
   for (int r = 0; r < nrows; r++) {
     extra_init_[first + r] = init ? init[r] : 0.0;
     k_fill_row<<<div_up((long long)cap_, 256), 256, 0, stream_>>>(extra_.as<double>() + (size_t)(first + r) * cap_, (int)cap_,
                                                                  extra_init_[first + r]);
   }
-  nextra_ += nrows;
+  extra_used_ |= ((1u << nrows) - 1u) << first;
+  nextra_ = 32 - __builtin_clz(extra_used_);   // rows [0, nextra_) are permuted by re-sorts and travel with migrating atoms
   return first;
+}
+
+void DemEngine::unregister_extra(int first, int nrows)
+{
+  if (first < 0 || nrows < 1 || first + nrows > kMaxExtra) return;
+  extra_used_ &= ~(((1u << nrows) - 1u) << first);
+  nextra_ = extra_used_ ? 32 - __builtin_clz(extra_used_) : 0;
 }
 
 void DemEngine::set_max_neigh(int m)
@@ -327,6 +343,9 @@ void DemEngine::create_atoms(int n, const double* x, const double* v, const doub
   up(tag_, ht.data(), sizeof(int) * n, sizeof(int) * n0);
   up(type_, hty.data(), sizeof(int) * n, sizeof(int) * n0);
   up(mask_, hm.data(), sizeof(int) * n, sizeof(int) * n0);
+  for (int r = 0; r < nextra_ && n > 0; r++)   // client rows registered before the atoms existed: their initial value
+    if (extra_used_ & (1u << r))
+      k_fill_row<<<div_up(n, 256), 256, 0, stream_>>>(extra_.as<double>() + (size_t)r * cap_ + n0, n, extra_init_[r]);
   sync();
   nlocal_ = n0 + n;
   order_version_++;
@@ -1252,6 +1271,7 @@ void DemEngine::rebuild_finish()
 void DemEngine::rebuild()
 {
   Range r("neighbor rebuild");   // (inside the reference's "lammps" bucket)
+  if (!in_run_) predict_.external(nsteps_);
   rebuild_begin();
   rebuild_sort();
   rebuild_finish();
@@ -1527,7 +1547,9 @@ void DemEngine::run(int nsteps)
       const int done = trig + 1 - k;
       cur_ = (base + done) & 1;
       k = trig + 1;
+      in_run_ = true;
       rebuild();
+      in_run_ = false;
       predict_.rebuilt(run_base_step_ + k);
     }
   }

@@ -125,7 +125,7 @@ struct MigratePtrs {
 
 __global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, double xshift, MigratePtrs P, size_t cap,
                                                       int nwalls, int mrec, int have_list, int rec, double* buf,
-                                                      int* leave, int code)
+                                                      int* leave, int code, int* flags)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -145,7 +145,11 @@ __global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, do
   b[24] = P.wtouch[i];
   for (int c = 0; c < 3 * nwalls; c++) b[25 + c] = P.wshear[(size_t)c * cap + i];
   double* h = b + 25 + 3 * nwalls;
-  const int nn = have_list ? min(P.numneigh[i], mrec) : 0;
+  int nn = have_list ? P.numneigh[i] : 0;
+  if (nn > mrec) {   // the record has mrec slots (the global max of max_neigh_used): more would lose history -- an error
+    flags[F_MIG_TRUNC] = nn;
+    nn = mrec;
+  }
   h[0] = nn;
   for (int s = 0; s < mrec; s++) {
     const bool ok = s < nn;
@@ -553,10 +557,14 @@ long long DemEngine::migrate_pack(int side, double xshift, double* buf, long lon
     MigratePtrs P = mig_ptrs(xr_[cur_], vm_[cur_], om_[cur_], tag_, type_, mask_, foamCpuId_, numneigh_, ptag_,
                              fdrag_, DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_, extra_, nextra_);
     k_migrate_pack<<<div_up(n, 128), 128, 0, stream_>>>(list.as<int>(), n, xshift, P, cap_, nwalls_, mrec_,
-                                                        have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1);
+                                                        have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1,
+                                                        d_flags_);
   }
   migrate_leavers_ += n;
-  sync();
+  read_flags();
+  if (h_flags_[F_MIG_TRUNC])
+    fail("migrate_pack: an atom lists %d neighbours but the migrate record carries %d history slots (call "
+         "sf_dem_migrate_set_slots with the maximum of max_neigh_used over ALL ranks)", h_flags_[F_MIG_TRUNC], mrec_);
   return (long long)n * rec;
 }
 

@@ -113,7 +113,7 @@ struct HaloComm {
   GrowBuf mig[2], bor[2], rx[2], a2a_tx, a2a_rx;
   long long* d_counts = nullptr;             // [4] device: counts to left, to right ; from left, from right
   long long* h_counts = nullptr;             // pinned twin
-  double* d_red = nullptr;                   // [2] all-reduce scratch
+  double* d_red = nullptr;                   // [4] all-reduce scratch (in, out)
   double* h_red = nullptr;
   int* d_hdr = nullptr;                      // [2 * world] header offsets: send, receive
   int* h_hdr = nullptr;                      // pinned twin
@@ -190,8 +190,8 @@ static void slab_scratch(HaloComm& hc)
   if (hc.d_counts) return;
   SF_HIP(hipMalloc(&hc.d_counts, sizeof(long long) * 4));
   SF_HIP(hipHostMalloc(&hc.h_counts, sizeof(long long) * 4));
-  SF_HIP(hipMalloc(&hc.d_red, sizeof(double) * 2));
-  SF_HIP(hipHostMalloc(&hc.h_red, sizeof(double) * 2));
+  SF_HIP(hipMalloc(&hc.d_red, sizeof(double) * 4));
+  SF_HIP(hipHostMalloc(&hc.h_red, sizeof(double) * 4));
   SF_HIP(hipMalloc(&hc.d_hdr, sizeof(int) * 2 * hc.world));
   SF_HIP(hipHostMalloc(&hc.h_hdr, sizeof(int) * 2 * hc.world));
 }
@@ -206,6 +206,20 @@ static double slab_allreduce(HaloComm& hc, hipStream_t st, double v, ncclRedOp_t
   SF_HIP(hipMemcpyAsync(hc.h_red + 1, hc.d_red + 1, sizeof(double), hipMemcpyDeviceToHost, st));
   SF_HIP(hipStreamSynchronize(st));
   return hc.h_red[1];
+}
+
+// two values, each reduced with MAX (one collective)
+static void slab_allreduce_max2(HaloComm& hc, hipStream_t st, double& a, double& b)
+{
+  if (hc.world == 1) return;
+  hc.h_red[0] = a;
+  hc.h_red[1] = b;
+  SF_HIP(hipMemcpyAsync(hc.d_red, hc.h_red, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+  SF_NCCL(rccl().AllReduce(hc.d_red, hc.d_red + 2, 2, ncclDouble, ncclMax, hc.comm, st));
+  SF_HIP(hipMemcpyAsync(hc.h_red + 2, hc.d_red + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  SF_HIP(hipStreamSynchronize(st));
+  a = hc.h_red[2];
+  b = hc.h_red[3];
 }
 
 // send[0][:n0] goes to the left neighbour, send[1][:n1] to the right one (doubles); returns what arrived from the
@@ -328,14 +342,15 @@ static void slab_rebuild(SfLammps& S, HaloComm& hc)
   };
   e.rebuild_begin();
   lap("rebuild_begin (partner tags)");
-  // one all-reduce carries the history slots a migrating atom needs (max over ranks of max_neigh_used) and, above
-  // them, whether any rank has an atom outside its slab: the usual rebuild migrates nothing and skips that round
+  // one all-reduce (two values, MAX each) carries the history slots a migrating atom needs -- max_neigh_used over
+  // ALL ranks, whoever migrates -- and whether any rank has an atom outside its slab: the usual rebuild migrates
+  // nothing and skips that round
   const long long crossed = e.migrate_count();
-  const double v = slab_allreduce(hc, st, (double)e.max_neigh_used() + (crossed ? 1048576.0 : 0.0), ncclMax);
-  const long long vi = (long long)v;
+  double slots = (double)e.max_neigh_used(), any_crossed = crossed ? 1.0 : 0.0;
+  slab_allreduce_max2(hc, st, slots, any_crossed);
   lap("allreduce");
-  e.migrate_set_slots((int)(vi & 1048575));
-  if (vi >> 20) {
+  e.migrate_set_slots((int)slots);
+  if (any_crossed != 0.0) {
     const int rec = e.migrate_record_doubles();
     const size_t cap = (size_t)(crossed + 1) * rec;
     double* b0 = hc.mig[0].need(cap);
@@ -589,6 +604,7 @@ int sf_slab_rebuild(void* ptr)
   SF_API_BEGIN
   SfLammps* L = H(ptr);
   sf::slab_rebuild(*L, *slab_of(L));
+  slab_of(L)->predict.external(L->eng.nsteps());   // (not a trigger of the stepping loop: the interval estimate stands)
   SF_API_END(0)
 }
 

@@ -331,6 +331,14 @@ class SlabDriver:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
+    def _allreduce_max2(self, a, b):
+        if self.world == 1 and not self.self_comm:
+            return int(a), int(b)
+        t = self.torch.tensor([int(a), int(b)], dtype=self.torch.int64,
+                              device=self.e.device if self.transport != "host" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t[0].item()), int(t[1].item())
+
     def _exchange(self, send_l, n_l, send_r, n_r, known=None):
         """send_l[:n_l] goes to the left neighbour, send_r[:n_r] to the right one.
         Returns (from_left, n_from_left, from_right, n_from_right) in doubles.  `known` = receive sizes
@@ -403,9 +411,10 @@ class SlabDriver:
         # the bits above, whether any rank has an atom outside its slab: the usual rebuild migrates nothing and then
         # skips the pack / count exchange / data exchange / unpack round
         crossed = e.migrate_count() if hasattr(e, "migrate_count") else 1
-        v = self._allreduce_max(int(e.info().max_neigh_used) + ((1 << 20) if crossed else 0))
-        e.migrate_set_slots(v & ((1 << 20) - 1))
-        if v >> 20:
+        # (one collective, two values, MAX each: the slot count over ALL ranks whoever migrates)
+        v, c = self._allreduce_max2(int(e.info().max_neigh_used), 1 if crossed else 0)
+        e.migrate_set_slots(v)
+        if c:
             rec = e.migrate_record_doubles()
             nmax = max(self._cap_atoms // 8, 1024)
             b0 = self._buf("mig_l", nmax * rec)
