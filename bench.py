@@ -4,8 +4,9 @@
 One "step" = one `lammps_step(S)` call (S = 50 DEM sub-steps, BASELINE.json configs[2..3]) of the fused
 Hertz-history contact / fix fdrag / wall / gravity / nve-sphere kernel over a synthetic 1 M-particle
 monodisperse Hertz packing, particle state resident in HBM before timing starts.
-With --gpus N (launched through torch.distributed.run, one rank per GPU) every rank owns one such slab
-of a periodic channel N times as long, with a ghost-particle halo over RCCL: weak scaling.
+With --gpus N (launched through torch.distributed.run, one rank per GPU) the SAME 1 M-particle bed is split into N
+spatial domains with a ghost-particle halo over RCCL (BASELINE config C4: strong scaling, the `value` of the line);
+the weak-scaling run (every rank one 1 M slab of a channel N times as long) goes into the side object `weak_scaling`.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_substep): algorithmic bytes
 per launch (284 + 52*K_half bytes per particle-substep) / its mean duration from HIP
@@ -24,7 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_SUMMARY = "r02_d_pmc_summary.json"   # the committed PMC passes of the current kernel (tests/profile_round.sh)
+PMC_SUMMARIES = ("r03_pmc_summary.json", "r02_d_pmc_summary.json")   # committed PMC passes, newest first (tests/profile_round.sh)
 
 
 def build_engine(bed, script):
@@ -46,8 +47,9 @@ def _synthetic():
     return mod
 
 
-def cpu_baseline(ncells, script_kw, substeps, seed=12345 + 3):
-    """Oracle (CPU port of the reference algorithm) on the same kind of bed: particle-substeps/s."""
+def cpu_baseline(ncells, script_kw, substeps, seed=12345 + 3, keep_state=False):
+    """Oracle (CPU port of the reference algorithm) on the same kind of bed: particle-substeps/s.  keep_state: also the
+    oracle's x, v, omega (sorted by tag) after those sub-steps -- the parity leg compares them with the GPU's."""
     from oracle import binding as ob
     synthetic = _synthetic()
     bed = synthetic.fcc_bed(ncells, seed=seed)
@@ -65,10 +67,13 @@ def cpu_baseline(ncells, script_kw, substeps, seed=12345 + 3):
     t0 = time.perf_counter()
     dem.run(substeps)
     dt = time.perf_counter() - t0
+    if keep_state:
+        return bed["n"] * substeps / dt, bed["n"], dt, dem.get()
     return bed["n"] * substeps / dt, bed["n"], dt
 
 
 KW = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
+FLUIDISED = dict(jitter=0.3, spacing=1.1)   # --bed fluidised
 
 
 def cpu_worker(argv):
@@ -139,9 +144,17 @@ def main():
     ap.add_argument("--cpu-all-particles", type=int, default=100000,
                     help="particles per process of the all-cores CPU leg (one oracle process per host core), 0 = skip")
     ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
-                    help="N > 1: weak = every rank owns one --particles slab (the `value` of the JSON line); strong = "
-                         "--particles in total, split into N x-slabs (BASELINE config C4), reported as "
-                         "`strong_scaling` next to it; both (default) measures one after the other.  N = 1: identical")
+                    help="N > 1: strong = --particles in total, split into N domains (BASELINE config C4: the `value` of "
+                         "the JSON line); weak = every rank owns one --particles slab (`value` only with --scaling weak); "
+                         "both (default) = strong as `value`, weak next to it as `weak_scaling`.  N = 1: identical")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the C++ RCCL driver cannot come up, measure the Python loop over torch.distributed "
+                         "instead of exiting non-zero (config.decomposition says so)")
+    ap.add_argument("--bed", choices=["packed", "fluidised"], default="packed",
+                    help="packed = the lattice bed of BASELINE's headline; fluidised = a loose disordered bed (jitter 0.3 d, "
+                         "spacing 1.1 d: K_half ~4, a third of the listed neighbours touch, a rebuild every ~11 sub-steps)")
+    ap.add_argument("--no-fluidised", action="store_true", help="N = 1: skip the `fluidised_bed` side measurement")
+    ap.add_argument("--no-parity", action="store_true", help="N = 1: skip the GPU-vs-oracle comparison of the final state")
     ap.add_argument("--one-gpu", action="store_true",
                     help="development: all ranks share GPU 0, halo over gloo through host memory (RCCL refuses two "
                          "ranks on one device); exercises the N > 1 code on a 1-GPU box")
@@ -184,6 +197,8 @@ def main():
     kw = KW
     ncells = synthetic.fcc_cells_for(args.particles)
     bed_kw = {}
+    if args.bed == "fluidised":
+        bed_kw = dict(FLUIDISED)
     if args.jitter is not None:
         bed_kw["jitter"] = args.jitter
     if args.spacing is not None:
@@ -237,10 +252,12 @@ def main():
         return el, n_own, launches, kernel_ms, info0, lmp.info()
 
     fallback_note = [None]
+    comm_info = [None]
 
     def make_driver(factory, the_bed):
-        """the C++ driver over RCCL; if it cannot come up on EVERY rank alike (an exception, not a hang), say so loudly
-        and measure the same protocol driven from Python over torch.distributed instead of measuring nothing"""
+        """the C++ driver over RCCL.  If it cannot come up the run FAILS (rc != 0): a slow number from another code path
+        is worse than none.  --allow-fallback: say so loudly and measure the same protocol driven from Python over
+        torch.distributed instead."""
         from sedifoam_amd.halo import SlabDriver
         err = None
         try:
@@ -255,42 +272,52 @@ def main():
         else:
             failed = err is not None
         if not failed:
+            if hasattr(drv, "comm_info"):
+                comm_info[0] = drv.comm_info()
             return drv
-        if args.one_gpu or transport not in (None, "rccl"):
+        if not args.allow_fallback or args.one_gpu or transport not in (None, "rccl"):
             raise err if err is not None else RuntimeError("another rank could not create its halo driver")
-        sys.stderr.write("bench.py: the C++ RCCL halo driver did not come up (%s) -- FALLING BACK to the Python loop over "
-                         "torch.distributed (slower; config.decomposition says so)\n" % (err,))
+        sys.stderr.write("bench.py: the C++ RCCL halo driver did not come up (%s) -- --allow-fallback: measuring the Python "
+                         "loop over torch.distributed (slower; config.decomposition says so)\n" % (err,))
         fallback_note[0] = "x-slabs, ghost halo driven from Python over torch.distributed (the C++ RCCL driver failed: %s)" % (err,)
         return getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport="direct")
 
-    strong = None
-    if world > 1 and args.scaling in ("both", "strong"):
-        # BASELINE config C4: ONE --particles bed, split into `world` x-slabs (strong scaling)
-        from sedifoam_amd.halo import SlabDriver
-        gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
-        sdrv = make_driver("from_global_bed", gbed)
-        el_s, n_s, _l, _k, _i0, _i1 = timed_run(sdrv)
-        strong = {"value": n_s * args.substeps * args.steps / el_s, "unit": "particle-substeps/s",
-                  "halo_exchange_us_per_substep": exchange_us[0],
-                  "ms_per_step": 1e3 * el_s / args.steps, "particles_total": int(n_s), "scaling": "strong",
-                  "workload": "the SAME %d-particle bed split into %d x-slabs (BASELINE config C4)" % (int(n_s), world)}
-        if args.scaling == "strong":
-            elapsed, n_total, launches, kernel_ms, info = el_s, n_s, _l, _k, _i0
-            lmp = sdrv
-            N = info.nlocal
-        else:
-            del sdrv
-        del gbed
+    def side_line(el, n_tot, launches_, kernel_ms_, info_, label, scaling):
+        o = {"value": n_tot * args.substeps * args.steps / el, "unit": "particle-substeps/s",
+             "halo_exchange_us_per_substep": exchange_us[0], "ms_per_step": 1e3 * el / args.steps,
+             "particles_total": int(n_tot), "scaling": scaling, "workload": label}
+        if launches_:
+            kh = info_.npairs_full / 2.0 / max(info_.nlocal, 1)
+            o["rank0_kernel_us"] = 1e3 * kernel_ms_ / launches_
+            o["rank0_roofline_frac"] = (284.0 + 52.0 * kh) * info_.nlocal / (1e-3 * kernel_ms_ / launches_) / 1e9 / HBM_PEAK_GBS
+        return o
 
-    if world > 1 and args.scaling == "strong":
-        pass
-    elif world > 1 or args.slab_driver:
-        from sedifoam_amd.halo import SlabDriver
+    # N > 1: BASELINE config C4 -- ONE --particles bed split into `world` spatial domains -- is the headline (`value`,
+    # scaling "strong"); the weak-scaling run (every rank one --particles slab) is the side object `weak_scaling`
+    side = {}
+    lmp = None
+    if world > 1 and args.scaling in ("both", "weak"):
+        wdrv = make_driver("from_bed", bed)
+        el_w, n_w, l_w, k_w, i_w, _ia = timed_run(wdrv)
+        if args.scaling == "weak":
+            lmp, elapsed, n_total, launches, kernel_ms, info = wdrv, el_w, n_w, l_w, k_w, i_w
+        else:
+            side["weak_scaling"] = side_line(el_w, n_w, l_w, k_w, i_w, "every rank owns one %d-particle slab of a channel "
+                                             "%d times as long" % (N, world), "weak")
+            del wdrv
+    if world > 1 and args.scaling in ("both", "strong"):
+        gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
+        lmp = make_driver("from_global_bed", gbed)
+        elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
+        N = info.nlocal
+        del gbed
+    elif world == 1 and args.slab_driver:
         lmp = make_driver("from_bed", bed)
         elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
-    else:
+    elif world == 1:
         lmp = build_engine(bed, script)
         elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
+    is_strong = world > 1 and args.scaling != "weak"
     k_half = info.npairs_full / 2.0 / max(info.nlocal, 1)
 
     value = n_total * args.substeps * args.steps / elapsed
@@ -307,13 +334,19 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if (world > 1 and args.scaling == "strong") else "weak",
+        "scaling": "strong" if is_strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "1M-particle monodisperse Hertz-history packing (FCC bed, d=1mm, 2%% overlap), "
-                        "periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step" % args.substeps,
+            "workload": ("%s, periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step%s"
+                         % ("%.1fM-particle loose disordered (fluidised) Hertz-history bed (jitter 0.3 d, spacing 1.1 d)"
+                            % (n_total / 1e6) if args.bed == "fluidised" else
+                            "%.0fM-particle monodisperse Hertz-history packing (FCC bed, d=1mm, 2%% overlap)"
+                            % (n_total / 1e6), args.substeps,
+                            "; the SAME bed split into %d spatial domains (BASELINE config C4)" % world if is_strong else
+                            ("; one such slab per GPU of a channel %d times as long" % world if world > 1 else ""))),
+            "particles_total": int(n_total),
             "particles_per_gpu": N, "substeps_per_step": args.substeps, "k_half": round(k_half, 3),
             "neighbor_rebuilds_in_run": int(info2.nbuilds - info.nbuilds),
             **({"halo_exchange_us_per_substep": exchange_us[0]} if exchange_us[0] is not None else {}),
@@ -324,8 +357,12 @@ def main():
                                "x-slabs, ghost halo over gloo through host memory (--one-gpu)") if args.one_gpu else
                               (fallback_note[0] or "x-slabs, C++ driver (sf_slab_*), ghost halo over RCCL")) if world > 1 else
                              ("single slab through the halo driver" if args.slab_driver else "single domain"),
+            **({"transport": ("stand-in for librccl over host memory" if transport == "rccl" else "gloo through host memory")
+                if args.one_gpu else ("torch.distributed point-to-point (Python loop)" if fallback_note[0] else
+                                      "RCCL point-to-point (ncclSend/ncclRecv groups) from the C++ driver")} if world > 1 else {}),
+            **(comm_info[0] or {}),
         },
-        **({"strong_scaling": strong} if strong else {}),
+        **side,
         "roofline": {
             "bound": "hbm", "kernel": "k_substep<hertz>", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -334,20 +371,32 @@ def main():
             "traffic": None,
         },
     }
-    # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes
-    # (separate passes; the summary file holds the calibration of FETCH_SIZE on known byte counts)
-    pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-    if os.path.exists(pmc) and args.particles == 1000000 and not bed_kw:
-        try:
-            hb = json.load(open(pmc))["hbm_bytes_per_launch"]
-            out["roofline"]["traffic"] = hb["total_calibrated"]
-            out["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc bytes per launch of this kernel on this "
-                                                 "workload, WRITE_SIZE + calibrated reads (FETCH_SIZE counts every "
-                                                 "coalesced stream at 1/2: calibrated on tests/micro/stream_bench)"
-                                                 % PMC_SUMMARY)
-            out["roofline"]["traffic_raw_counters"] = hb["total_raw"]
-        except Exception:
-            pass
+    # HBM traffic per launch of the same kernel on the same workload from the committed rocprofv3 PMC passes (separate
+    # passes; the summary file holds the calibration of FETCH_SIZE on known byte counts).  The summary carries a hash of
+    # the kernel's sources: counters of another kernel are not reported (traffic = null, traffic_stale says why)
+    if args.particles == 1000000 and not bed_kw and world == 1:
+        from sedifoam_amd.build import kernel_source_hash
+        now = kernel_source_hash()
+        for name in PMC_SUMMARIES:
+            pmc = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(pmc):
+                continue
+            try:
+                doc = json.load(open(pmc))
+                if doc.get("kernel_source_sha256_16") != now:
+                    out["roofline"]["traffic_stale"] = ("profiles/%s was collected on kernel sources %s, the library is "
+                                                        "built from %s" % (name, doc.get("kernel_source_sha256_16"), now))
+                    break
+                hb = doc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic"] = hb["total_calibrated"]
+                out["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc bytes per launch of this kernel (source "
+                                                     "hash %s) on this workload, WRITE_SIZE + calibrated reads (FETCH_SIZE "
+                                                     "counts every coalesced stream at 1/2: calibrated on "
+                                                     "tests/micro/stream_bench)" % (name, now))
+                out["roofline"]["traffic_raw_counters"] = hb["total_raw"]
+            except Exception:   # noqa: BLE001
+                pass
+            break
     # secondary metric of BASELINE.json: coupled CFD-DEM steps/s (drag closure + drag assembly + S sub-steps +
     # cell owner + void-fraction / Ue scatter + Asrc) through the device-resident enhancedCloud, frozen fluid
     if world == 1 and not args.slab_driver and not args.no_coupled:
@@ -432,14 +481,66 @@ def main():
         out["config"]["coupled_step"] = ("decomposed particles, %dx%dx%d mesh on every rank, all-reduced per-cell sums; "
                                          "ErgunWenYu + %d sub-steps + scatter + Asrc + smoothing (6 mm, 6 steps)"
                                          % (mesh_n[0], mesh_n[1], mesh_n[2], args.substeps))
+    # N = 1: the loose disordered ("fluidised") bed of the same size next to the headline -- BASELINE config C3 is a
+    # fluidised bed; the lattice of the headline is the best case (every listed neighbour touches, a rebuild every ~170
+    # sub-steps).  Same engine path, same timing rules, shorter run.
+    if world == 1 and not args.slab_driver and not args.no_fluidised and args.bed == "packed" and not bed_kw:
+        fbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **FLUIDISED)
+        flmp = build_engine(fbed, synthetic.hertz_script(fbed, **kw))
+        keep = (args.steps, args.warmup)
+        args.steps, args.warmup = max(2, args.steps // 2), 1
+        el_f, n_f, l_f, k_f, i_f, i_f1 = timed_run(flmp)
+        kh_f = i_f1.npairs_full / 2.0 / max(i_f1.nlocal, 1)
+        fo = {"value": n_f * args.substeps * args.steps / el_f, "unit": "particle-substeps/s",
+              "ms_per_step": 1e3 * el_f / args.steps, "steps": args.steps, "warmup": args.warmup,
+              "workload": "%d-particle loose disordered Hertz bed (FCC sites at spacing 1.1 d, jitter 0.3 d), same fixes, %d "
+                          "sub-steps per step" % (int(n_f), args.substeps),
+              "k_half": round(kh_f, 3), "neighbor_rebuilds_in_run": int(i_f1.nbuilds - i_f.nbuilds)}
+        if l_f:
+            fo["mean_kernel_us"] = 1e3 * k_f / l_f
+            fo["roofline_frac"] = (284.0 + 52.0 * kh_f) * i_f1.nlocal / (1e-3 * k_f / l_f) / 1e9 / HBM_PEAK_GBS
+            fo["roofline_frac_whole_run"] = (284.0 + 52.0 * kh_f) * fo["value"] / 1e9 / HBM_PEAK_GBS
+        out["fluidised_bed"] = fo
+        args.steps, args.warmup = keep
+        del flmp, fbed
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (the CPU baseline is an N = 1 measurement)
         sample_n = args.cpu_sample or 1000000
         sub = 50
-        v, n_s, secs = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub)
+        do_parity = (not args.no_parity and not args.slab_driver and sample_n == args.particles and not bed_kw)
+        gpu_state = None
+        if do_parity:
+            # the SAME bed from the SAME start through the product path: setup + `sub` sub-steps, outside the timed region
+            plmp = build_engine(bed, script)
+            plmp.setup()
+            plmp.step(sub)
+            gpu_state = plmp.get_state()
+            p_builds = int(plmp.info().nbuilds)
+            del plmp
+        res = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub, keep_state=do_parity)
+        v, n_s, secs = res[:3]
         out["cpu_baseline"] = {"value": v, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
                                "buckets_ms_per_step": {"lammps (%d sub-steps)" % sub: 1e3 * secs},
                                "sample": "%d-particle bed of the same packing, %d sub-steps, %.1f s, "
                                          "oracle/ (C, gcc -O2) single thread" % (n_s, sub, secs)}
+        if do_parity:
+            o = res[3]
+            d = float(np.max(bed["diameter"]))
+            same = bool(np.array_equal(o["tag"], gpu_state["tag"]))
+
+            def rel(a, b):
+                sc = float(np.max(np.abs(b)))
+                return float(np.max(np.abs(a - b)) / (sc if sc > 0 else 1.0))
+            out["parity"] = {"against": "oracle/ (CPU restatement of the reference) from the same start, setup + %d sub-steps, "
+                                        "the whole %d-particle bed of the headline" % (sub, n_s),
+                             "n": int(n_s), "substeps": sub, "tags_identical": same,
+                             "max_abs_dx_over_d": float(np.max(np.abs(gpu_state["x"] - o["x"])) / d) if same else None,
+                             "max_rel_v": rel(gpu_state["v"], o["v"]) if same else None,
+                             "max_rel_omega": rel(gpu_state["omega"], o["omega"]) if same else None,
+                             "max_rel_f": rel(gpu_state["f"], o["f"]) if same else None,
+                             "tolerance": "x 1e-9 d, v / omega 1e-9 of max (SURVEY.md 8d)",
+                             "gpu_rebuilds": p_builds}
+            out["parity"]["ok"] = bool(same and out["parity"]["max_abs_dx_over_d"] <= 1e-9
+                                       and out["parity"]["max_rel_v"] <= 1e-9 and out["parity"]["max_rel_omega"] <= 1e-9)
         allc = cpu_baseline_all_cores(args.cpu_all_particles, 20) if args.cpu_all_particles > 0 else None
         if allc:
             out["cpu_baseline_all_cores"] = allc

@@ -230,6 +230,9 @@ int sf_slab_setup(void *ptr);
 int sf_slab_rebuild(void *ptr);
 int sf_slab_step(void *ptr, int n);
 long long sf_slab_rebuild_count(void *ptr);
+/* the communicator behind this engine: ranks as RCCL counts them (ncclCommCount), ncclGetVersion, and the shared
+ * object the nccl* symbols were loaded from */
+int sf_slab_comm_info(void *ptr, int *comm_ranks, int *rccl_version, char *lib_path, int lib_path_len);
 /* while sf_dem_set_profiling is on: HIP-event time of the sampled forward exchanges (vote + ghosts: RCCL kernel and
  * unpack, measured on this rank's stream from the end of the sub-step kernel before); returns and resets the sums */
 int sf_slab_exchange_profile(void *ptr, long long *exchanges, double *ms);

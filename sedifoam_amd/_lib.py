@@ -145,6 +145,7 @@ _SIGS = {
     "sf_slab_rebuild": (C.c_int, [vp]),
     "sf_slab_step": (C.c_int, [vp, C.c_int]),
     "sf_slab_rebuild_count": (C.c_longlong, [vp]),
+    "sf_slab_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "sf_slab_exchange_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "sf_slab_rebuild_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "sf_slab_layout_get": (C.c_int, [vp, vp]),

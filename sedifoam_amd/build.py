@@ -29,6 +29,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the sources the sub-step kernel is compiled from: stored next to a PMC summary
+    (tests/pmc_summarize.py) so that bench.py can tell whether the committed HBM-traffic counters still describe the
+    kernel it is timing"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sf_dem_kernels.h", "sf_physics.h", "sf_dem.h", "sf_common.h"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = _headers()

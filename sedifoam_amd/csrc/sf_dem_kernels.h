@@ -37,7 +37,12 @@
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
-// Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md)
+// Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md).
+// They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
+// SF_VARIANT_BUILD); the shipped library never carries them.
+#if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT)) && !defined(SF_VARIANT_BUILD)
+#error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
+#endif
 #ifndef SF_EXP_NOSHLD
 #define SF_EXP_NOSHLD 0       // skip the shear-history loads
 #endif

@@ -32,6 +32,9 @@ struct RcclApi {
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  char path[256] = {0};   // the library these symbols come from (dladdr of ncclSend)
 };
 
 static RcclApi& rccl()
@@ -63,6 +66,10 @@ static RcclApi& rccl()
   api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+  api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
+  Dl_info di;
+  if (dladdr(reinterpret_cast<void*>(api.Send), &di) && di.dli_fname) snprintf(api.path, sizeof(api.path), "%s", di.dli_fname);
   return api;
 }
 
@@ -637,6 +644,22 @@ int sf_slab_rebuild_profile(void* ptr, long long* rebuilds, double* ms)
   sf::HaloComm* hc = slab_of(H(ptr));
   *rebuilds = hc->n_rebuilds - hc->rebuilds_at_setup;
   *ms = hc->rebuild_ms;
+  SF_API_END(0)
+}
+
+// what the communicator of this engine really is: ranks RCCL itself counts on it (ncclCommCount), the library's
+// version and the file its symbols were loaded from -- so that a benchmark line can prove which transport it ran on
+int sf_slab_comm_info(void* ptr, int* comm_ranks, int* rccl_version, char* lib_path, int lib_path_len)
+{
+  SF_API_BEGIN
+  sf::HaloComm* hc = slab_of(H(ptr));
+  sf::RcclApi& a = sf::rccl();
+  int n = 0, v = 0;
+  SF_NCCL(a.CommCount(hc->comm, &n));
+  SF_NCCL(a.GetVersion(&v));
+  if (comm_ranks) *comm_ranks = n;
+  if (rccl_version) *rccl_version = v;
+  if (lib_path && lib_path_len > 0) snprintf(lib_path, (size_t)lib_path_len, "%s", a.path);
   SF_API_END(0)
 }
 

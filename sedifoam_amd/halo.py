@@ -702,6 +702,17 @@ class SlabDriver:
         self.e.check(self.e.L.sf_slab_rebuild_profile(self.e.lmp.ptr, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
+    def comm_info(self):
+        """{"rccl_ranks", "rccl_version", "rccl_library"} of the C++ driver's communicator (ncclCommCount, ncclGetVersion, the
+        shared object its nccl* symbols come from); None when the Python loop drives the halo"""
+        if not getattr(self, "_cxx", False):
+            return None
+        import ctypes as C
+        n, v = C.c_int(0), C.c_int(0)
+        path = C.create_string_buffer(256)
+        self.e.check(self.e.L.sf_slab_comm_info(self.e.lmp.ptr, C.byref(n), C.byref(v), path, 256))
+        return {"rccl_ranks": int(n.value), "rccl_version": int(v.value), "rccl_library": path.value.decode()}
+
     def get_exchange_profile(self):
         """(sampled forward exchanges, their summed ms) since profiling was switched on -- C++ driver only"""
         if not getattr(self, "_cxx", False):

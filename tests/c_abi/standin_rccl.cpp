@@ -209,6 +209,18 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count)
+{
+  *count = c->world;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclGetVersion(int* version)
+{
+  *version = 0;   // (0: not a real RCCL)
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
   if (!c) return ncclSuccess;

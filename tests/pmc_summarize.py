@@ -28,7 +28,12 @@ for path in glob.glob(f"gpurun_out/kt_{tag}/*kernel_trace.csv"):
             durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 ex = [d for d in durs if d > 50.0]
 
-out = {"workload": "bench.py default (1,000,188-particle Hertz bed), kernel k_substep<2,false,false>, executed launches "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sedifoam_amd.build import kernel_source_hash  # noqa: E402
+
+out = {"kernel_source_sha256_16": kernel_source_hash(),
+       "workload": "bench.py default (1,000,188-particle Hertz bed), kernel k_substep<2,false,false>, executed launches "
                    "only (duration > 50 us); code = " + desc,
        "particles": N, "counters": c}
 if durs:

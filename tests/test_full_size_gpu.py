@@ -245,3 +245,78 @@ def test_c5_500k_full_physics_is_bitwise_reproducible_and_order_independent(c5be
     assert a.info().nbuilds == b.info().nbuilds and a.info().nbuilds - builds0 >= 1
     for k in ("x", "v", "omega", "f", "torque"):
         assert np.isfinite(sa[k]).all() and np.array_equal(sa[k], sb[k]), k
+
+
+# ---- the oracle at the sizes the numbers are quoted on ----
+def _history_arrays(lmp=None, orc=None):
+    """(key, shear) of every touching pair, key = tag_i * 2^32 + tag_j with tag_i < tag_j, sorted by key -- vectorised
+    (the dict accessors of the small tests would take minutes for 6 M pairs)"""
+    if lmp is not None:
+        from sedifoam_amd.lammps import _p
+        cap = int(lmp.info().npairs_full)
+        ti = np.zeros(cap, np.int32); tj = np.zeros(cap, np.int32); sh = np.zeros((cap, 3))
+        n = lmp.L.sf_dem_get_history(lmp.ptr, cap, _p(ti), _p(tj), _p(sh))
+    else:
+        from oracle import binding as ob
+        cap = max(orc.npairs, 1)
+        ti = np.zeros(cap, np.int32); tj = np.zeros(cap, np.int32); sh = np.zeros((cap, 3))
+        n = orc.L.orc_dem_get_history(orc.h, cap, ob.P(ti), ob.P(tj), ob.P(sh))
+    ti, tj, sh = ti[:n].astype(np.int64), tj[:n].astype(np.int64), sh[:n].copy()
+    flip = ti > tj
+    sh[flip] *= -1.0
+    key = np.where(flip, tj, ti) * (1 << 32) + np.where(flip, ti, tj)
+    o = np.argsort(key, kind="stable")
+    return key[o], sh[o]
+
+
+def _compare_with_oracle(lmp, orc, d, tol=1e-9):
+    from tests import dem_cases as dc
+    a, b = lmp.get_state(), orc.get()
+    assert np.array_equal(a["tag"], b["tag"])
+    assert np.max(np.abs(a["x"] - b["x"])) <= tol * d
+    assert dc.rel_err(a["v"], b["v"]) <= tol
+    assert dc.rel_err(a["omega"], b["omega"]) <= tol
+    ka, sa = _history_arrays(lmp=lmp)
+    kb, sb = _history_arrays(orc=orc)
+    assert np.array_equal(ka, kb)                      # the same set of touching pairs
+    assert dc.rel_err(sa, sb) <= tol
+    return a, b
+
+
+def test_headline_1m_bed_matches_the_oracle_after_50_substeps():
+    """The bed bench.py quotes its number on (1 000 188 grains, walls in y, gravity + fix fdrag, seed of rank 0), setup +
+    50 sub-steps, HIP vs oracle: the only place where the large-N launch shape (one lane per atom, XCD remap), the
+    non-temporal policy chosen above the 256 MB memory-side cache and one history copy per contact run together.
+    SURVEY.md 8d gates: x 1e-9 d, v / omega / shear 1e-9."""
+    from tests import dem_cases as dc
+    bed = synthetic.fcc_bed(synthetic.fcc_cells_for(N_TARGET), seed=12345 + 3)
+    assert bed["n"] >= N_TARGET
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    lmp = dc.make_hip(bed, cfg)
+    orc = dc.make_oracle(bed, cfg)
+    lmp.setup(); orc.setup()
+    rng = np.random.default_rng(7)
+    fd = rng.normal(scale=1e-6, size=(bed["n"], 3))
+    tags = np.arange(1, bed["n"] + 1, dtype=np.int32)
+    lmp.put_local_info(fd, tags)
+    orc.put_fdrag(fd, tags)
+    lmp.step(50); orc.run(50)
+    a, b = _compare_with_oracle(lmp, orc, 1.0e-3)
+    assert dc.rel_err(a["f"], b["f"]) <= 1e-10          # (the last sub-step's stored force)
+    assert lmp.info().nbuilds == orc.nbuilds
+
+
+def test_c5_500k_full_physics_matches_the_oracle_after_10_substeps(c5bed):
+    """BASELINE config C5 at its named size -- 500 k polydisperse grains, Hertz history + fix cohesive + pair
+    lubricate/poly (flagfld 1, flagVF 1) -- HIP vs oracle after setup + 10 sub-steps."""
+    from tests import dem_cases as dc
+    bed = dict(c5bed)
+    bed["periodic"] = (1, 1, 1)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=0.0, dt=1.0e-6, skin=0.06e-3, walls=[],
+               cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1), lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1))
+    lmp = dc.make_hip(bed, cfg)
+    orc = dc.make_oracle(bed, cfg)
+    lmp.setup(); orc.setup()
+    lmp.step(10); orc.run(10)
+    _compare_with_oracle(lmp, orc, 1.0e-3)
