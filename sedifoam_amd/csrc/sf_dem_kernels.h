@@ -40,7 +40,8 @@
 // Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md).
 // They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
 // SF_VARIANT_BUILD); the shipped library never carries them.
-#if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT)) && !defined(SF_VARIANT_BUILD)
+#if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT) || defined(SF_EXP_SC1_GATHER) || \
+     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST)) && !defined(SF_VARIANT_BUILD)
 #error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
 #endif
 #ifndef SF_EXP_NOSHLD
@@ -49,10 +50,53 @@
 #ifndef SF_EXP_NOSHST
 #define SF_EXP_NOSHST 0       // skip the shear-history stores
 #endif
+// pricing of the agent-coherent access forms a persistent multi-sub-step kernel would need (valid results):
+#ifndef SF_EXP_SC1_GATHER
+#define SF_EXP_SC1_GATHER 0   // neighbour records and partner-side history gathered with sc1 loads (bypass the vector L1)
+#endif
+#ifndef SF_EXP_SC1_RECST
+#define SF_EXP_SC1_RECST 0    // output records stored write-through (sc1)
+#endif
+#ifndef SF_EXP_SC1_SHST
+#define SF_EXP_SC1_SHST 0     // shear-history stores write-through (sc1, 8 bytes per lane)
+#endif
+#ifndef SF_EXP_PERSIST_NOWAIT
+#define SF_EXP_PERSIST_NOWAIT 0   // upper bound of a persistent kernel: n sub-steps in one launch, NO dependency waits
+                                  // (every sub-step recomputes the same in -> out: valid inputs, timing only)
+#endif
 
 namespace sf {
 
 __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
+
+// agent-coherent (sc1) accesses to a record array through a raw buffer descriptor: they bypass the CU's vector L1
+// (loads) / write through the XCD's L2 (stores); the compiler counts them like any other memory operation
+typedef int sf_v4i __attribute__((ext_vector_type(4)));
+typedef double sf_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rec_rsrc(const void* base)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00027000);
+}
+__device__ __forceinline__ double4 ld_rec_sc1(const double4* base, int j)
+{
+  const __amdgpu_buffer_rsrc_t r = rec_rsrc(base);
+  const sf_v2d a = __builtin_bit_cast(sf_v2d, __builtin_amdgcn_raw_buffer_load_b128(r, j * 32, 0, 16));
+  const sf_v2d b = __builtin_bit_cast(sf_v2d, __builtin_amdgcn_raw_buffer_load_b128(r, j * 32 + 16, 0, 16));
+  return {a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ void st_half_sc1(double4* base, int half_index, double2 v)
+{
+  const sf_v2d t = {v.x, v.y};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_v4i, t), rec_rsrc(base), half_index * 16, 0, 16);
+}
+__device__ __forceinline__ double ld_f64_sc1(const double* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_f64_sc1(double* p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Streamed (read-once / write-once per sub-step) rows can be marked non-temporal so that they do not evict the
 // neighbour records the gathers want to find again in the 32 KB vector L1 and the 4 MB L2 of the XCD.  Whether that
@@ -142,7 +186,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     sh = {0.0, 0.0, 0.0};
     if (STYLE == 0 || !(jraw & kTouchBit) || (SF_EXP_NOSHLD && S.kstep >= 0)) return;
     const bool own = (jraw & kOwnBit) != 0;
-    auto ldh = [&](const double* p) { return ld_stream<NT_HIST>(p); };
+    auto ldh = [&](const double* p) { return SF_EXP_SC1_GATHER ? ld_f64_sc1(p) : ld_stream<NT_HIST>(p); };
     if (own) {
       const double* const hin = P.shear_in + (size_t)(3 * slotrow) * cap;
       sh.x = ldh(&hin[i]);
@@ -168,11 +212,19 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     } else {
       const int j = neigh_index(jraw, ROOTS);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
-      R.x = P.xr_in[j];
       R.vw = wants_vw(jraw);
-      if (R.vw) {
-        R.v = P.vm_in[j];
-        R.w = P.om_in[j];
+      if (SF_EXP_SC1_GATHER) {
+        R.x = ld_rec_sc1(P.xr_in, j);
+        if (R.vw) {
+          R.v = ld_rec_sc1(P.vm_in, j);
+          R.w = ld_rec_sc1(P.om_in, j);
+        }
+      } else {
+        R.x = P.xr_in[j];
+        if (R.vw) {
+          R.v = P.vm_in[j];
+          R.w = P.om_in[j];
+        }
       }
     }
     if (SF_HIST_PREFETCH) load_history(jraw, slotrow, R.sh);
@@ -301,9 +353,15 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
 #if !SF_EXP_NOSHST
         if (own) {
-          st_stream<NT_ST>(&hout[i], sh.x);
-          st_stream<NT_ST>(&(hout + cap)[i], sh.y);
-          st_stream<NT_ST>(&(hout + 2 * cap)[i], sh.z);
+          if (SF_EXP_SC1_SHST) {
+            st_f64_sc1(&hout[i], sh.x);
+            st_f64_sc1(&(hout + cap)[i], sh.y);
+            st_f64_sc1(&(hout + 2 * cap)[i], sh.z);
+          } else {
+            st_stream<NT_ST>(&hout[i], sh.x);
+            st_stream<NT_ST>(&(hout + cap)[i], sh.y);
+            st_stream<NT_ST>(&(hout + 2 * cap)[i], sh.z);
+          }
         }
 #else
         if (sh.x == 1.2345) hout[i] = sh.y + sh.z;
@@ -504,7 +562,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         const int src = 32 * half + (lane >> 1);
         const double b0 = __shfl(a0, src, 64), b1 = __shfl(a1, src, 64);
         const double b2 = __shfl(a2, src, 64), b3 = __shfl(a3, src, 64);
-        dst[64 * half + lane] = (lane & 1) ? double2{b2, b3} : double2{b0, b1};
+        const double2 val = (lane & 1) ? double2{b2, b3} : double2{b0, b1};
+        if (SF_EXP_SC1_RECST) st_half_sc1(arr, 2 * base + 64 * half + lane, val);
+        else dst[64 * half + lane] = val;
       }
     };
     store_shuffled(P.xr_out, xn.x, xn.y, xn.z, radi);
@@ -568,6 +628,44 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   }
   substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
 }
+
+#if SF_EXP_PERSIST_NOWAIT
+// Upper bound of what a persistent multi-sub-step kernel can gain (measurement only): `nsub` sub-steps in ONE launch,
+// one wave per workgroup, as many workgroups as the chip holds at once; XCD x walks the tiles (64 / LPA atoms) of its
+// contiguous eighth of the atoms, sub-step after sub-step, its waves taking the items round-robin.  No dependency
+// waits and every sub-step reads the SAME input buffer (so that the inputs stay valid): this prices the per-launch
+// fill / drain that the real kernel pays, nothing else.
+// The parameters live in constant memory and are re-read (scalar loads) per tile through a laundered pointer: passed by
+// value the compiler hoists every field out of the tile loop and spills ~120 SGPRs.
+struct PersistArgs {
+  DemPtrs P;
+  StepParams S;
+};
+__constant__ PersistArgs c_persist[4];
+template <int STYLE, bool COHE, bool LUB, int LPA, bool TP, int NTP>
+__global__ __launch_bounds__(64) SF_SUBSTEP_ATTR void k_substep_persist_nowait(int slot, int nsub)
+{
+  const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3, Wx = gridDim.x >> 3;
+  constexpr int APT = 64 / LPA;
+  const int nlocal = c_persist[slot].S.nlocal;
+  const int ntiles = (nlocal + APT - 1) / APT;
+  const int per = (ntiles + 7) / 8;
+  const int t0 = xcd * per, t1 = min(ntiles, t0 + per), cnt = max(0, t1 - t0);
+  const int total = cnt * nsub;
+  for (int p = r; p < total; p += Wx) {
+    const int k = p / cnt;
+    const int t = t0 + (p - k * cnt);
+    const int i = t * APT + (int)threadIdx.x / LPA;
+    const int q = (int)threadIdx.x % LPA;
+    typedef const __attribute__((address_space(4))) PersistArgs* CArgs;
+    CArgs A = (CArgs)&c_persist[slot];
+    asm volatile("" : "+s"(A));   // (not loop-invariant for the compiler)
+    if (i < nlocal)
+      substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(*(const DemPtrs*)&A->P, *(const StepParams*)&A->S, i, q,
+                                                              nullptr, nullptr, nullptr);
+  }
+}
+#endif
 
 // LDS-staged cell bins: one workgroup per tile of T x T x T bins.  The x/v/omega records of every atom in
 // the tile and in the one-bin shell around it (owned and ghost) are copied ONCE into LDS with mostly
