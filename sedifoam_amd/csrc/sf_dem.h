@@ -558,6 +558,7 @@ private:
   int tx_nhdr_ = 0, tx_n_[2] = {0, 0};
   bool tx_ready_ = false, tx_written_ = false;
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
+  int lanes_per_atom(int nwork) const;
   int nb_ = 0;                         // boundary atoms = [0, n_lo_) and [n_hi_, nlocal_) of the x-slowest order
   int n_lo_ = 0, n_hi_ = 0;
   bool overlap_ = false;

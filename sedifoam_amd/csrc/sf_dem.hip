@@ -711,6 +711,12 @@ static void launch_lds_style(bool cohe, bool lub, dim3 grid, size_t lds, hipStre
   else launch_lds_one<STYLE, false, false>(grid, lds, s, P, S);
 }
 
+int DemEngine::lanes_per_atom(int nwork) const
+{
+  return (opt_lpa_ == 1 || opt_lpa_ == 2 || opt_lpa_ == 4) ? opt_lpa_
+                                                            : (nwork < 20 * 1024 ? 4 : (nwork < 150 * 1024 ? 2 : 1));
+}
+
 void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
 {
   if (!nlocal_) return;
@@ -788,8 +794,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     if (nwork <= 0) return;
     // lanes per atom: small systems are latency bound (one lane walks all ~12 neighbours).  Measured: 10 k atoms
     // 17.3 -> 10.5 us per sub-step with 4 lanes, while at 100 k (1.5 waves per SIMD already) more lanes are slower
-    const int lpa = (opt_lpa_ == 1 || opt_lpa_ == 2 || opt_lpa_ == 4) ? opt_lpa_
-                                                                      : (nwork < 20 * 1024 ? 4 : (nwork < 150 * 1024 ? 2 : 1));
+    const int lpa = lanes_per_atom(nwork);
     const long long lanes = (long long)nwork * lpa;
     // one wave per workgroup: the dispatcher then balances single waves (a 256-thread workgroup holds its CU slots
     // until its slowest wave is done); measured 207.0 -> 203.2 us per sub-step at 1 M atoms, never slower below

@@ -41,7 +41,7 @@
 // They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
 // SF_VARIANT_BUILD); the shipped library never carries them.
 #if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT) || defined(SF_EXP_SC1_GATHER) || \
-     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST)) && !defined(SF_VARIANT_BUILD)
+     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ)) && !defined(SF_VARIANT_BUILD)
 #error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
 #endif
 #ifndef SF_EXP_NOSHLD
@@ -59,6 +59,9 @@
 #endif
 #ifndef SF_EXP_SC1_SHST
 #define SF_EXP_SC1_SHST 0     // shear-history stores write-through (sc1, 8 bytes per lane)
+#endif
+#ifndef SF_EXP_ACQ
+#define SF_EXP_ACQ 0          // an agent-scope acquire (vector-L1 invalidate) at the start of every wave
 #endif
 #ifndef SF_EXP_PERSIST_NOWAIT
 #define SF_EXP_PERSIST_NOWAIT 0   // upper bound of a persistent kernel: n sub-steps in one launch, NO dependency waits
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   } else if (i >= S.nlocal) {
     return;
   }
+  if (SF_EXP_ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
 }
 

@@ -111,8 +111,11 @@ def test_script_errors_use_reference_wording():
     with pytest.raises(SfError, match="fix cohesive on a group"):
         lmp.command("fix c bottom cohesive 1e-20 1e-7 1e-9 1e-4 1")
     lmp.command("fix 4 bottom freeze")
+    # force fixes may follow fix freeze (the reference's bed scripts put wall/gran after it; they then act on frozen
+    # grains too); only fix cohesive, which the pair loop adds before every post_force fix, must come first
+    lmp.command("fix 2 all gravity 9.8 vector 0 -1 0")
     with pytest.raises(SfError, match="after fix freeze"):
-        lmp.command("fix 2 all gravity 9.8 vector 0 -1 0")
+        lmp.command("fix c all cohesive 1e-20 1e-7 1e-9 1e-4 1")
 
 
 def test_put_local_info_rejects_foreign_tag():
