@@ -430,6 +430,7 @@ private:
   void bin_and_build();
   void read_flags();
   void reset_flag(int idx, int value);
+  void reset_flags(int idx, int count, int value);   // `count` adjacent flags, one launch
   void compute_grid();
   double max_radius();
   void sync() const { SF_HIP(hipStreamSynchronize(stream_)); }
@@ -507,6 +508,9 @@ private:
   // from the measured fraction of listed neighbours that touch (SF_TOUCH_PREFETCH=0 / 1 pins it)
   bool touch_prefetch_ = true;
   int touch_prefetch_env_ = -1;
+  // touching neighbours in the first slots of a row (k_build_neigh): loose beds only
+  bool touch_first_ = false;
+  int touch_first_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
   bool in_run_ = false;                      // rebuild() called from the stepping loop of run()
   RebuildPredictor predict_;                 // single-domain run(): how far to queue (SF_QUEUE_PREDICT=0: everything)

@@ -102,6 +102,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
   if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
   if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);
+  if (const char* e = getenv("SF_TOUCH_FIRST")) touch_first_env_ = atoi(e);
   if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
   if (const char* e = getenv("SF_LPA")) opt_lpa_ = atoi(e);
   if (const char* e = getenv("SF_QUEUE_PREDICT")) predict_.on = atoi(e) != 0;
@@ -546,10 +547,19 @@ double DemEngine::cutneighmax() const
   return c + lskin();
 }
 
-void DemEngine::reset_flag(int idx, int value)
+// (a one-thread kernel: ~2 us on the stream; a 4-byte host-to-device copy is a 5 us blit each, and a rebuild resets
+// sixteen of them)
+__global__ static void k_set_flags(int* flags, int idx, int count, int value)
 {
-  h_flags_[idx] = value;
-  SF_HIP(hipMemcpyAsync(d_flags_ + idx, h_flags_ + idx, sizeof(int), hipMemcpyHostToDevice, stream_));
+  if ((int)threadIdx.x < count) flags[idx + threadIdx.x] = value;
+}
+
+void DemEngine::reset_flag(int idx, int value) { reset_flags(idx, 1, value); }
+
+void DemEngine::reset_flags(int idx, int count, int value)
+{
+  for (int k = 0; k < count; k++) h_flags_[idx + k] = value;
+  k_set_flags<<<1, 32, 0, stream_>>>(d_flags_, idx, count, value);
 }
 
 void DemEngine::read_flags()
@@ -1135,6 +1145,19 @@ void DemEngine::bin_and_build()
     static const bool dbg = getenv("SF_DEBUG_HIST") != nullptr;
     if (dbg) fprintf(stderr, "[sedifoam_amd] partner-side coalescing %.3f -> %s history copy\n", frac, hist_single_ ? "one" : "two");
   }
+  // slot order of this list: touching neighbours first when the previous list touched fewer than about half of what
+  // it listed (k_build_neigh, touch_first; hysteresis 0.40 / 0.50; SF_TOUCH_FIRST=0 / 1 pins it)
+  if (touch_first_env_ >= 0) touch_first_ = touch_first_env_ != 0;
+  else if (have_list_ && h_flags_[F_LIST_SLOTS] > 0) {
+    const double frac = (double)h_flags_[F_LIST_TOUCH] / (double)h_flags_[F_LIST_SLOTS];
+    const bool before = touch_first_;
+    if (!touch_first_ && frac < 0.40) touch_first_ = true;
+    else if (touch_first_ && frac > 0.50) touch_first_ = false;
+    static const bool dbg = getenv("SF_DEBUG_HIST") != nullptr;
+    if (dbg && before != touch_first_)
+      fprintf(stderr, "[sedifoam_amd] %.3f of the listed neighbours touch -> touching neighbours %s\n", frac,
+              touch_first_ ? "first in their rows" : "in candidate order");
+  }
   int* cellLS = cell_start_;        // interleaved per cell: {owned start, owned end, ghost start, ghost end}
   int* cellLE = cell_start_ + 1;
   int* cellGS = cell_start_ + 2;
@@ -1160,6 +1183,7 @@ void DemEngine::bin_and_build()
   }
   build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {
+    static_assert(F_MAXNEIGH == F_NEIGH_OVER + 3, "one launch resets F_NEIGH_OVER and F_MAXNEIGH separately");
     reset_flag(F_NEIGH_OVER, 0);
     reset_flag(F_MAXNEIGH, 0);
     BuildParams B;
@@ -1177,6 +1201,7 @@ void DemEngine::bin_and_build()
     B.nloc = nloc_.as<unsigned short>();
     B.old_index = hist_indirect_ ? hist_perm_.as<int>() : nullptr;
     B.two_copies = hist_single_ ? 0 : 1;
+    B.touch_first = touch_first_ ? 1 : 0;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
     B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;
     B.roots = roots_ ? 1 : 0;
@@ -1187,7 +1212,7 @@ void DemEngine::bin_and_build()
     k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
         have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), neigh_.as<int>(),
-        numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_);
+        numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
     k_max_int<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_old_.as<int>(), nlocal_, d_flags_ + F_MAXNEIGH);
     read_flags();
     if (h_flags_[F_NEIGH_OVER] > M_) {
@@ -1212,9 +1237,7 @@ void DemEngine::bin_and_build()
                                                           roots_ ? 1 : 0);
   measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
-  k_store_xhold<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_,
-                                                           cap_);
-  have_list_ = true;
+  have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
   nbuilds_++;
 }
 
@@ -1225,7 +1248,7 @@ void DemEngine::measure_list()
   if (!nlocal_ || !roots_) return;
   static_assert(F_PART_COAL == F_PART_SLOTS + 1 && F_LIST_SLOTS == F_PART_SLOTS + 2 && F_LIST_TOUCH == F_PART_SLOTS + 3,
                 "adjacent counters");
-  for (int k = 0; k < 4; k++) reset_flag(F_PART_SLOTS + k, 0);
+  reset_flags(F_PART_SLOTS, 4, 0);
   k_partner_coalescing<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_,
                                                                    cap_, d_flags_ + F_PART_SLOTS);
 }
@@ -1433,9 +1456,8 @@ void DemEngine::mark_boundary()
   int cx_hi = (int)std::floor((subhi_x_ - cut - grid_.lo[0]) / cell + 1e-9);
   cx_lo = std::max(0, std::min(cx_lo, grid_.n[0]));
   cx_hi = std::max(cx_lo, std::min(cx_hi, grid_.n[0]));
-  reset_flag(F_SEND_COUNT, 0);
-  reset_flag(F_SEND_COUNT2, 0);
   static_assert(F_SEND_COUNT2 == F_SEND_COUNT + 1, "adjacent counters");
+  reset_flags(F_SEND_COUNT, 2, 0);
   k_count_layers<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, grid_, cx_lo, cx_hi,
                                                             d_flags_ + F_SEND_COUNT);
   read_flags();

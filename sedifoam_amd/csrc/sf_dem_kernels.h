@@ -1155,6 +1155,7 @@ struct BuildParams {
   const int* lb_ghost;
   const int* old_index;   // new index -> index before the re-sort (history rows not permuted), or nullptr
   int two_copies;         // every side of every contact keeps its own history copy (see k_partner_coalescing)
+  int touch_first;        // row path: touching neighbours take the first slots of a row (loose beds)
 };
 
 // ---- counting sort of the owned atoms by cell key (plain keys): a by-product is first[b], the first sorted position
@@ -1196,11 +1197,16 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
                                                      const int* cellGS, const int* cellGE,
                                                      const int* ghost_order, const int* numneigh_old,
                                                      const int* ptag_old, const double* shear_old,
-                                                     int* neigh, int* numneigh, double* shear, int* flags)
+                                                     int* neigh, int* numneigh, double* shear, int* flags, int* cand,
+                                                     double* xhold)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B.nlocal) return;
   const double4 xi = xr[i];
+  // [3P] Neighbor::build: the positions the skin/2 displacement check (Neighbor::check_distance) refers to
+  xhold[i] = xi.x;
+  xhold[B.cap + i] = xi.y;
+  xhold[2 * B.cap + i] = xi.z;
   int lost = 0;
   const int cx = bin_coord(xi.x, B.g.lo[0], B.g.inv[0], B.g.n[0], lost);
   const int cy = bin_coord(xi.y, B.g.lo[1], B.g.inv[1], B.g.n[1], lost);
@@ -1236,6 +1242,23 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     return j != i && rsq <= cut * cut;
   };
   // neighbour j enters the list; pos = its position in the tile's staged copy (LDS kernel only)
+  // partner tag of the old list that equals tj (-1: the pair did not touch)
+  auto find_old = [&](const int tj) {
+    int found = -1;
+#pragma unroll
+    for (int s = 0; s < kPT; s++)
+      if (pt[s] == tj) found = s;             // tags are unique: at most one match
+    if (found < 0)
+      for (int s = kPT; s < nold; s++)
+        if (ptag_old[(size_t)s * B.cap + io] == tj) {
+          found = s;
+          break;
+        }
+    return found;
+  };
+  // row path: slot of the next touching / next non-touching neighbour (touching ones first, see the second sweep)
+  int slot_touch = -1, slot_free = -1;
+  int found_known = -2;   // >= -1: the old slot of the pair was looked up before (touch-first placement)
   auto accept = [&](const int j, const int tj, const int pos) {
     if (n < B.M) {
       int entry = j;
@@ -1259,16 +1282,8 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       }
       if (own) entry |= kOwnBit;
       double sx = 0.0, sy = 0.0, sz = 0.0;
-      int found = -1;
-#pragma unroll
-      for (int s = 0; s < kPT; s++)
-        if (pt[s] == tj) found = s;             // tags are unique: at most one match
-      if (found < 0)
-        for (int s = kPT; s < nold; s++)
-          if (ptag_old[(size_t)s * B.cap + io] == tj) {
-            found = s;
-            break;
-          }
+      const int found = found_known >= -1 ? found_known : find_old(tj);
+      const int dst = slot_touch < 0 ? n : (found >= 0 ? slot_touch++ : slot_free++);
       if (found >= 0) {
         entry |= kTouchBit;
         const size_t ob = (size_t)(3 * found) * B.cap + io;
@@ -1276,9 +1291,9 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
         sy = shear_old[ob + B.cap];
         sz = shear_old[ob + 2 * B.cap];
       }
-      neigh[(size_t)n * B.cap + i] = entry;
-      if (eo) B.nloc[(size_t)n * B.cap + i] = (unsigned short)pos;
-      const size_t nb = (size_t)(3 * n) * B.cap + i;
+      neigh[(size_t)dst * B.cap + i] = entry;
+      if (eo) B.nloc[(size_t)dst * B.cap + i] = (unsigned short)pos;
+      const size_t nb = (size_t)(3 * dst) * B.cap + i;
       shear[nb] = sx;
       shear[nb + B.cap] = sy;
       shear[nb + 2 * B.cap] = sz;
@@ -1290,7 +1305,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   };
   int n_total = 0;   // row path: accepted candidates of the first sweep (may exceed the slots: overflow report)
   auto note = [&](const int j) {
-    if (n_total < B.M) neigh[(size_t)n_total * B.cap + i] = j;
+    if (n_total < B.M) cand[(size_t)n_total * B.cap + i] = j;
     n_total++;
   };
   if (B.lb_own) {
@@ -1342,15 +1357,44 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // second sweep, slot by slot: every lane of the wave is at the same row of the slot-major arrays, so the history
     // re-injection reads and the neigh/shear stores are coalesced even when the lanes found their neighbours at
     // different moments of the candidate walk (disordered beds)
+    // B.touch_first (loose beds: far fewer touching than listed neighbours): the neighbours that touched in the old
+    // list (their history is re-injected) take the FIRST slots of the row, in candidate order, the others follow.  The
+    // sub-step kernel then evaluates the contact law in the first slots, where most lanes of a wave touch, and skips
+    // it wave-wide in the rest, instead of running it in every slot for the few lanes that touch there (loose bed:
+    // 230 -> 184 us per sub-step at 1 M grains).  In an ordered bed the same shuffle costs the lane-to-lane
+    // regularity of the slots -- slot s of adjacent lanes = adjacent atoms -- that the gathers coalesce on (+35 %
+    // there), hence the switch.  Two passes over the candidates: look every pair up in the old list and count
+    // (the result parked in the nloc rows, unused on this path), then place.
     const int nacc = n_total < B.M ? n_total : B.M;
+    const bool tf = B.touch_first && nold > 0;
+    if (tf) {
+      int ntouch = 0;
+      // (two slots ahead: candidate index, one slot ahead: its tag -- the look-up itself runs on registers)
+      int c1 = nacc > 0 ? cand[i] : 0, c2 = nacc > 1 ? cand[B.cap + i] : 0;
+      int t1 = nacc > 0 ? tag[c1] : 0;
+      for (int s = 0; s < nacc; s++) {
+        const int tj = t1;
+        c1 = c2;
+        if (s + 1 < nacc) t1 = tag[c1];
+        if (s + 2 < nacc) c2 = cand[(size_t)(s + 2) * B.cap + i];
+        const int f = find_old(tj);
+        B.nloc[(size_t)s * B.cap + i] = (unsigned short)(f + 1);
+        ntouch += f >= 0 ? 1 : 0;
+      }
+      slot_touch = 0;
+      slot_free = ntouch;
+    }
     n = 0;
-    int jn = nacc > 0 ? neigh[i] : 0;
-    int tn = nacc > 0 ? tag[jn] : 0;
+    int jn = nacc > 0 ? cand[i] : 0;
+    int tn = (nacc > 0 && !tf) ? tag[jn] : 0;
+    int fn = (nacc > 0 && tf) ? (int)B.nloc[i] - 1 : -2;
     for (int s = 0; s < nacc; s++) {
       const int j = jn, tj = tn;
+      found_known = fn;
       if (s + 1 < nacc) {
-        jn = neigh[(size_t)(s + 1) * B.cap + i];
-        tn = tag[jn];
+        jn = cand[(size_t)(s + 1) * B.cap + i];
+        if (tf) fn = (int)B.nloc[(size_t)(s + 1) * B.cap + i] - 1;
+        else tn = tag[jn];
       }
       accept(j, tj, 0);
     }
@@ -1433,16 +1477,6 @@ __global__ __launch_bounds__(128) void k_tile_stage_fill(BinGrid g, const int* c
       }
     }
   }
-}
-
-__global__ __launch_bounds__(256) void k_store_xhold(const double4* xr, double* xhold, int nlocal, size_t cap)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlocal) return;
-  const double4 x = xr[i];
-  xhold[i] = x.x;
-  xhold[cap + i] = x.y;
-  xhold[2 * cap + i] = x.z;
 }
 
 // ------------------------------------------------------------------------------------------------
