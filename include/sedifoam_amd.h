@@ -226,6 +226,14 @@ int sf_dem_halo_run(void *ptr, int first_k, int n, const sf_halo_layout *lay, in
  * Particles are handed over per rank with sf_dem_create_atoms / read_data before sf_slab_setup (every rank its own
  * slab's atoms).  The rebuild-time exchanges use ncclSend/ncclRecv on device buffers; nothing goes through Python. */
 int sf_slab_init(void *ptr, const char *id128, int rank, int world, double xlo, double xhi, int periodic_x);
+/* 3-D brick decomposition ([3P] `processors px py pz`; the reference's parallel cases cut two dimensions,
+ * cases/example-cases/transport-bedload/system/decomposeParDict: n (14 1 6)): px * py * pz = world bricks over the
+ * engine's box (set_box / `boundary` before this call), rank r owns brick (r % px, (r / px) % py, r / (px py)).
+ * Collective, instead of sf_slab_init; sf_slab_setup / sf_slab_step / sf_slab_rebuild then drive the bricks:
+ * migration staged over the dimensions, every ghost sent straight by its owner to the (up to 26) neighbour bricks --
+ * ONE grouped ncclSend/ncclRecv per sub-step --, the rebuild vote in a header word to every rank.  Dimensions the
+ * grid does not cut keep their periodic images local. */
+int sf_brick_init(void *ptr, const char *id128, int rank, int world, int px, int py, int pz);
 int sf_slab_setup(void *ptr);
 int sf_slab_rebuild(void *ptr);
 int sf_slab_step(void *ptr, int n);

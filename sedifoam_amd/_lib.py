@@ -141,6 +141,7 @@ _SIGS = {
     "sf_dem_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
     "sf_dem_halo_run": (C.c_int, [vp, C.c_int, C.c_int, vp, ip]),
     "sf_slab_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "sf_brick_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sf_slab_setup": (C.c_int, [vp]),
     "sf_slab_rebuild": (C.c_int, [vp]),
     "sf_slab_step": (C.c_int, [vp, C.c_int]),

@@ -287,6 +287,7 @@ class DemEngine {
   void set_max_neigh(int m);
   void set_velocity_all(double vx, double vy, double vz);
   void set_subdomain(int rank, int nranks, double sublo, double subhi);
+  void set_subdomain3(int rank, int nranks, const double lo[3], const double hi[3], const int ext[3]);
 
   // ---- stepping ----
   void setup();            // first run: build list, forces with shearupdate = 0
@@ -327,6 +328,14 @@ class DemEngine {
   int rank() const { return rank_; }
   int nranks() const { return nranks_; }
   void sublo_hi(double out[6]) const;
+  void box(double lo[3], double hi[3], int periodic[3]) const
+  {
+    for (int k = 0; k < 3; k++) {
+      lo[k] = boxlo_[k];
+      hi[k] = boxhi_[k];
+      periodic[k] = periodic_[k];
+    }
+  }
   void get_local_info(double* x, double* v, int* foamCpuId, int* tag);
   void get_initial_info(double* x, double* v, double* diam, double* rho, int* tag, int* type);
   void put_local_info(int n, const double* fdrag, const int* foamCpuId, const int* tagIn);
@@ -359,6 +368,28 @@ class DemEngine {
                       int nhdr);
   bool forward_tx_written() const { return tx_written_; }
   bool profiling() const { return profiling_; }
+  // ---- 3-D brick decomposition (sf_brick_*, csrc/sf_brick_rccl.hip): up to 26 send directions instead of two x faces.
+  // A direction d = (dx, dy, dz), components in {-1, 0, 1}, names the neighbour brick the atoms go to; an owned atom
+  // belongs to it when it lies within the ghost cutoff of EVERY face d points through (a corner atom is sent in 7
+  // directions).  shift = what is added to its position so that it lands in the receiver's frame (a box length across
+  // a periodic face of the global box).  All ghosts come straight from their owners: one exchange stage per sub-step.
+  static constexpr int kMaxDirs = 26;
+  struct BrickBlocks {             // blocks of one exchange, passed by value to the pack / unpack kernels
+    int n;
+    int first[kMaxDirs + 1];       // send: positions in the concatenated send list; receive: ghost slots after nlocal
+    long long off[kMaxDirs];       // where the block's records start in the send / receive buffer (doubles)
+    double shift[kMaxDirs][3];     // send only
+  };
+  void brick_set_dirs(int ndir, const int* d3, const double* shift3);
+  void brick_border_select(long long* counts);             // fills the send lists; counts[ndir]
+  void brick_border_pack(double* buf);                     // every block in direction order, kBorderDoubles per atom
+  void brick_ghost_unpack(const double* buf, long long natoms);   // border records -> external ghosts (appended)
+  void brick_forward_pack(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr);
+  void brick_forward_unpack(const BrickBlocks& rcv, const double* recvbuf, const int* hdr_off, int nhdr);
+  const BrickBlocks& brick_send_blocks() const { return bsend_blocks_; }
+  long long migrate_count3();      // owned atoms outside the brick in any external dimension
+  long long migrate_pack_dim(int dim, int side, double shift, double* buf, long long max_doubles);
+  bool brick() const { return brick_; }
   long long migrate_pack(int side, double xshift, double* buf, long long max_doubles);
   void migrate_unpack(const double* buf, long long ndoubles);
   int migrate_record_doubles() const;
@@ -422,7 +453,7 @@ private:
   void permute_locals(const int* perm, int n_new, bool rows = true);
   void migrate_compact();
   void compute_partner_tags();
-  int select_locals(int mode, double bound, DevArray& list);
+  int select_locals(int mode, double bound, DevArray& list, int dim = 0);
  public:
   long long migrate_count();   // owned atoms outside [sublo, subhi): what the two migrate_pack calls would send
  private:
@@ -452,8 +483,13 @@ private:
   double boxlo_[3] = {0, 0, 0}, boxhi_[3] = {1, 1, 1};
   int periodic_[3] = {0, 0, 0};
   int rank_ = 0, nranks_ = 1;
-  double sublo_x_ = 0.0, subhi_x_ = 1.0;
-  bool have_subdomain_ = false;   // true: the x halo is external (driven through sf_dem_border_* etc.)
+  // sub-domain of this GPU and the dimensions whose halo is EXTERNAL (ghosts come from other GPUs through the driver;
+  // every other periodic dimension gets its images locally, as (root, image code) neighbour words).  Slab driver: x.
+  // Brick driver (set_subdomain3): every dimension the processor grid cuts.
+  double sublo_[3] = {0.0, 0.0, 0.0}, subhi_[3] = {1.0, 1.0, 1.0};
+  bool ext_[3] = {false, false, false};
+  bool have_subdomain_ = false;   // true: some halo is external (driven through sf_dem_border_* / sf_brick_*)
+  bool brick_ = false;            // set_subdomain3: 3-D processor grid (direction lists instead of two x faces)
   // environment overrides, all measured: SF_SUB sort cells per cutoff length, SF_TILE tile-major
   // sort, SF_XCD_REMAP contiguous block range per XCD, SF_LDS the LDS-staged kernel
   int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
@@ -562,6 +598,15 @@ private:
   int tx_nhdr_ = 0, tx_n_[2] = {0, 0};
   bool tx_ready_ = false, tx_written_ = false;
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
+  // brick decomposition: directions, face masks of the owned atoms, concatenated send lists
+  int bndir_ = 0;
+  int bdir_[kMaxDirs][3];
+  BrickBlocks bsend_blocks_{};
+  DevArray bmask_;
+  int* bsend_list_ = nullptr;
+  size_t bsend_alloc_ = 0;
+  int* d_bcount_ = nullptr;            // [2 * kMaxDirs] device counters / cursors
+  int* h_bcount_ = nullptr;            // pinned twin
   int lanes_per_atom(int nwork) const;
   int nb_ = 0;                         // boundary atoms = [0, n_lo_) and [n_hi_, nlocal_) of the x-slowest order
   int n_lo_ = 0, n_hi_ = 0;

@@ -113,7 +113,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &extra_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_[0], &shear_[1], &neigh_old_, &numneigh_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_, &bmask_};
 }
 
 DemEngine::~DemEngine()
@@ -122,6 +122,9 @@ DemEngine::~DemEngine()
   for (DevArray* a : per_atom_) a->release();
   if (cell_start_) (void)hipFree(cell_start_);
   if (tile_tab_) (void)hipFree(tile_tab_);
+  if (bsend_list_) (void)hipFree(bsend_list_);
+  if (d_bcount_) (void)hipFree(d_bcount_);
+  if (h_bcount_) (void)hipHostFree(h_bcount_);
   if (stage_idx_) (void)hipFree(stage_idx_);
   if (eoff_) (void)hipFree(eoff_);
   if (tagmap_) (void)hipFree(tagmap_);
@@ -204,6 +207,7 @@ void DemEngine::alloc_all(size_t cap)
   leave_.alloc(sizeof(int), 1, cap, s);
   nloc_.alloc(sizeof(unsigned short), M_, cap, s);
   isb_.alloc(sizeof(unsigned char), 1, cap, s);
+  bmask_.alloc(sizeof(unsigned char), 1, cap, s);
   cap_ = cap;
 }
 
@@ -283,10 +287,11 @@ void DemEngine::set_box(const double lo[3], const double hi[3])
     boxlo_[k] = lo[k];
     boxhi_[k] = hi[k];
   }
-  if (!have_subdomain_) {
-    sublo_x_ = lo[0];
-    subhi_x_ = hi[0];
-  }
+  for (int k = 0; k < 3; k++)
+    if (!ext_[k]) {
+      sublo_[k] = lo[k];
+      subhi_[k] = hi[k];
+    }
 }
 
 void DemEngine::set_periodic(int px, int py, int pz)
@@ -300,19 +305,31 @@ void DemEngine::set_subdomain(int rank, int nranks, double sublo, double subhi)
 {
   rank_ = rank;
   nranks_ = nranks;
-  sublo_x_ = sublo;
-  subhi_x_ = subhi;
+  sublo_[0] = sublo;
+  subhi_[0] = subhi;
+  ext_[0] = true;
   have_subdomain_ = true;
+}
+
+void DemEngine::set_subdomain3(int rank, int nranks, const double lo[3], const double hi[3], const int ext[3])
+{
+  rank_ = rank;
+  nranks_ = nranks;
+  for (int k = 0; k < 3; k++) {
+    ext_[k] = ext[k] != 0;
+    sublo_[k] = ext_[k] ? lo[k] : boxlo_[k];
+    subhi_[k] = ext_[k] ? hi[k] : boxhi_[k];
+  }
+  have_subdomain_ = true;
+  brick_ = true;
 }
 
 void DemEngine::sublo_hi(double out[6]) const
 {
-  out[0] = sublo_x_;
-  out[1] = subhi_x_;
-  out[2] = boxlo_[1];
-  out[3] = boxhi_[1];
-  out[4] = boxlo_[2];
-  out[5] = boxhi_[2];
+  for (int k = 0; k < 3; k++) {
+    out[2 * k] = sublo_[k];
+    out[2 * k + 1] = subhi_[k];
+  }
 }
 
 void DemEngine::create_atoms(int n, const double* x, const double* v, const double* omega,
@@ -752,8 +769,8 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   if (tx_ready_ && mode == 0 && part != 1 && !lds_active_) {
     S.tx_fused = 1;
     const double cut = cutneighmax() + skin_;   // (an atom is within skin/2 of where the border lists were made)
-    S.tx_xlo = sublo_x_ + cut;
-    S.tx_xhi = subhi_x_ - cut;
+    S.tx_xlo = sublo_[0] + cut;
+    S.tx_xhi = subhi_[0] - cut;
     S.tx_shift[0] = tx_shift_[0];
     S.tx_shift[1] = tx_shift_[1];
     S.tx_n[0] = tx_n_[0];
@@ -877,11 +894,11 @@ void DemEngine::compute_grid()
 {
   const double cut = cutneighmax();
   if (!(cut > 0.0)) fail("neighbor cutoff is zero: define a pair style and/or `neighbor <skin> bin`");
-  double lo[3] = {sublo_x_, boxlo_[1], boxlo_[2]};
-  double hi[3] = {subhi_x_, boxhi_[1], boxhi_[2]};
+  const double* lo = sublo_;   // (= the box in every dimension whose halo is not external)
+  const double* hi = subhi_;
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
-    const bool ext = periodic_[k] || (k == 0 && have_subdomain_);
+    const bool ext = periodic_[k] || ext_[k];
     const double l = ext ? lo[k] - cut : lo[k];
     const double h = ext ? hi[k] + cut : hi[k];
     int n = (int)((h - l) / cut);
@@ -892,7 +909,7 @@ void DemEngine::compute_grid()
   }
   grid_.stencil = opt_sub_;
   grid_.tile = opt_tile_ > 1 ? opt_tile_ * opt_sub_ : 1;   // tiles keep their physical size
-  grid_.xslow = (have_subdomain_ && grid_.tile <= 1) ? 1 : 0;
+  grid_.xslow = (have_subdomain_ && !brick_ && grid_.tile <= 1) ? 1 : 0;
   grid_.nbins = 1;
   for (int k = 0; k < 3; k++) {
     grid_.nt[k] = (grid_.n[k] + grid_.tile - 1) / grid_.tile;
@@ -996,7 +1013,7 @@ void DemEngine::rebuild_sort()
     pb.hi[k] = boxhi_[k];
     // x is wrapped here only when this GPU owns the whole periodic length; with several slabs the
     // wrap is applied by the migration shift
-    pb.wrap[k] = periodic_[k] && !(k == 0 && have_subdomain_);
+    pb.wrap[k] = periodic_[k] && !ext_[k];
   }
   const int nb = div_up(nlocal_, 256);
   k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
@@ -1058,7 +1075,7 @@ void DemEngine::make_periodic_ghosts()
     bool over = false;
     for (int dim = 0; dim < 3; dim++) {
       if (!periodic_[dim]) continue;
-      if (dim == 0 && have_subdomain_) continue;  // x images come from the neighbour GPUs (or the driver's self loop)
+      if (ext_[dim]) continue;  // images across an external face come from the neighbour GPUs (or the driver's self loop)
       GhostPtrs G{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
                   type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
       // F_GHOST_COUNT counts ghosts (external ones included); list slot = ghost slot
@@ -1452,8 +1469,8 @@ void DemEngine::mark_boundary()
   if (!grid_.xslow) fail("overlapped halo: needs the x-slowest atom order (no SF_TILE)");
   const double cut = cutneighmax();
   const double cell = 1.0 / grid_.inv[0];
-  int cx_lo = (int)std::ceil((sublo_x_ + cut - grid_.lo[0]) / cell - 1e-9);
-  int cx_hi = (int)std::floor((subhi_x_ - cut - grid_.lo[0]) / cell + 1e-9);
+  int cx_lo = (int)std::ceil((sublo_[0] + cut - grid_.lo[0]) / cell - 1e-9);
+  int cx_hi = (int)std::floor((subhi_[0] - cut - grid_.lo[0]) / cell + 1e-9);
   cx_lo = std::max(0, std::min(cx_lo, grid_.n[0]));
   cx_hi = std::max(cx_lo, std::min(cx_hi, grid_.n[0]));
   static_assert(F_SEND_COUNT2 == F_SEND_COUNT + 1, "adjacent counters");

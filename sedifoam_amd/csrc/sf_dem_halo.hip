@@ -23,11 +23,13 @@ constexpr int kMigrateFixed = 26;  // + 3*nwalls + 4*mrec + nextra
 
 // key 0 = selected, 1 = not (a stable compaction then lists the selected atoms, ascending)
 // mode 0: x < bound ; mode 1: x >= bound
-__global__ __launch_bounds__(256) void k_select_keys(const double4* xr, int n, int mode, double bound, unsigned* keys)
+__global__ __launch_bounds__(256) void k_select_keys(const double4* xr, int n, int mode, double bound, unsigned* keys,
+                                                     int dim = 0)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double x = xr[i].x;
+  const double4 p = xr[i];
+  const double x = dim == 0 ? p.x : (dim == 1 ? p.y : p.z);
   keys[i] = (mode == 0 ? (x < bound) : (x >= bound)) ? 0u : 1u;
 }
 
@@ -125,7 +127,7 @@ struct MigratePtrs {
 
 __global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, double xshift, MigratePtrs P, size_t cap,
                                                       int nwalls, int mrec, int have_list, int rec, double* buf,
-                                                      int* leave, int code, int* flags)
+                                                      int* leave, int code, int* flags, int dim = 0)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(128) void k_migrate_pack(const int* list, int n, do
   leave[i] = code;
   double* b = buf + (size_t)k * rec;
   const double4 x = P.xr[i], v = P.vm[i], w = P.om[i];
-  b[0] = x.x + xshift; b[1] = x.y; b[2] = x.z; b[3] = x.w;
+  b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = x.w;
+  b[dim] += xshift;   // (the migration shift of the face's dimension)
   b[4] = v.x; b[5] = v.y; b[6] = v.z; b[7] = v.w;
   b[8] = w.x; b[9] = w.y; b[10] = w.z;
   b[11] = P.tag[i]; b[12] = P.type[i]; b[13] = P.mask[i]; b[14] = P.foamCpuId[i];
@@ -197,11 +200,11 @@ __global__ __launch_bounds__(256) void k_stay_keys(const int* leave, int n, unsi
 }
 
 // ------------------------------------------------------------------------------------------------
-int DemEngine::select_locals(int mode, double bound, DevArray& list)
+int DemEngine::select_locals(int mode, double bound, DevArray& list, int dim)
 {
   if (!nlocal_) return 0;
   k_select_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, mode, bound,
-                                                         keys_.as<unsigned>());
+                                                         keys_.as<unsigned>(), dim);
   select_zero_keys(sort_tmp_, sort_tmp_bytes_, keys_.as<unsigned>(), list.as<int>(), d_flags_ + F_SEND_COUNT,
                    nlocal_, stream_);
   read_flags();
@@ -212,7 +215,7 @@ long long DemEngine::border_pack(int side, double xshift, double* buf, long long
 {
   if (side < 0 || side > 1) fail("border_pack: side must be 0 or 1");
   const double cut = cutneighmax();
-  const int n = select_locals(side == 0 ? 0 : 1, side == 0 ? sublo_x_ + cut : subhi_x_ - cut, sendlist_[side]);
+  const int n = select_locals(side == 0 ? 0 : 1, side == 0 ? sublo_[0] + cut : subhi_[0] - cut, sendlist_[side]);
   if (n > max_atoms) fail("border_pack: %d atoms do not fit the %lld-atom buffer", n, max_atoms);
   nsend_[side] = n;
   if (n)
@@ -231,7 +234,7 @@ void DemEngine::border_pack_both(double xshift0, double* buf0, double xshift1, d
   nsend_[0] = nsend_[1] = 0;
   if (!nlocal_) return;
   const double cut = cutneighmax();
-  const double bound[2] = {sublo_x_ + cut, subhi_x_ - cut};
+  const double bound[2] = {sublo_[0] + cut, subhi_[0] - cut};
   for (int side = 0; side < 2; side++) {
     k_select_keys<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, side, bound[side],
                                                            keys_.as<unsigned>());
@@ -535,7 +538,7 @@ long long DemEngine::migrate_count()
 {
   if (!nlocal_) return 0;
   reset_flag(F_SEND_COUNT, 0);
-  k_count_outside<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, sublo_x_, subhi_x_,
+  k_count_outside<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, sublo_[0], subhi_[0],
                                                              d_flags_ + F_SEND_COUNT);
   read_flags();
   return h_flags_[F_SEND_COUNT];
@@ -543,13 +546,18 @@ long long DemEngine::migrate_count()
 
 long long DemEngine::migrate_pack(int side, double xshift, double* buf, long long max_doubles)
 {
-  if (side < 0 || side > 1) fail("migrate_pack: side must be 0 or 1");
+  return migrate_pack_dim(0, side, xshift, buf, max_doubles);
+}
+
+long long DemEngine::migrate_pack_dim(int dim, int side, double xshift, double* buf, long long max_doubles)
+{
+  if (side < 0 || side > 1 || dim < 0 || dim > 2) fail("migrate_pack: side must be 0 or 1, dim 0..2");
   if (!migrate_pending_ && nlocal_) {
     SF_HIP(hipMemsetAsync(leave_.ptr, 0, sizeof(int) * nlocal_, stream_));
     migrate_pending_ = true;
   }
   DevArray& list = sendlist_[side];  // reused: the border exchange refills it afterwards
-  const int n = select_locals(side == 0 ? 0 : 1, side == 0 ? sublo_x_ : subhi_x_, list);
+  const int n = select_locals(side == 0 ? 0 : 1, side == 0 ? sublo_[dim] : subhi_[dim], list, dim);
   const int rec = migrate_record_doubles();
   if ((long long)n * rec > max_doubles)
     fail("migrate_pack: %d atoms x %d doubles do not fit the %lld-double buffer", n, rec, max_doubles);
@@ -558,7 +566,7 @@ long long DemEngine::migrate_pack(int side, double xshift, double* buf, long lon
                              fdrag_, DuDt_, vOld_, wshear_, shear_[hist_buf_], wtouch_, extra_, nextra_);
     k_migrate_pack<<<div_up(n, 128), 128, 0, stream_>>>(list.as<int>(), n, xshift, P, cap_, nwalls_, mrec_,
                                                         have_list_ ? 1 : 0, rec, buf, leave_.as<int>(), side + 1,
-                                                        d_flags_);
+                                                        d_flags_, dim);
   }
   migrate_leavers_ += n;
   read_flags();
@@ -607,6 +615,268 @@ void DemEngine::migrate_unpack(const double* buf, long long ndoubles)
     max_tag_ = std::max(max_tag_, (int)hb[(size_t)k * rec + 11]);
     rmax_ = std::max(rmax_, hb[(size_t)k * rec + 3]);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-D brick decomposition: direction lists ([3P] Comm::borders / forward_comm on a 3-D processor grid, with every
+// ghost sent by its owner in ONE stage instead of LAMMPS' three staged dimensions: one exchange latency per sub-step)
+// ------------------------------------------------------------------------------------------------
+struct BrickSel {
+  int ndir;
+  int need[DemEngine::kMaxDirs];   // the face bits (1 << 2 dim = low face, 2 << 2 dim = high face) a direction needs
+  double lo[3], hi[3];             // x_d < lo[d]: within the cutoff of the low face; x_d >= hi[d]: of the high face
+  int ext[3];
+};
+
+__device__ __forceinline__ int face_mask(const double4& x, const BrickSel& B)
+{
+  int m = 0;
+  const double c[3] = {x.x, x.y, x.z};
+  for (int d = 0; d < 3; d++) {
+    if (!B.ext[d]) continue;
+    if (c[d] < B.lo[d]) m |= 1 << (2 * d);
+    if (c[d] >= B.hi[d]) m |= 2 << (2 * d);
+  }
+  return m;
+}
+
+// face mask of every owned atom + how many atoms every direction sends (one global atomic per block and direction)
+__global__ __launch_bounds__(1024) void k_brick_count(const double4* xr, int n, BrickSel B, unsigned char* mask,
+                                                      int* counts)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = 0;
+  if (i < n) {
+    m = face_mask(xr[i], B);
+    mask[i] = (unsigned char)m;
+  }
+  if (!__syncthreads_or(m)) return;   // (most blocks hold no border atom)
+  for (int q = 0; q < B.ndir; q++) {
+    const int t = block_sum_int_1024((m & B.need[q]) == B.need[q] ? 1 : 0);
+    if (threadIdx.x == 0 && t) atomicAdd(&counts[q], t);
+  }
+}
+
+// the send list of every direction (block q of the concatenated list starts at first[q]); one cursor atomic per
+// wave and direction
+__global__ __launch_bounds__(256) void k_brick_fill(const unsigned char* mask, int n, BrickSel B,
+                                                    DemEngine::BrickBlocks blk, int* cursor, int* list)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = i < n ? mask[i] : 0;
+  if (!__ballot(m != 0)) return;
+  const int lane = threadIdx.x & 63;
+  for (int q = 0; q < B.ndir; q++) {
+    const bool in = m != 0 && (m & B.need[q]) == B.need[q];
+    const unsigned long long b = __ballot(in);
+    if (!b) continue;
+    int base = 0;
+    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&cursor[q], __popcll(b));
+    base = __shfl(base, __ffsll((long long)b) - 1, 64);
+    if (in) list[blk.first[q] + base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+  }
+}
+
+__device__ __forceinline__ int block_of(const DemEngine::BrickBlocks& blk, int k)
+{
+  int b = 0;
+  while (b + 1 < blk.n && k >= blk.first[b + 1]) b++;
+  return b;
+}
+
+__global__ __launch_bounds__(256) void k_brick_border_pack(const int* list, DemEngine::BrickBlocks blk, const double4* xr,
+                                                           const double4* vm, const double4* om, const int* tag,
+                                                           const int* type, const int* mask, double* buf)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= blk.first[blk.n]) return;
+  const int q = block_of(blk, k);
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double* b = buf + (size_t)k * kBorderDoubles;
+  b[0] = x.x + blk.shift[q][0]; b[1] = x.y + blk.shift[q][1]; b[2] = x.z + blk.shift[q][2]; b[3] = x.w;
+  b[4] = v.x; b[5] = v.y; b[6] = v.z; b[7] = v.w;
+  b[8] = w.x; b[9] = w.y; b[10] = w.z;
+  b[11] = (double)tag[i];
+  b[12] = (double)type[i];
+  b[13] = (double)mask[i];
+}
+
+// forward halo of one sub-step: the records of every block go to its place in the per-peer chunks, every chunk's
+// header carries this rank's rebuild trigger (the MIN over the headers a rank receives is the global vote)
+__global__ __launch_bounds__(256) void k_brick_forward_pack(const int* list, DemEngine::BrickBlocks blk,
+                                                            const int* hdr_off, int nhdr, double* sendbuf,
+                                                            const int* trig_word, const double4* xr, const double4* vm,
+                                                            const double4* om)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tot = blk.first[blk.n];
+  if (k >= tot) {
+    k -= tot;
+    if (k < nhdr) {
+      sendbuf[hdr_off[k]] = 0.0;
+      *header_vote_ptr(sendbuf + hdr_off[k]) = __atomic_load_n(trig_word, __ATOMIC_RELAXED);
+    }
+    return;
+  }
+  const int q = block_of(blk, k);
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double* b = sendbuf + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  b[0] = x.x + blk.shift[q][0]; b[1] = x.y + blk.shift[q][1]; b[2] = x.z + blk.shift[q][2];
+  b[3] = v.x; b[4] = v.y; b[5] = v.z;
+  b[6] = w.x; b[7] = w.y; b[8] = w.z;
+}
+
+__global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBlocks blk, const int* hdr_off, int nhdr,
+                                                              const double* recvbuf, int* vote_word, int nlocal,
+                                                              double4* xr, double4* vm, double4* om)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tot = blk.first[blk.n];
+  if (k >= tot) {
+    k -= tot;
+    if (k < nhdr) atomicMin(vote_word, header_vote(recvbuf + hdr_off[k]));
+    return;
+  }
+  const int q = block_of(blk, k);
+  const double* b = recvbuf + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  const int g = nlocal + k;
+  double4 x = xr[g], v = vm[g];
+  x.x = b[0]; x.y = b[1]; x.z = b[2];
+  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  xr[g] = x;   // radius / mass (.w) were set by the border exchange
+  vm[g] = v;
+  om[g] = {b[6], b[7], b[8], om[g].w};
+}
+
+void DemEngine::brick_set_dirs(int ndir, const int* d3, const double* shift3)
+{
+  if (ndir < 0 || ndir > kMaxDirs) fail("brick_set_dirs: %d directions", ndir);
+  bndir_ = ndir;
+  bsend_blocks_.n = ndir;
+  for (int q = 0; q < ndir; q++)
+    for (int k = 0; k < 3; k++) {
+      bdir_[q][k] = d3[3 * q + k];
+      if (bdir_[q][k] && !ext_[k]) fail("brick_set_dirs: direction %d points through a face that is not external", q);
+      bsend_blocks_.shift[q][k] = shift3[3 * q + k];
+    }
+  if (!d_bcount_) {
+    SF_HIP(hipMalloc(&d_bcount_, sizeof(int) * 2 * kMaxDirs));
+    SF_HIP(hipHostMalloc(&h_bcount_, sizeof(int) * 2 * kMaxDirs));
+  }
+}
+
+void DemEngine::brick_border_select(long long* counts)
+{
+  BrickSel B;
+  B.ndir = bndir_;
+  const double cut = cutneighmax();
+  for (int d = 0; d < 3; d++) {
+    B.ext[d] = ext_[d] ? 1 : 0;
+    B.lo[d] = sublo_[d] + cut;
+    B.hi[d] = subhi_[d] - cut;
+  }
+  for (int q = 0; q < bndir_; q++) {
+    int need = 0;
+    for (int d = 0; d < 3; d++) need |= bdir_[q][d] < 0 ? 1 << (2 * d) : (bdir_[q][d] > 0 ? 2 << (2 * d) : 0);
+    B.need[q] = need;
+  }
+  for (int q = 0; q <= bndir_; q++) bsend_blocks_.first[q] = 0;
+  tx_ready_ = tx_written_ = false;
+  if (nlocal_ && bndir_) {
+    SF_HIP(hipMemsetAsync(d_bcount_, 0, sizeof(int) * 2 * kMaxDirs, stream_));
+    k_brick_count<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, B,
+                                                             bmask_.as<unsigned char>(), d_bcount_);
+    SF_HIP(hipMemcpyAsync(h_bcount_, d_bcount_, sizeof(int) * kMaxDirs, hipMemcpyDeviceToHost, stream_));
+    sync();
+    for (int q = 0; q < bndir_; q++) bsend_blocks_.first[q + 1] = bsend_blocks_.first[q] + h_bcount_[q];
+    const size_t tot = (size_t)bsend_blocks_.first[bndir_];
+    if (tot > bsend_alloc_) {
+      if (bsend_list_) SF_HIP(hipFree(bsend_list_));
+      bsend_alloc_ = tot + tot / 4 + 1024;
+      SF_HIP(hipMalloc(&bsend_list_, sizeof(int) * bsend_alloc_));
+    }
+    if (tot)
+      k_brick_fill<<<div_up(nlocal_, 256), 256, 0, stream_>>>(bmask_.as<unsigned char>(), nlocal_, B, bsend_blocks_,
+                                                             d_bcount_ + kMaxDirs, bsend_list_);
+  }
+  for (int q = 0; q < bndir_; q++) counts[q] = bsend_blocks_.first[q + 1] - bsend_blocks_.first[q];
+}
+
+void DemEngine::brick_border_pack(double* buf)
+{
+  const int tot = bsend_blocks_.first[bndir_];
+  if (tot)
+    k_brick_border_pack<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, bsend_blocks_, xr_[cur_].as<double4>(),
+                                                              vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
+                                                              tag_.as<int>(), type_.as<int>(), mask_.as<int>(), buf);
+}
+
+void DemEngine::brick_ghost_unpack(const double* buf, long long natoms)
+{
+  const int n = (int)natoms;
+  ensure_capacity((size_t)nlocal_ + next_ghost_ + n + 1024);
+  const int first = nlocal_ + next_ghost_;
+  if (n)
+    k_border_unpack<<<div_up(n, 256), 256, 0, stream_>>>(buf, n, first, xr_[cur_].as<double4>(),
+                                                         vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
+                                                         xr_[cur_ ^ 1].as<double4>(), vm_[cur_ ^ 1].as<double4>(),
+                                                         om_[cur_ ^ 1].as<double4>(), tag_.as<int>(), type_.as<int>(),
+                                                         mask_.as<int>(), gsrc_.as<int>(), freeze_bit_);
+  next_ghost_ += n;
+}
+
+void DemEngine::brick_forward_pack(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr)
+{
+  const int tot = snd.first[snd.n] + nhdr;
+  if (tot)
+    k_brick_forward_pack<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, snd, hdr_off, nhdr, sendbuf,
+                                                               d_flags_ + F_TRIGGER, xr_[cur_].as<double4>(),
+                                                               vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+}
+
+void DemEngine::brick_forward_unpack(const BrickBlocks& rcv, const double* recvbuf, const int* hdr_off, int nhdr)
+{
+  if (rcv.first[rcv.n] != next_ghost_)
+    fail("brick_forward_unpack: %d ghosts in the layout, the border exchange set up %d", rcv.first[rcv.n], next_ghost_);
+  const int tot = rcv.first[rcv.n] + nhdr;
+  if (tot)
+    k_brick_forward_unpack<<<div_up(tot, 256), 256, 0, stream_>>>(rcv, hdr_off, nhdr, recvbuf, d_flags_ + F_TRIGGER,
+                                                                 nlocal_, xr_[cur_].as<double4>(),
+                                                                 vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+  launch_ghost_forward(cur_, INT_MIN);   // (index mode only: local images of everything, received ghosts included)
+}
+
+// owned atoms outside the brick in any external dimension
+__global__ __launch_bounds__(1024) void k_count_outside3(const double4* xr, int n, BrickSel B, int* counter)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool out = false;
+  if (i < n) {
+    const double4 x = xr[i];
+    const double c[3] = {x.x, x.y, x.z};
+    for (int d = 0; d < 3; d++) out = out || (B.ext[d] && (c[d] < B.lo[d] || c[d] >= B.hi[d]));
+  }
+  const int t = block_sum_int_1024(out ? 1 : 0);
+  if (threadIdx.x == 0 && t) atomicAdd(counter, t);
+}
+
+long long DemEngine::migrate_count3()
+{
+  if (!nlocal_) return 0;
+  BrickSel B;
+  B.ndir = 0;
+  for (int d = 0; d < 3; d++) {
+    B.ext[d] = ext_[d] ? 1 : 0;
+    B.lo[d] = sublo_[d];
+    B.hi[d] = subhi_[d];
+  }
+  reset_flag(F_SEND_COUNT, 0);
+  k_count_outside3<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, B,
+                                                              d_flags_ + F_SEND_COUNT);
+  read_flags();
+  return h_flags_[F_SEND_COUNT];
 }
 
 // ------------------------------------------------------------------------------------------------

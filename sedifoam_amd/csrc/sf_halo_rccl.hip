@@ -106,8 +106,38 @@ struct GrowBuf {
   }
 };
 
+// ---- 3-D brick decomposition (sf_brick_init): processor grid P, direct exchange with up to 26 neighbour bricks ----
+struct BrickState {
+  int P[3] = {1, 1, 1}, c[3] = {0, 0, 0};
+  double lo[3], hi[3];
+  int periodic[3];
+  bool ext[3];
+  struct SDir {   // a send direction: the neighbour brick at offset d
+    int d[3], code, peer;
+    double shift[3];
+  };
+  struct RDir {   // a block this rank receives: what the neighbour at offset s sends in ITS direction -s
+    int peer, sender_code;
+  };
+  std::vector<SDir> sdirs;   // sorted by (peer, code): the blocks for one peer are contiguous, in the sender's order
+  std::vector<RDir> rdirs;   // sorted by (peer, sender's code): the same order seen from the receiving side
+  int nbr[3][2];             // face neighbours per dimension (-1: none), for the staged migration
+  double mshift[3][2];
+  std::vector<long long> nsend, nrecv;   // atoms per block
+  DemEngine::BrickBlocks snd{}, rcv{};
+  long long* d_cnt = nullptr;   // [2 * 26] block sizes: mine, then the neighbours'
+  long long* h_cnt = nullptr;
+  GrowBuf btx, brx;
+  ~BrickState()
+  {
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (h_cnt) (void)hipHostFree(h_cnt);
+  }
+};
+
 struct HaloComm {
   ncclComm_t comm = nullptr;
+  BrickState* brick = nullptr;
   int rank = 0, world = 1;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
   // ---- the slab driver (sf_slab_*): what sedifoam_amd/halo.py SlabDriver does, in C++ ----
@@ -150,6 +180,7 @@ struct HaloComm {
   }
   ~HaloComm()
   {
+    delete brick;
     if (comm) (void)rccl().CommDestroy(comm);
     if (ev_boundary) (void)hipEventDestroy(ev_boundary);
     if (ev_halo) (void)hipEventDestroy(ev_halo);
@@ -233,21 +264,30 @@ static void slab_allreduce_max2(HaloComm& hc, hipStream_t st, double& a, double&
 // left / right in hc.rx[0] / hc.rx[1] and their sizes.  known = receive sizes when both sides already know them.
 // Message order with one peer on both sides (2 ranks, periodic): sends left then right, receives from-right then
 // from-left -- what I sent leftwards reaches my left neighbour from its right.
+static void pair_exchange(HaloComm& hc, hipStream_t st, int left, int right, const double* s0, long long n0,
+                          const double* s1, long long n1, long long& m0, long long& m1);
 static void slab_exchange(HaloComm& hc, hipStream_t st, const double* s0, long long n0, const double* s1, long long n1,
                           long long& m0, long long& m1)
 {
+  pair_exchange(hc, st, hc.left, hc.right, s0, n0, s1, n1, m0, m1);
+}
+
+// (left / right: the two neighbours along one dimension)
+static void pair_exchange(HaloComm& hc, hipStream_t st, int left, int right, const double* s0, long long n0,
+                          const double* s1, long long n1, long long& m0, long long& m1)
+{
   RcclApi& a = rccl();
-  if (hc.left < 0) n0 = 0;
-  if (hc.right < 0) n1 = 0;
+  if (left < 0) n0 = 0;
+  if (right < 0) n1 = 0;
   hc.h_counts[0] = n0;
   hc.h_counts[1] = n1;
   hc.h_counts[2] = hc.h_counts[3] = 0;
   SF_HIP(hipMemcpyAsync(hc.d_counts, hc.h_counts, sizeof(long long) * 4, hipMemcpyHostToDevice, st));
   SF_NCCL(a.GroupStart());
-  if (hc.left >= 0) SF_NCCL(a.Send(hc.d_counts + 0, 1, ncclInt64, hc.left, hc.comm, st));
-  if (hc.right >= 0) SF_NCCL(a.Send(hc.d_counts + 1, 1, ncclInt64, hc.right, hc.comm, st));
-  if (hc.right >= 0) SF_NCCL(a.Recv(hc.d_counts + 3, 1, ncclInt64, hc.right, hc.comm, st));   // leftward traffic comes from my right
-  if (hc.left >= 0) SF_NCCL(a.Recv(hc.d_counts + 2, 1, ncclInt64, hc.left, hc.comm, st));
+  if (left >= 0) SF_NCCL(a.Send(hc.d_counts + 0, 1, ncclInt64, left, hc.comm, st));
+  if (right >= 0) SF_NCCL(a.Send(hc.d_counts + 1, 1, ncclInt64, right, hc.comm, st));
+  if (right >= 0) SF_NCCL(a.Recv(hc.d_counts + 3, 1, ncclInt64, right, hc.comm, st));   // leftward traffic comes from my right
+  if (left >= 0) SF_NCCL(a.Recv(hc.d_counts + 2, 1, ncclInt64, left, hc.comm, st));
   SF_NCCL(a.GroupEnd());
   SF_HIP(hipMemcpyAsync(hc.h_counts, hc.d_counts, sizeof(long long) * 4, hipMemcpyDeviceToHost, st));
   SF_HIP(hipStreamSynchronize(st));
@@ -256,10 +296,10 @@ static void slab_exchange(HaloComm& hc, hipStream_t st, const double* s0, long l
   double* r0 = hc.rx[0].need((size_t)m0 + 1);
   double* r1 = hc.rx[1].need((size_t)m1 + 1);
   SF_NCCL(a.GroupStart());
-  if (hc.left >= 0 && n0) SF_NCCL(a.Send(s0, (size_t)n0, ncclDouble, hc.left, hc.comm, st));
-  if (hc.right >= 0 && n1) SF_NCCL(a.Send(s1, (size_t)n1, ncclDouble, hc.right, hc.comm, st));
-  if (hc.right >= 0 && m1) SF_NCCL(a.Recv(r1, (size_t)m1, ncclDouble, hc.right, hc.comm, st));
-  if (hc.left >= 0 && m0) SF_NCCL(a.Recv(r0, (size_t)m0, ncclDouble, hc.left, hc.comm, st));
+  if (left >= 0 && n0) SF_NCCL(a.Send(s0, (size_t)n0, ncclDouble, left, hc.comm, st));
+  if (right >= 0 && n1) SF_NCCL(a.Send(s1, (size_t)n1, ncclDouble, right, hc.comm, st));
+  if (right >= 0 && m1) SF_NCCL(a.Recv(r1, (size_t)m1, ncclDouble, right, hc.comm, st));
+  if (left >= 0 && m0) SF_NCCL(a.Recv(r0, (size_t)m0, ncclDouble, left, hc.comm, st));
   SF_NCCL(a.GroupEnd());
 }
 
@@ -506,6 +546,303 @@ static int slab_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int 
   return halo_run_layout(S, hc, first_k, end_k, n, hc.lay);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The brick driver: [3P] Comm on a 3-D processor grid (LAMMPS' `processors Px Py Pz`; the reference's parallel cases
+// decompose in two dimensions, cases/example-cases/transport-bedload/system/decomposeParDict: n (14 1 6)).
+//   * migration at a rebuild: staged, dimension by dimension, like Comm::exchange (an atom that left through an edge
+//     is forwarded by the rank it reaches first);
+//   * ghosts: every owned atom within the ghost cutoff of a face / edge / corner goes STRAIGHT to the brick behind
+//     it (up to 26 directions), so the forward halo of a sub-step is ONE grouped ncclSend/ncclRecv with the
+//     neighbours -- LAMMPS' three staged swaps would be three exchange latencies per sub-step;
+//   * the rebuild vote: a header word in every chunk, to every rank (a rank that is not a neighbour gets the header
+//     alone): MIN over what a rank receives = Neighbor::decide's MPI_Allreduce, exact on any grid.
+// Dimensions the grid does not cut (P_d = 1) keep their periodic images local ((root, image code) neighbour words).
+// ------------------------------------------------------------------------------------------------
+static int brick_rank(const BrickState& B, const int c[3]) { return c[0] + B.P[0] * (c[1] + B.P[1] * c[2]); }
+
+// the brick at offset d from coordinates c: its rank (-1: beyond a non-periodic box face) and the shift that takes a
+// position of this brick's frame into that brick's
+static int brick_neighbour(const BrickState& B, const int c[3], const int d[3], double shift[3])
+{
+  int n[3];
+  for (int k = 0; k < 3; k++) {
+    shift[k] = 0.0;
+    n[k] = c[k] + d[k];
+    if (n[k] < 0 || n[k] >= B.P[k]) {
+      if (!B.periodic[k]) return -1;
+      shift[k] = n[k] < 0 ? (B.hi[k] - B.lo[k]) : -(B.hi[k] - B.lo[k]);
+      n[k] = (n[k] + B.P[k]) % B.P[k];
+    }
+  }
+  return brick_rank(B, n);
+}
+
+static void brick_topology(HaloComm& hc, DemEngine& e)
+{
+  BrickState& B = *hc.brick;
+  B.sdirs.clear();
+  B.rdirs.clear();
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int d[3] = {dx, dy, dz};
+        if (!dx && !dy && !dz) continue;
+        bool ok = true;
+        for (int k = 0; k < 3; k++) ok = ok && (B.ext[k] || d[k] == 0);
+        if (!ok) continue;
+        BrickState::SDir sd;
+        sd.peer = brick_neighbour(B, B.c, d, sd.shift);
+        if (sd.peer < 0) continue;
+        for (int k = 0; k < 3; k++) sd.d[k] = d[k];
+        sd.code = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+        B.sdirs.push_back(sd);
+        // the neighbour at offset d also SENDS to this rank, in its direction -d
+        BrickState::RDir rd;
+        rd.peer = sd.peer;
+        rd.sender_code = (-dx + 1) + 3 * (-dy + 1) + 9 * (-dz + 1);
+        B.rdirs.push_back(rd);
+      }
+  std::sort(B.sdirs.begin(), B.sdirs.end(), [](const BrickState::SDir& a, const BrickState::SDir& b) {
+    return a.peer != b.peer ? a.peer < b.peer : a.code < b.code;
+  });
+  std::sort(B.rdirs.begin(), B.rdirs.end(), [](const BrickState::RDir& a, const BrickState::RDir& b) {
+    return a.peer != b.peer ? a.peer < b.peer : a.sender_code < b.sender_code;
+  });
+  for (int k = 0; k < 3; k++)
+    for (int side = 0; side < 2; side++) {
+      int d[3] = {0, 0, 0};
+      d[k] = side ? 1 : -1;
+      double sh[3];
+      B.nbr[k][side] = B.ext[k] ? brick_neighbour(B, B.c, d, sh) : -1;
+      B.mshift[k][side] = sh[k];
+    }
+  std::vector<int> d3;
+  std::vector<double> s3;
+  for (const auto& sd : B.sdirs)
+    for (int k = 0; k < 3; k++) {
+      d3.push_back(sd.d[k]);
+      s3.push_back(sd.shift[k]);
+    }
+  e.brick_set_dirs((int)B.sdirs.size(), d3.data(), s3.data());
+  B.nsend.assign(B.sdirs.size(), 0);
+  B.nrecv.assign(B.rdirs.size(), 0);
+  if (!B.d_cnt) {
+    SF_HIP(hipMalloc(&B.d_cnt, sizeof(long long) * 2 * DemEngine::kMaxDirs));
+    SF_HIP(hipHostMalloc(&B.h_cnt, sizeof(long long) * 2 * DemEngine::kMaxDirs));
+  }
+}
+
+// one grouped exchange of per-peer segments: segment p of `send` (sizes scnt, contiguous in peer order) to rank p,
+// segment p of `recv` from rank p
+template <class T>
+static void brick_segments(HaloComm& hc, hipStream_t st, const T* send, const std::vector<long long>& soff,
+                           const std::vector<long long>& scnt, T* recv, const std::vector<long long>& roff,
+                           const std::vector<long long>& rcnt, ncclDataType_t ty)
+{
+  RcclApi& a = rccl();
+  SF_NCCL(a.GroupStart());
+  for (int p = 0; p < hc.world; p++) {
+    if (scnt[p]) SF_NCCL(a.Send(send + soff[p], (size_t)scnt[p], ty, p, hc.comm, st));
+    if (rcnt[p]) SF_NCCL(a.Recv(recv + roff[p], (size_t)rcnt[p], ty, p, hc.comm, st));
+  }
+  SF_NCCL(a.GroupEnd());
+}
+
+static void brick_rebuild(SfLammps& S, HaloComm& hc)
+{
+  Range r("neighbor rebuild");
+  const auto t_begin = std::chrono::steady_clock::now();
+  BrickState& B = *hc.brick;
+  DemEngine& e = S.eng;
+  hipStream_t st = e.stream();
+  const int W = hc.world;
+  e.rebuild_begin();
+  // ---- migration, staged over the dimensions ([3P] Comm::exchange) ----
+  const long long crossed = e.migrate_count3();
+  double slots = (double)e.max_neigh_used(), any_crossed = crossed ? 1.0 : 0.0;
+  slab_allreduce_max2(hc, st, slots, any_crossed);
+  e.migrate_set_slots((int)slots);
+  if (any_crossed != 0.0) {
+    const int rec = e.migrate_record_doubles();
+    for (int k = 0; k < 3; k++) {
+      if (!B.ext[k]) continue;
+      // (atoms handed on by an earlier stage may leave through this one: the buffers follow the owned count)
+      const size_t cap = (size_t)(e.nlocal() + 1) * rec;
+      double* b0 = hc.mig[0].need(cap);
+      double* b1 = hc.mig[1].need(cap);
+      const long long n0 = e.migrate_pack_dim(k, 0, B.mshift[k][0], b0, (long long)cap);
+      const long long n1 = e.migrate_pack_dim(k, 1, B.mshift[k][1], b1, (long long)cap);
+      if ((B.nbr[k][0] < 0 && n0) || (B.nbr[k][1] < 0 && n1))
+        fail("Lost atoms: an atom left the non-periodic box in dimension %d", k);
+      long long m0 = 0, m1 = 0;
+      pair_exchange(hc, st, B.nbr[k][0], B.nbr[k][1], b0, n0, b1, n1, m0, m1);
+      e.migrate_unpack(hc.rx[0].p, m0);
+      e.migrate_unpack(hc.rx[1].p, m1);
+    }
+  }
+  e.rebuild_sort();
+  // ---- borders: every direction's atoms straight to the brick behind it ----
+  const int ns = (int)B.sdirs.size(), nr = (int)B.rdirs.size();
+  e.brick_border_select(B.nsend.data());
+  std::vector<long long> soff(W, 0), scnt(W, 0), roff(W, 0), rcnt(W, 0);
+  for (int q = 0; q < ns; q++) {
+    if (!scnt[B.sdirs[q].peer]) soff[B.sdirs[q].peer] = q;
+    scnt[B.sdirs[q].peer]++;
+    B.h_cnt[q] = B.nsend[q];
+  }
+  for (int q = 0; q < nr; q++) {
+    if (!rcnt[B.rdirs[q].peer]) roff[B.rdirs[q].peer] = q;
+    rcnt[B.rdirs[q].peer]++;
+  }
+  if (ns) SF_HIP(hipMemcpyAsync(B.d_cnt, B.h_cnt, sizeof(long long) * ns, hipMemcpyHostToDevice, st));
+  brick_segments<long long>(hc, st, B.d_cnt, soff, scnt, B.d_cnt + DemEngine::kMaxDirs, roff, rcnt, ncclInt64);
+  if (nr)
+    SF_HIP(hipMemcpyAsync(B.h_cnt + DemEngine::kMaxDirs, B.d_cnt + DemEngine::kMaxDirs, sizeof(long long) * nr,
+                          hipMemcpyDeviceToHost, st));
+  SF_HIP(hipStreamSynchronize(st));
+  for (int q = 0; q < nr; q++) B.nrecv[q] = B.h_cnt[DemEngine::kMaxDirs + q];
+  // block q of the border buffers: kBorderDoubles per atom, blocks in direction order (contiguous per peer)
+  std::vector<long long> sb(ns + 1, 0), rb(nr + 1, 0);
+  for (int q = 0; q < ns; q++) sb[q + 1] = sb[q] + B.nsend[q] * kBorderDoublesC;
+  for (int q = 0; q < nr; q++) rb[q + 1] = rb[q] + B.nrecv[q] * kBorderDoublesC;
+  double* btx = B.btx.need((size_t)sb[ns] + 1);
+  double* brx = B.brx.need((size_t)rb[nr] + 1);
+  e.brick_border_pack(btx);
+  std::fill(soff.begin(), soff.end(), 0);
+  std::fill(scnt.begin(), scnt.end(), 0);
+  std::fill(roff.begin(), roff.end(), 0);
+  std::fill(rcnt.begin(), rcnt.end(), 0);
+  for (int q = ns - 1; q >= 0; q--) {
+    soff[B.sdirs[q].peer] = sb[q];
+    scnt[B.sdirs[q].peer] += sb[q + 1] - sb[q];
+  }
+  for (int q = nr - 1; q >= 0; q--) {
+    roff[B.rdirs[q].peer] = rb[q];
+    rcnt[B.rdirs[q].peer] += rb[q + 1] - rb[q];
+  }
+  brick_segments<double>(hc, st, btx, soff, scnt, brx, roff, rcnt, ncclDouble);
+  e.brick_ghost_unpack(brx, rb[nr] / kBorderDoublesC);
+  e.rebuild_finish();
+  hc.n_rebuilds++;
+  // ---- layout of the forward halo (valid until the next rebuild): per rank one header double + the blocks ----
+  hc.send_cnt.assign(W, 1);
+  hc.recv_cnt.assign(W, 1);
+  hc.send_cnt[hc.rank] = hc.recv_cnt[hc.rank] = 0;
+  for (int q = 0; q < ns; q++) hc.send_cnt[B.sdirs[q].peer] += B.nsend[q] * kForwardDoublesC;
+  for (int q = 0; q < nr; q++) hc.recv_cnt[B.rdirs[q].peer] += B.nrecv[q] * kForwardDoublesC;
+  hc.send_off.assign(W, 0);
+  hc.recv_off.assign(W, 0);
+  for (int p = 1; p < W; p++) {
+    hc.send_off[p] = hc.send_off[p - 1] + hc.send_cnt[p - 1];
+    hc.recv_off[p] = hc.recv_off[p - 1] + hc.recv_cnt[p - 1];
+  }
+  B.snd = e.brick_send_blocks();
+  B.rcv.n = nr;
+  B.rcv.first[0] = 0;
+  {
+    std::vector<long long> fill(W, 1);   // doubles already placed in every chunk (the header)
+    for (int q = 0; q < ns; q++) {
+      const int p = B.sdirs[q].peer;
+      B.snd.off[q] = hc.send_off[p] + fill[p];
+      fill[p] += B.nsend[q] * kForwardDoublesC;
+    }
+    std::fill(fill.begin(), fill.end(), 1);
+    for (int q = 0; q < nr; q++) {
+      const int p = B.rdirs[q].peer;
+      B.rcv.off[q] = hc.recv_off[p] + fill[p];
+      fill[p] += B.nrecv[q] * kForwardDoublesC;
+      B.rcv.first[q + 1] = B.rcv.first[q] + (int)B.nrecv[q];
+    }
+  }
+  int nh = 0;
+  for (int p = 0; p < W; p++) {
+    if (p == hc.rank) continue;
+    hc.h_hdr[nh] = (int)hc.send_off[p];
+    hc.h_hdr[W + nh] = (int)hc.recv_off[p];
+    nh++;
+  }
+  SF_HIP(hipMemcpyAsync(hc.d_hdr, hc.h_hdr, sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
+  sf_halo_layout& L = hc.lay;
+  L.world = W;
+  L.send_off = hc.send_off.data();
+  L.send_cnt = hc.send_cnt.data();
+  L.recv_off = hc.recv_off.data();
+  L.recv_cnt = hc.recv_cnt.data();
+  L.dev_shdr = hc.d_hdr;
+  L.dev_rhdr = hc.d_hdr + W;
+  L.dev_tx = hc.a2a_tx.need((size_t)(hc.send_off[W - 1] + hc.send_cnt[W - 1]) + 1);
+  L.dev_rx = hc.a2a_rx.need((size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1);
+  hc.lay_valid = true;
+  hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+}
+
+// sub-steps first_k .. end_k - 1 of a run of n: per sub-step one pack kernel, ONE grouped ncclSend/ncclRecv with the
+// neighbour bricks, one unpack kernel, the sub-step kernel; one synchronisation; returns the voted rebuild trigger
+static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int n)
+{
+  if (!hc.lay_valid) fail("sf_brick_step: no halo layout (rebuild first)");
+  BrickState& B = *hc.brick;
+  DemEngine& e = S.eng;
+  hipStream_t main = e.stream();
+  const int nh = hc.world - 1;
+  auto exchange = [&]() {
+    e.brick_forward_pack(B.snd, hc.lay.dev_tx, hc.lay.dev_shdr, nh);
+    hc.all_to_all(hc.lay, main);
+    e.brick_forward_unpack(B.rcv, hc.lay.dev_rx, hc.lay.dev_rhdr, nh);
+  };
+  for (int s = first_k; s < end_k; s++) {
+    if (s == first_k && hc.pre_exchanged) {   // (ghosts and votes in front of this sub-step are in place)
+      hc.pre_exchanged = false;
+      e.substep_k(s == n - 1, s);
+      continue;
+    }
+    const bool timed = e.profiling() && s % 8 == 4 && s > first_k;
+    if (timed) {
+      if (hc.xev_used + 2 > hc.xev.size())
+        for (int k = 0; k < 2; k++) {
+          hipEvent_t ev;
+          SF_HIP(hipEventCreate(&ev));
+          hc.xev.push_back(ev);
+        }
+      SF_HIP(hipEventRecord(hc.xev[hc.xev_used], main));
+    }
+    exchange();
+    if (timed) {
+      SF_HIP(hipEventRecord(hc.xev[hc.xev_used + 1], main));
+      hc.xev_used += 2;
+    }
+    e.substep_k(s == n - 1, s);
+  }
+  if (end_k < n) {   // (a piece that stops early closes with the vote exchange: see halo_run_layout)
+    exchange();
+    hc.pre_exchanged = true;
+  }
+  const int trigger = e.batch_end(first_k, end_k - first_k);
+  hc.harvest_exchange_profile();
+  return trigger;
+}
+
+static void brick_step(SfLammps& S, HaloComm& hc, int n)
+{
+  Range r("lammps");
+  DemEngine& e = S.eng;
+  e.run_begin();
+  hc.pre_exchanged = false;
+  int k = 0;
+  while (k < n) {
+    const int end = k + hc.predict.chunk(e.nsteps(), n - k);
+    const int trig = brick_halo_run(S, hc, k, end, n);
+    if (trig >= end) {
+      k = end;
+      continue;
+    }
+    k = trig + 1;
+    hc.pre_exchanged = false;
+    brick_rebuild(S, hc);
+    hc.predict.rebuilt(e.nsteps());
+  }
+}
+
 }  // namespace sf
 
 using sf::SfLammps;
@@ -580,6 +917,37 @@ int sf_slab_init(void* ptr, const char* id128, int rank, int world, double xlo, 
   SF_API_END(0)
 }
 
+// 3-D processor grid px x py x pz (= world) over the engine's box (set_box / boundary before this call); rank r owns
+// the brick (r % px, (r / px) % py, r / (px py)).  sf_slab_setup / _step / _rebuild then drive the brick decomposition.
+int sf_brick_init(void* ptr, const char* id128, int rank, int world, int px, int py, int pz)
+{
+  SF_API_BEGIN
+  SfLammps* L = H(ptr);
+  if (px < 1 || py < 1 || pz < 1 || px * py * pz != world) sf::fail("sf_brick_init: %d x %d x %d bricks for %d ranks", px, py, pz, world);
+  if (sf_dem_comm_init(ptr, id128, rank, world) != 0) sf::fail("%s", sf::last_error().c_str());
+  auto* hc = static_cast<sf::HaloComm*>(L->halo);
+  hc->slab = true;
+  hc->brick = new sf::BrickState();
+  sf::BrickState& B = *hc->brick;
+  B.P[0] = px; B.P[1] = py; B.P[2] = pz;
+  B.c[0] = rank % px; B.c[1] = (rank / px) % py; B.c[2] = rank / (px * py);
+  L->eng.box(B.lo, B.hi, B.periodic);
+  double lo[3], hi[3];
+  int ext[3];
+  for (int k = 0; k < 3; k++) {
+    B.ext[k] = B.P[k] > 1;
+    ext[k] = B.ext[k] ? 1 : 0;
+    const double w = (B.hi[k] - B.lo[k]) / B.P[k];
+    lo[k] = B.lo[k] + B.c[k] * w;
+    hi[k] = B.c[k] == B.P[k] - 1 ? B.hi[k] : B.lo[k] + (B.c[k] + 1) * w;
+  }
+  L->eng.set_subdomain3(rank, world, lo, hi, ext);
+  sf::slab_scratch(*hc);
+  sf::brick_topology(*hc, L->eng);
+  if (const char* q = getenv("SF_QUEUE_PREDICT")) hc->predict.on = atoi(q) != 0;
+  SF_API_END(0)
+}
+
 static sf::HaloComm* slab_of(SfLammps* L)
 {
   auto* hc = static_cast<sf::HaloComm*>(L->halo);
@@ -596,7 +964,8 @@ int sf_slab_setup(void* ptr)
   hipStream_t st = e.stream();
   // list / ghost cutoff 2 r_max + skin: r_max over ALL ranks ([3P] MPI_Allreduce of maxrad_dynamic)
   e.set_global_max_radius(sf::slab_allreduce(*hc, st, e.local_max_radius(), ncclMax));
-  sf::slab_rebuild(*L, *hc);
+  if (hc->brick) sf::brick_rebuild(*L, *hc);
+  else sf::slab_rebuild(*L, *hc);
   // pair lubricate/poly: volume fraction of ALL particles (MPI_Allreduce, pair_lubricate_poly.cpp:540-543)
   e.set_global_particle_volume(sf::slab_allreduce(*hc, st, e.local_particle_volume(), ncclSum));
   e.setup();
@@ -610,7 +979,8 @@ int sf_slab_rebuild(void* ptr)
 {
   SF_API_BEGIN
   SfLammps* L = H(ptr);
-  sf::slab_rebuild(*L, *slab_of(L));
+  if (slab_of(L)->brick) sf::brick_rebuild(*L, *slab_of(L));
+  else sf::slab_rebuild(*L, *slab_of(L));
   slab_of(L)->predict.external(L->eng.nsteps());   // (not a trigger of the stepping loop: the interval estimate stands)
   SF_API_END(0)
 }
@@ -623,7 +993,10 @@ int sf_slab_step(void* ptr, int n)
   if (!hc->is_setup) {
     if (sf_slab_setup(ptr) != 0) sf::fail("%s", sf::last_error().c_str());
   }
-  if (n > 0) sf::slab_step(*L, *hc, n);
+  if (n > 0) {
+    if (hc->brick) sf::brick_step(*L, *hc, n);
+    else sf::slab_step(*L, *hc, n);
+  }
   SF_API_END(0)
 }
 

@@ -172,6 +172,19 @@ class HipSlabEngine:
         self.check(self.L.sf_slab_init(self.lmp.ptr, ident[0], int(rank), int(world), float(xlo), float(xhi),
                                        int(bool(periodic_x))))
 
+    def brick_init(self, dist, rank, world, grid):
+        """3-D processor grid `grid` = (px, py, pz) over the engine's box (sf_brick_init); setup / step / rebuild are
+        then the slab_* calls"""
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            self.check(self.L.sf_dem_comm_unique_id(buf))
+            ident[0] = buf.raw
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self.check(self.L.sf_brick_init(self.lmp.ptr, ident[0], int(rank), int(world), int(grid[0]), int(grid[1]),
+                                        int(grid[2])))
+
     def slab_setup(self):
         self.check(self.L.sf_slab_setup(self.lmp.ptr))
 
@@ -723,9 +736,11 @@ class SlabDriver:
         return int(n.value), float(ms.value)
 
     @classmethod
-    def from_global_bed(cls, bed, script, dist, rank, world, transport=None):
+    def from_global_bed(cls, bed, script, dist, rank, world, transport=None, grid=None):
         """bench.py, strong scaling (BASELINE config C4): ONE bed for all ranks, every rank owns the atoms of its
-        x slab (tags = global index + 1)."""
+        x slab (tags = global index + 1) -- or, with grid = (px, py, pz), of its brick (BrickDriver)."""
+        if grid is not None and tuple(grid) != (world, 1, 1):
+            return BrickDriver.from_global_bed(bed, script, dist, rank, world, grid)
         from . import Lammps
         if transport is None:
             transport = os.environ.get("SF_HALO_TRANSPORT", "rccl")
@@ -763,3 +778,66 @@ class SlabDriver:
             lmp.command(line)
         return cls(HipSlabEngine(lmp), dist, rank, world, lo[0], hi[0], periodic_x=bool(bed["periodic"][0]),
                    transport=transport)
+
+
+def brick_grid(world, bed=None):
+    """processor grid of the brick driver for `world` ranks: as cubic as the factorisation allows, never cutting a
+    non-periodic (wall) dimension of `bed` before the periodic ones are cut (8 -> 2x2x2, 4 -> 2x2x1 / 2x1x2, 2 -> 2x1x1)"""
+    periodic = tuple(bed["periodic"]) if bed is not None else (1, 1, 1)
+    best = None
+    for px in range(1, world + 1):
+        if world % px:
+            continue
+        for py in range(1, world // px + 1):
+            if (world // px) % py:
+                continue
+            g = (px, py, world // px // py)
+            walls_cut = sum(1 for k in range(3) if g[k] > 1 and not periodic[k])
+            key = (walls_cut, max(g) - min(g), -g[0], -g[2])
+            if best is None or key < best[0]:
+                best = (key, g)
+    return best[1]
+
+
+def brick_mask(bed, rank, grid):
+    """atoms of `bed` inside the brick of `rank` (x fastest in the rank numbering, like sf_brick_init)"""
+    c = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+    x = np.asarray(bed["x"])
+    m = np.ones(len(x), dtype=bool)
+    for k in range(3):
+        lo, hi = float(bed["boxlo"][k]), float(bed["boxhi"][k])
+        w = (hi - lo) / grid[k]
+        m &= (x[:, k] >= lo + c[k] * w) if c[k] > 0 else True
+        m &= (x[:, k] < lo + (c[k] + 1) * w) if c[k] < grid[k] - 1 else True
+    return m
+
+
+class BrickDriver(SlabDriver):
+    """lammps_step() for one brick of a domain cut by a 3-D processor grid.  The whole driver is C++ over RCCL
+    (sf_brick_init, then sf_slab_setup / _step / _rebuild: csrc/sf_halo_rccl.hip); this class only forwards."""
+
+    def __init__(self, eng, dist, rank, world, grid):
+        import torch
+        self.torch, self.e, self.dist = torch, eng, dist
+        self.rank, self.world, self.grid = rank, world, tuple(int(g) for g in grid)
+        self.transport = "rccl"
+        self.self_comm = False
+        self.overlap = False
+        self.fused = True
+        eng.brick_init(dist, rank, world, self.grid)
+        self._cxx = True
+        self._n_rebuilds = 0
+        self.is_setup = False
+
+    @classmethod
+    def from_global_bed(cls, bed, script, dist, rank, world, grid):
+        from . import Lammps
+        mine = brick_mask(bed, rank, grid)
+        x = np.asarray(bed["x"])
+        lmp = Lammps()
+        lmp.set_box(bed["boxlo"], bed["boxhi"])
+        lmp.create_atoms(x[mine], np.asarray(bed["diameter"])[mine], np.asarray(bed["density"])[mine],
+                         v=np.asarray(bed["v"])[mine], tag=(np.nonzero(mine)[0] + 1).astype(np.int64))
+        for line in script:
+            lmp.command(line)
+        return cls(HipSlabEngine(lmp), dist, rank, world, grid)

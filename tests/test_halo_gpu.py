@@ -70,10 +70,10 @@ def test_self_halo_with_frozen_bottom_layer():
     assert np.array_equal(a["x"][bottom], bed["x"][a["tag"] - 1][bottom])
 
 
-def _c5_case():
+def _c5_case(ncells=(8, 5, 5)):
     """BASELINE config C5's physics at test size: polydisperse grains, fix cohesive, hybrid/overlay lubricate/poly
     with flagVF = flagfld = 1 (the FLD terms need the particle volume of ALL ranks)"""
-    bed = T._bed((8, 5, 5), periodic=True, seed=43, vmax=0.5, poly=(0.85e-3, 1.0e-3), spacing=0.95)
+    bed = T._bed(tuple(ncells), periodic=True, seed=43, vmax=0.5, poly=(0.85e-3, 1.0e-3), spacing=0.95)
     cfg = dict(T.BASE, skin=0.06e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
                lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1))
     cfg["walls"] = T._walls(bed)
@@ -90,7 +90,7 @@ def _walled_x(bed, cfg):
 
 
 def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="hertz", transport="host", rccl_lib=None,
-                     ncells=(8, 5, 5), periodic_x=True):
+                     ncells=(8, 5, 5), periodic_x=True, grid=None):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if rccl_lib:
@@ -105,7 +105,7 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     if physics == "c5":
-        bed, cfg = _c5_case()
+        bed, cfg = _c5_case(ncells) if grid is not None else _c5_case()
     else:
         bed = T._bed(tuple(ncells), periodic=True, seed=41, vmax=0.5)
         cfg = dict(T.BASE, skin=0.05e-3)
@@ -113,10 +113,15 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
     if not periodic_x:
         bed, cfg = _walled_x(bed, cfg)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
-    lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=periodic_x, transport=transport,
-                     overlap=overlap)
-    assert drv.overlap == overlap and drv.transport == transport
+    if grid is not None:   # 3-D processor grid: the brick driver (C++ only)
+        from sedifoam_amd.halo import BrickDriver, brick_mask
+        lmp = dc.make_hip(dc.subset(bed, brick_mask(bed, rank, grid)), cfg)
+        drv = BrickDriver(HipSlabEngine(lmp), dist, rank, world, grid)
+    else:
+        lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
+        drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=periodic_x, transport=transport,
+                         overlap=overlap)
+        assert drv.overlap == overlap and drv.transport == transport
     drv.setup()
     if overlap:
         nb = lmp.L.sf_dem_boundary_count(lmp.ptr)
@@ -230,6 +235,66 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
         if k == "x":
             if periodic_x:
                 got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            assert np.max(np.abs(got - want)) <= 1e-12
+        else:
+            assert dc.rel_err(got, want) <= 1e-9, k
+    assert all(int(p["rebuilds"]) >= 3 for p in parts)
+    hb = {}
+    for p in parts:
+        for (i, j), sv in zip(p["hk"], p["hv"]):
+            hb.setdefault((int(i), int(j)), sv)
+    assert set(hb) == set(ha)
+
+
+@pytest.mark.parametrize("grid,ncells,physics,periodic_x",
+                         [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "hertz", True),
+                          ((3, 1, 2), (9, 5, 8), "hertz", True), ((1, 1, 2), (6, 5, 8), "hertz", True),
+                          ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False)])
+def test_cxx_brick_driver_on_a_processor_grid(tmp_path, grid, ncells, physics, periodic_x):
+    """The brick driver (sf_brick_init + sf_slab_setup / _step / _rebuild): a 3-D processor grid -- 2 x 1 x 2 and
+    2 x 2 x 2 (BASELINE config C4's 8 GPUs; the y cut crosses the wall dimension, the end bricks have a face without a
+    neighbour), 3 x 1 x 2 (left and right neighbour differ), 1 x 1 x 2 (x keeps its images local), 2 x 2 x 1 with
+    config C5's physics (cohesion + lubricate/poly: global particle volume and radius over the bricks), x between
+    walls -- against the single-domain run: staged migration through faces, edges and corners, ghosts sent straight
+    to the up to 26 neighbour bricks, one grouped exchange per sub-step, the rebuild vote in the chunk headers.  The
+    ranks share the one GPU of the box over the stand-in wire (tests/c_abi/standin_rccl.cpp)."""
+    import socket
+    import torch.multiprocessing as mp
+    lib = _standin_rccl(tmp_path)
+    world = grid[0] * grid[1] * grid[2]
+    steps = (50, 50) if physics == "hertz" else (40, 40)
+    if physics == "c5":
+        bed, cfg = _c5_case(ncells)
+    else:
+        bed = T._bed(ncells, periodic=True, seed=41, vmax=0.5)
+        cfg = dict(T.BASE, skin=0.05e-3)
+        cfg["walls"] = T._walls(bed)
+    if not periodic_x:
+        bed, cfg = _walled_x(bed, cfg)
+    ref = dc.make_hip(bed, cfg)
+    ref.setup()
+    for n in steps:
+        ref.step(n)
+    a = ref.get_state(); ha = ref.history()
+    assert ref.info().nbuilds >= 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path)
+    mp.spawn(_two_rank_worker, args=(world, port, out, steps, False, physics, "rccl", lib, ncells, periodic_x, grid),
+             nprocs=world, join=True)
+    parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+    tag = np.concatenate([p["tag"] for p in parts])
+    assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
+    assert sum(1 for p in parts if len(p["tag"])) == world          # every brick owns atoms
+    order = np.argsort(tag)
+    oa = np.argsort(a["tag"])
+    for k in ("x", "v", "omega", "f", "torque"):
+        got = np.concatenate([p[k] for p in parts])[order]
+        want = a[k][oa].copy()
+        if k == "x":
+            for d in range(3):
+                if bed["periodic"][d]:
+                    Ld = bed["boxhi"][d] - bed["boxlo"][d]
+                    got[:, d] = np.mod(got[:, d] - bed["boxlo"][d], Ld); want[:, d] = np.mod(want[:, d] - bed["boxlo"][d], Ld)
             assert np.max(np.abs(got - want)) <= 1e-12
         else:
             assert dc.rel_err(got, want) <= 1e-9, k
