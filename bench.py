@@ -147,6 +147,10 @@ def main():
                     help="N > 1: strong = --particles in total, split into N domains (BASELINE config C4: the `value` of "
                          "the JSON line); weak = every rank owns one --particles slab (`value` only with --scaling weak); "
                          "both (default) = strong as `value`, weak next to it as `weak_scaling`.  N = 1: identical")
+    ap.add_argument("--decomposition", choices=["auto", "slabs", "bricks"], default="auto",
+                    help="N > 1, strong scaling: x-slabs, or bricks of a 3-D processor grid (sedifoam_amd.halo.brick_grid: "
+                         "periodic dimensions first, as cubic as N allows: 8 -> 4x1x2, 4 -> 2x1x2 on the channel bed); "
+                         "auto = bricks from 4 ranks on (half the bytes per face, two to three links busy at once)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: if the C++ RCCL driver cannot come up, measure the Python loop over torch.distributed "
                          "instead of exiting non-zero (config.decomposition says so)")
@@ -254,14 +258,23 @@ def main():
     fallback_note = [None]
     comm_info = [None]
 
+    grid_used = [None]
+
     def make_driver(factory, the_bed):
         """the C++ driver over RCCL.  If it cannot come up the run FAILS (rc != 0): a slow number from another code path
         is worse than none.  --allow-fallback: say so loudly and measure the same protocol driven from Python over
         torch.distributed instead."""
         from sedifoam_amd.halo import SlabDriver
+        from sedifoam_amd.halo import brick_grid
         err = None
+        kw_grid = {}
+        if factory == "from_global_bed" and (args.decomposition == "bricks" or (args.decomposition == "auto" and world >= 4)):
+            if args.one_gpu and transport != "rccl":
+                raise SystemExit("bench.py --one-gpu with bricks needs SF_RCCL_LIB (the brick driver is C++ only)")
+            kw_grid = {"grid": brick_grid(world, the_bed)}
+            grid_used[0] = kw_grid["grid"]
         try:
-            drv = getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport=transport)
+            drv = getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport=transport, **kw_grid)
         except Exception as ex:   # noqa: BLE001
             drv, err = None, ex
         if dist is not None and world > 1:
@@ -355,7 +368,9 @@ def main():
             "decomposition": (("x-slabs, C++ driver over a stand-in for librccl through host memory (--one-gpu)"
                                if transport == "rccl" else
                                "x-slabs, ghost halo over gloo through host memory (--one-gpu)") if args.one_gpu else
-                              (fallback_note[0] or "x-slabs, C++ driver (sf_slab_*), ghost halo over RCCL")) if world > 1 else
+                              (fallback_note[0] or ("%dx%dx%d bricks, C++ driver (sf_brick_init + sf_slab_*), ghosts straight to "
+                                                    "the neighbour bricks over RCCL" % tuple(grid_used[0]) if grid_used[0] else
+                                                    "x-slabs, C++ driver (sf_slab_*), ghost halo over RCCL"))) if world > 1 else
                              ("single slab through the halo driver" if args.slab_driver else "single domain"),
             **({"transport": ("stand-in for librccl over host memory" if transport == "rccl" else "gloo through host memory")
                 if args.one_gpu else ("torch.distributed point-to-point (Python loop)" if fallback_note[0] else

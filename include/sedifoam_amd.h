@@ -234,6 +234,11 @@ int sf_slab_init(void *ptr, const char *id128, int rank, int world, double xlo, 
  * ONE grouped ncclSend/ncclRecv per sub-step --, the rebuild vote in a header word to every rank.  Dimensions the
  * grid does not cut keep their periodic images local. */
 int sf_brick_init(void *ptr, const char *id128, int rank, int world, int px, int py, int pz);
+/* the exchange pattern sf_brick_init sets up for `rank`, host logic only (no device needed): blocks sent -- (peer,
+ * direction code (dx+1) + 3 (dy+1) + 9 (dz+1)) in send order, blocks received -- (peer, the sender's direction code) in
+ * receive order (arrays of 26), and the face neighbours [dim][low, high] used by the staged migration (-1: none) */
+int sf_brick_pattern(int rank, int px, int py, int pz, const int *periodic, int *nsend, int *send_peer, int *send_code,
+                     int *nrecv, int *recv_peer, int *recv_code, int *face_nbr);
 int sf_slab_setup(void *ptr);
 int sf_slab_rebuild(void *ptr);
 int sf_slab_step(void *ptr, int n);

@@ -142,6 +142,7 @@ _SIGS = {
     "sf_dem_halo_run": (C.c_int, [vp, C.c_int, C.c_int, vp, ip]),
     "sf_slab_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "sf_brick_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sf_brick_pattern": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 8),
     "sf_slab_setup": (C.c_int, [vp]),
     "sf_slab_rebuild": (C.c_int, [vp]),
     "sf_slab_step": (C.c_int, [vp, C.c_int]),

@@ -94,6 +94,7 @@ struct WallMotion {
 };
 
 constexpr int kForwardDoubles = 9;   // forward halo record: x | v | omega
+constexpr int kBrickSlots = 7;       // directions that can send one atom (3 faces + 3 edges + 1 corner)
 // the rebuild vote in the one-double header of a forward chunk: an int in the slot's first four bytes (so that the
 // kernel that finds an atom beyond skin/2 can lower it with an integer atomicMin)
 __host__ __device__ inline int* header_vote_ptr(double* slot) { return reinterpret_cast<int*>(slot); }
@@ -125,6 +126,8 @@ struct DemPtrs {
   const int* sendslot[2];
   double* tx[2];
   double* tx_sendbuf;           // vote headers: the 8-byte slot at tx_sendbuf + tx_hdr_off[p] holds an int (header_vote)
+  const int* bslot;             // brick driver (tx_fused == 2): [kBrickSlots][cap] where an atom's forward records go, in
+                                // doubles from tx_sendbuf (-1: no further direction sends this atom)
   const int* tx_hdr_off;
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
@@ -165,6 +168,10 @@ struct StepParams {
   // mode 0 only: atoms with x < tx_xlo or x >= tx_xhi look their send slots up and write their new x (+ tx_shift of the
   // face), v, omega into DemPtrs::tx -- the pack kernel of the forward halo, fused
   int tx_fused, tx_nhdr;   // tx_nhdr > 0 (any part, mode 0): a trigger also lowers the tx_nhdr vote headers
+                           // tx_fused == 2: brick driver -- an atom beyond tx_lo3 / tx_hi3 in some dimension looks its (up
+                           // to kBrickSlots) record positions up in DemPtrs::bslot and writes its new x, v, omega there,
+                           // unshifted (the receiver adds the periodic shift of the block)
+  double tx_lo3[3], tx_hi3[3];
   int tx_n[2];             // atoms in the left / right send list (a face's block is [kForwardDoubles][tx_n])
   double tx_xlo, tx_xhi, tx_shift[2];
 };
@@ -385,6 +392,9 @@ class DemEngine {
   void brick_border_pack(double* buf);                     // every block in direction order, kBorderDoubles per atom
   void brick_ghost_unpack(const double* buf, long long natoms);   // border records -> external ghosts (appended)
   void brick_forward_pack(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr);
+  // the sub-step kernel writes the forward records itself from now on (until the next rebuild): record positions of
+  // every sent atom from the blocks' offsets in the send buffer
+  void brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr);
   void brick_forward_unpack(const BrickBlocks& rcv, const double* recvbuf, const int* hdr_off, int nhdr);
   const BrickBlocks& brick_send_blocks() const { return bsend_blocks_; }
   long long migrate_count3();      // owned atoms outside the brick in any external dimension
@@ -604,6 +614,7 @@ private:
   BrickBlocks bsend_blocks_{};
   DevArray bmask_;
   int* bsend_list_ = nullptr;
+  DevArray bslot_;                     // [kBrickSlots + 1][cap]: record positions, then a per-atom cursor
   size_t bsend_alloc_ = 0;
   int* d_bcount_ = nullptr;            // [2 * kMaxDirs] device counters / cursors
   int* h_bcount_ = nullptr;            // pinned twin

@@ -616,6 +616,7 @@ DemPtrs DemEngine::ptrs(int in_buf) const
     P.tx[f] = tx_ptr_[f];
   }
   P.tx_sendbuf = tx_sendbuf_;
+  P.bslot = bslot_.as<int>();
   P.tx_hdr_off = tx_hdr_off_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
   P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
@@ -766,7 +767,15 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   // the forward halo of the exchange that follows: written by the kernel that integrates the border atoms
   if (part != 1) tx_written_ = false;   // (the interior part sends nothing: what the boundary part wrote stands)
   if (tx_ready_ && mode == 0 && !lds_active_) S.tx_nhdr = tx_nhdr_;
-  if (tx_ready_ && mode == 0 && part != 1 && !lds_active_) {
+  if (tx_ready_ && brick_ && mode == 0 && part == 0 && !lds_active_) {
+    S.tx_fused = 2;
+    const double cut = cutneighmax() + skin_;   // (an atom is within skin/2 of where the send lists were made)
+    for (int k = 0; k < 3; k++) {
+      S.tx_lo3[k] = ext_[k] ? sublo_[k] + cut : -1.0e300;
+      S.tx_hi3[k] = ext_[k] ? subhi_[k] - cut : 1.0e300;
+    }
+    tx_written_ = true;
+  } else if (tx_ready_ && mode == 0 && part != 1 && !lds_active_) {
     S.tx_fused = 1;
     const double cut = cutneighmax() + skin_;   // (an atom is within skin/2 of where the border lists were made)
     S.tx_xlo = sublo_[0] + cut;

@@ -723,9 +723,22 @@ __global__ __launch_bounds__(256) void k_brick_forward_pack(const int* list, Dem
   const int i = list[k];
   const double4 x = xr[i], v = vm[i], w = om[i];
   double* b = sendbuf + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
-  b[0] = x.x + blk.shift[q][0]; b[1] = x.y + blk.shift[q][1]; b[2] = x.z + blk.shift[q][2];
+  // (unshifted, like the records the sub-step kernel writes itself: the receiver adds the block's periodic shift)
+  b[0] = x.x; b[1] = x.y; b[2] = x.z;
   b[3] = v.x; b[4] = v.y; b[5] = v.z;
   b[6] = w.x; b[7] = w.y; b[8] = w.z;
+}
+
+// where the forward records of a sent atom go: slot s of atom i <- position of its record in block q (arrival order)
+__global__ __launch_bounds__(256) void k_brick_slots(const int* list, DemEngine::BrickBlocks blk, int* slots, int* cursor,
+                                                     size_t cap)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= blk.first[blk.n]) return;
+  const int q = block_of(blk, k);
+  const int i = list[k];
+  const int s = atomicAdd(&cursor[i], 1);
+  if (s < kBrickSlots) slots[(size_t)s * cap + i] = (int)(blk.off[q] + (long long)(k - blk.first[q]) * kForwardDoubles);
 }
 
 __global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBlocks blk, const int* hdr_off, int nhdr,
@@ -743,11 +756,30 @@ __global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBl
   const double* b = recvbuf + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
   const int g = nlocal + k;
   double4 x = xr[g], v = vm[g];
-  x.x = b[0]; x.y = b[1]; x.z = b[2];
+  x.x = b[0] + blk.shift[q][0]; x.y = b[1] + blk.shift[q][1]; x.z = b[2] + blk.shift[q][2];
   v.x = b[3]; v.y = b[4]; v.z = b[5];
   xr[g] = x;   // radius / mass (.w) were set by the border exchange
   vm[g] = v;
   om[g] = {b[6], b[7], b[8], om[g].w};
+}
+
+void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr)
+{
+  static const bool off = getenv("SF_HALO_FUSED_PACK") && !atoi(getenv("SF_HALO_FUSED_PACK"));
+  tx_ready_ = tx_written_ = false;
+  if (off || !nlocal_) return;
+  if (bslot_.cap < cap_) bslot_.alloc(sizeof(int), kBrickSlots + 1, cap_, stream_);
+  SF_HIP(hipMemsetAsync(bslot_.ptr, 0xFF, sizeof(int) * kBrickSlots * bslot_.cap, stream_));
+  int* cursor = bslot_.as<int>() + (size_t)kBrickSlots * bslot_.cap;
+  SF_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * bslot_.cap, stream_));
+  const int tot = snd.first[snd.n];
+  if (snd.n && (size_t)(snd.off[snd.n - 1] + (long long)tot * kForwardDoubles) >= (size_t)INT_MAX)
+    fail("brick_set_forward_tx: send buffer beyond 2^31 doubles");
+  if (tot) k_brick_slots<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, snd, bslot_.as<int>(), cursor, bslot_.cap);
+  tx_sendbuf_ = sendbuf;
+  tx_hdr_off_ = hdr_off;
+  tx_nhdr_ = nhdr;
+  tx_ready_ = true;
 }
 
 void DemEngine::brick_set_dirs(int ndir, const int* d3, const double* shift3)

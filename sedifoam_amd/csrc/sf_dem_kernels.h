@@ -423,10 +423,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 
   // (fused forward pack: the send slots of a border atom, requested here so that they have arrived by the end)
   int txk0 = -1, txk1 = -1;
-  if (S.tx_fused && (xi.x < S.tx_xlo || xi.x >= S.tx_xhi)) {
+  if (S.tx_fused == 1 && (xi.x < S.tx_xlo || xi.x >= S.tx_xhi)) {
     txk0 = P.sendslot[0][i];
     txk1 = P.sendslot[1][i];
   }
+  // (brick driver: near an external face in any dimension)
+  const bool txb = S.tx_fused == 2 && (xi.x < S.tx_lo3[0] || xi.x >= S.tx_hi3[0] || xi.y < S.tx_lo3[1] ||
+                                       xi.y >= S.tx_hi3[1] || xi.z < S.tx_lo3[2] || xi.z >= S.tx_hi3[2]);
 
   // ---- post_force fixes: gravity -> fdrag -> walls; fix freeze zeroes what the fixes BEFORE it in the script (and
   // the pair styles) gave a frozen atom, the fixes after it still act ([3P] Modify::post_force runs them in script
@@ -543,7 +546,17 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   }
   // the forward halo record of an atom another GPU (or the periodic image of this slab) sees as a ghost: what
   // k_forward_pack_fused would gather after this kernel
-  if (S.tx_fused) {
+  if (txb) {
+    for (int k = 0; k < kBrickSlots; k++) {
+      const int off = P.bslot[(size_t)k * cap + i];
+      if (off < 0) break;
+      double* b = P.tx_sendbuf + off;
+      b[0] = xn.x; b[1] = xn.y; b[2] = xn.z;
+      b[3] = vn.x; b[4] = vn.y; b[5] = vn.z;
+      b[6] = wn.x; b[7] = wn.y; b[8] = wn.z;
+    }
+  }
+  if (S.tx_fused == 1) {
     auto put = [&](double* b, size_t n, double shift) {
       b[0] = xn.x + shift; b[n] = xn.y; b[2 * n] = xn.z;
       b[3 * n] = vn.x; b[4 * n] = vn.y; b[5 * n] = vn.z;

@@ -577,9 +577,8 @@ static int brick_neighbour(const BrickState& B, const int c[3], const int d[3], 
   return brick_rank(B, n);
 }
 
-static void brick_topology(HaloComm& hc, DemEngine& e)
+static void brick_directions(BrickState& B)
 {
-  BrickState& B = *hc.brick;
   B.sdirs.clear();
   B.rdirs.clear();
   for (int dz = -1; dz <= 1; dz++)
@@ -616,6 +615,12 @@ static void brick_topology(HaloComm& hc, DemEngine& e)
       B.nbr[k][side] = B.ext[k] ? brick_neighbour(B, B.c, d, sh) : -1;
       B.mshift[k][side] = sh[k];
     }
+}
+
+static void brick_topology(HaloComm& hc, DemEngine& e)
+{
+  BrickState& B = *hc.brick;
+  brick_directions(B);
   std::vector<int> d3;
   std::vector<double> s3;
   for (const auto& sd : B.sdirs)
@@ -737,6 +742,17 @@ static void brick_rebuild(SfLammps& S, HaloComm& hc)
     hc.recv_off[p] = hc.recv_off[p - 1] + hc.recv_cnt[p - 1];
   }
   B.snd = e.brick_send_blocks();
+  // the shift of a received block: what its sender -- the brick at offset -d of the block's direction d, seen from
+  // here the neighbour at offset s -- adds when it sends in direction -s; recomputed from the sender's coordinates
+  for (int q = 0; q < nr; q++) {
+    const int code = B.rdirs[q].sender_code;
+    const int d[3] = {code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1};   // the sender's direction
+    int cs[3];
+    for (int k = 0; k < 3; k++) cs[k] = ((B.c[k] - d[k]) % B.P[k] + B.P[k]) % B.P[k];   // the sender's coordinates
+    double sh[3];
+    (void)brick_neighbour(B, cs, d, sh);
+    for (int k = 0; k < 3; k++) B.rcv.shift[q][k] = sh[k];
+  }
   B.rcv.n = nr;
   B.rcv.first[0] = 0;
   {
@@ -773,6 +789,7 @@ static void brick_rebuild(SfLammps& S, HaloComm& hc)
   L.dev_tx = hc.a2a_tx.need((size_t)(hc.send_off[W - 1] + hc.send_cnt[W - 1]) + 1);
   L.dev_rx = hc.a2a_rx.need((size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1);
   hc.lay_valid = true;
+  e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1);
   hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -786,7 +803,9 @@ static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int
   hipStream_t main = e.stream();
   const int nh = hc.world - 1;
   auto exchange = [&]() {
-    e.brick_forward_pack(B.snd, hc.lay.dev_tx, hc.lay.dev_shdr, nh);
+    // (the sub-step kernel that integrated the border atoms has written their records and the vote headers itself;
+    // the pack kernel runs only in front of the first sub-step after a rebuild / at the start of a run)
+    if (!e.forward_tx_written()) e.brick_forward_pack(B.snd, hc.lay.dev_tx, hc.lay.dev_shdr, nh);
     hc.all_to_all(hc.lay, main);
     e.brick_forward_unpack(B.rcv, hc.lay.dev_rx, hc.lay.dev_rhdr, nh);
   };
@@ -945,6 +964,41 @@ int sf_brick_init(void* ptr, const char* id128, int rank, int world, int px, int
   sf::slab_scratch(*hc);
   sf::brick_topology(*hc, L->eng);
   if (const char* q = getenv("SF_QUEUE_PREDICT")) hc->predict.on = atoi(q) != 0;
+  SF_API_END(0)
+}
+
+// The exchange pattern of one rank of a px x py x pz grid, host logic only (no device, no communicator): the blocks it
+// sends -- (peer, direction code (dx+1) + 3 (dy+1) + 9 (dz+1)) in send order -- and the blocks it receives -- (peer,
+// the SENDER's direction code) in receive order.  For every pair of ranks the sender's list restricted to the receiver
+// must equal the receiver's list restricted to the sender: what tests/test_abi_and_host.py checks on the CPU.
+int sf_brick_pattern(int rank, int px, int py, int pz, const int* periodic, int* nsend, int* send_peer, int* send_code,
+                     int* nrecv, int* recv_peer, int* recv_code, int* face_nbr)
+{
+  SF_API_BEGIN
+  if (px < 1 || py < 1 || pz < 1 || rank < 0 || rank >= px * py * pz) sf::fail("sf_brick_pattern: rank %d of %d x %d x %d", rank, px, py, pz);
+  sf::BrickState B;
+  B.P[0] = px; B.P[1] = py; B.P[2] = pz;
+  B.c[0] = rank % px; B.c[1] = (rank / px) % py; B.c[2] = rank / (px * py);
+  for (int k = 0; k < 3; k++) {
+    B.lo[k] = 0.0;
+    B.hi[k] = 1.0;
+    B.periodic[k] = periodic[k];
+    B.ext[k] = B.P[k] > 1;
+  }
+  sf::brick_directions(B);
+  *nsend = (int)B.sdirs.size();
+  *nrecv = (int)B.rdirs.size();
+  for (size_t q = 0; q < B.sdirs.size(); q++) {
+    send_peer[q] = B.sdirs[q].peer;
+    send_code[q] = B.sdirs[q].code;
+  }
+  for (size_t q = 0; q < B.rdirs.size(); q++) {
+    recv_peer[q] = B.rdirs[q].peer;
+    recv_code[q] = B.rdirs[q].sender_code;
+  }
+  if (face_nbr)
+    for (int k = 0; k < 3; k++)
+      for (int side = 0; side < 2; side++) face_nbr[2 * k + side] = B.nbr[k][side];
   SF_API_END(0)
 }
 

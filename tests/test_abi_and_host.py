@@ -114,3 +114,52 @@ def test_bench_cpu_legs_run_without_a_gpu():
     assert 1 <= cores <= len(__import__("os").sched_getaffinity(0))
     r = bench.cpu_baseline_all_cores(500, 2)
     assert r["cores"] == cores and r["value"] > 0 and r["kind"] == "port"
+
+
+@pytest.mark.parametrize("grid,periodic", [((2, 2, 2), (1, 1, 1)), ((2, 2, 2), (1, 0, 1)), ((4, 1, 2), (1, 0, 1)),
+                                           ((3, 2, 1), (1, 1, 0)), ((2, 1, 1), (1, 0, 1)), ((3, 3, 3), (0, 1, 1)),
+                                           ((1, 1, 4), (1, 0, 1))])
+def test_brick_exchange_pattern_is_consistent_between_every_pair_of_ranks(grid, periodic):
+    """The host logic of the brick driver (sf_brick_init) without a device: for every pair of ranks, the blocks the
+    sender lists for the receiver -- in its send order -- are the blocks the receiver expects from the sender, in its
+    receive order (one grouped ncclSend / ncclRecv per sub-step relies on it); directions never point through a
+    non-periodic box face or along a dimension the grid does not cut; the face neighbours of the staged migration
+    are mutual."""
+    import ctypes as C
+    import sedifoam_amd
+    L = sedifoam_amd.lib()
+    world = grid[0] * grid[1] * grid[2]
+    per = (C.c_int * 3)(*periodic)
+    pat = []
+    for r in range(world):
+        ns, nr = C.c_int(), C.c_int()
+        sp, sc, rp, rc = ((C.c_int * 26)() for _ in range(4))
+        fn = (C.c_int * 6)()
+        assert L.sf_brick_pattern(r, grid[0], grid[1], grid[2], per, C.byref(ns), sp, sc, C.byref(nr), rp, rc, fn) == 0
+        pat.append(dict(send=[(sp[q], sc[q]) for q in range(ns.value)], recv=[(rp[q], rc[q]) for q in range(nr.value)],
+                        face=list(fn)))
+    coord = lambda r: (r % grid[0], (r // grid[0]) % grid[1], r // (grid[0] * grid[1]))
+    for a in range(world):
+        assert pat[a]["send"] == sorted(pat[a]["send"]) and pat[a]["recv"] == sorted(pat[a]["recv"])
+        for b in range(world):
+            to_b = [c for p, c in pat[a]["send"] if p == b]
+            from_a = [c for p, c in pat[b]["recv"] if p == a]
+            assert to_b == from_a, (a, b)
+        ca = coord(a)
+        for peer, code in pat[a]["send"]:
+            d = (code % 3 - 1, (code // 3) % 3 - 1, code // 9 - 1)
+            want = []
+            for k in range(3):
+                assert d[k] == 0 or grid[k] > 1                  # uncut dimensions keep their images local
+                n = ca[k] + d[k]
+                assert 0 <= n < grid[k] or periodic[k]           # never through a wall
+                want.append(n % grid[k])
+            assert peer == want[0] + grid[0] * (want[1] + grid[1] * want[2])
+        for k in range(3):
+            for side in range(2):
+                nb = pat[a]["face"][2 * k + side]
+                if nb >= 0:
+                    assert pat[nb]["face"][2 * k + (1 - side)] == a
+    # a fully periodic 2 x 2 x 2 grid: every rank exchanges with all 7 others (26 blocks)
+    if grid == (2, 2, 2) and periodic == (1, 1, 1):
+        assert all(len(p["send"]) == 26 and len({q for q, _ in p["send"]}) == 7 for p in pat)
