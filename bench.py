@@ -365,9 +365,10 @@ def main():
             **({"halo_exchange_us_per_substep": exchange_us[0]} if exchange_us[0] is not None else {}),
             **({"decomposed_rebuild_ms_rank0": rebuild_ms[0]} if rebuild_ms[0] is not None else {}),
             **({"bed_override": bed_kw} if bed_kw else {}),
-            "decomposition": (("x-slabs, C++ driver over a stand-in for librccl through host memory (--one-gpu)"
-                               if transport == "rccl" else
-                               "x-slabs, ghost halo over gloo through host memory (--one-gpu)") if args.one_gpu else
+            "decomposition": (((("%dx%dx%d bricks" % tuple(grid_used[0])) if grid_used[0] else "x-slabs")
+                               + (", C++ driver over a stand-in for librccl through host memory (--one-gpu)"
+                                  if transport == "rccl" else ", ghost halo over gloo through host memory (--one-gpu)"))
+                              if args.one_gpu else
                               (fallback_note[0] or ("%dx%dx%d bricks, C++ driver (sf_brick_init + sf_slab_*), ghosts straight to "
                                                     "the neighbour bricks over RCCL" % tuple(grid_used[0]) if grid_used[0] else
                                                     "x-slabs, C++ driver (sf_slab_*), ghost halo over RCCL"))) if world > 1 else
