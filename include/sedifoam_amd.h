@@ -423,6 +423,18 @@ int sf_cloud_phase(void *cloud, int phase);   /* 0: done ; 1 (slab mesh): paused
  * first_line = the number of its first line), transposes back so that every rank also gets the two columns next to
  * its slab (its ghost layers), and calls the same phase again. */
 int sf_cloud_smooth_work(void *cloud, double **dev_work, int *nfields);
+/* The two exchanges of a slab mesh over the engine's own RCCL communicator (the one sf_slab_init made), on the engine's
+ * stream -- what the host otherwise does between the sf_cloud_phase calls with MPI:
+ *   sf_cloud_slab_halo_add(cloud, fields)  fields = bit 0 gamma | bit 1 Ue | bit 2 Asrc: what this rank's particles
+ *       deposited in its two ghost layers is sent to the face neighbours and added to their edge layers, then the ghost
+ *       layers are refreshed with the neighbours' edge values (two face messages each way per field);
+ *   sf_cloud_slab_phase(cloud, phase)      sf_cloud_phase(phase); when it pauses for the x solve: the all-to-all that
+ *       turns the planar work array into complete x-lines, sf_cloud_smooth_xsolve on this rank's share, the all-to-all
+ *       back (every rank also gets the two columns next to its slab), and the phase again.
+ * Cells are partitioned by the same planes as the particles (mesh.n[0] - 2 owned layers per rank). */
+int sf_cloud_slab_halo_add(void *cloud, int fields);
+int sf_cloud_slab_phase(void *cloud, int phase);
+int sf_cloud_slab_info(void *cloud, void **lammps, int *n3, int *nx_global, int *periodic_x, int *smoothing);
 int sf_cloud_smooth_xsolve(void *cloud, double *dev_lines, long long nlines, long long first_line);
 int sf_cloud_sub_cycling(void *cloud, int *subCycles, int *subSteps);
 int sf_cloud_device_fields(void *cloud, double **gamma, double **Ue, double **Asrc, int *ncells);

@@ -143,6 +143,9 @@ _SIGS = {
     "sf_slab_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "sf_brick_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sf_brick_pattern": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 8),
+    "sf_cloud_slab_halo_add": (C.c_int, [vp, C.c_int]),
+    "sf_cloud_slab_phase": (C.c_int, [vp, C.c_int]),
+    "sf_cloud_slab_info": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sf_slab_setup": (C.c_int, [vp]),
     "sf_slab_rebuild": (C.c_int, [vp]),
     "sf_slab_step": (C.c_int, [vp, C.c_int]),

@@ -7,6 +7,8 @@
 Everything numerical happens in libsedifoam_amd.so on the GPU; this file only marshals."""
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -266,6 +268,10 @@ class enhancedCloud:
         self._right = r + 1 if r < W - 1 else (0 if self._per_x else None)
         nxg, ny, nz = self.mesh_n_global
         self._shape = (nz, ny, self.nxl + 2)
+        # the exchanges in C++ over the engine's own RCCL communicator (sf_cloud_slab_halo_add / sf_cloud_slab_phase)
+        # whenever the C++ slab driver is up; the torch.distributed versions below serve the gloo / host transports
+        self._cxx_slab = bool(getattr(d, "_cxx", False)) and d.transport == "rccl" and not hasattr(d, "grid") \
+            and os.environ.get("SF_CLOUD_SLAB_PY", "0") != "1"
 
     def _dev_tensor(self, ptr, shape):
         torch = self._torch
@@ -317,6 +323,10 @@ class enhancedCloud:
     def _slab_halo_add(self, *names):
         """what this rank's particles deposited in its ghost layers belongs to the neighbours' edge layers: send it,
         add what arrives, then refresh the ghost layers with the neighbours' edge values"""
+        if self._cxx_slab:
+            mask = sum({"gamma": 1, "Ue": 2, "Asrc": 4}[nm] for nm in names)
+            check(self.L.sf_cloud_slab_halo_add(self.ptr, mask))
+            return
         for nm in names:
             f = self._field(nm)                      # [nz, ny, nxs(, 3)]
             gl, gr = f[:, :, 0].clone(), f[:, :, -1].clone()
@@ -383,6 +393,9 @@ class enhancedCloud:
         work[:, :] = back.reshape(W * nlq, nxs)[:NL]
 
     def _slab_phase(self, ph):
+        if self._cxx_slab:
+            check(self.L.sf_cloud_slab_phase(self.ptr, int(ph)))
+            return
         if self._phase(ph) == 1:
             self._slab_xsolve()
             if self._phase(ph) != 0:

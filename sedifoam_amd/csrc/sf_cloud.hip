@@ -630,6 +630,8 @@ class Cloud {
                              mesh.faces[2] ? width[2].data() : nullptr};
     smoother_.configure(mesh.n, mesh.dx, props.smoothDirection, props.diffusionBandWidth, props.diffusionSteps, s_,
                         wptr, mesh.periodic);
+    slab_nx_global_ = mesh.slab_nx_global;
+    slab_per_x_ = mesh.periodic[0] ? 1 : 0;
     if (mesh.slab_nx_global > 0) {
       // this block is one x-slab of a larger mesh plus a ghost layer on each side (the mesh partitioned by
       // the particle slab planes)
@@ -902,6 +904,14 @@ class Cloud {
   }
 
   int particle_count() const { return lmp_->eng.nlocal(); }
+  void slab_info(void** lammps, int* n3, int* nx_global, int* periodic_x, int* smoothing)
+  {
+    *lammps = lmp_;
+    for (int k = 0; k < 3; k++) n3[k] = mesh_.n[k];
+    *nx_global = slab_nx_global_;
+    *periodic_x = slab_per_x_;
+    *smoothing = (smoother_.slab() && smoother_.enabled()) ? 1 : 0;
+  }
   const sf_cloud_timers& timers() const { return t_; }
 
  private:
@@ -1071,6 +1081,7 @@ public:
  private:
 
   SfLammps* lmp_;
+  int slab_nx_global_ = 0, slab_per_x_ = 0;
   sf_cloud_props props_;
   double deltaT_;
   MeshDev mesh_{};
@@ -1134,6 +1145,14 @@ int sf_cloud_phase(void* cloud, int phase)
   SF_API_BEGIN
   const int rc = static_cast<Cloud*>(cloud)->phase(phase);
   SF_API_END(rc)
+}
+
+// what the slab exchanges (csrc/sf_halo_rccl.hip: sf_cloud_slab_halo_add / sf_cloud_slab_phase) need to know of a cloud
+int sf_cloud_slab_info(void* cloud, void** lammps, int* n3, int* nx_global, int* periodic_x, int* smoothing)
+{
+  SF_API_BEGIN
+  static_cast<Cloud*>(cloud)->slab_info(lammps, n3, nx_global, periodic_x, smoothing);
+  SF_API_END(0)
 }
 
 int sf_cloud_smooth_work(void* cloud, double** dev_work, int* nfields)

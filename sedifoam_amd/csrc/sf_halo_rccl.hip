@@ -862,6 +862,172 @@ static void brick_step(SfLammps& S, HaloComm& hc, int n)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mesh partitioned by the slab planes: the exchanges of the coupled step over the engine's communicator.
+// Fields are [nz][ny][nxs][ncomp], nxs = owned layers + one ghost layer on each side.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plane_get(const double* f, int nlines, int nxs, int ncomp, int ix, double* out)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nlines * ncomp) return;
+  const int line = k / ncomp, c = k - line * ncomp;
+  out[k] = f[((size_t)line * nxs + ix) * ncomp + c];
+}
+// mode 0: f[ix] += in ; 1: f[ix] = in ; 2: f[ix] = f[ix_src] (no neighbour: zero gradient)
+__global__ __launch_bounds__(256) void k_plane_put(double* f, int nlines, int nxs, int ncomp, int ix, const double* in,
+                                                   int mode, int ix_src)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nlines * ncomp) return;
+  const int line = k / ncomp, c = k - line * ncomp;
+  double* dst = &f[((size_t)line * nxs + ix) * ncomp + c];
+  if (mode == 0) *dst += in[k];
+  else if (mode == 1) *dst = in[k];
+  else *dst = f[((size_t)line * nxs + ix_src) * ncomp + c];
+}
+// owned columns of the work array [NL][nxs] -> [W * nlq][nxl] (rows beyond NL: zero)
+__global__ __launch_bounds__(256) void k_lines_interior(const double* work, long long NL, int nxs, long long rows, double* out)
+{
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nxl = nxs - 2;
+  if (k >= rows * nxl) return;
+  const long long l = k / nxl;
+  const int x = (int)(k - l * nxl);
+  out[k] = l < NL ? work[l * nxs + 1 + x] : 0.0;
+}
+// recv [W][nlq][nxl] (chunk p = rank p's columns of my lines) -> lines [nlq][W * nxl]
+__global__ __launch_bounds__(256) void k_lines_assemble(const double* recv, int W, long long nlq, int nxl, double* lines)
+{
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nxg = (long long)W * nxl;
+  if (k >= nlq * nxg) return;
+  const long long l = k / nxg;
+  const int xg = (int)(k - l * nxg);
+  const int p = xg / nxl, x = xg - p * nxl;
+  lines[k] = recv[((long long)p * nlq + l) * nxl + x];
+}
+// lines [nlq][nxg] -> send [W][nlq][nxs]: for rank p its owned columns and the two next to its slab (wrapped / clamped)
+__global__ __launch_bounds__(256) void k_lines_columns(const double* lines, int W, long long nlq, int nxl, int periodic,
+                                                       double* send)
+{
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nxs = nxl + 2;
+  const long long nxg = (long long)W * nxl;
+  if (k >= (long long)W * nlq * nxs) return;
+  const int c = (int)(k % nxs);
+  const long long l = (k / nxs) % nlq;
+  const int p = (int)(k / ((long long)nxs * nlq));
+  long long xg = (long long)p * nxl - 1 + c;
+  if (periodic) xg = (xg + nxg) % nxg;
+  else xg = xg < 0 ? 0 : (xg >= nxg ? nxg - 1 : xg);
+  send[k] = lines[l * nxg + xg];
+}
+
+struct CloudSlab {
+  SfLammps* L = nullptr;
+  HaloComm* hc = nullptr;
+  int n[3] = {0, 0, 0}, nxg = 0, per_x = 0, smoothing = 0;
+  int left = -1, right = -1;
+};
+
+static CloudSlab cloud_slab(void* cloud)
+{
+  CloudSlab C;
+  void* lmp = nullptr;
+  if (sf_cloud_slab_info(cloud, &lmp, C.n, &C.nxg, &C.per_x, &C.smoothing) != 0) fail("%s", last_error().c_str());
+  C.L = static_cast<SfLammps*>(lmp);
+  C.hc = static_cast<HaloComm*>(C.L->halo);
+  if (!C.hc || !C.hc->comm || C.hc->brick) fail("sf_cloud_slab_*: the engine has no slab communicator (sf_slab_init first)");
+  if (C.nxg <= 0) fail("sf_cloud_slab_*: not a slab mesh (sf_cloud_mesh.slab_nx_global)");
+  const int W = C.hc->world, r = C.hc->rank;
+  if ((long long)(C.n[0] - 2) * W != C.nxg) fail("sf_cloud_slab_*: %d owned layers x %d ranks != %d layers", C.n[0] - 2, W, C.nxg);
+  C.left = r > 0 ? r - 1 : (C.per_x ? W - 1 : -1);
+  C.right = r < W - 1 ? r + 1 : (C.per_x ? 0 : -1);
+  return C;
+}
+
+// two face messages: s_left -> left neighbour, s_right -> right neighbour; r_left / r_right <- what they sent
+static void face_exchange(CloudSlab& C, hipStream_t st, const double* s_left, const double* s_right, double* r_left,
+                          double* r_right, size_t n)
+{
+  RcclApi& a = rccl();
+  HaloComm& hc = *C.hc;
+  if (hc.world == 1) {   // (a single periodic slab is its own neighbour on both sides)
+    if (C.left >= 0) SF_HIP(hipMemcpyAsync(r_left, s_right, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    if (C.right >= 0) SF_HIP(hipMemcpyAsync(r_right, s_left, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    return;
+  }
+  SF_NCCL(a.GroupStart());
+  if (C.left >= 0) SF_NCCL(a.Send(s_left, n, ncclDouble, C.left, hc.comm, st));
+  if (C.right >= 0) SF_NCCL(a.Send(s_right, n, ncclDouble, C.right, hc.comm, st));
+  if (C.right >= 0) SF_NCCL(a.Recv(r_right, n, ncclDouble, C.right, hc.comm, st));   // (leftward traffic comes from my right)
+  if (C.left >= 0) SF_NCCL(a.Recv(r_left, n, ncclDouble, C.left, hc.comm, st));
+  SF_NCCL(a.GroupEnd());
+}
+
+static void cloud_halo_add_field(CloudSlab& C, hipStream_t st, double* f, int ncomp)
+{
+  HaloComm& hc = *C.hc;
+  const int nxs = C.n[0], nlines = C.n[1] * C.n[2];
+  const size_t np = (size_t)nlines * ncomp;
+  double* buf = hc.mig[0].need(4 * np + 4);
+  double *sl = buf, *sr = buf + np, *rl = buf + 2 * np, *rr = buf + 3 * np;
+  const int nb = div_up((int)np, 256);
+  // what this rank's particles deposited in its ghost layers belongs to the neighbours' edge layers
+  k_plane_get<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, 0, sl);
+  k_plane_get<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, nxs - 1, sr);
+  face_exchange(C, st, sl, sr, rl, rr, np);
+  if (C.left >= 0) k_plane_put<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, 1, rl, 0, 0);
+  if (C.right >= 0) k_plane_put<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, nxs - 2, rr, 0, 0);
+  // refresh the ghost layers with the neighbours' edge values (no neighbour: zero gradient)
+  k_plane_get<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, 1, sl);
+  k_plane_get<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, nxs - 2, sr);
+  face_exchange(C, st, sl, sr, rl, rr, np);
+  k_plane_put<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, 0, rl, C.left >= 0 ? 1 : 2, 1);
+  k_plane_put<<<nb, 256, 0, st>>>(f, nlines, nxs, ncomp, nxs - 1, rr, C.right >= 0 ? 1 : 2, nxs - 2);
+}
+
+// chunk p of `send` (equal sizes) to rank p, chunk p of `recv` from rank p
+static void equal_all_to_all(HaloComm& hc, hipStream_t st, const double* send, double* recv, size_t chunk)
+{
+  RcclApi& a = rccl();
+  SF_HIP(hipMemcpyAsync(recv + (size_t)hc.rank * chunk, send + (size_t)hc.rank * chunk, sizeof(double) * chunk,
+                        hipMemcpyDeviceToDevice, st));
+  if (hc.world == 1) return;
+  SF_NCCL(a.GroupStart());
+  for (int p = 0; p < hc.world; p++) {
+    if (p == hc.rank) continue;
+    SF_NCCL(a.Send(send + (size_t)p * chunk, chunk, ncclDouble, p, hc.comm, st));
+    SF_NCCL(a.Recv(recv + (size_t)p * chunk, chunk, ncclDouble, p, hc.comm, st));
+  }
+  SF_NCCL(a.GroupEnd());
+}
+
+static void cloud_xsolve(CloudSlab& C, void* cloud, hipStream_t st)
+{
+  HaloComm& hc = *C.hc;
+  const int W = hc.world, r = hc.rank, nxs = C.n[0], nxl = nxs - 2;
+  double* work = nullptr;
+  int nf = 0;
+  if (sf_cloud_smooth_work(cloud, &work, &nf) != 0) fail("%s", last_error().c_str());
+  const long long NL = (long long)nf * C.n[2] * C.n[1];
+  const long long nlq = (NL + W - 1) / W;
+  const size_t fwd = (size_t)W * nlq * nxl, bwd = (size_t)W * nlq * nxs;
+  double* a = hc.mig[0].need(fwd + bwd + 8);        // a: send / lines ; b: recv / send back
+  double* b = hc.mig[1].need(fwd + bwd + 8);
+  k_lines_interior<<<div_up((long long)fwd, 256), 256, 0, st>>>(work, NL, nxs, (long long)W * nlq, a);
+  equal_all_to_all(hc, st, a, b, (size_t)nlq * nxl);                  // b[p] = rank p's columns of my lines
+  double* lines = a;
+  k_lines_assemble<<<div_up((long long)fwd, 256), 256, 0, st>>>(b, W, nlq, nxl, lines);
+  const long long nvalid = std::max(0LL, std::min(nlq, NL - (long long)r * nlq));
+  if (sf_cloud_smooth_xsolve(cloud, lines, nvalid, (long long)r * nlq) != 0) fail("%s", last_error().c_str());
+  double* cols = b;
+  k_lines_columns<<<div_up((long long)bwd, 256), 256, 0, st>>>(lines, W, nlq, nxl, C.per_x, cols);
+  double* back = a + fwd;
+  equal_all_to_all(hc, st, cols, back, (size_t)nlq * nxs);            // back[q] = rank q's lines, my columns
+  SF_HIP(hipMemcpyAsync(work, back, sizeof(double) * (size_t)NL * nxs, hipMemcpyDeviceToDevice, st));
+}
+
 }  // namespace sf
 
 using sf::SfLammps;
@@ -999,6 +1165,34 @@ int sf_brick_pattern(int rank, int px, int py, int pz, const int* periodic, int*
   if (face_nbr)
     for (int k = 0; k < 3; k++)
       for (int side = 0; side < 2; side++) face_nbr[2 * k + side] = B.nbr[k][side];
+  SF_API_END(0)
+}
+
+int sf_cloud_slab_halo_add(void* cloud, int fields)
+{
+  SF_API_BEGIN
+  sf::CloudSlab C = sf::cloud_slab(cloud);
+  hipStream_t st = C.L->eng.stream();
+  double *g = nullptr, *u = nullptr, *a = nullptr;
+  int nc = 0;
+  if (sf_cloud_device_fields(cloud, &g, &u, &a, &nc) != 0) sf::fail("%s", sf::last_error().c_str());
+  if (fields & 1) sf::cloud_halo_add_field(C, st, g, 1);
+  if (fields & 2) sf::cloud_halo_add_field(C, st, u, 3);
+  if (fields & 4) sf::cloud_halo_add_field(C, st, a, 3);
+  SF_API_END(0)
+}
+
+int sf_cloud_slab_phase(void* cloud, int phase)
+{
+  SF_API_BEGIN
+  int rc = sf_cloud_phase(cloud, phase);
+  if (rc < 0) sf::fail("%s", sf::last_error().c_str());
+  if (rc == 1) {
+    sf::CloudSlab C = sf::cloud_slab(cloud);
+    sf::cloud_xsolve(C, cloud, C.L->eng.stream());
+    rc = sf_cloud_phase(cloud, phase);
+    if (rc != 0) sf::fail("sf_cloud_slab_phase %d did not finish after its x solve (%d)", phase, rc);
+  }
   SF_API_END(0)
 }
 

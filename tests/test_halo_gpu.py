@@ -570,9 +570,11 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
             assert dc.rel_err(got, want) <= 1e-8, k
 
 
-def _partition_worker(rank, world, port, outdir, ncfd, smooth, per, mesh):
+def _partition_worker(rank, world, port, outdir, ncfd, smooth, per, mesh, rccl_lib=None):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if rccl_lib:
+        os.environ["SF_RCCL_LIB"] = rccl_lib
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -587,10 +589,12 @@ def _partition_worker(rank, world, port, outdir, ncfd, smooth, per, mesh):
     cfg["walls"] = T._walls(bed)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
     lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport="host")
+    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True,
+                     transport="rccl" if rccl_lib else "host")
     mesh_n, dx, fluid, cloudDict, transDict = _partition_setup(bed, smooth, mesh)
     cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, driver=drv,
                           mesh_periodic=per, mesh_partition=True)
+    assert cloud._cxx_slab == bool(rccl_lib)     # the exchanges run in C++ over the engine's communicator, or in Python
     cloud.setFluid(**fluid)
     g0 = cloud.owned(cloud.gamma())
     for _ in range(ncfd):
@@ -619,16 +623,20 @@ def _partition_setup(bed, smooth, mesh):
     return mesh_n, dx, fluid, cloudDict, dict(rhob=1000.0, nub=1.0e-6)
 
 
-@pytest.mark.parametrize("smooth,per,mesh", [(True, (1, 0, 1), (4, 5, 4)), (False, (1, 0, 1), (2, 3, 2)),
-                                             (True, (1, 0, 0), (4, 5, 4))])
-def test_cloud_mesh_partitioned_by_the_slab_planes(smooth, per, mesh):
+@pytest.mark.parametrize("smooth,per,mesh,cxx", [(True, (1, 0, 1), (4, 5, 4), False), (False, (1, 0, 1), (2, 3, 2), False),
+                                                 (True, (1, 0, 0), (4, 5, 4), False), (True, (1, 0, 1), (4, 5, 4), True),
+                                                 (False, (1, 0, 1), (2, 3, 2), True), (True, (1, 0, 0), (4, 5, 4), True)])
+def test_cloud_mesh_partitioned_by_the_slab_planes(tmp_path, smooth, per, mesh, cxx):
     """the mesh partitioned by the planes of the particle decomposition (mesh_partition=True) instead of
     replicated -- local scatter, ghost-layer sums moved to the face neighbours, distributed smoothing solve (local y / z
     transforms, x on transposed lines), no collective of the size of the mesh -- against the single-GPU cloud on the
-    whole (cyclic) mesh; grains cross the slab face and the cyclic box face during the run."""
+    whole (cyclic) mesh; grains cross the slab face and the cyclic box face during the run.  cxx: the face-halo adds
+    and the x-line all-to-all run in C++ over the engine's RCCL communicator (sf_cloud_slab_halo_add /
+    sf_cloud_slab_phase, the stand-in wire on this one-GPU box), otherwise in Python over torch.distributed."""
     import os, socket, tempfile
     import torch.multiprocessing as mp
     from sedifoam_amd import enhancedCloud
+    lib = _standin_rccl(tmp_path) if cxx else None
     ncfd = 3
     bed = _coupled_bed()
     cfg = dict(T.BASE, skin=_COUPLED_SKIN)
@@ -645,7 +653,7 @@ def test_cloud_mesh_partitioned_by_the_slab_planes(smooth, per, mesh):
     a = ref.get_state()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_partition_worker, args=(2, port, out, ncfd, smooth, per, mesh), nprocs=2, join=True)
+        mp.spawn(_partition_worker, args=(2, port, out, ncfd, smooth, per, mesh, lib), nprocs=2, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
     nx, ny, nz = [int(k) for k in mesh_n]
 
