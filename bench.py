@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--one-gpu", action="store_true",
                     help="development: all ranks share GPU 0, halo over gloo through host memory (RCCL refuses two "
                          "ranks on one device); exercises the N > 1 code on a 1-GPU box")
+    ap.add_argument("--coupled-replicated", action="store_true",
+                    help="--coupled-multi: keep the whole mesh on every rank (three mesh-sized all-reduces per CFD step) "
+                         "instead of cutting it by the slab planes")
     ap.add_argument("--coupled-multi", action="store_true",
                     help="with --gpus N > 1 also time coupled steps: enhancedCloud over the decomposed particles, "
                          "whole mesh on every rank, per-cell sums all-reduced")
@@ -475,15 +478,22 @@ def main():
         from sedifoam_amd import enhancedCloud
         glo = np.array(bed["boxlo"], dtype=np.float64)
         ghi = np.array(bed["boxhi"], dtype=np.float64)
-        ghi[0] = glo[0] + world * (bed["boxhi"][0] - bed["boxlo"][0])
         mesh_n = np.clip(((bed["boxhi"] - bed["boxlo"]) / 3.0e-3).astype(int), 1, 32)
-        mesh_n[0] *= world
+        if is_strong:     # the bed's own box, cell layers along x a multiple of the ranks
+            mesh_n[0] = max(world, (int(mesh_n[0]) // world) * world)
+        else:             # one bed per rank, side by side
+            ghi[0] = glo[0] + world * (bed["boxhi"][0] - bed["boxlo"][0])
+            mesh_n[0] *= world
         dx = (ghi - glo) / mesh_n
         nc = int(np.prod(mesh_n))
+        # the mesh cut by the slab planes (every rank its nx / N layers + ghost layers, exchanges in C++ over the engine's
+        # communicator) whenever the particles are in x-slabs and the layers divide; else the whole mesh on every rank
+        part = grid_used[0] is None and int(mesh_n[0]) % world == 0 and not args.coupled_replicated
         cloud = enhancedCloud(lmp.e.lmp, glo, dx, mesh_n,
                               dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65,
                                    diffusionBandWidth=0.006, diffusionSteps=6),
-                              dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"], driver=lmp)
+                              dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"], driver=lmp,
+                              mesh_partition=part, mesh_periodic=(1, 0, 1) if part else None)
         cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (nc, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (nc, 1)))
         cloud.calcTcFields()
         cloud.evolve(); cloud.calcTcFields()
@@ -494,9 +504,11 @@ def main():
             cloud.evolve(); cloud.calcTcFields()
         barrier()
         out["config"]["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
-        out["config"]["coupled_step"] = ("decomposed particles, %dx%dx%d mesh on every rank, all-reduced per-cell sums; "
-                                         "ErgunWenYu + %d sub-steps + scatter + Asrc + smoothing (6 mm, 6 steps)"
-                                         % (mesh_n[0], mesh_n[1], mesh_n[2], args.substeps))
+        out["config"]["coupled_step"] = ("decomposed particles, %dx%dx%d mesh %s; ErgunWenYu + %d sub-steps + scatter + Asrc "
+                                         "+ smoothing (6 mm, 6 steps)"
+                                         % (mesh_n[0], mesh_n[1], mesh_n[2],
+                                            "cut by the slab planes (face-halo adds + x-line all-to-all in C++ over RCCL)"
+                                            if part else "on every rank, all-reduced per-cell sums", args.substeps))
     # N = 1: the loose disordered ("fluidised") bed of the same size next to the headline -- BASELINE config C3 is a
     # fluidised bed; the lattice of the headline is the best case (every listed neighbour touches, a rebuild every ~170
     # sub-steps).  Same engine path, same timing rules, shorter run.

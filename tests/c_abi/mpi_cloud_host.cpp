@@ -10,6 +10,11 @@
 // of sf_cloud_device_fields straight to MPI_Allreduce.  Added mass and the Basset history force are on, so the
 // cloud's per-particle state (previous velocity, history sums) has to follow the grains that change rank.
 //
+// Third argument "partition": the mesh is cut by the same planes as the particles -- every rank holds its
+// nx / ranks cell layers plus a ghost layer on each side, and the exchanges are the library's own, over the engine's RCCL
+// communicator: sf_cloud_slab_halo_add (ghost-layer sums to the face neighbours) and sf_cloud_slab_phase (the x-line
+// all-to-all of the distributed smoothing solve); no MPI collective of the size of the mesh is left in the loop.
+//
 // Rank 0 also runs the whole bed on one engine with sf_cloud_evolve / sf_cloud_calc_tc_fields and compares fields and
 // particles.  Built and run by tests/test_halo_gpu.py like mpi_slab_host.cpp (SF_RCCL_LIB stand-in on a one-GPU box).
 // Prints "OK ranks <N> cells <n> rel(gamma) <e> rel(Ue) <e> rel(Asrc) <e> max|dx| <e>" or "FAIL ...".
@@ -52,6 +57,7 @@ int main(int argc, char** argv)
   MPI_Comm_size(MPI_COMM_WORLD, &world);
   const int ncx = argc > 1 ? std::atoi(argv[1]) : 8;
   const int ncfd = argc > 2 ? std::atoi(argv[2]) : 3;
+  const bool partition = argc > 3 && std::strcmp(argv[3], "partition") == 0;
   const Bed bed = make_bed(ncx, 5, 5, 0.3);
   const int n = (int)bed.tag.size();
   const double L = bed.hi[0] - bed.lo[0], w = L / world;
@@ -63,7 +69,15 @@ int main(int argc, char** argv)
     mesh.origin[k] = bed.lo[k];
     mesh.n[k] = (int)std::fmax(1.0, std::floor((bed.hi[k] - bed.lo[k]) / 3.0e-3));
     mesh.dx[k] = (bed.hi[k] - bed.lo[k]) / mesh.n[k];
+    if (k == 0 && partition) {   // the slab planes must be cell faces
+      mesh.n[0] = world * (mesh.n[0] / world > 0 ? mesh.n[0] / world : 1);
+      mesh.dx[0] = (bed.hi[0] - bed.lo[0]) / mesh.n[0];
+    }
     nc *= mesh.n[k];
+  }
+  if (partition) {
+    mesh.periodic[0] = 1;   // the channel is cyclic in x and z, for the particles and for the smoothing
+    mesh.periodic[2] = 1;
   }
   sf_cloud_props pr;
   std::memset(&pr, 0, sizeof pr);
@@ -110,46 +124,122 @@ int main(int argc, char** argv)
   sf_dem_device_view view;
   CHECK(sf_dem_device_view_get(slab, &view));
   void* cloud = nullptr;
-  CHECK(sf_cloud_create(slab, &mesh, &pr, deltaT, &cloud));
+  sf_cloud_mesh lmesh = mesh;
+  const int nxl = mesh.n[0] / world, nxs = nxl + 2;
+  if (partition) {
+    lmesh.origin[0] = mesh.origin[0] + (rank * nxl - 1) * mesh.dx[0];
+    lmesh.n[0] = nxs;
+    lmesh.slab_nx_global = mesh.n[0];
+  }
+  CHECK(sf_cloud_create(slab, partition ? &lmesh : &mesh, &pr, deltaT, &cloud));
   int subCycles = 0, subSteps = 0, ncells = 0;
   CHECK(sf_cloud_sub_cycling(cloud, &subCycles, &subSteps));
   double *d_gamma = nullptr, *d_Ue = nullptr, *d_Asrc = nullptr;
   CHECK(sf_cloud_device_fields(cloud, &d_gamma, &d_Ue, &d_Asrc, &ncells));
-  if (ncells != nc) {
-    std::printf("FAIL cells %d %d\n", ncells, nc);
+  const int nc_local = partition ? nxs * mesh.n[1] * mesh.n[2] : nc;
+  if (ncells != nc_local) {
+    std::printf("FAIL cells %d %d\n", ncells, nc_local);
     MPI_Abort(MPI_COMM_WORLD, 1);
   }
+  // this rank's cells (ghost layers included, wrapped at the cyclic ends) of a whole-mesh [nz][ny][nx][3] array
+  auto take = [&](const std::vector<double>& g) {
+    std::vector<double> l(3 * (size_t)nc_local);
+    for (int iz = 0; iz < mesh.n[2]; iz++)
+      for (int iy = 0; iy < mesh.n[1]; iy++)
+        for (int c = 0; c < nxs; c++) {
+          const int ix = ((rank * nxl - 1 + c) % mesh.n[0] + mesh.n[0]) % mesh.n[0];
+          for (int k = 0; k < 3; k++)
+            l[3 * ((size_t)c + nxs * (iy + (size_t)mesh.n[1] * iz)) + k] =
+                g[3 * ((size_t)ix + mesh.n[0] * (iy + (size_t)mesh.n[1] * iz)) + k];
+        }
+    return l;
+  };
+  auto sphase = [&](int ph) {
+    if (sf_cloud_slab_phase(cloud, ph) != 0) {
+      std::printf("FAIL sf_cloud_slab_phase(%d): %s\n", ph, sf_last_error());
+      MPI_Abort(MPI_COMM_WORLD, 1);
+    }
+  };
   auto phase = [&](int ph) {
     if (sf_cloud_phase(cloud, ph) < 0) {
       std::printf("FAIL sf_cloud_phase(%d): %s\n", ph, sf_last_error());
       MPI_Abort(MPI_COMM_WORLD, 1);
     }
   };
-  // (the constructor scattered this rank's particles only: redo the averaging over all ranks)
-  phase(2);
-  add_over_ranks(d_gamma, nc, view.stream);
-  add_over_ranks(d_Ue, 3 * (size_t)nc, view.stream);
-  phase(3);
-  phase(6);
-  CHECK(sf_cloud_set_fluid(cloud, Uf.data(), DDtUf.data(), gradp.data(), nullptr));
-  for (int step = 0; step < ncfd; step++) {
-    phase(0);                                   // evolve()
-    for (int k = 0; k < subCycles; k++) {
-      phase(1);
-      CHECK(sf_slab_step(slab, subSteps));
-      if (k == 0) {
-        phase(2);
-        add_over_ranks(d_gamma, nc, view.stream);
-        add_over_ranks(d_Ue, 3 * (size_t)nc, view.stream);
-        phase(3);
-      }
-    }
-    phase(4);                                   // calcTcFields()
-    add_over_ranks(d_Asrc, 3 * (size_t)nc, view.stream);
-    phase(5);
-  }
   Fields got(nc);
-  CHECK(sf_cloud_get_fields(cloud, got.gamma.data(), got.Ue.data(), got.Asrc.data(), got.Omega.data()));
+  if (partition) {
+    // (the constructor scattered this rank's particles into its slab + ghost layers)
+    CHECK(sf_cloud_slab_halo_add(cloud, 1 | 2));
+    sphase(3);
+    sphase(6);
+    const std::vector<double> lU = take(Uf), lD = take(DDtUf), lG = take(gradp);
+    CHECK(sf_cloud_set_fluid(cloud, lU.data(), lD.data(), lG.data(), nullptr));
+    sphase(6);                                  // UfSmoothed of the initial condition (enhancedCloud.C:641-655)
+    for (int step = 0; step < ncfd; step++) {
+      sphase(0);                                // evolve()
+      for (int k = 0; k < subCycles; k++) {
+        phase(1);
+        CHECK(sf_slab_step(slab, subSteps));
+        if (k == 0) {
+          phase(2);
+          CHECK(sf_cloud_slab_halo_add(cloud, 1 | 2));
+          sphase(3);
+        }
+      }
+      phase(4);                                 // calcTcFields()
+      CHECK(sf_cloud_slab_halo_add(cloud, 4));
+      sphase(5);
+    }
+    // owned cells of every rank -> whole-mesh arrays on every rank
+    Fields loc(nc_local);
+    CHECK(sf_cloud_get_fields(cloud, loc.gamma.data(), loc.Ue.data(), loc.Asrc.data(), loc.Omega.data()));
+    const int nown = nxl * mesh.n[1] * mesh.n[2];
+    auto gather = [&](const std::vector<double>& l, int ncomp, std::vector<double>& g) {
+      std::vector<double> own((size_t)nown * ncomp), all((size_t)nown * ncomp * world);
+      for (int iz = 0; iz < mesh.n[2]; iz++)
+        for (int iy = 0; iy < mesh.n[1]; iy++)
+          for (int x = 0; x < nxl; x++)
+            for (int k = 0; k < ncomp; k++)
+              own[ncomp * ((size_t)x + nxl * (iy + (size_t)mesh.n[1] * iz)) + k] =
+                  l[ncomp * ((size_t)(x + 1) + nxs * (iy + (size_t)mesh.n[1] * iz)) + k];
+      MPI_Allgather(own.data(), nown * ncomp, MPI_DOUBLE, all.data(), nown * ncomp, MPI_DOUBLE, MPI_COMM_WORLD);
+      for (int r = 0; r < world; r++)
+        for (int iz = 0; iz < mesh.n[2]; iz++)
+          for (int iy = 0; iy < mesh.n[1]; iy++)
+            for (int x = 0; x < nxl; x++)
+              for (int k = 0; k < ncomp; k++)
+                g[ncomp * ((size_t)(r * nxl + x) + mesh.n[0] * (iy + (size_t)mesh.n[1] * iz)) + k] =
+                    all[(size_t)r * nown * ncomp + ncomp * ((size_t)x + nxl * (iy + (size_t)mesh.n[1] * iz)) + k];
+    };
+    gather(loc.gamma, 1, got.gamma);
+    gather(loc.Ue, 3, got.Ue);
+    gather(loc.Asrc, 3, got.Asrc);
+  } else {
+    // (the constructor scattered this rank's particles only: redo the averaging over all ranks)
+    phase(2);
+    add_over_ranks(d_gamma, nc, view.stream);
+    add_over_ranks(d_Ue, 3 * (size_t)nc, view.stream);
+    phase(3);
+    phase(6);
+    CHECK(sf_cloud_set_fluid(cloud, Uf.data(), DDtUf.data(), gradp.data(), nullptr));
+    for (int step = 0; step < ncfd; step++) {
+      phase(0);                                   // evolve()
+      for (int k = 0; k < subCycles; k++) {
+        phase(1);
+        CHECK(sf_slab_step(slab, subSteps));
+        if (k == 0) {
+          phase(2);
+          add_over_ranks(d_gamma, nc, view.stream);
+          add_over_ranks(d_Ue, 3 * (size_t)nc, view.stream);
+          phase(3);
+        }
+      }
+      phase(4);                                   // calcTcFields()
+      add_over_ranks(d_Asrc, 3 * (size_t)nc, view.stream);
+      phase(5);
+    }
+    CHECK(sf_cloud_get_fields(cloud, got.gamma.data(), got.Ue.data(), got.Asrc.data(), got.Omega.data()));
+  }
 
   std::vector<int> tag;
   std::vector<double> x, v;
@@ -209,8 +299,8 @@ int main(int argc, char** argv)
                   nc, total, n, eg, eu, ea, ex);
       fail = 1;
     } else {
-      std::printf("OK ranks %d cells %d rel(gamma) %.3e rel(Ue) %.3e rel(Asrc) %.3e max|dx| %.3e\n", world, nc, eg, eu,
-                  ea, ex);
+      std::printf("OK ranks %d cells %d%s rel(gamma) %.3e rel(Ue) %.3e rel(Asrc) %.3e max|dx| %.3e\n", world, nc,
+                  partition ? " (mesh partitioned)" : "", eg, eu, ea, ex);
     }
     CHECK(sf_cloud_destroy(ref));
     CHECK(sf_lammps_close(one));

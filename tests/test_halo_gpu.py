@@ -354,6 +354,11 @@ def test_mpi_cxx_host_runs_the_coupled_step_on_slabs(tmp_path, world, ncx):
     r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "3"], capture_output=True, text=True, timeout=600,
                        env=env)
     assert r.returncode == 0 and "OK ranks %d" % world in r.stdout, r.stdout + r.stderr
+    # the same step with the mesh cut by the slab planes: the library's own exchanges over the engine's communicator
+    # (sf_cloud_slab_halo_add / sf_cloud_slab_phase), no mesh-sized MPI collective in the loop
+    r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "3", "partition"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "OK ranks %d" % world in r.stdout and "mesh partitioned" in r.stdout, r.stdout + r.stderr
 
 
 def test_two_ranks_cohesive_lubricate_match_single_domain_and_oracle():
