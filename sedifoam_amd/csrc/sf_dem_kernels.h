@@ -1317,8 +1317,28 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     if (in_range(j, xr[j])) accept(j, tag[j], pos);
   };
   int n_total = 0;   // row path: accepted candidates of the first sweep (may exceed the slots: overflow report)
+  // Row path, first sweep: an accepted candidate is looked up in the old list right away (its tag is one gather, the
+  // comparison runs on the partner tags held in registers) and parked as j | (old slot + 1) << 25 in the scratch rows
+  // `cand`.  B.touch_first: the neighbours that touched (found in the old list) fill the rows from the front, the
+  // others from the back, so that the second sweep can place the touching ones first without another pass.
+  constexpr int kFoundUnknown = 127;
+  const bool tf = B.touch_first && nold > 0;
+  int n_touch = 0, n_free = 0;
   auto note = [&](const int j) {
-    if (n_total < B.M) cand[(size_t)n_total * B.cap + i] = j;
+    // (candidate order kept: the look-up waits for the second sweep, where the tag gathers of a wave are coalesced)
+    int f = -1;
+    if (tf) f = find_old(tag[j]);
+    const int word = j | ((!tf || f + 1 >= kFoundUnknown ? kFoundUnknown : f + 1) << kIdxBits);
+    if (tf) {
+      if (n_total < B.M) {
+        const int row = f >= 0 ? n_touch : B.M - 1 - n_free;
+        cand[(size_t)row * B.cap + i] = word;
+      }
+      if (f >= 0) n_touch++;
+      else n_free++;
+    } else if (n_total < B.M) {
+      cand[(size_t)n_total * B.cap + i] = word;
+    }
     n_total++;
   };
   if (B.lb_own) {
@@ -1374,42 +1394,29 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // list (their history is re-injected) take the FIRST slots of the row, in candidate order, the others follow.  The
     // sub-step kernel then evaluates the contact law in the first slots, where most lanes of a wave touch, and skips
     // it wave-wide in the rest, instead of running it in every slot for the few lanes that touch there (loose bed:
-    // 230 -> 184 us per sub-step at 1 M grains).  In an ordered bed the same shuffle costs the lane-to-lane
+    // 236 -> 189 us per sub-step at 1 M grains).  In an ordered bed the same shuffle costs the lane-to-lane
     // regularity of the slots -- slot s of adjacent lanes = adjacent atoms -- that the gathers coalesce on (+35 %
-    // there), hence the switch.  Two passes over the candidates: look every pair up in the old list and count
-    // (the result parked in the nloc rows, unused on this path), then place.
+    // there), hence the switch (DemEngine::bin_and_build).
     const int nacc = n_total < B.M ? n_total : B.M;
-    const bool tf = B.touch_first && nold > 0;
+    // (overflowing rows are rebuilt with more slots: what was dropped does not matter)
+    const int nt = tf ? (n_touch < nacc ? n_touch : nacc) : 0;
+    auto cand_row = [&](const int s) { return !tf || s < nt ? s : B.M - 1 - (s - nt); };
     if (tf) {
-      int ntouch = 0;
-      // (two slots ahead: candidate index, one slot ahead: its tag -- the look-up itself runs on registers)
-      int c1 = nacc > 0 ? cand[i] : 0, c2 = nacc > 1 ? cand[B.cap + i] : 0;
-      int t1 = nacc > 0 ? tag[c1] : 0;
-      for (int s = 0; s < nacc; s++) {
-        const int tj = t1;
-        c1 = c2;
-        if (s + 1 < nacc) t1 = tag[c1];
-        if (s + 2 < nacc) c2 = cand[(size_t)(s + 2) * B.cap + i];
-        const int f = find_old(tj);
-        B.nloc[(size_t)s * B.cap + i] = (unsigned short)(f + 1);
-        ntouch += f >= 0 ? 1 : 0;
-      }
       slot_touch = 0;
-      slot_free = ntouch;
+      slot_free = nt;
     }
     n = 0;
-    int jn = nacc > 0 ? cand[i] : 0;
-    int tn = (nacc > 0 && !tf) ? tag[jn] : 0;
-    int fn = (nacc > 0 && tf) ? (int)B.nloc[i] - 1 : -2;
+    int wn = nacc > 0 ? cand[(size_t)cand_row(0) * B.cap + i] : 0;
+    int tn = (nacc > 0 && !tf) ? tag[wn & kIdxMask] : 0;   // (one slot ahead, like the candidate word)
     for (int s = 0; s < nacc; s++) {
-      const int j = jn, tj = tn;
-      found_known = fn;
+      const int w = wn, tj = tn;
       if (s + 1 < nacc) {
-        jn = cand[(size_t)(s + 1) * B.cap + i];
-        if (tf) fn = (int)B.nloc[(size_t)(s + 1) * B.cap + i] - 1;
-        else tn = tag[jn];
+        wn = cand[(size_t)cand_row(s + 1) * B.cap + i];
+        if (!tf) tn = tag[wn & kIdxMask];
       }
-      accept(j, tj, 0);
+      const int j = w & kIdxMask, fcode = (w >> kIdxBits) & 127;
+      found_known = fcode == kFoundUnknown ? -2 : fcode - 1;
+      accept(j, tf && found_known == -2 ? tag[j] : tj, 0);
     }
     n = n_total;
   } else {
