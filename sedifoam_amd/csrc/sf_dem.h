@@ -562,6 +562,7 @@ private:
   RebuildPredictor predict_;                 // single-domain run(): how far to queue (SF_QUEUE_PREDICT=0: everything)
   int nt_policy_ = 2, nt_policy_env_ = -1;   // non-temporal policy of the row streams (sf_dem_kernels.h, NTP)
   void measure_list();     // queue k_partner_coalescing on the current list (results with the next flag read)
+  long long list_sampled_ = 0;   // atoms the last measure_list looked at
   void choose_kernel();    // pick touch_prefetch_ from the last measurement
   DevArray nloc_;                      // [M][cap] uint16 (see DemPtrs::nloc)
   int* tile_tab_ = nullptr;            // [2][ntiles] tile_first / tile_last, then [ntiles+1] counts, starts

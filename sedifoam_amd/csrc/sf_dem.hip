@@ -1275,8 +1275,13 @@ void DemEngine::measure_list()
   static_assert(F_PART_COAL == F_PART_SLOTS + 1 && F_LIST_SLOTS == F_PART_SLOTS + 2 && F_LIST_TOUCH == F_PART_SLOTS + 3,
                 "adjacent counters");
   reset_flags(F_PART_SLOTS, 4, 0);
-  k_partner_coalescing<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_,
-                                                                   cap_, d_flags_ + F_PART_SLOTS);
+  // a sample of one block of 1024 atoms in eight above 64 k atoms (ratios and a mean are all that is used)
+  const int nblk = div_up(nlocal_, 1024), stride = nlocal_ > 65536 ? 8 : 1;
+  const int nsamp = div_up(nblk, stride);
+  list_sampled_ = 0;
+  for (int b = 0; b < nsamp; b++) list_sampled_ += std::min(1024, nlocal_ - b * stride * 1024);
+  k_partner_coalescing<<<nsamp, 1024, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_, cap_,
+                                                    d_flags_ + F_PART_SLOTS, stride);
 }
 
 void DemEngine::choose_kernel()
@@ -1285,8 +1290,8 @@ void DemEngine::choose_kernel()
   // Non-temporal policy of the row streams (sf_dem_kernels.h, NTP): what one sub-step touches against the 256 MB
   // memory-side cache.  Records in + out 192 B, history in + out 48 B per stored copy, list words, fix arrays.
   {
-    const double khalf = (nlocal_ > 0 && h_flags_[F_LIST_SLOTS] > 0)
-                             ? 0.5 * (double)h_flags_[F_LIST_SLOTS] / (double)nlocal_ : 6.0;
+    const double khalf = (list_sampled_ > 0 && h_flags_[F_LIST_SLOTS] > 0)
+                             ? 0.5 * (double)h_flags_[F_LIST_SLOTS] / (double)list_sampled_ : 6.0;
     const double copies = hist_single_ ? 1.0 : 2.0;
     const double touched = (double)nlocal_ * (252.0 + (8.0 + 48.0 * copies) * khalf);
     const double mall = 256.0 * 1024.0 * 1024.0;

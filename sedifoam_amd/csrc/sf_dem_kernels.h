@@ -882,10 +882,11 @@ __global__ __launch_bounds__(128) void k_back_slots(int* neigh, const int* numne
 // slots that point at a LOWER-indexed atom of this GPU itself (the would-be partner sides, whichever mode the list
 // was built in), how many have such a lane neighbour.  The engine picks the mode of the NEXT list build from the
 // ratio (with hysteresis): the answer depends on the particles only, so runs stay reproducible.
+// (statistics: every `stride`-th block of 1024 atoms is looked at -- the same atoms on every run)
 __global__ __launch_bounds__(1024) void k_partner_coalescing(const int* neigh, const int* numneigh, int nlocal,
-                                                            size_t cap, int* counters)
+                                                            size_t cap, int* counters, int stride)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * stride * blockDim.x + threadIdx.x;
   int total = 0, coal = 0, listed = 0, touching = 0;
   if (i < nlocal) {
     const int nn = numneigh[i];
