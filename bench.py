@@ -337,6 +337,7 @@ def main():
     k_half = info.npairs_full / 2.0 / max(info.nlocal, 1)
 
     value = n_total * args.substeps * args.steps / elapsed
+    nlabel = ("%.0fM" % (n_total / 1e6)) if abs(n_total / 1e6 - round(n_total / 1e6)) < 0.01 and n_total >= 1e6 else "%d" % int(n_total)
     b_alg = 284.0 + 52.0 * k_half
     mean_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
     achieved = b_alg * N / mean_kernel_s / 1e9 if launches else 0.0
@@ -356,10 +357,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": ("%s, periodic x/z, wall y, gravity + fix fdrag, %d DEM sub-steps per step%s"
-                         % ("%.1fM-particle loose disordered (fluidised) Hertz-history bed (jitter 0.3 d, spacing 1.1 d)"
-                            % (n_total / 1e6) if args.bed == "fluidised" else
-                            "%.0fM-particle monodisperse Hertz-history packing (FCC bed, d=1mm, 2%% overlap)"
-                            % (n_total / 1e6), args.substeps,
+                         % ("%s-particle loose disordered (fluidised) Hertz-history bed (jitter 0.3 d, spacing 1.1 d)" % nlabel
+                            if args.bed == "fluidised" else
+                            "%s-particle monodisperse Hertz-history packing (FCC bed, d=1mm, 2%% overlap)" % nlabel,
+                            args.substeps,
                             "; the SAME bed split into %d spatial domains (BASELINE config C4)" % world if is_strong else
                             ("; one such slab per GPU of a channel %d times as long" % world if world > 1 else ""))),
             "particles_total": int(n_total),
