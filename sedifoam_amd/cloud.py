@@ -126,6 +126,9 @@ class enhancedCloud:
         self.mesh_n_global = tuple(int(k) for k in mesh_n)
         if self.partition:
             W, r = driver.world, driver.rank
+            if hasattr(driver, "grid"):
+                raise SfError("mesh_partition: the mesh is cut by x-slab planes; over a brick decomposition "
+                              "(BrickDriver) keep the whole mesh on every rank")
             if mesh_faces is not None and mesh_faces[0] is not None:
                 raise SfError("mesh_partition: the mesh must be uniform along x")
             if mesh_labels is not None:

@@ -808,6 +808,10 @@ void DemEngine::brick_border_select(long long* counts)
     B.ext[d] = ext_[d] ? 1 : 0;
     B.lo[d] = sublo_[d] + cut;
     B.hi[d] = subhi_[d] - cut;
+    // every ghost comes from an ADJACENT brick: a brick thinner than the ghost cutoff would need its second neighbours
+    if (ext_[d] && subhi_[d] - sublo_[d] < cut)
+      fail("brick decomposition: the sub-domain is %.6g wide in dimension %d, less than the ghost cutoff %.6g -- use "
+           "fewer bricks along it", subhi_[d] - sublo_[d], d, cut);
   }
   for (int q = 0; q < bndir_; q++) {
     int need = 0;

@@ -491,7 +491,7 @@ def _coupled_setup(bed):
     return mesh_n, dx, fluid, cloudDict, dict(rhob=1000.0, nub=1.0e-6)
 
 
-def _coupled_worker(rank, world, port, outdir, ncfd, transport="host", rccl_lib=None):
+def _coupled_worker(rank, world, port, outdir, ncfd, transport="host", rccl_lib=None, grid=None):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if rccl_lib:
@@ -509,8 +509,15 @@ def _coupled_worker(rank, world, port, outdir, ncfd, transport="host", rccl_lib=
     cfg = dict(T.BASE, skin=_COUPLED_SKIN)
     cfg["walls"] = T._walls(bed)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
-    lmp = dc.make_hip(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)
-    drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport=transport)
+    if grid is not None:
+        from sedifoam_amd.halo import BrickDriver, brick_mask
+        mine = brick_mask(bed, rank, grid)
+        lmp = dc.make_hip(dc.subset(bed, mine), cfg)
+        drv = BrickDriver(HipSlabEngine(lmp), dist, rank, world, grid)
+    else:
+        mine = dc.slab_mask(bed, rank, world)
+        lmp = dc.make_hip(dc.subset(bed, mine), cfg)
+        drv = SlabDriver(HipSlabEngine(lmp), dist, rank, world, lo, hi, periodic_x=True, transport=transport)
     assert drv.transport == transport
     mesh_n, dx, fluid, cloudDict, transDict = _coupled_setup(bed)
     cloud = enhancedCloud(lmp, bed["boxlo"], dx, mesh_n, cloudDict, transDict, 40e-6, driver=drv)
@@ -520,12 +527,12 @@ def _coupled_worker(rank, world, port, outdir, ncfd, transport="host", rccl_lib=
         cloud.evolve()
         cloud.calcTcFields()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), g0=g0, gamma=cloud.gamma(), Ue=cloud.Ue(), Asrc=cloud.Asrc(),
-             rebuilds=drv.n_rebuilds, tag0=(np.nonzero(dc.slab_mask(bed, rank, world))[0] + 1), **lmp.get_state())
+             rebuilds=drv.n_rebuilds, tag0=(np.nonzero(mine)[0] + 1), **lmp.get_state())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transport", ["host", "rccl"])
+@pytest.mark.parametrize("transport", ["host", "rccl", "bricks"])
 def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
     """enhancedCloud over a decomposed particle set (sf_cloud_phase + all-reduce of the per-cell sums, whole mesh on
     every rank) against the single-GPU cloud: drag closure, 2 sub-cycles of DEM sub-steps through the halo driver,
@@ -534,6 +541,10 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
     import os, socket, tempfile
     import torch.multiprocessing as mp
     from sedifoam_amd import enhancedCloud
+    grid = (2, 1, 2) if transport == "bricks" else None      # the same coupled step over a 2 x 1 x 2 processor grid
+    if grid:
+        transport = "rccl"
+    world = 4 if grid else 2
     lib = _standin_rccl(tmp_path) if transport == "rccl" else None
     ncfd = 3
     bed = _coupled_bed()
@@ -551,8 +562,8 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
     a = ref.get_state()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_coupled_worker, args=(2, port, out, ncfd, transport, lib), nprocs=2, join=True)
-        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+        mp.spawn(_coupled_worker, args=(world, port, out, ncfd, transport, lib, grid), nprocs=world, join=True)
+        parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
     for p in parts:     # every rank holds the same global fields
         assert dc.rel_err(p["g0"], g0) <= 1e-12
         assert dc.rel_err(p["gamma"], cloud.gamma()) <= 1e-9
@@ -564,12 +575,14 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
     assert len(np.unique(tag)) == bed["n"]
     # particles really changed rank during the run (their previous velocity / history sums travelled with them)
     assert any(set(p["tag"].tolist()) != set(p["tag0"].tolist()) for p in parts)
-    L = bed["boxhi"][0] - bed["boxlo"][0]
     for k in ("x", "v", "omega"):
         got = np.concatenate([p[k] for p in parts])[order]
         want = a[k].copy()
         if k == "x":
-            got[:, 0] = np.mod(got[:, 0] - bed["boxlo"][0], L); want[:, 0] = np.mod(want[:, 0] - bed["boxlo"][0], L)
+            for d in range(3):
+                if bed["periodic"][d]:
+                    Ld = bed["boxhi"][d] - bed["boxlo"][d]
+                    got[:, d] = np.mod(got[:, d] - bed["boxlo"][d], Ld); want[:, d] = np.mod(want[:, d] - bed["boxlo"][d], Ld)
             assert np.max(np.abs(got - want)) <= 1e-11
         else:
             assert dc.rel_err(got, want) <= 1e-8, k
