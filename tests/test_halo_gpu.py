@@ -80,6 +80,16 @@ def _c5_case(ncells=(8, 5, 5)):
     return bed, cfg
 
 
+def _loose_case(ncells):
+    """a loose, hot, disordered bed (FCC sites at spacing 1.1 d, jitter 0.3 d: ~8 listed and 2-3 touching neighbours
+    per grain, overlaps that throw the grains apart): a rebuild every few sub-steps, grains crossing faces, edges and
+    corners of the bricks all the time, the list built with the touching neighbours first"""
+    bed = T._bed(tuple(ncells), periodic=True, seed=47, vmax=0.5, jitter=0.3, spacing=1.1)
+    cfg = dict(T.BASE, skin=0.25e-3)
+    cfg["walls"] = T._walls(bed)
+    return bed, cfg
+
+
 def _walled_x(bed, cfg):
     """the same bed between two walls in x instead of periodic: the end slabs have no neighbour on one side"""
     bed["periodic"] = (0, 0, 1)
@@ -106,6 +116,8 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     if physics == "c5":
         bed, cfg = _c5_case(ncells) if grid is not None else _c5_case()
+    elif physics == "loose":
+        bed, cfg = _loose_case(ncells)
     else:
         bed = T._bed(tuple(ncells), periodic=True, seed=41, vmax=0.5)
         cfg = dict(T.BASE, skin=0.05e-3)
@@ -249,7 +261,8 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
 @pytest.mark.parametrize("grid,ncells,physics,periodic_x",
                          [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "hertz", True),
                           ((3, 1, 2), (9, 5, 8), "hertz", True), ((1, 1, 2), (6, 5, 8), "hertz", True),
-                          ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False)])
+                          ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False),
+                          ((2, 2, 2), (8, 8, 8), "loose", True)])
 def test_cxx_brick_driver_on_a_processor_grid(tmp_path, grid, ncells, physics, periodic_x):
     """The brick driver (sf_brick_init + sf_slab_setup / _step / _rebuild): a 3-D processor grid -- 2 x 1 x 2 and
     2 x 2 x 2 (BASELINE config C4's 8 GPUs; the y cut crosses the wall dimension, the end bricks have a face without a
@@ -262,9 +275,11 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, grid, ncells, physics, p
     import torch.multiprocessing as mp
     lib = _standin_rccl(tmp_path)
     world = grid[0] * grid[1] * grid[2]
-    steps = (50, 50) if physics == "hertz" else (40, 40)
+    steps = {"hertz": (50, 50), "c5": (40, 40), "loose": (20, 20)}[physics]
     if physics == "c5":
         bed, cfg = _c5_case(ncells)
+    elif physics == "loose":
+        bed, cfg = _loose_case(ncells)
     else:
         bed = T._bed(ncells, periodic=True, seed=41, vmax=0.5)
         cfg = dict(T.BASE, skin=0.05e-3)
