@@ -328,6 +328,7 @@ class DemEngine {
   void rebuild_begin();
   void rebuild_sort();
   void rebuild_finish();
+  void set_in_run(bool on) { in_run_ = on; }   // the driver's stepping loop brackets its rebuilds with it
 
   // ---- data exchange ----
   int nlocal() const { return nlocal_; }

@@ -979,8 +979,13 @@ void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
   g4(xr_[cur_]);
   g4(vm_[cur_]);
   g4(om_[cur_]);
-  g4(force_);
-  g4(torque_);
+  // force / torque are stored by the LAST sub-step of a run only (and read by the first half-kick of the next run): a
+  // rebuild inside a run -- always followed by at least one more sub-step, the last one storing them for every atom in
+  // the new order -- need not carry them along
+  if (!in_run_) {
+    g4(force_);
+    g4(torque_);
+  }
   gi(tag_);
   gi(type_);
   gi(mask_);

@@ -457,7 +457,9 @@ static void slab_step(SfLammps& S, HaloComm& hc, int n)
     }
     k = trig + 1;   // sub-steps k..trig ran (trig = -1: the list was stale for sub-step 0)
     hc.pre_exchanged = false;
+    e.set_in_run(true);
     slab_rebuild(S, hc);
+    e.set_in_run(false);
     hc.predict.rebuilt(e.nsteps());
     if (e.overlap()) e.overlap_begin();
   }
@@ -857,7 +859,9 @@ static void brick_step(SfLammps& S, HaloComm& hc, int n)
     }
     k = trig + 1;
     hc.pre_exchanged = false;
+    e.set_in_run(true);
     brick_rebuild(S, hc);
+    e.set_in_run(false);
     hc.predict.rebuilt(e.nsteps());
   }
 }
