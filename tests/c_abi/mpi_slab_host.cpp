@@ -6,6 +6,9 @@
 // run inside the library (csrc/sf_halo_rccl.hip).  Rank 0 also runs the WHOLE bed on a second, single-domain engine;
 // the slabs' atoms are gathered by tag with MPI_Gatherv and compared with it.
 //
+// Arguments 3..5 (px py pz, px py pz = ranks): a 3-D processor grid instead of slabs -- sf_brick_init, every rank the
+// atoms of its brick (the bed then has ncz = 8 cells along z so that two bricks fit), everything else the same calls.
+//
 // Built and run by tests/test_halo_gpu.py (g++ against the image's MPICH, `mpirun -np 2|3`).  On a one-GPU box the
 // ranks share the GPU and SF_RCCL_LIB points the library at tests/c_abi/standin_rccl.cpp instead of librccl (which
 // refuses two ranks on one device); on a multi-GPU node the same binary runs on librccl with one GPU per rank
@@ -21,16 +24,28 @@ int main(int argc, char** argv)
   const int ncx = argc > 1 ? std::atoi(argv[1]) : 8;
   const int nsteps = argc > 2 ? std::atoi(argv[2]) : 50;
   const int nruns = 2;
-  const Bed bed = make_bed(ncx, 5, 5, 0.5);
+  int P[3] = {world, 1, 1};
+  const bool bricks = argc > 5;
+  if (bricks)
+    for (int k = 0; k < 3; k++) P[k] = std::atoi(argv[3 + k]);
+  if (P[0] * P[1] * P[2] != world) {
+    std::printf("FAIL %d x %d x %d bricks for %d ranks\n", P[0], P[1], P[2], world);
+    MPI_Abort(MPI_COMM_WORLD, 1);
+  }
+  const Bed bed = make_bed(ncx, 5, bricks ? 8 : 5, 0.5);
   const int n = (int)bed.tag.size();
-  const double L = bed.hi[0] - bed.lo[0], w = L / world;
+  const double L = bed.hi[0] - bed.lo[0];
 
-  // this rank's slab: x in [lo + rank w, lo + (rank + 1) w)
+  // this rank's slab / brick: coordinate k in [lo + c_k w_k, lo + (c_k + 1) w_k), rank = cx + px (cy + py cz)
   std::vector<int> mine;
   for (int i = 0; i < n; i++) {
-    int r = (int)std::floor((bed.x[3 * i] - bed.lo[0]) / w);
-    r = r < 0 ? 0 : (r >= world ? world - 1 : r);
-    if (r == rank) mine.push_back(i);
+    int c[3];
+    for (int k = 0; k < 3; k++) {
+      const double w = (bed.hi[k] - bed.lo[k]) / P[k];
+      c[k] = (int)std::floor((bed.x[3 * i + k] - bed.lo[k]) / w);
+      c[k] = c[k] < 0 ? 0 : (c[k] >= P[k] ? P[k] - 1 : c[k]);
+    }
+    if (c[0] + P[0] * (c[1] + P[1] * c[2]) == rank) mine.push_back(i);
   }
   MPI_Comm comm;
   MPI_Comm_dup(MPI_COMM_WORLD, &comm);
@@ -38,7 +53,8 @@ int main(int argc, char** argv)
   char id[128];
   if (rank == 0) CHECK(sf_dem_comm_unique_id(id));
   MPI_Bcast(id, 128, MPI_CHAR, 0, MPI_COMM_WORLD);
-  CHECK(sf_slab_init(slab, id, rank, world, bed.lo[0], bed.hi[0], 1));
+  if (bricks) CHECK(sf_brick_init(slab, id, rank, world, P[0], P[1], P[2]));
+  else CHECK(sf_slab_init(slab, id, rank, world, bed.lo[0], bed.hi[0], 1));
   CHECK(sf_slab_setup(slab));
   for (int r = 0; r < nruns; r++) CHECK(sf_slab_step(slab, nsteps));
   const long long rebuilds = sf_slab_rebuild_count(slab);
@@ -89,6 +105,7 @@ int main(int argc, char** argv)
       for (int c = 0; c < 3; c++) {
         double dx = gx[3 * k + c] - rx[3 * i + c];
         if (c == 0) dx -= L * std::round(dx / L);   // (an atom that crossed the periodic face is wrapped at a rebuild)
+        if (c == 2) dx -= (bed.hi[2] - bed.lo[2]) * std::round(dx / (bed.hi[2] - bed.lo[2]));
         ex = std::fmax(ex, std::fabs(dx));
         ev = std::fmax(ev, std::fabs(gv[3 * k + c] - rv[3 * i + c]));
         sv = std::fmax(sv, std::fabs(rv[3 * i + c]));

@@ -343,17 +343,18 @@ def _build_mpi_host(tmp_path, name):
     return mpirun, exe
 
 
-@pytest.mark.parametrize("world,ncx", [(2, 8), (3, 9)])
-def test_mpi_cxx_host_drives_the_slabs_through_the_c_abi(tmp_path, world, ncx):
+@pytest.mark.parametrize("world,ncx,grid", [(2, 8, None), (3, 9, None), (4, 8, (2, 1, 2))])
+def test_mpi_cxx_host_drives_the_slabs_through_the_c_abi(tmp_path, world, ncx, grid):
     """lammpsFoam's side of a decomposed run, stood in for by tests/c_abi/mpi_slab_host.cpp: an MPI program in C++ (the
     image's MPICH) that opens one engine per rank, hands over the script lines and its slab's atoms, broadcasts the
     communicator id with MPI_Bcast and then only calls sf_slab_init / setup / step -- no Python, no torch in the loop.
-    Rank 0 runs the whole bed on a second engine and compares (positions 1e-12, velocities 1e-9, >= 3 rebuilds)."""
+    Rank 0 runs the whole bed on a second engine and compares (positions 1e-12, velocities 1e-9, >= 3 rebuilds).
+    grid: the same host on a 2 x 1 x 2 processor grid (sf_brick_init instead of sf_slab_init)."""
     import subprocess
     mpirun, exe = _build_mpi_host(tmp_path, "mpi_slab_host")
     env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path))
-    r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "50"], capture_output=True, text=True, timeout=600,
-                       env=env)
+    r = subprocess.run([mpirun, "-np", str(world), exe, str(ncx), "50"] + ([str(g) for g in grid] if grid else []),
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "OK ranks %d" % world in r.stdout, r.stdout + r.stderr
 
 
