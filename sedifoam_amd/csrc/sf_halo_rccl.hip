@@ -1058,6 +1058,7 @@ int sf_dem_comm_init(void* ptr, const char* id128, int rank, int world)
   SF_API_BEGIN
   SfLammps* L = H(ptr);
   if (world < 1 || rank < 0 || rank >= world) sf::fail("sf_dem_comm_init: rank %d of %d", rank, world);
+  if (L->halo && L->halo_delete) L->halo_delete(L->halo);   // (a second init replaces the communicator)
   auto* hc = new sf::HaloComm();
   L->halo = hc;
   L->halo_delete = sf::halo_deleter;
