@@ -165,7 +165,7 @@ struct StepParams {
   // gap at the build <= its own displacement since then + the largest displacement of any atom (triangle inequality;
   // exact: a skipped pair cannot overlap).  Hertz / Hooke contacts only (cohesion and lubrication act at a distance).
   int prune;
-  double prune_inv_w;   // 7 / skin: class width of DemPtrs::nbucket
+  double prune_inv_w;   // 8 / skin: bucket width of DemPtrs::nbucket
   WallParams wall[kMaxWalls];
   int have_gravity;
   double gacc[3];
@@ -574,7 +574,7 @@ private:
   int prune_env_ = -1;                 // SF_PRUNE=0 / 1
   DevArray nbucket_, disp_;
   unsigned long long* d_dmax_ = nullptr;
-  DevArray tilemax_, gapf_;            // per-tile maxima; scratch of the gap-ordered list build [M][cap] ints
+  DevArray tilemax_, gapf_;            // per-tile maxima; scratch of the gap-ordered list build [M][cap] floats
   void refresh_displacements();        // disp / tile maxima / dmax from x and xhold (after the first half-kick of a run)
   int touch_first_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)

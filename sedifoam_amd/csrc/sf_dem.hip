@@ -692,7 +692,7 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.freeze_bit = freeze_bit_;
   S.post_freeze = post_freeze_;
   S.prune = (list_gap_order_ && mode != 2) ? 1 : 0;
-  S.prune_inv_w = 7.0 / lskin();
+  S.prune_inv_w = 8.0 / lskin();
   return S;
 }
 
@@ -1267,9 +1267,9 @@ void DemEngine::bin_and_build()
     const bool can_prune = !have_subdomain_ && row_tables_ && roots_ && gran_.style != 0 && !cohe_.enabled &&
                            !lub_.enabled && !overlap_ && M_ <= 64;
     B.gap_order = (can_prune && (prune_env_ >= 0 ? prune_env_ != 0 : touch_first_)) ? 1 : 0;
-    B.gap_inv_w = 7.0 / lskin();
-    if (B.gap_order && (gapf_.cap != cap_ || gapf_.rows < M_)) gapf_.alloc(sizeof(int), M_, cap_, stream_);   // scratch
-    B.gapc = gapf_.as<int>();
+    B.gap_inv_w = 8.0 / lskin();
+    if (B.gap_order && (gapf_.cap != cap_ || gapf_.rows < M_)) gapf_.alloc(sizeof(float), M_, cap_, stream_);   // scratch
+    B.gapf = gapf_.as<float>();
     B.nbucket = nbucket_.as<unsigned long long>();
     gap_order_built = B.gap_order != 0;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;

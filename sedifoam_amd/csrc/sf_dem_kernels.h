@@ -175,8 +175,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     dmax_seen = *P.dmax;
     (void)dmax_seen;
     const double bound = ((double)P.disp[i] * (1.0 + 1.0e-6) + sqrt(__longlong_as_double((long long)dmax_seen))) * (1.0 + 1.0e-12);
-    // (class k >= 1 holds the gaps in ((k-1) w, k w]: it can touch once (k-1) w < bound)
-    int bk = (int)(bound * S.prune_inv_w) + 1;
+    int bk = (int)(bound * S.prune_inv_w);
     bk = bk > 7 ? 7 : bk;
     const int nb = (int)((P.nbucket[i] >> (8 * bk)) & 255ull);
     nn_all = nb < nn_all ? nb : nn_all;
@@ -1237,13 +1236,13 @@ struct BuildParams {
   const int* old_index;   // new index -> index before the re-sort (history rows not permuted), or nullptr
   int two_copies;         // every side of every contact keeps its own history copy (see k_partner_coalescing)
   int touch_first;        // row path: touching neighbours take the first slots of a row (loose beds)
-  // row path, loose beds: the slots of a row by GAP CLASS of the pair at the build -- class 0: touching (gap r - (ri +
-  // rj) <= 0, or history re-injected), class k = 1..7: gap in ((k-1) w, k w], w = skin / 7 -- in candidate order inside
-  // a class, and per atom how many slots lie in classes <= k: the sub-step kernel then only looks at the classes that
-  // CAN touch given how far the atoms have moved since the build (substep_particle, S.prune)
+  // row path, loose beds: the slots of a row in ascending order of the pair's GAP r - (ri + rj) at the build (touching
+  // pairs first, then the nearest misses), and per atom how many slots have a gap below k skin / 8, k = 1..8: the
+  // sub-step kernel then only looks at the slots that CAN touch given how far the atoms have moved since the build
+  // (substep_particle, S.prune)
   int gap_order;
-  double gap_inv_w;       // 7 / skin
-  int* gapc;              // scratch [M][cap]: class of a candidate
+  double gap_inv_w;       // 8 / skin
+  float* gapf;            // scratch [M][cap]
   unsigned long long* nbucket;   // [cap] eight cumulative 8-bit counts
 };
 
@@ -1351,7 +1350,6 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   // row path: slot of the next touching / next non-touching neighbour (touching ones first, see the second sweep)
   int slot_touch = -1, slot_free = -1;
   int found_known = -2;   // >= -1: the old slot of the pair was looked up before (touch-first placement)
-  int dst_fixed = -1;     // >= 0: the slot this neighbour goes to (gap order)
   auto accept = [&](const int j, const int tj, const int pos) {
     if (n < B.M) {
       int entry = j;
@@ -1376,7 +1374,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       if (own) entry |= kOwnBit;
       double sx = 0.0, sy = 0.0, sz = 0.0;
       const int found = found_known >= -1 ? found_known : find_old(tj);
-      const int dst = dst_fixed >= 0 ? dst_fixed : (slot_touch < 0 ? n : (found >= 0 ? slot_touch++ : slot_free++));
+      const int dst = slot_touch < 0 ? n : (found >= 0 ? slot_touch++ : slot_free++);
       if (found >= 0) {
         entry |= kTouchBit;
         const size_t ob = (size_t)(3 * found) * B.cap + io;
@@ -1404,25 +1402,16 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   constexpr int kFoundUnknown = 127;
   const bool tf = (B.touch_first || B.gap_order) && nold > 0;
   int n_touch = 0, n_free = 0;
-  unsigned long long class_counts = 0;   // gap order: candidates per class, 8 bits each
   auto note = [&](const int j) {
     // (candidate order kept: the look-up waits for the second sweep, where the tag gathers of a wave are coalesced)
     int f = -1;
     if (tf) f = find_old(tag[j]);
     const int word = j | ((!tf || f + 1 >= kFoundUnknown ? kFoundUnknown : f + 1) << kIdxBits);
     if (B.gap_order) {
-      // class of the pair: 0 = touching (or carrying history), k = ceil(gap / w) clamped to 7; the product is rounded
-      // DOWN a little so that a gap on a class boundary falls into the lower class (the kernel rounds its bound up)
-      const double gap = sqrt(last_rsq) - (xi.w + last_radj);
-      int c = 0;
-      if (gap > 0.0 && f < 0) {
-        c = (int)(gap * B.gap_inv_w * (1.0 - 1.0e-12)) + 1;
-        c = c > 7 ? 7 : c;
-      }
-      class_counts += 1ull << (8 * c);
       if (n_total < B.M) {
         cand[(size_t)n_total * B.cap + i] = word;
-        B.gapc[(size_t)n_total * B.cap + i] = c;
+        // the gap rounded DOWN: the bucket the kernel derives from it never lies above the true gap's
+        B.gapf[(size_t)n_total * B.cap + i] = __double2float_rd(sqrt(last_rsq) - (xi.w + last_radj));
       }
     } else if (tf) {
       if (n_total < B.M) {
@@ -1493,32 +1482,43 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // regularity of the slots -- slot s of adjacent lanes = adjacent atoms -- that the gathers coalesce on (+35 %
     // there), hence the switch (DemEngine::bin_and_build).
     const int nacc = n_total < B.M ? n_total : B.M;
-    if (B.gap_order && n_total <= B.M && n_total <= 255) {
-      // one pass: a candidate goes to the next free slot of its class (classes in ascending order, candidate order
-      // inside a class); the class cursors are eight bytes of one register
-      unsigned long long cum = 0, run = 0, cursor = 0;
-      for (int k = 0; k < 8; k++) {
-        cursor |= run << (8 * k);                       // first slot of class k
-        run += (class_counts >> (8 * k)) & 255ull;
-        cum |= run << (8 * k);                          // slots in classes <= k
-      }
+    if (B.gap_order && nacc <= 64) {
+      // ascending gap (ties: candidate order), by selection over the scratch rows -- a handful of entries per atom
+      unsigned long long used = 0, counts = 0;
       n = 0;
-      int wn = nacc > 0 ? cand[i] : 0, cn = nacc > 0 ? B.gapc[i] : 0;
-      for (int s = 0; s < nacc; s++) {
-        const int w = wn, c = cn;
-        if (s + 1 < nacc) {
-          wn = cand[(size_t)(s + 1) * B.cap + i];
-          cn = B.gapc[(size_t)(s + 1) * B.cap + i];
+      for (int p = 0; p < nacc; p++) {
+        int best = 0;
+        float bg = 3.0e38f;
+        for (int s = 0; s < nacc; s++) {
+          if ((used >> s) & 1ull) continue;
+          const float g = B.gapf[(size_t)s * B.cap + i];
+          if (g < bg) {
+            bg = g;
+            best = s;
+          }
         }
+        used |= 1ull << best;
+        const int w = cand[(size_t)best * B.cap + i];
         const int j = w & kIdxMask, fcode = (w >> kIdxBits) & 127;
         found_known = fcode == kFoundUnknown ? -2 : fcode - 1;
-        dst_fixed = (int)((cursor >> (8 * c)) & 255ull);
-        cursor += 1ull << (8 * c);
         accept(j, found_known == -2 ? tag[j] : 0, 0);
+        int b = bg <= 0.0f ? 0 : (int)((double)bg * B.gap_inv_w);
+        b = b > 7 ? 7 : b;
+        counts += 1ull << (8 * b);
       }
-      dst_fixed = -1;
+      // cumulative: byte k = slots whose gap lies below (k + 1) skin / 8
+      unsigned long long cum = 0, run = 0;
+      for (int k = 0; k < 8; k++) {
+        run += (counts >> (8 * k)) & 255ull;
+        cum |= (run > 255ull ? 255ull : run) << (8 * k);
+      }
       B.nbucket[i] = cum;
-      numneigh[i] = n_total;
+      n = n_total;
+      if (n > B.M) {
+        atomicMax(&flags[F_NEIGH_OVER], n);
+        n = B.M;
+      }
+      numneigh[i] = n;
       return;
     }
     if (B.gap_order) B.nbucket[i] = 0x0101010101010101ull * (unsigned long long)(nacc > 255 ? 255 : nacc);   // (every slot, always)
