@@ -126,12 +126,6 @@ struct DemPtrs {
   const int* sendslot[2];
   double* tx[2];
   double* tx_sendbuf;           // vote headers: the 8-byte slot at tx_sendbuf + tx_hdr_off[p] holds an int (header_vote)
-  // loose beds (StepParams::prune): per atom eight cumulative 8-bit slot counts by gap at the build, the atom's
-  // displacement since the build after the previous sub-step, and the largest displacement of any atom (bits of d^2)
-  const unsigned long long* nbucket;
-  float* disp;
-  const unsigned long long* dmax;   // bits of the largest d^2 of the positions this sub-step reads (k_dmax_reduce)
-  unsigned long long* tilemax;      // [tiles of 64 atoms] bits of the largest d^2 of the positions this sub-step WRITES
   const int* bslot;             // brick driver (tx_fused == 2): [kBrickSlots][cap] where an atom's forward records go, in
                                 // doubles from tx_sendbuf (-1: no further direction sends this atom)
   const int* tx_hdr_off;
@@ -161,11 +155,6 @@ struct StepParams {
   int nwalls;
   int stage_cap;   // LDS slots per workgroup in k_substep_lds
   int xcd_remap;   // blockIdx -> contiguous chunk per XCD (8 XCDs, block b runs on XCD b % 8)
-  // The list was built in gap order (BuildParams::gap_order): an atom only looks at the slots whose pair CAN touch --
-  // gap at the build <= its own displacement since then + the largest displacement of any atom (triangle inequality;
-  // exact: a skipped pair cannot overlap).  Hertz / Hooke contacts only (cohesion and lubrication act at a distance).
-  int prune;
-  double prune_inv_w;   // 8 / skin: bucket width of DemPtrs::nbucket
   WallParams wall[kMaxWalls];
   int have_gravity;
   double gacc[3];
@@ -568,14 +557,6 @@ private:
   int touch_prefetch_env_ = -1;
   // touching neighbours in the first slots of a row (k_build_neigh): loose beds only
   bool touch_first_ = false;
-  // ... and, single domain with contact styles only, the whole row in ascending gap order with per-atom bucket counts:
-  // the sub-step kernel skips the slots that cannot touch yet (StepParams::prune)
-  bool list_gap_order_ = false;        // the CURRENT list was built that way
-  int prune_env_ = -1;                 // SF_PRUNE=0 / 1
-  DevArray nbucket_, disp_;
-  unsigned long long* d_dmax_ = nullptr;
-  DevArray tilemax_, gapf_;            // per-tile maxima; scratch of the gap-ordered list build [M][cap] floats
-  void refresh_displacements();        // disp / tile maxima / dmax from x and xhold (after the first half-kick of a run)
   int touch_first_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
   bool in_run_ = false;                      // rebuild() called from the stepping loop of run()

@@ -103,7 +103,6 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_HIST_COPIES")) hist_mode_env_ = atoi(e);
   if (const char* e = getenv("SF_TOUCH_PREFETCH")) touch_prefetch_env_ = atoi(e);
   if (const char* e = getenv("SF_TOUCH_FIRST")) touch_first_env_ = atoi(e);
-  if (const char* e = getenv("SF_PRUNE")) prune_env_ = atoi(e);
   if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
   if (const char* e = getenv("SF_LPA")) opt_lpa_ = atoi(e);
   if (const char* e = getenv("SF_QUEUE_PREDICT")) predict_.on = atoi(e) != 0;
@@ -114,7 +113,7 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &extra_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_[0], &shear_[1], &neigh_old_, &numneigh_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_, &bmask_, &nbucket_, &disp_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_, &bmask_};
 }
 
 DemEngine::~DemEngine()
@@ -124,9 +123,6 @@ DemEngine::~DemEngine()
   if (cell_start_) (void)hipFree(cell_start_);
   if (tile_tab_) (void)hipFree(tile_tab_);
   if (bsend_list_) (void)hipFree(bsend_list_);
-  if (d_dmax_) (void)hipFree(d_dmax_);
-  tilemax_.release();
-  gapf_.release();
   if (d_bcount_) (void)hipFree(d_bcount_);
   if (h_bcount_) (void)hipHostFree(h_bcount_);
   if (stage_idx_) (void)hipFree(stage_idx_);
@@ -212,9 +208,6 @@ void DemEngine::alloc_all(size_t cap)
   nloc_.alloc(sizeof(unsigned short), M_, cap, s);
   isb_.alloc(sizeof(unsigned char), 1, cap, s);
   bmask_.alloc(sizeof(unsigned char), 1, cap, s);
-  nbucket_.alloc(sizeof(unsigned long long), 1, cap, s);
-  disp_.alloc(sizeof(float), 1, cap, s);
-  tilemax_.alloc(sizeof(unsigned long long), 1, cap / 64 + 64, s);
   cap_ = cap;
 }
 
@@ -624,10 +617,6 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   }
   P.tx_sendbuf = tx_sendbuf_;
   P.bslot = bslot_.as<int>();
-  P.nbucket = nbucket_.as<unsigned long long>();
-  P.disp = disp_.as<float>();
-  P.dmax = d_dmax_;
-  P.tilemax = tilemax_.as<unsigned long long>();
   P.tx_hdr_off = tx_hdr_off_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
   P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
@@ -691,8 +680,6 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.cohe_bit = cohe_bit_;
   S.freeze_bit = freeze_bit_;
   S.post_freeze = post_freeze_;
-  S.prune = (list_gap_order_ && mode != 2) ? 1 : 0;
-  S.prune_inv_w = 8.0 / lskin();
   return S;
 }
 
@@ -857,19 +844,6 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   }
   SF_HIP(hipGetLastError());
   if (e1) SF_HIP(hipEventRecord(e1, stream_));
-  // gap-ordered list: fold the per-tile displacement maxima this sub-step left into the one number the next reads
-  if (S.prune && mode == 0 && part == 0 && !lds_active_)
-    k_dmax_reduce<<<1, 1024, 0, stream_>>>(tilemax_.as<unsigned long long>(), div_up(nlocal_, 64), d_dmax_);
-}
-
-void DemEngine::refresh_displacements()
-{
-  if (!list_gap_order_ || !nlocal_) return;
-  const int nt = div_up(nlocal_, 64);
-  SF_HIP(hipMemsetAsync(tilemax_.ptr, 0, sizeof(unsigned long long) * nt, stream_));
-  k_disp_refresh<<<div_up(nlocal_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), xhold_.as<double>(), nlocal_, cap_,
-                                                            disp_.as<float>(), tilemax_.as<unsigned long long>());
-  k_dmax_reduce<<<1, 1024, 0, stream_>>>(tilemax_.as<unsigned long long>(), nt, d_dmax_);
 }
 
 void DemEngine::set_profiling(bool on)
@@ -920,7 +894,6 @@ void DemEngine::launch_initial_integrate()
       xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), force_.as<double4>(),
       torque_.as<double4>(), xhold_.as<double>(), d_flags_ + (overlap_ ? F_TRIG_LOCAL : F_TRIGGER), nlocal_, cap_,
       dt_, (0.5 * skin_) * (0.5 * skin_), use_groups_ ? mask_.as<int>() : nullptr, nve_bit_);
-  refresh_displacements();   // (gap-ordered list: the first sub-step's bound belongs to the positions after this half-kick)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1240,7 +1213,6 @@ void DemEngine::bin_and_build()
     }
   }
   build_stage_tables();
-  bool gap_order_built = false;
   for (int attempt = 0; attempt < 3; attempt++) {
     static_assert(F_MAXNEIGH == F_NEIGH_OVER + 3, "one launch resets F_NEIGH_OVER and F_MAXNEIGH separately");
     reset_flag(F_NEIGH_OVER, 0);
@@ -1261,17 +1233,6 @@ void DemEngine::bin_and_build()
     B.old_index = hist_indirect_ ? hist_perm_.as<int>() : nullptr;
     B.two_copies = hist_single_ ? 0 : 1;
     B.touch_first = touch_first_ ? 1 : 0;
-    // gap order + pruning (substep_particle, S.prune): loose beds of a single domain with contact styles only -- the
-    // bound needs the largest displacement of EVERY atom a neighbour word can refer to, and cohesion / lubrication act
-    // at a distance; SF_PRUNE=0 / 1 pins it
-    const bool can_prune = !have_subdomain_ && row_tables_ && roots_ && gran_.style != 0 && !cohe_.enabled &&
-                           !lub_.enabled && !overlap_ && M_ <= 64;
-    B.gap_order = (can_prune && (prune_env_ >= 0 ? prune_env_ != 0 : touch_first_)) ? 1 : 0;
-    B.gap_inv_w = 8.0 / lskin();
-    if (B.gap_order && (gapf_.cap != cap_ || gapf_.rows < M_)) gapf_.alloc(sizeof(float), M_, cap_, stream_);   // scratch
-    B.gapf = gapf_.as<float>();
-    B.nbucket = nbucket_.as<unsigned long long>();
-    gap_order_built = B.gap_order != 0;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
     B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;
     B.roots = roots_ ? 1 : 0;
@@ -1308,13 +1269,6 @@ void DemEngine::bin_and_build()
   measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
-  list_gap_order_ = gap_order_built;
-  if (list_gap_order_) {   // nobody has moved since this build
-    if (!d_dmax_) SF_HIP(hipMalloc(&d_dmax_, sizeof(unsigned long long)));
-    SF_HIP(hipMemsetAsync(d_dmax_, 0, sizeof(unsigned long long), stream_));
-    SF_HIP(hipMemsetAsync(disp_.ptr, 0, sizeof(float) * nlocal_, stream_));
-    SF_HIP(hipMemsetAsync(tilemax_.ptr, 0, sizeof(unsigned long long) * div_up(nlocal_, 64), stream_));
-  }
   nbuilds_++;
 }
 

@@ -165,21 +165,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const double radi = xi4.w, mi = vi4.w;
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
-  int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
-  unsigned long long dmax_seen = 0;
-  if (STYLE != 0 && !COHE && !LUB && S.prune) {
-    // Loose beds: the row is in ascending order of the pair's gap at the build.  A pair whose gap exceeds this atom's
-    // displacement since the build plus the largest displacement of ANY atom cannot overlap (triangle inequality):
-    // only the slots below that bound are looked at.  Both displacements belong to the positions this sub-step reads
-    // (the previous sub-step stored them); the bound is rounded up, the stored gaps were rounded down.
-    dmax_seen = *P.dmax;
-    (void)dmax_seen;
-    const double bound = ((double)P.disp[i] * (1.0 + 1.0e-6) + sqrt(__longlong_as_double((long long)dmax_seen))) * (1.0 + 1.0e-12);
-    int bk = (int)(bound * S.prune_inv_w);
-    bk = bk > 7 ? 7 : bk;
-    const int nb = (int)((P.nbucket[i] >> (8 * bk)) & 255ull);
-    nn_all = nb < nn_all ? nb : nn_all;
-  }
+  const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
   const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
@@ -547,23 +533,6 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       wn = wn + dtirot * T;
       const double dx = xn.x - ld_stream<NT_LD>(&P.xhold[i]), dy = xn.y - ld_stream<NT_LD>(&P.xhold[cap + i]),
                    dz = xn.z - ld_stream<NT_LD>(&P.xhold[2 * cap + i]);
-      if (STYLE != 0 && !COHE && !LUB && S.prune) {
-        // what the next sub-step's bound needs: this atom's displacement (float, rounded up) and the largest one
-        // (the largest of a tile of 64 atoms, no atomics when the wave holds the whole tile; k_dmax_reduce folds the
-        // tiles into the one number the next sub-step reads)
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        P.disp[i] = __double2float_ru(sqrt(d2));
-        unsigned long long m = (unsigned long long)__double_as_longlong(d2);   // (d2 >= 0: the bits order like the values)
-        if (LPA == 1 && __ballot(1) == ~0ull) {
-          for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(m, off, 64);
-            m = o > m ? o : m;
-          }
-          if ((threadIdx.x & 63) == 0) P.tilemax[i >> 6] = m;
-        } else {
-          atomicMax(&P.tilemax[i >> 6], m);   // (stale larger values only loosen the bound)
-        }
-      }
       if (dx * dx + dy * dy + dz * dz > S.trigger_sq) {
         atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
         // (fused forward pack: no kernel will copy the trigger word into the vote headers before the exchange)
@@ -749,41 +718,6 @@ __global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
   __syncthreads();
   for (int i = first + threadIdx.x; i < last; i += blockDim.x)
     substep_particle<STYLE, COHE, LUB, true, 1, true, 2>(P, S, i, 0, lx, lv, lw);
-}
-
-// the largest squared displacement of any atom, from the per-tile maxima the sub-step kernel left (one block)
-__global__ __launch_bounds__(1024) void k_dmax_reduce(const unsigned long long* tilemax, int ntiles,
-                                                      unsigned long long* dmax)
-{
-  __shared__ unsigned long long ws[16];
-  unsigned long long m = 0;
-  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-    const unsigned long long v = tilemax[t];
-    m = v > m ? v : m;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(m, off, 64);
-    m = o > m ? o : m;
-  }
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < (int)(blockDim.x >> 6); k++) m = ws[k] > m ? ws[k] : m;
-    *dmax = m;
-  }
-}
-
-// displacement of every owned atom since the list was built and the per-tile maxima (after k_initial_integrate)
-__global__ __launch_bounds__(256) void k_disp_refresh(const double4* xr, const double* xhold, int nlocal, size_t cap,
-                                                      float* disp, unsigned long long* tilemax)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlocal) return;
-  const double4 x = xr[i];
-  const double dx = x.x - xhold[i], dy = x.y - xhold[cap + i], dz = x.z - xhold[2 * cap + i];
-  const double d2 = dx * dx + dy * dy + dz * dz;
-  disp[i] = __double2float_ru(sqrt(d2));
-  atomicMax(&tilemax[i >> 6], (unsigned long long)__double_as_longlong(d2));
 }
 
 // first half-kick of a run with the forces stored by the previous run's last sub-step
@@ -1236,14 +1170,6 @@ struct BuildParams {
   const int* old_index;   // new index -> index before the re-sort (history rows not permuted), or nullptr
   int two_copies;         // every side of every contact keeps its own history copy (see k_partner_coalescing)
   int touch_first;        // row path: touching neighbours take the first slots of a row (loose beds)
-  // row path, loose beds: the slots of a row in ascending order of the pair's GAP r - (ri + rj) at the build (touching
-  // pairs first, then the nearest misses), and per atom how many slots have a gap below k skin / 8, k = 1..8: the
-  // sub-step kernel then only looks at the slots that CAN touch given how far the atoms have moved since the build
-  // (substep_particle, S.prune)
-  int gap_order;
-  double gap_inv_w;       // 8 / skin
-  float* gapf;            // scratch [M][cap]
-  unsigned long long* nbucket;   // [cap] eight cumulative 8-bit counts
 };
 
 // ---- counting sort of the owned atoms by cell key (plain keys): a by-product is first[b], the first sorted position
@@ -1319,12 +1245,9 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   const int co = B.g.xslow ? cx : cz, no = B.g.xslow ? B.g.n[0] : B.g.n[2];
   const int ci = B.g.xslow ? cz : cx, ni = B.g.xslow ? B.g.n[2] : B.g.n[0];
   // distance test of one candidate
-  double last_rsq = 0.0, last_radj = 0.0;   // of the candidate in_range() looked at last
   auto in_range = [&](const int j, const double4 xj) {
     const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
     const double rsq = dx * dx + dy * dy + dz * dz;
-    last_rsq = rsq;
-    last_radj = xj.w;
     double cut = B.cut_lub;
     if (B.skin_gran >= 0.0) {
       const double cg = xi.w + xj.w + B.skin_gran;
@@ -1400,20 +1323,14 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   // `cand`.  B.touch_first: the neighbours that touched (found in the old list) fill the rows from the front, the
   // others from the back, so that the second sweep can place the touching ones first without another pass.
   constexpr int kFoundUnknown = 127;
-  const bool tf = (B.touch_first || B.gap_order) && nold > 0;
+  const bool tf = B.touch_first && nold > 0;
   int n_touch = 0, n_free = 0;
   auto note = [&](const int j) {
     // (candidate order kept: the look-up waits for the second sweep, where the tag gathers of a wave are coalesced)
     int f = -1;
     if (tf) f = find_old(tag[j]);
     const int word = j | ((!tf || f + 1 >= kFoundUnknown ? kFoundUnknown : f + 1) << kIdxBits);
-    if (B.gap_order) {
-      if (n_total < B.M) {
-        cand[(size_t)n_total * B.cap + i] = word;
-        // the gap rounded DOWN: the bucket the kernel derives from it never lies above the true gap's
-        B.gapf[(size_t)n_total * B.cap + i] = __double2float_rd(sqrt(last_rsq) - (xi.w + last_radj));
-      }
-    } else if (tf) {
+    if (tf) {
       if (n_total < B.M) {
         const int row = f >= 0 ? n_touch : B.M - 1 - n_free;
         cand[(size_t)row * B.cap + i] = word;
@@ -1482,51 +1399,10 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // regularity of the slots -- slot s of adjacent lanes = adjacent atoms -- that the gathers coalesce on (+35 %
     // there), hence the switch (DemEngine::bin_and_build).
     const int nacc = n_total < B.M ? n_total : B.M;
-    if (B.gap_order && nacc <= 64) {
-      // ascending gap (ties: candidate order), by selection over the scratch rows -- a handful of entries per atom
-      unsigned long long used = 0, counts = 0;
-      n = 0;
-      for (int p = 0; p < nacc; p++) {
-        int best = 0;
-        float bg = 3.0e38f;
-        for (int s = 0; s < nacc; s++) {
-          if ((used >> s) & 1ull) continue;
-          const float g = B.gapf[(size_t)s * B.cap + i];
-          if (g < bg) {
-            bg = g;
-            best = s;
-          }
-        }
-        used |= 1ull << best;
-        const int w = cand[(size_t)best * B.cap + i];
-        const int j = w & kIdxMask, fcode = (w >> kIdxBits) & 127;
-        found_known = fcode == kFoundUnknown ? -2 : fcode - 1;
-        accept(j, found_known == -2 ? tag[j] : 0, 0);
-        int b = bg <= 0.0f ? 0 : (int)((double)bg * B.gap_inv_w);
-        b = b > 7 ? 7 : b;
-        counts += 1ull << (8 * b);
-      }
-      // cumulative: byte k = slots whose gap lies below (k + 1) skin / 8
-      unsigned long long cum = 0, run = 0;
-      for (int k = 0; k < 8; k++) {
-        run += (counts >> (8 * k)) & 255ull;
-        cum |= (run > 255ull ? 255ull : run) << (8 * k);
-      }
-      B.nbucket[i] = cum;
-      n = n_total;
-      if (n > B.M) {
-        atomicMax(&flags[F_NEIGH_OVER], n);
-        n = B.M;
-      }
-      numneigh[i] = n;
-      return;
-    }
-    if (B.gap_order) B.nbucket[i] = 0x0101010101010101ull * (unsigned long long)(nacc > 255 ? 255 : nacc);   // (every slot, always)
     // (overflowing rows are rebuilt with more slots: what was dropped does not matter)
-    const bool place_tf = tf && !B.gap_order;
-    const int nt = place_tf ? (n_touch < nacc ? n_touch : nacc) : 0;
-    auto cand_row = [&](const int s) { return !place_tf || s < nt ? s : B.M - 1 - (s - nt); };
-    if (place_tf) {
+    const int nt = tf ? (n_touch < nacc ? n_touch : nacc) : 0;
+    auto cand_row = [&](const int s) { return !tf || s < nt ? s : B.M - 1 - (s - nt); };
+    if (tf) {
       slot_touch = 0;
       slot_free = nt;
     }
