@@ -71,6 +71,8 @@ enum Flag {
   F_LIST_SLOTS,     // listed neighbours of the owned atoms (same kernel) ...
   F_LIST_TOUCH,     // ... and how many of them touch
   F_MIG_TRUNC,      // a migrating atom had more history slots than the migrate record carries (an error, never truncated)
+  F_GHOST_BEFORE,   // + dim: ghosts that existed before the images of periodic dimension `dim` were made (3 words)
+  F_GHOST_BEFORE_Z = F_GHOST_BEFORE + 2,
   F_NFLAGS = 32
 };
 
@@ -473,6 +475,7 @@ private:
   void read_flags();
   void reset_flag(int idx, int value);
   void reset_flags(int idx, int count, int value);   // `count` adjacent flags, one launch
+  void set_flags3(int i0, int v0, int i1, int v1, int i2, int v2);   // three (flag, value) pairs, one launch
   void compute_grid();
   double max_radius();
   void sync() const { SF_HIP(hipStreamSynchronize(stream_)); }
@@ -576,6 +579,8 @@ private:
   bool lds_active_ = false;
   void build_stage_tables();
   DevArray tmp4_, tmpd_, tmpi_;        // gather scratch
+  // (one scratch array per permuted array: permute_locals gathers everything in one launch and swaps allocations)
+  DevArray tmp4b_, tmp4c_, tmpi_b_, tmpi_c_, tmpi_d_, fdrag_alt_, DuDt_alt_, vOld_alt_, extra_alt_, wtouch_alt_;
   DevArray keys_, keys_alt_, perm_, perm_alt_, keys64_, keys64_alt_;
   int* cell_start_ = nullptr;          // [nbins][4]: owned start/end, ghost start/end of every cell (hipMalloc: 16-byte aligned)
   size_t cell_alloc_ = 0;
@@ -632,6 +637,7 @@ private:
   long long nsend_[2] = {0, 0};
   int recv_first_[2] = {0, 0}, recv_count_[2] = {0, 0};
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  hipEvent_t ev_flags_ = nullptr;   // "the flag words have reached the host" (bin_and_build)
   bool profiling_ = false;
   std::vector<hipEvent_t> prof_ev_;   // pairs (start, stop) of launches not yet harvested
   size_t prof_used_ = 0;

@@ -95,6 +95,7 @@ DemEngine::DemEngine()
   SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
   SF_HIP(hipEventCreate(&ev0_));
   SF_HIP(hipEventCreate(&ev1_));
+  SF_HIP(hipEventCreateWithFlags(&ev_flags_, hipEventDisableTiming));
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
@@ -113,7 +114,8 @@ DemEngine::DemEngine()
                &mask_, &foamCpuId_, &fdrag_, &DuDt_, &vOld_, &xhold_, &extra_, &wshear_, &wtouch_, &gsrc_, &gshift_,
                &neigh_, &numneigh_, &shear_[0], &shear_[1], &neigh_old_, &numneigh_old_, &ptag_, &tmp4_,
                &tmpd_, &tmpi_, &keys_, &keys_alt_, &perm_, &perm_alt_, &keys64_, &keys64_alt_,
-               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_, &bmask_};
+               &sendlist_[0], &sendlist_[1], &leave_, &nloc_, &isb_, &hist_perm_, &bmask_, &tmp4b_, &tmp4c_,
+               &tmpi_b_, &tmpi_c_, &tmpi_d_, &fdrag_alt_, &DuDt_alt_, &vOld_alt_, &extra_alt_, &wtouch_alt_};
 }
 
 DemEngine::~DemEngine()
@@ -138,6 +140,7 @@ DemEngine::~DemEngine()
   if (h_flags_) (void)hipHostFree(h_flags_);
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
+  if (ev_flags_) (void)hipEventDestroy(ev_flags_);
   for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
   if (masked_main_) (void)hipStreamDestroy(masked_main_);
@@ -195,6 +198,16 @@ void DemEngine::alloc_all(size_t cap)
   tmp4_.alloc(sizeof(double4), 1, cap, s);
   tmpd_.alloc(sizeof(double), 3 * kMaxWalls, cap, s);
   tmpi_.alloc(sizeof(int), 1, cap, s);
+  tmp4b_.alloc(sizeof(double4), 1, cap, s);
+  tmp4c_.alloc(sizeof(double4), 1, cap, s);
+  tmpi_b_.alloc(sizeof(int), 1, cap, s);
+  tmpi_c_.alloc(sizeof(int), 1, cap, s);
+  tmpi_d_.alloc(sizeof(int), 1, cap, s);
+  fdrag_alt_.alloc(sizeof(double), 3, cap, s);
+  DuDt_alt_.alloc(sizeof(double), 3, cap, s);
+  vOld_alt_.alloc(sizeof(double), 3, cap, s);
+  extra_alt_.alloc(sizeof(double), kMaxExtra, cap, s);
+  wtouch_alt_.alloc(sizeof(unsigned char), 1, cap, s);
   keys_.alloc(sizeof(unsigned), 1, cap, s);
   keys_alt_.alloc(sizeof(unsigned), 1, cap, s);
   perm_.alloc(sizeof(int), 1, cap, s);
@@ -566,6 +579,14 @@ double DemEngine::cutneighmax() const
 
 // (a one-thread kernel: ~2 us on the stream; a 4-byte host-to-device copy is a 5 us blit each, and a rebuild resets
 // sixteen of them)
+__global__ static void k_set_flags3(int* flags, int i0, int v0, int i1, int v1, int i2, int v2)
+{
+  if (threadIdx.x == 0) {
+    flags[i0] = v0;
+    flags[i1] = v1;
+    flags[i2] = v2;
+  }
+}
 __global__ static void k_set_flags(int* flags, int idx, int count, int value)
 {
   if ((int)threadIdx.x < count) flags[idx + threadIdx.x] = value;
@@ -577,6 +598,14 @@ void DemEngine::reset_flags(int idx, int count, int value)
 {
   for (int k = 0; k < count; k++) h_flags_[idx + k] = value;
   k_set_flags<<<1, 32, 0, stream_>>>(d_flags_, idx, count, value);
+}
+
+void DemEngine::set_flags3(int i0, int v0, int i1, int v1, int i2, int v2)
+{
+  h_flags_[i0] = v0;
+  h_flags_[i1] = v1;
+  h_flags_[i2] = v2;
+  k_set_flags3<<<1, 32, 0, stream_>>>(d_flags_, i0, v0, i1, v1, i2, v2);
 }
 
 void DemEngine::read_flags()
@@ -968,17 +997,49 @@ void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
     k_gather4<<<nb, 256, 0, stream_>>>(tmp4_.as<double4>(), a.as<double4>(), perm, n_new);
     std::swap(a.ptr, tmp4_.ptr);
   };
-  auto gd = [&](DevArray& a, int rows) {
-    k_gather_rows<double><<<nb, 256, 0, stream_>>>(tmpd_.as<double>(), a.as<double>(), perm, n_new, rows, cap_);
-    k_copy_rows<double><<<nb, 256, 0, stream_>>>(a.as<double>(), tmpd_.as<double>(), n_new, rows, cap_);
+  // ONE gather kernel for the records and every per-atom fix array (a launch per array -- up to 15 of them at ~5 us of
+  // launch floor each -- was a tenth of a rebuild): each array is gathered into a scratch array of its own shape and
+  // the two allocations are swapped (device pointers handed out are valid until the next rebuild, sedifoam_amd.h)
+  PermuteJobs J;
+  memset(&J, 0, sizeof(J));
+  DevArray* rec[3] = {&xr_[cur_], &vm_[cur_], &om_[cur_]};
+  DevArray* rec_alt[3] = {&tmp4_, &tmp4b_, &tmp4c_};
+  for (int k = 0; k < 3; k++) {
+    J.s4[k] = rec[k]->as<double4>();
+    J.d4[k] = rec_alt[k]->as<double4>();
+  }
+  DevArray* ints[4] = {&tag_, &type_, &mask_, &foamCpuId_};
+  DevArray* ints_alt[4] = {&tmpi_, &tmpi_b_, &tmpi_c_, &tmpi_d_};
+  for (int k = 0; k < 4; k++) {
+    J.si[k] = ints[k]->as<int>();
+    J.di[k] = ints_alt[k]->as<int>();
+  }
+  DevArray* rows_a[PermuteJobs::kRowArrays];
+  DevArray* rows_alt[PermuteJobs::kRowArrays];
+  auto add_rows = [&](DevArray& a, DevArray& alt, int nrows) {
+    rows_a[J.nd] = &a;
+    rows_alt[J.nd] = &alt;
+    J.sd[J.nd] = a.as<double>();
+    J.dd[J.nd] = alt.as<double>();
+    J.rd[J.nd] = nrows;
+    J.nd++;
   };
-  auto gi = [&](DevArray& a) {
-    k_gather_rows<int><<<nb, 256, 0, stream_>>>(tmpi_.as<int>(), a.as<int>(), perm, n_new, 1, cap_);
-    std::swap(a.ptr, tmpi_.ptr);
-  };
-  g4(xr_[cur_]);
-  g4(vm_[cur_]);
-  g4(om_[cur_]);
+  add_rows(fdrag_, fdrag_alt_, 3);
+  if (carrier_rho_ != 0.0) {
+    add_rows(DuDt_, DuDt_alt_, 3);
+    add_rows(vOld_, vOld_alt_, 3);
+  }
+  if (nextra_) add_rows(extra_, extra_alt_, nextra_);
+  if (nwalls_) {
+    add_rows(wshear_, tmpd_, 3 * nwalls_);
+    J.sb = wtouch_.as<unsigned char>();
+    J.db = wtouch_alt_.as<unsigned char>();
+  }
+  k_permute_all<<<nb, 256, 0, stream_>>>(J, perm, n_new, cap_);
+  for (int k = 0; k < 3; k++) std::swap(rec[k]->ptr, rec_alt[k]->ptr);
+  for (int k = 0; k < 4; k++) std::swap(ints[k]->ptr, ints_alt[k]->ptr);
+  for (int k = 0; k < J.nd; k++) std::swap(rows_a[k]->ptr, rows_alt[k]->ptr);
+  if (nwalls_) std::swap(wtouch_.ptr, wtouch_alt_.ptr);
   // force / torque are stored by the LAST sub-step of a run only (and read by the first half-kick of the next run): a
   // rebuild inside a run -- always followed by at least one more sub-step, the last one storing them for every atom in
   // the new order -- need not carry them along
@@ -986,24 +1047,10 @@ void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
     g4(force_);
     g4(torque_);
   }
-  gi(tag_);
-  gi(type_);
-  gi(mask_);
-  gi(foamCpuId_);
-  gd(fdrag_, 3);
-  if (carrier_rho_ != 0.0) {
-    gd(DuDt_, 3);
-    gd(vOld_, 3);
-  }
-  if (nextra_) gd(extra_, nextra_);
-  if (nwalls_) {
-    gd(wshear_, 3 * nwalls_);
-    k_gather_rows<unsigned char><<<nb, 256, 0, stream_>>>((unsigned char*)tmpi_.ptr, wtouch_.as<unsigned char>(),
-                                                          perm, n_new, 1, cap_);
-    SF_HIP(hipMemcpyAsync(wtouch_.ptr, tmpi_.ptr, n_new, hipMemcpyDeviceToDevice, stream_));
-  }
   if (have_list_ && max_neigh_used_ > 0 && !rows) {
-    SF_HIP(hipMemcpyAsync(hist_perm_.ptr, perm, sizeof(int) * n_new, hipMemcpyDeviceToDevice, stream_));
+    // (the permutation itself becomes the index of the old rows: keep the array instead of copying it)
+    if (perm == perm_alt_.as<int>()) std::swap(hist_perm_.ptr, perm_alt_.ptr);
+    else SF_HIP(hipMemcpyAsync(hist_perm_.ptr, perm, sizeof(int) * n_new, hipMemcpyDeviceToDevice, stream_));
     hist_indirect_ = true;
   } else if (have_list_ && max_neigh_used_ > 0) {
     k_gather_rows<int><<<nb, 256, 0, stream_>>>(numneigh_old_.as<int>(), numneigh_.as<int>(), perm, n_new, 1, cap_);
@@ -1082,38 +1129,34 @@ void DemEngine::make_periodic_ghosts()
   // external ghosts (other GPUs) were appended by border_unpack: slots [nlocal, nlocal+next_ghost_)
   nghost_ = next_ghost_;
   const double cut = cutneighmax();
+  int dims[3], nd = 0;
+  for (int dim = 0; dim < 3; dim++)   // images across an external face come from the neighbour GPUs (or the driver's self loop)
+    if (periodic_[dim] && !ext_[dim]) dims[nd++] = dim;
+  if (!nd || cap_ == 0 || nlocal_ + next_ghost_ == 0) return;
+  GhostPtrs G{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
+              type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
   for (int attempt = 0; attempt < 4; attempt++) {
-    reset_flag(F_GHOST_COUNT, next_ghost_);
-    reset_flag(F_GHOST_OVER, 0);
-    int nall0 = nlocal_ + next_ghost_;
-    bool over = false;
-    for (int dim = 0; dim < 3; dim++) {
-      if (!periodic_[dim]) continue;
-      if (ext_[dim]) continue;  // images across an external face come from the neighbour GPUs (or the driver's self loop)
-      GhostPtrs G{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
-                  type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
-      // F_GHOST_COUNT counts ghosts (external ones included); list slot = ghost slot
-      const int before = nall0 - nlocal_;
-      if (nall0)
-        k_ghost_select<<<div_up(nall0, 1024), 1024, 0, stream_>>>(xr_[cur_].as<double4>(), nall0, dim, boxlo_[dim],
-                                                                boxhi_[dim], cut, perm_.as<int>(),
-                                                                d_flags_ + F_GHOST_COUNT);
-      read_flags();
-      const int created = h_flags_[F_GHOST_COUNT] - before;
-      if ((size_t)nlocal_ + h_flags_[F_GHOST_COUNT] > cap_) {
-        over = true;
-        ensure_capacity((size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] * 2 + 1024);
-        break;
-      }
-      if (created > 0)
-        k_ghost_create<<<div_up(created, 256), 256, 0, stream_>>>(G, perm_.as<int>(), before, created, nlocal_, dim,
-                                                                  boxhi_[dim] - boxlo_[dim], cap_, d_flags_);
-      nall0 = nlocal_ + h_flags_[F_GHOST_COUNT];
+    // F_GHOST_COUNT counts ghosts (external ones included); list slot = ghost slot.  Every dimension looks at the owned
+    // atoms + the ghosts made before it; those counts stay on the device (k_ghost_select), the host reads the total
+    set_flags3(F_GHOST_COUNT, next_ghost_, F_GHOST_OVER, 0, F_GHOST_BEFORE + dims[0], next_ghost_);
+    for (int q = 0; q < nd; q++) {
+      const int dim = dims[q];
+      k_ghost_select<<<div_up((long long)cap_, 1024), 1024, 0, stream_>>>(
+          G.xr, d_flags_, F_GHOST_BEFORE + dim, nlocal_, dim, boxlo_[dim], boxhi_[dim], cut, perm_.as<int>(),
+          d_flags_ + F_GHOST_COUNT, cap_);
+      k_ghost_create<<<std::max(1, div_up((long long)(cap_ - nlocal_), 256)), 256, 0, stream_>>>(
+          G, perm_.as<int>(), nlocal_, dim, boxhi_[dim] - boxlo_[dim], cap_, d_flags_, F_GHOST_BEFORE + dim,
+          q + 1 < nd ? F_GHOST_BEFORE + dims[q + 1] : -1);
     }
-    if (!over) {
-      nghost_ = nall0 - nlocal_;
+    read_flags();
+    if (!h_flags_[F_GHOST_OVER] && (size_t)nlocal_ + h_flags_[F_GHOST_COUNT] <= cap_) {
+      nghost_ = h_flags_[F_GHOST_COUNT];
       return;
     }
+    // (a count cut short by the capacity is a lower bound of what is needed)
+    ensure_capacity((size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] * 2 + 1024);
+    G = GhostPtrs{xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>(), tag_.as<int>(),
+                  type_.as<int>(), mask_.as<int>(), gsrc_.as<int>(), gshift_.as<double>()};
   }
   fail("ghost creation: capacity could not be grown");
 }
@@ -1214,9 +1257,7 @@ void DemEngine::bin_and_build()
   }
   build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {
-    static_assert(F_MAXNEIGH == F_NEIGH_OVER + 3, "one launch resets F_NEIGH_OVER and F_MAXNEIGH separately");
-    reset_flag(F_NEIGH_OVER, 0);
-    reset_flag(F_MAXNEIGH, 0);
+    set_flags3(F_NEIGH_OVER, 0, F_MAXNEIGH, 0, F_MAXNEIGH, 0);
     BuildParams B;
     B.nlocal = nlocal_;
     B.M = M_;
@@ -1245,7 +1286,14 @@ void DemEngine::bin_and_build()
         have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), neigh_.as<int>(),
         numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
     k_max_int<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_old_.as<int>(), nlocal_, d_flags_ + F_MAXNEIGH);
-    read_flags();
+    // the host looks at the counts (overflow, widest row) while the partner-slot pass below is already running: it
+    // needs nothing but the list, and a list that overflowed -- rare -- is built again and the pass repeated
+    SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
+    SF_HIP(hipEventRecord(ev_flags_, stream_));
+    // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
+    k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_old_.as<int>(), nlocal_, cap_,
+                                                            roots_ ? 1 : 0);
+    SF_HIP(hipEventSynchronize(ev_flags_));
     if (h_flags_[F_NEIGH_OVER] > M_) {
       // more neighbours than slots: widen the slot-major arrays and build again.  The old-history
       // arrays keep their first rows, so the re-injection still finds every partner.
@@ -1263,9 +1311,6 @@ void DemEngine::bin_and_build()
   // the new list's history was built into shear_[hist_buf_ ^ 1]: that buffer is the one the next sub-step reads
   if ((hist_buf_ ^ 1) != cur_) std::swap(shear_[0].ptr, shear_[1].ptr);
   hist_indirect_ = false;   // the old rows are gone with the old list
-  // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
-  k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_, cap_,
-                                                          roots_ ? 1 : 0);
   measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)

@@ -613,6 +613,15 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 #else
 #define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu((COHE || LUB) ? 1 : 3)))
 #endif
+// The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by bin, so giving
+// every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of the XCD that gathers them
+// (bijective remap, speed only: any placement gives the same result).
+__device__ __forceinline__ int xcd_contiguous_block()
+{
+  const int bid = blockIdx.x, nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // TP: v and omega of a neighbour are requested with its x only when the pair touched one sub-step ago (a bed that
 // lists many more neighbours than it touches: -11 % in the loose disordered bed), or always (a bed whose listed
 // neighbours nearly all touch: the bookkeeping of the former costs 4 % there)
@@ -815,7 +824,7 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
                                                       int* ptag, const double* shear, double* hist_out, int nlocal,
                                                       size_t cap, int M, int roots)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_contiguous_block() * blockDim.x + threadIdx.x;   // (gathers from the neighbours' rows)
   if (i >= nlocal) return;
   const int nn = numneigh[i];
   for (int s = 0; s < M; s++) {
@@ -849,7 +858,7 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
 // to bitwise opposite values.  Index mode (LDS-staged kernel) has no spare bits: every slot owns its copy.
 __global__ __launch_bounds__(128) void k_back_slots(int* neigh, const int* numneigh, int nlocal, size_t cap, int roots)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_contiguous_block() * blockDim.x + threadIdx.x;   // (walks the rows of this atom's neighbours)
   if (i >= nlocal) return;
   const int nn = numneigh[i];
   const int codemask = 31 << kIdxBits;
@@ -1014,6 +1023,42 @@ __global__ __launch_bounds__(256) void k_gather4(double4* dst, const double4* sr
   if (i < n) dst[i] = src[perm[i]];
 }
 
+// every per-atom array of the owned atoms in one launch: dst[i] = src[perm[i]] (DemEngine::permute_locals)
+struct PermuteJobs {
+  static constexpr int kRowArrays = 5;
+  const double4* s4[3];
+  double4* d4[3];
+  const int* si[4];
+  int* di[4];
+  int nd;                       // component-major double arrays, rd[a] rows each
+  const double* sd[kRowArrays];
+  double* dd[kRowArrays];
+  int rd[kRowArrays];
+  const unsigned char* sb;      // (nullptr: none)
+  unsigned char* db;
+};
+__global__ __launch_bounds__(256) void k_permute_all(PermuteJobs J, const int* perm, int n, size_t cap)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = perm[i];
+  const double4 a = J.s4[0][p], b = J.s4[1][p], c = J.s4[2][p];
+  const int t0 = J.si[0][p], t1 = J.si[1][p], t2 = J.si[2][p], t3 = J.si[3][p];
+  J.d4[0][i] = a;
+  J.d4[1][i] = b;
+  J.d4[2][i] = c;
+  J.di[0][i] = t0;
+  J.di[1][i] = t1;
+  J.di[2][i] = t2;
+  J.di[3][i] = t3;
+  for (int k = 0; k < J.nd; k++) {
+    const double* s = J.sd[k];
+    double* d = J.dd[k];
+    for (int r = 0; r < J.rd[k]; r++) d[(size_t)r * cap + i] = s[(size_t)r * cap + p];
+  }
+  if (J.sb) J.db[i] = J.sb[p];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_gather_rows(T* dst, const T* src, const int* perm, int n, int rows,
                                                      size_t cap)
@@ -1022,14 +1067,6 @@ __global__ __launch_bounds__(256) void k_gather_rows(T* dst, const T* src, const
   if (i >= n) return;
   const int p = perm[i];
   for (int r = 0; r < rows; r++) dst[(size_t)r * cap + i] = src[(size_t)r * cap + p];
-}
-
-template <class T>
-__global__ __launch_bounds__(256) void k_copy_rows(T* dst, const T* src, int n, int rows, size_t cap)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for (int r = 0; r < rows; r++) dst[(size_t)r * cap + i] = src[(size_t)r * cap + i];
 }
 
 // [3P] Comm::borders on one processor, one periodic dimension: atoms (owned or already-ghost)
@@ -1045,15 +1082,21 @@ struct GhostPtrs {
 // (4 bytes each; along the fastest sort dimension they are scattered one per row of atoms, and letting each of them
 // write its ~150 bytes of ghost record next to another XCD's took 360 us at 1 M atoms), then one thread per listed
 // atom writes the complete ghost, coalesced.
-__global__ __launch_bounds__(1024) void k_ghost_select(const double4* xr, int nall0, int dim, double lo, double hi,
-                                                       double cut, int* list, int* counter)
+// The number of atoms to look at -- owned + ghosts made so far, flags[before_idx] -- and the running ghost count live
+// on the device: the images of two or three periodic dimensions are made back to back without a host round trip each
+// (the host reads the total once, after the last dimension).
+__global__ __launch_bounds__(1024) void k_ghost_select(const double4* xr, const int* flags, int before_idx, int nlocal,
+                                                       int dim, double lo, double hi, double cut, int* list,
+                                                       int* counter, size_t cap)
 {
   // ONE global atomic per 1024-thread block: same-address atomics from different XCDs cost ~11 ns each, and along
   // the fastest sort dimension nearly every wave holds a taker (one atomic per wave was 360 us at 1 M atoms)
   __shared__ int wcount[16];
   __shared__ int wbase[16];
+  const size_t nall0 = min((size_t)nlocal + (size_t)flags[before_idx], cap);   // (a word nothing changes meanwhile)
+  if ((size_t)blockIdx.x * blockDim.x >= nall0) return;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = p < nall0;
+  const bool valid = (size_t)p < nall0;
   double xp = 0.0;
   if (valid) {
     const double4 x = xr[p];
@@ -1078,23 +1121,29 @@ __global__ __launch_bounds__(1024) void k_ghost_select(const double4* xr, int na
   }
   __syncthreads();
   const unsigned long long below = (1ull << lane) - 1ull;
-  if (t0) list[wbase[w] + __popcll(m0 & below)] = p;
-  if (t1) list[wbase[w] + n0 + __popcll(m1 & below)] = p | 0x40000000;
+  // (a list entry beyond the capacity belongs to a ghost that will not be created: the host grows and repeats)
+  const size_t k0 = (size_t)wbase[w] + __popcll(m0 & below), k1 = (size_t)wbase[w] + n0 + __popcll(m1 & below);
+  if (t0 && k0 < cap) list[k0] = p;
+  if (t1 && k1 < cap) list[k1] = p | 0x40000000;
 }
 
-__global__ __launch_bounds__(256) void k_ghost_create(GhostPtrs G, const int* list, int first, int count, int nlocal,
-                                                      int dim, double prd, size_t cap, int* flags)
+// ghosts [flags[before_idx], flags[F_GHOST_COUNT]) of this dimension; flags[next_idx] <- the count the next dimension
+// starts from
+__global__ __launch_bounds__(256) void k_ghost_create(GhostPtrs G, const int* list, int nlocal, int dim, double prd,
+                                                      size_t cap, int* flags, int before_idx, int next_idx)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
+  const int first = flags[before_idx], total = flags[F_GHOST_COUNT];
+  const bool over = (size_t)nlocal + (size_t)total > cap;
+  if (k == 0) {
+    if (next_idx >= 0) flags[next_idx] = total;
+    if (over) flags[F_GHOST_OVER] = 1;
+  }
+  if (over || k >= total - first) return;
   const int e = list[first + k];
   const int p = e & 0x3FFFFFFF;
   const int dir = (e >> 30) & 1;
   const size_t g = (size_t)nlocal + first + k;
-  if (g >= cap) {
-    flags[F_GHOST_OVER] = 1;
-    return;
-  }
   const double sh = (dir == 0) ? prd : -prd;
   double4 xg = G.xr[p];
   if (dim == 0) xg.x += sh;
@@ -1214,7 +1263,8 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
                                                      int* neigh, int* numneigh, double* shear, int* flags, int* cand,
                                                      double* xhold)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // (every candidate record is read by the ~35 atoms around it: neighbouring blocks on the same XCD share them in L2)
+  const int i = xcd_contiguous_block() * blockDim.x + threadIdx.x;
   if (i >= B.nlocal) return;
   const double4 xi = xr[i];
   // [3P] Neighbor::build: the positions the skin/2 displacement check (Neighbor::check_distance) refers to
@@ -1245,14 +1295,12 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   const int co = B.g.xslow ? cx : cz, no = B.g.xslow ? B.g.n[0] : B.g.n[2];
   const int ci = B.g.xslow ? cz : cx, ni = B.g.xslow ? B.g.n[2] : B.g.n[0];
   // distance test of one candidate
+  // (no granular criterion: ri + rj + -inf never exceeds the absolute cutoff -- one max instead of a select per candidate)
+  const double skinv = B.skin_gran >= 0.0 ? B.skin_gran : -INFINITY;
   auto in_range = [&](const int j, const double4 xj) {
     const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
     const double rsq = dx * dx + dy * dy + dz * dz;
-    double cut = B.cut_lub;
-    if (B.skin_gran >= 0.0) {
-      const double cg = xi.w + xj.w + B.skin_gran;
-      cut = cg > cut ? cg : cut;
-    }
+    const double cut = fmax(xi.w + xj.w + skinv, B.cut_lub);
     return j != i && rsq <= cut * cut;
   };
   // neighbour j enters the list; pos = its position in the tile's staged copy (LDS kernel only)
@@ -1295,22 +1343,22 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
         entry |= code << kIdxBits;
       }
       if (own) entry |= kOwnBit;
-      double sx = 0.0, sy = 0.0, sz = 0.0;
       const int found = found_known >= -1 ? found_known : find_old(tj);
       const int dst = slot_touch < 0 ? n : (found >= 0 ? slot_touch++ : slot_free++);
       if (found >= 0) {
+        // (the history of a slot is read only while its touch bit is set, and a contact that forms later starts from
+        // zero in registers: the slots of neighbours that do not touch are left as they are -- two thirds of the
+        // history stores of a loose bed)
         entry |= kTouchBit;
         const size_t ob = (size_t)(3 * found) * B.cap + io;
-        sx = shear_old[ob];
-        sy = shear_old[ob + B.cap];
-        sz = shear_old[ob + 2 * B.cap];
+        const double sx = shear_old[ob], sy = shear_old[ob + B.cap], sz = shear_old[ob + 2 * B.cap];
+        const size_t nb = (size_t)(3 * dst) * B.cap + i;
+        shear[nb] = sx;
+        shear[nb + B.cap] = sy;
+        shear[nb + 2 * B.cap] = sz;
       }
       neigh[(size_t)dst * B.cap + i] = entry;
       if (eo) B.nloc[(size_t)dst * B.cap + i] = (unsigned short)pos;
-      const size_t nb = (size_t)(3 * dst) * B.cap + i;
-      shear[nb] = sx;
-      shear[nb + B.cap] = sy;
-      shear[nb + 2 * B.cap] = sz;
     }
     n++;
   };
@@ -1318,27 +1366,16 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     if (in_range(j, xr[j])) accept(j, tag[j], pos);
   };
   int n_total = 0;   // row path: accepted candidates of the first sweep (may exceed the slots: overflow report)
-  // Row path, first sweep: an accepted candidate is looked up in the old list right away (its tag is one gather, the
-  // comparison runs on the partner tags held in registers) and parked as j | (old slot + 1) << 25 in the scratch rows
-  // `cand`.  B.touch_first: the neighbours that touched (found in the old list) fill the rows from the front, the
-  // others from the back, so that the second sweep can place the touching ones first without another pass.
+  // Row path, first sweep: an accepted candidate is parked in the scratch rows `cand`, in candidate order; the old-list
+  // look-up (tag gather + comparison with the partner tags held in registers) waits for the second sweep, where every
+  // lane of a wave is at the same slot.
   constexpr int kFoundUnknown = 127;
   const bool tf = B.touch_first && nold > 0;
-  int n_touch = 0, n_free = 0;
+  int* cand_next = cand + i;   // (a running pointer: the row stride is added per accepted candidate, not multiplied)
   auto note = [&](const int j) {
-    // (candidate order kept: the look-up waits for the second sweep, where the tag gathers of a wave are coalesced)
-    int f = -1;
-    if (tf) f = find_old(tag[j]);
-    const int word = j | ((!tf || f + 1 >= kFoundUnknown ? kFoundUnknown : f + 1) << kIdxBits);
-    if (tf) {
-      if (n_total < B.M) {
-        const int row = f >= 0 ? n_touch : B.M - 1 - n_free;
-        cand[(size_t)row * B.cap + i] = word;
-      }
-      if (f >= 0) n_touch++;
-      else n_free++;
-    } else if (n_total < B.M) {
-      cand[(size_t)n_total * B.cap + i] = word;
+    if (n_total < B.M) {
+      *cand_next = j;
+      cand_next += B.cap;
     }
     n_total++;
   };
@@ -1349,24 +1386,31 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // are loaded at once, then tested and entered in order.
     const int W = 2 * R + 1;
     const int bi0 = ci - R < 0 ? 0 : ci - R, bi1 = ci + R >= ni ? ni - 1 : ci + R;
+    // keys of successive rows differ by a constant: key(ro, ry) = bi0 + ni (cy - R + ry) + ni n1 (co - R + ro)
+    const int n1 = B.g.n[1], nin1 = ni * n1, width = bi1 - bi0 + 1;
+    const int key00 = bi0 + ni * (cy - R) + nin1 * (co - R);
     for (int pass = 0; pass < 2; pass++) {
       const int* lb = pass ? B.lb_ghost : B.lb_own;   // owned atoms first, then ghosts in their (cell, tag) order
       if (!lb) break;
-      auto row_range = [&](const int ro, const int ry, int& lo, int& hi) {
+      auto row_range = [&](const int ro, const int ry, const int key, int& lo, int& hi) {
         const int bo = co - R + ro, by = cy - R + ry;
         lo = hi = 0;
-        if (ro >= W || bo < 0 || bo >= no || by < 0 || by >= B.g.n[1]) return;
-        const int b0 = B.g.xslow ? bin_key(B.g, bo, by, bi0) : bin_key(B.g, bi0, by, bo);
-        lo = lb[b0];
-        hi = lb[b0 + (bi1 - bi0) + 1];
+        if (ro >= W || (unsigned)bo >= (unsigned)no || (unsigned)by >= (unsigned)n1) return;
+        lo = lb[key];
+        hi = lb[key + width];
       };
-      int nlo, nhi;
-      row_range(0, 0, nlo, nhi);
+      int nlo, nhi, nkey = key00;
+      row_range(0, 0, nkey, nlo, nhi);
       for (int ro = 0; ro < W; ro++) {
         for (int ry = 0; ry < W; ry++) {
           const int lo = nlo, hi = nhi;
-          if (ry + 1 < W) row_range(ro, ry + 1, nlo, nhi);
-          else row_range(ro + 1, 0, nlo, nhi);
+          if (ry + 1 < W) {
+            nkey += ni;
+            row_range(ro, ry + 1, nkey, nlo, nhi);
+          } else {
+            nkey += nin1 - ni * (W - 1);
+            row_range(ro + 1, 0, nkey, nlo, nhi);
+          }
           if (pass) {
             for (int k = lo; k < hi; k++) {
               const int j = ghost_order[k];
@@ -1374,12 +1418,12 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
             }
             continue;
           }
+          // four records per step, loaded unconditionally (a lane whose row is shorter reads its last record again:
+          // plain 16-byte loads instead of a branch around every 8 bytes), tested and entered in order
           for (int k = lo; k < hi; k += 4) {
-            const double4 z4 = {0.0, 0.0, 0.0, 0.0};
-            const double4 x0 = xr[k];
-            const double4 x1 = k + 1 < hi ? xr[k + 1] : z4;
-            const double4 x2 = k + 2 < hi ? xr[k + 2] : z4;
-            const double4 x3 = k + 3 < hi ? xr[k + 3] : z4;
+            const int last = hi - 1;
+            const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
+            const double4 x0 = xr[k], x1 = xr[k1], x2 = xr[k2], x3 = xr[k3];
             if (in_range(k, x0)) note(k);
             if (k + 1 < hi && in_range(k + 1, x1)) note(k + 1);
             if (k + 2 < hi && in_range(k + 2, x2)) note(k + 2);
@@ -1400,23 +1444,39 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // there), hence the switch (DemEngine::bin_and_build).
     const int nacc = n_total < B.M ? n_total : B.M;
     // (overflowing rows are rebuilt with more slots: what was dropped does not matter)
-    const int nt = tf ? (n_touch < nacc ? n_touch : nacc) : 0;
-    auto cand_row = [&](const int s) { return !tf || s < nt ? s : B.M - 1 - (s - nt); };
+    // Touch-first needs to know how many of the accepted candidates touched before it can place any of them: one more
+    // pass over the parked candidates looks each of them up in the old list (kept in the word: j | (old slot + 1) << 25)
+    // and counts.  Doing the look-up inside the candidate walk instead -- where a wave runs it once per candidate
+    // POSITION of any lane, ~100 times, not once per accepted candidate, ~13 times -- cost a third of this kernel.
+    int nt = 0;
     if (tf) {
+      int wn = nacc > 0 ? cand[i] : 0;
+      int wn2 = nacc > 1 ? cand[B.cap + i] : 0;
+      int tn = nacc > 0 ? tag[wn] : 0;
+      for (int s = 0; s < nacc; s++) {
+        const int j = wn, tj = tn;
+        wn = wn2;
+        if (s + 1 < nacc) tn = tag[wn];
+        if (s + 2 < nacc) wn2 = cand[(size_t)(s + 2) * B.cap + i];
+        const int f = find_old(tj);
+        if (f >= 0) nt++;
+        cand[(size_t)s * B.cap + i] = j | ((f + 1 >= kFoundUnknown ? kFoundUnknown : f + 1) << kIdxBits);
+      }
       slot_touch = 0;
       slot_free = nt;
     }
     n = 0;
-    int wn = nacc > 0 ? cand[(size_t)cand_row(0) * B.cap + i] : 0;
-    int tn = (nacc > 0 && !tf) ? tag[wn & kIdxMask] : 0;   // (one slot ahead, like the candidate word)
+    // the candidate word two slots ahead, its tag one slot ahead: neither load waits for the other inside an iteration
+    int wn = nacc > 0 ? cand[i] : 0;
+    int wn2 = nacc > 1 ? cand[B.cap + i] : 0;
+    int tn = (nacc > 0 && !tf) ? tag[wn & kIdxMask] : 0;
     for (int s = 0; s < nacc; s++) {
       const int w = wn, tj = tn;
-      if (s + 1 < nacc) {
-        wn = cand[(size_t)cand_row(s + 1) * B.cap + i];
-        if (!tf) tn = tag[wn & kIdxMask];
-      }
+      wn = wn2;
+      if (s + 1 < nacc && !tf) tn = tag[wn & kIdxMask];
+      if (s + 2 < nacc) wn2 = cand[(size_t)(s + 2) * B.cap + i];
       const int j = w & kIdxMask, fcode = (w >> kIdxBits) & 127;
-      found_known = fcode == kFoundUnknown ? -2 : fcode - 1;
+      found_known = !tf || fcode == kFoundUnknown ? -2 : fcode - 1;
       accept(j, tf && found_known == -2 ? tag[j] : tj, 0);
     }
     n = n_total;

@@ -48,9 +48,19 @@ flight per CU, L2 hit rate {s['l2_hit_rate']:.2f}; wave cycles {100 * s['wave_cy
 What overlapping consecutive sub-steps could add, and why it was not built: `r03_a_README.md`.
 
 Neighbour rebuild (1 M grains): `k_build_neigh` {avg('k_build_neigh'):.0f} us on this lattice (candidate order kept, look-ups coalesced in
-the second sweep), ~520 us on the loose bed where the touching neighbours are placed first; whole rebuild of the loose
-bed 1.18-1.31 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.37 at the
-start of the round).
+the second sweep), 440-480 us on the loose bed where the touching neighbours are placed first; whole rebuild of the loose
+bed 1.02-1.12 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.18 before the
+last batch of the round, 1.37 at its start).  That batch, library against library on the same box
+(`tests/ab_rebuild.sh`, rocprofv3 per-kernel averages over the 34 rebuilds of a loose-bed run): every per-atom array
+re-ordered by ONE kernel (`k_permute_all` 60-69 us instead of 14 launches summing to ~115), periodic ghosts of two
+dimensions made without a host round trip in between, the host's look at the list counts overlapped with
+`k_back_slots`, history of non-touching slots no longer zero-filled, candidate walk rewritten (unconditional 16-byte
+record loads, running row keys and scratch pointer: 270 -> 128 instructions per four candidates) and given the XCD-
+contiguous block order of the sub-step kernel: `k_build_neigh` 505-524 -> 437-465 us, loose-bed throughput +5-7 %.
+Measured and dropped: the old-list look-up inside the walk against after it (equal), the walk as its own kernel at
+5 / 6 / 8 waves per SIMD (249 / 243 / 234 us against ~238 inside the fused kernel: not latency-bound), cells of the full
+cutoff instead of half (`SF_SUB=1`: walk 228 -> 184 us on the loose bed, but the sub-step kernel 191 -> 330 us on the
+lattice and 180 -> 250 us on dense jittered beds: the finer cells are what orders the atoms for its gathers).
 
 Loose disordered ("fluidised") bed, the `fluidised_bed` object of the line: {f['mean_kernel_us']:.0f} us per sub-step kernel at K_half {f['k_half']}
 = {f['roofline_frac']:.2f} of the roofline (236 us / 0.26-0.28 with the round-2 slot order on the same boxes), {f['value'] / 1e9:.2f}e9
