@@ -138,6 +138,8 @@ def _declare(L):
                  C.c_int, C.POINTER(NeighList), dp, dp]
     L.orc_pair_gran_hertzfix_history.argtypes = pair_args
     L.orc_pair_gran_hooke_history.argtypes = pair_args
+    L.orc_pair_gran_hooke.argtypes = [C.POINTER(GranParams), C.c_int, dp, dp, dp, dp, dp, ip, C.c_int,
+                                      C.POINTER(NeighList), dp, dp]
     L.orc_fix_cohesive.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, dp, dp, ip,
                                                       C.c_int, C.POINTER(NeighList), dp]
     L.orc_fix_cohesive.restype = C.c_int
@@ -220,8 +222,9 @@ class OracleDem:
             self.h = None
 
     def pair_gran(self, style, kn, kt, gamman, gammat, xmu, dampflag):
-        """style 'hooke'|'hertz'; kt/gammat None = NULL."""
-        st = {"hooke": 1, "hertz": 2, None: 0}[style]
+        """style 'hooke' (gran/hooke/history) | 'hertz' (gran/hertzFix/history) | 'hooke_plain' (gran/hooke, no
+        history); kt/gammat None = NULL."""
+        st = {"hooke": 1, "hertz": 2, "hooke_plain": 3, None: 0}[style]
         rc = self.L.orc_dem_pair_gran(self.h, st, kn, kt is None, kt or 0.0, gamman,
                                       gammat is None, gammat or 0.0, xmu, dampflag)
         if rc:

@@ -4,8 +4,11 @@
  *   orc_pair_gran_hooke_history    : [3P] LAMMPS 1Feb14 pair_gran_hooke_history.cpp compute();
  *                                    the Hookean law itself is the one the reference carries in
  *                                    interfaceToLammps/fix_wall_granFix.cpp:441-554
+ *   orc_pair_gran_hooke            : [3P] LAMMPS 1Feb14 pair_gran_hooke.cpp compute() (absent from the reference
+ *                                    tree; restated from the published algorithm).  The law itself is the one the
+ *                                    reference carries as FixWallGranFix::hooke, fix_wall_granFix.cpp:347-437
  *   orc_fix_wall_gran              : interfaceToLammps/fix_wall_granFix.cpp:247-345 (plane walls),
- *                                    hooke_history :441-554, hertz_history :558-679
+ *                                    hooke :347-437, hooke_history :441-554, hertz_history :558-679
  *   orc_gran_settings              : pair_gran_hertzFix_history.cpp:293-317
  *
  * The floating-point expression order of the reference is kept (the repeated sub-expressions are
@@ -165,8 +168,44 @@ static void hooke_history_law(const orc_gran_params *p, double dt, int shearupda
   o->tor[2] = rinv * (c->del[0] * fs[1] - c->del[1] * fs[0]);
 }
 
-/* the ii/jj double loop shared by both pair styles (pair_gran_hertzFix_history.cpp:109-286) */
-static void pair_gran_loop(int hertz, const orc_gran_params *p, double dt, int shearupdate,
+/* Plain Hookean law, no shear history: FixWallGranFix::hooke, fix_wall_granFix.cpp:347-437 (wall), and its pair twin
+ * [3P] PairGranHooke::compute with radsum / the summed rotation in place of radius / radius*omega. */
+static void hooke_law(const orc_gran_params *p, const contact_in *c, contact_out *o)
+{
+  const double kn = p->kn, xmu = p->xmu, gamman = p->gamman, gammat = p->gammat;
+  double r = sqrt(c->rsq);                                            /* :358-360 */
+  double rinv = 1.0 / r;
+  double rsqinv = 1.0 / c->rsq;
+  double vnnr = c->vr[0] * c->del[0] + c->vr[1] * c->del[1] + c->vr[2] * c->del[2];   /* :370 */
+  double vn[3], vt[3], vtr[3], fs[3];
+  int k;
+  for (k = 0; k < 3; k++) {
+    vn[k] = c->del[k] * vnnr * rsqinv;                                /* :371-373 */
+    vt[k] = c->vr[k] - vn[k];                                         /* :377-379 */
+  }
+  double damp = c->meff * gamman * vnnr * rsqinv;                     /* :389-391 */
+  double ccel = kn * c->overlap * rinv - damp;
+  vtr[0] = vt[0] - (c->del[2] * c->wr[1] - c->del[1] * c->wr[2]);     /* :395-399 */
+  vtr[1] = vt[1] - (c->del[0] * c->wr[2] - c->del[2] * c->wr[0]);
+  vtr[2] = vt[2] - (c->del[1] * c->wr[0] - c->del[0] * c->wr[1]);
+  double vrel = vtr[0] * vtr[0] + vtr[1] * vtr[1] + vtr[2] * vtr[2];
+  vrel = sqrt(vrel);
+  double fn = xmu * fabs(ccel * r);                                   /* :403-406 */
+  double fsd = c->meff * gammat * vrel;
+  double ft;
+  if (vrel != 0.0) ft = (fn < fsd ? fn : fsd) / vrel;
+  else ft = 0.0;
+  for (k = 0; k < 3; k++) fs[k] = -ft * vtr[k];                       /* :410-412 */
+  for (k = 0; k < 3; k++) o->F[k] = c->del[k] * ccel + fs[k];         /* :416-418 */
+  o->tor[0] = rinv * (c->del[1] * fs[2] - c->del[2] * fs[1]);         /* :424-426 */
+  o->tor[1] = rinv * (c->del[2] * fs[0] - c->del[0] * fs[2]);
+  o->tor[2] = rinv * (c->del[0] * fs[1] - c->del[1] * fs[0]);
+}
+
+/* the ii/jj double loop shared by the pair styles (pair_gran_hertzFix_history.cpp:109-286); law 0 hooke/history,
+ * 1 hertzFix/history, 3 plain hooke (no FixShearHistory there: the list's touch flag is kept for the callers that
+ * count contacts, the shear slots stay zero) */
+static void pair_gran_loop(int law, const orc_gran_params *p, double dt, int shearupdate,
                            int nlocal, const double *x, const double *v, const double *omega,
                            const double *radius, const double *rmass, const int *mask,
                            int freeze_group_bit, const orc_neighlist *list, double *f,
@@ -205,8 +244,10 @@ static void pair_gran_loop(int hertz, const orc_gran_params *p, double dt, int s
       c.overlap = radsum - r;
       c.reff_term = (radsum - r) * radi * radj / radsum;            /* :192-199 */
       list->touch[jj] = 1;                                          /* :212 */
-      if (hertz)
+      if (law == 1)
         hertz_history_law(p, dt, shearupdate, 0, &c, shear, &o);
+      else if (law == 3)
+        hooke_law(p, &c, &o);
       else
         hooke_history_law(p, dt, shearupdate, &c, shear, &o);
       for (k = 0; k < 3; k++) {
@@ -241,6 +282,13 @@ void orc_pair_gran_hooke_history(const orc_gran_params *p, double dt, int shearu
 {
   pair_gran_loop(0, p, dt, shearupdate, nlocal, x, v, omega, radius, rmass, mask,
                  freeze_group_bit, list, f, torque);
+}
+
+void orc_pair_gran_hooke(const orc_gran_params *p, int nlocal, const double *x, const double *v,
+                         const double *omega, const double *radius, const double *rmass, const int *mask,
+                         int freeze_group_bit, const orc_neighlist *list, double *f, double *torque)
+{
+  pair_gran_loop(3, p, 0.0, 0, nlocal, x, v, omega, radius, rmass, mask, freeze_group_bit, list, f, torque);
 }
 
 /* FixWallGranFix::post_force, fix_wall_granFix.cpp:247-345, with the moving walls of :255-264 (wiggle: the wall
@@ -293,8 +341,8 @@ void orc_fix_wall_gran_moving(const orc_gran_params *p, int pairstyle, int walls
       }
     }
     c.rsq = c.del[0] * c.del[0] + c.del[1] * c.del[1] + c.del[2] * c.del[2];
-    if (c.rsq > rad * rad) {                                        /* :326-331 */
-      shear[3 * i] = shear[3 * i + 1] = shear[3 * i + 2] = 0.0;
+    if (c.rsq > rad * rad) {                                        /* :326-331 (HOOKE keeps no shear array) */
+      if (pairstyle != 3) shear[3 * i] = shear[3 * i + 1] = shear[3 * i + 2] = 0.0;
       continue;
     }
     double r = sqrt(c.rsq);
@@ -310,6 +358,8 @@ void orc_fix_wall_gran_moving(const orc_gran_params *p, int pairstyle, int walls
     c.reff_term = (rad - r) * rad;                                  /* :602-608 */
     if (pairstyle == 2)
       hertz_history_law(p, dt, shearupdate, 1, &c, &shear[3 * i], &o);
+    else if (pairstyle == 3)
+      hooke_law(p, &c, &o);                                         /* :333-335 */
     else
       hooke_history_law(p, dt, shearupdate, &c, &shear[3 * i], &o);
     for (k = 0; k < 3; k++) {

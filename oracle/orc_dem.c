@@ -541,6 +541,9 @@ void orc__compute_forces(orc_dem *d, int setupflag)
   else if (d->pair_style == 1)
     orc_pair_gran_hooke_history(&d->gp, d->dt, shearupdate, d->nlocal, d->x, d->v, d->omega,
                                 d->radius, d->rmass, d->mask, d->freeze_bit, &gl, d->f, d->torque);
+  else if (d->pair_style == 3)
+    orc_pair_gran_hooke(&d->gp, d->nlocal, d->x, d->v, d->omega, d->radius, d->rmass, d->mask, d->freeze_bit, &gl,
+                        d->f, d->torque);
   if (d->have_lub) {
     orc_neighlist fl;
     fl.inum = d->nlocal; fl.ilist = d->ilist; fl.first = d->ffirst; fl.jlist = d->fjlist;
@@ -560,7 +563,7 @@ void orc__compute_forces(orc_dem *d, int setupflag)
         break;
       case FIX_WALL:
         /* wall/granFix follows the pair style (fix_wall_granFix.cpp:217-229) */
-        orc_fix_wall_gran_moving(&fx->wp, d->pair_style == 2 ? 2 : 1, fx->wallstyle, fx->lo, fx->hi,
+        orc_fix_wall_gran_moving(&fx->wp, d->pair_style == 2 ? 2 : (d->pair_style == 3 ? 3 : 1), fx->wallstyle, fx->lo, fx->hi,
                                  fx->cylradius, fx->wiggleflag, fx->shearflag, fx->axis, fx->amplitude,
                                  fx->period > 0.0 ? fx->period : 1.0, fx->vshear,
                                  d->ntimestep - fx->time_origin, d->dt, shearupdate, d->nlocal, d->x, d->v,

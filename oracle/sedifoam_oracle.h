@@ -63,6 +63,11 @@ void orc_pair_gran_hertzfix_history(const orc_gran_params *p, double dt, int she
 
 /* [3P] PairGranHookeHistory::compute (LAMMPS 1Feb14); same skeleton, Hookean law as in
  * fix_wall_granFix.cpp:441-554 with meff of the pair */
+/* [3P] PairGranHooke::compute (LAMMPS 1Feb14 pair_gran_hooke.cpp; not in the reference tree): the plain Hookean law
+ * of fix_wall_granFix.cpp:347-437 between two grains, no shear history (list->shear stays zero) */
+void orc_pair_gran_hooke(const orc_gran_params *p, int nlocal, const double *x, const double *v,
+                         const double *omega, const double *radius, const double *rmass, const int *mask,
+                         int freeze_group_bit, const orc_neighlist *list, double *f, double *torque);
 void orc_pair_gran_hooke_history(const orc_gran_params *p, double dt, int shearupdate,
                                  int nlocal, const double *x, const double *v,
                                  const double *omega, const double *radius,
@@ -100,7 +105,7 @@ void orc_fix_fluid_drag(int nlocal, double dt, double carrier_rho, const double 
 
 /* N2: FixWallGranFix::post_force for plane walls  fix_wall_granFix.cpp:247-345,
  * hooke_history :441-554, hertz_history :558-679.  wallstyle 0/1/2 = x/y/z plane;
- * lo/hi = +-1e20 when NULL.  pairstyle 1 = hooke_history, 2 = hertz_history. */
+ * lo/hi = +-1e20 when NULL.  pairstyle 1 = hooke_history, 2 = hertz_history, 3 = hooke (:347-437). */
 void orc_fix_wall_gran_moving(const orc_gran_params *p, int pairstyle, int wallstyle, double lo, double hi,
                               double cylradius, int wiggle, int wshear, int axis, double amplitude,
                               double period, double vshear, long steps, double dt, int shearupdate,
@@ -139,7 +144,7 @@ orc_dem *orc_dem_create(int n, const double *x, const double *v, const double *o
                         const double *radius, const double *rmass, const int *tag,
                         const double boxlo[3], const double boxhi[3], const int periodic[3]);
 void orc_dem_destroy(orc_dem *d);
-/* style: 1 gran/hooke/history, 2 gran/hertzFix/history, 0 none */
+/* style: 1 gran/hooke/history, 2 gran/hertzFix/history, 3 gran/hooke [3P], 0 none */
 int orc_dem_pair_gran(orc_dem *d, int style, double kn, int kt_null, double kt, double gamman,
                       int gammat_null, double gammat, double xmu, int dampflag);
 void orc_dem_pair_lubricate(orc_dem *d, double mu, int flaglog, int flagfld, double cut_inner,

@@ -849,6 +849,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     const size_t lds = (size_t)stage_cap_ * 88;
     switch (gran_.style) {
       case 2: launch_lds_style<2>(cohe, lub, grid, lds, stream_, P, S); break;
+      case 3:   // (plain gran/hooke: the Hookean kernel, the law itself branches on GranParams::style)
       case 1: launch_lds_style<1>(cohe, lub, grid, lds, stream_, P, S); break;
       default: launch_lds_style<0>(cohe, lub, grid, lds, stream_, P, S); break;
     }
@@ -867,6 +868,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     const dim3 grid((unsigned)((lanes + block - 1) / block));
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
+      case 3:
       case 1: launch_substep_style<1>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
       default: launch_substep_style<0>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
     }

@@ -97,7 +97,7 @@ void cmd_pair_style(SfLammps& L, const std::vector<std::string>& w, size_t a)
     while (k < w.size()) {
       size_t e = k + 1;
       while (e < w.size() && w[e] != "gran/hertzFix/history" && w[e] != "gran/hooke/history" &&
-             w[e] != "lubricate/poly")
+             w[e] != "gran/hooke" && w[e] != "lubricate/poly")
         e++;
       std::vector<std::string> sub(w.begin() + k, w.begin() + e);
       sub.insert(sub.begin(), "pair_style");
@@ -107,10 +107,11 @@ void cmd_pair_style(SfLammps& L, const std::vector<std::string>& w, size_t a)
     L.pair_hybrid = true;
     return;
   }
-  if (st == "gran/hertzFix/history" || st == "gran/hooke/history") {
+  if (st == "gran/hertzFix/history" || st == "gran/hooke/history" || st == "gran/hooke") {
     if (w.size() - a - 1 != 6) sf::fail("Illegal pair_style command");  // pair_gran_hertzFix_history.cpp:295
     const bool ktn = w[a + 2] == "NULL", gtn = w[a + 4] == "NULL";
-    L.eng.set_pair_gran(st == "gran/hertzFix/history" ? 2 : 1, num(w[a + 1]), ktn, ktn ? 0.0 : num(w[a + 2]),
+    // 3: plain gran/hooke [3P] -- the style FixWallGranFix's HOOKE branch belongs to (fix_wall_granFix.cpp:219-220)
+    L.eng.set_pair_gran(st == "gran/hertzFix/history" ? 2 : (st == "gran/hooke" ? 3 : 1), num(w[a + 1]), ktn, ktn ? 0.0 : num(w[a + 2]),
                         num(w[a + 3]), gtn, gtn ? 0.0 : num(w[a + 4]), num(w[a + 5]), inum(w[a + 6]));
     return;
   }

@@ -7,7 +7,8 @@
 //   hertz_history_law  : interfaceToLammps/pair_gran_hertzFix_history.cpp:142-261 (pair),
 //                        interfaceToLammps/fix_wall_granFix.cpp:558-679 (wall twin)
 //   hooke_history_law  : interfaceToLammps/fix_wall_granFix.cpp:441-554 and its pair twin
-//                        (LAMMPS 1Feb14 gran/hooke/history)
+//                        (LAMMPS 1Feb14 gran/hooke/history); style 3 = the plain law without history,
+//                        fix_wall_granFix.cpp:347-437 and its pair twin (LAMMPS 1Feb14 gran/hooke)
 //   cohesive_ccel      : interfaceToLammps/fix_cohesive.cpp:184-196, :236-245
 //   lubricate_poly_pair: interfaceToLammps/pair_lubricate_poly.cpp:241-399
 #pragma once
@@ -182,6 +183,21 @@ __device__ __forceinline__ void hooke_history_law(const GranParams& p, double dt
   const double ccel = p.kn * c.overlap * c.rinv - damp;
   const Vec3 vtr = {vt.x - (c.del.z * wr.y - c.del.y * wr.z), vt.y - (c.del.x * wr.z - c.del.z * wr.x),
                     vt.z - (c.del.y * wr.x - c.del.x * wr.y)};
+  if (p.style == 3) {
+    // plain Hookean contact, no shear history (`pair_style gran/hooke` [3P]; its wall twin is
+    // FixWallGranFix::hooke, fix_wall_granFix.cpp:347-437): the tangential force is the velocity damping alone, capped
+    // by Coulomb.  The history slot of the pair stays zero.
+    const double vrel = sqrt(dot(vtr, vtr));
+    const double fn = p.xmu * fabs(ccel * c.r);
+    const double fsd = c.meff * p.gammat * vrel;
+    const double ft = vrel != 0.0 ? (fn < fsd ? fn : fsd) / vrel : 0.0;
+    const Vec3 fs = {-ft * vtr.x, -ft * vtr.y, -ft * vtr.z};
+    sh = {0.0, 0.0, 0.0};
+    o.F = {c.del.x * ccel + fs.x, c.del.y * ccel + fs.y, c.del.z * ccel + fs.z};
+    o.tor = {c.rinv * (c.del.y * fs.z - c.del.z * fs.y), c.rinv * (c.del.z * fs.x - c.del.x * fs.z),
+             c.rinv * (c.del.x * fs.y - c.del.y * fs.x)};
+    return;
+  }
   if (shearupdate) {
     sh.x += vtr.x * dt;
     sh.y += vtr.y * dt;

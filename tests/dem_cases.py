@@ -62,7 +62,8 @@ def make_oracle(bed, cfg):
 
 
 def script_lines(bed, cfg):
-    style = {"hertz": "gran/hertzFix/history", "hooke": "gran/hooke/history"}[cfg.get("pair", "hertz")]
+    style = {"hertz": "gran/hertzFix/history", "hooke": "gran/hooke/history",
+             "hooke_plain": "gran/hooke"}[cfg.get("pair", "hertz")]
     wall = "wall/granFix" if cfg.get("pair", "hertz") == "hertz" else "wall/gran"
     gran = "%s %.17g NULL %.17g NULL %.17g %d" % (style, cfg["kn"], cfg["gamman"], cfg["xmu"],
                                                    cfg.get("dampflag", 1))

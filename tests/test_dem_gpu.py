@@ -148,6 +148,21 @@ def test_periodic_hooke_bed():
     _run_case(bed, cfg)
 
 
+def test_periodic_plain_hooke_bed_with_wall_and_rebuilds():
+    """`pair_style gran/hooke` [3P] + the wall's HOOKE branch (fix_wall_granFix.cpp:219-220, :333-335, :347-437): no
+    shear history anywhere; fast grains and a thin skin so that lists are rebuilt while contacts are open."""
+    cfg = dict(BASE, pair="hooke_plain", kn=2.0e3, gamman=50.0, dampflag=1, skin=0.05e-3)
+    bed = _bed((6, 5, 6), periodic=True, seed=41, vmax=0.4)
+    lines = dc.script_lines(bed, dict(cfg, walls=_walls(bed)))
+    assert any(l.startswith("pair_style gran/hooke ") for l in lines)
+    # (torques here are sums of velocity-damping forces alone, ~1e-8 N m out of contact forces 1e3 x larger: after 100
+    # sub-steps of 0.4 m/s grains the worst component sits at 1e-11 of the largest)
+    lmp, orc = _run_case(bed, cfg, steps=(40, 60), tol_f=5e-11)
+    assert lmp.info().nbuilds >= 2 and orc.nbuilds == lmp.info().nbuilds
+    hist = lmp.history()
+    assert len(hist) > 0 and all(np.all(s == 0.0) for s in hist.values())   # contacts counted, history slots zero
+
+
 def test_rebuild_with_history_carry_over():
     # fast particles + thin skin: several neighbour rebuilds inside the run, shear history must survive
     bed = _bed((6, 6, 6), periodic=True, seed=99, vmax=0.5)

@@ -433,3 +433,57 @@ def test_fix_freeze_acts_where_it_stands_in_the_fix_list():
     assert f[True][0][0] == 0.0 and f[True][0][2] == 0.0                     # (no gravity: it came before the freeze)
     for k in (False, True):
         assert f[k][1][1] == pytest.approx(-m * 9.81, rel=1e-12)             # the free grain just falls
+
+
+def test_plain_hooke_pair_and_wall_closed_forms():
+    """`pair_style gran/hooke` [3P] and FixWallGranFix::hooke (fix_wall_granFix.cpp:347-437): Hookean spring + normal
+    damping along the line of centres, tangential force = velocity damping meff gammat vrel capped by mu |Fn|, no
+    history.  gammat = gamman / 2 (NULL), meff = m/2 between equal grains, m against a wall."""
+    R, delta, kn, gn, mu, m = 0.5e-3, 2.0e-5, 1e7, 50.0, 0.4, 2e-6
+    p = _params(kn, gamman=gn, xmu=mu)
+    x = ob.f64([[0, 0, 0], [2 * R - delta, 0, 0]])
+    w = np.zeros((2, 3)); r = ob.f64([R, R]); mm = ob.f64([m, m]); mask = ob.i32([1, 1])
+    ilist = ob.i32([0, 1]); first = ob.i32([0, 1, 1]); jlist = ob.i32([1])
+
+    def pair(v, p=p):
+        v = ob.f64(v)
+        touch = ob.i32([0]); shear = np.zeros(3)
+        nl = ob.NeighList(2, ob.P(ilist), ob.P(first), ob.P(jlist), ob.P(touch), ob.P(shear))
+        f = np.zeros((2, 3)); t = np.zeros((2, 3))
+        L.orc_pair_gran_hooke(C.byref(p), 2, ob.P(x), ob.P(v), ob.P(w), ob.P(r), ob.P(mm), ob.P(mask), 0,
+                              C.byref(nl), ob.P(f), ob.P(t))
+        assert np.all(shear == 0.0)
+        return f, t
+
+    # at rest: the spring alone, kn delta
+    f, t = pair(np.zeros((2, 3)))
+    assert f[1, 0] == pytest.approx(kn * delta, rel=1e-13) and f[0, 0] == -f[1, 0] and np.all(t == 0)
+    # closing at speed u: + meff gamman u
+    u = 0.05
+    f, _ = pair([[u / 2, 0, 0], [-u / 2, 0, 0]])
+    fn = kn * delta + 0.5 * m * gn * u
+    assert f[1, 0] == pytest.approx(fn, rel=1e-13)
+    # sliding slowly past each other at relative speed s along y: damping force meff (gamman/2) s, opposing the motion
+    sl = 1.0e-3
+    f, t = pair([[0, sl / 2, 0], [0, -sl / 2, 0]])
+    ft = 0.5 * m * (0.5 * gn) * sl
+    assert ft < mu * kn * delta
+    assert f[0, 1] == pytest.approx(-ft, rel=1e-12) and f[1, 1] == pytest.approx(ft, rel=1e-12)
+    # torque on grain 0: -radi * rinv (del x fs), del = x0 - x1 = (-(2R - delta), 0, 0), fs = (0, -ft, 0)
+    assert t[0, 2] == pytest.approx(-R * ft, rel=1e-12) and t[1, 2] == pytest.approx(-R * ft, rel=1e-12)
+    # sliding fast on a nearly frictionless contact: capped at mu |Fn|
+    f, _ = pair([[0, 50.0, 0], [0, -50.0, 0]], _params(kn, gamman=gn, xmu=1e-6))
+    assert 0.5 * m * (0.5 * gn) * 100.0 > 1e-6 * kn * delta
+    assert f[1, 1] == pytest.approx(1e-6 * kn * delta, rel=1e-12)
+
+    # the wall twin: meff = m, radius in place of radsum; a floor at y = 0
+    xs = ob.f64([[0, R - delta, 0]]); rr = ob.f64([R]); m1 = ob.f64([m]); mk = ob.i32([1])
+    for vel, want_y, want_x in (([0, 0, 0], kn * delta, 0.0),
+                                ([0, -u, 0], kn * delta + m * gn * u, 0.0),
+                                ([sl, 0, 0], kn * delta, -m * (0.5 * gn) * sl)):
+        v1 = ob.f64([vel]); sh = np.full((1, 3), 7.0); f = np.zeros((1, 3)); t = np.zeros((1, 3))
+        L.orc_fix_wall_gran(C.byref(p), 3, 1, 0.0, 1.0, 1e-6, 1, 1, ob.P(xs), ob.P(v1), ob.P(np.zeros((1, 3))),
+                            ob.P(rr), ob.P(m1), ob.P(mk), 1, ob.P(sh), ob.P(f), ob.P(t))
+        assert f[0, 1] == pytest.approx(want_y, rel=1e-13)
+        assert f[0, 0] == pytest.approx(want_x, rel=1e-12, abs=1e-30)
+        assert np.all(sh == 7.0)      # the plain law keeps no shear array (:327: `if (pairstyle != HOOKE)`)
