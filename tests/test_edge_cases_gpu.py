@@ -78,6 +78,25 @@ def test_neighbor_slots_grow_on_overflow():
     assert lmp.info().nbuilds >= 2
 
 
+def test_ghosts_outgrow_the_capacity_of_a_narrow_periodic_column():
+    """A tall column 3 lattice cells (4.2 d) wide, periodic in x and z: every grain has 1.5 periodic images on average
+    (those of the x faces, then the z images of grains AND of x images), which is more than the slack the per-atom
+    arrays are created with.  The ghost kernels keep their counts on the device and create nothing once the capacity
+    would be exceeded; the host grows the arrays and repeats (DemEngine::make_periodic_ghosts)."""
+    bed = T._bed((3, 600, 3), periodic=True, seed=3, vmax=0.1)
+    assert bed["n"] == 21600
+    cfg = dict(T.BASE, walls=T._walls(bed))
+    lmp = dc.make_hip(bed, cfg)
+    cap0 = lmp.info().capacity
+    orc = dc.make_oracle(bed, cfg)
+    lmp.setup(); orc.setup()
+    info = lmp.info()
+    assert info.nghost == orc.nghost and info.nlocal + info.nghost > cap0 and info.capacity > cap0
+    T._compare(lmp, orc, tol_f=5e-12)
+    lmp.step(5); orc.run(5)
+    T._compare(lmp, orc, tol_f=5e-12)
+
+
 def test_script_errors_use_reference_wording():
     from sedifoam_amd import Lammps, SfError
     lmp = Lammps()
