@@ -770,8 +770,20 @@ static void launch_lds_style(bool cohe, bool lub, dim3 grid, size_t lds, hipStre
 
 int DemEngine::lanes_per_atom(int nwork) const
 {
-  return (opt_lpa_ == 1 || opt_lpa_ == 2 || opt_lpa_ == 4) ? opt_lpa_
-                                                            : (nwork < 20 * 1024 ? 4 : (nwork < 150 * 1024 ? 2 : 1));
+  if (opt_lpa_ == 1 || opt_lpa_ == 2 || opt_lpa_ == 4) return opt_lpa_;
+  if (nwork < 20 * 1024) return 4;
+  if (nwork >= 300 * 1024) return 1;
+  // In between the kernel is a few rounds of resident waves (3 per SIMD): one lane per atom is N/64 waves that each walk
+  // all ~12 slots, two lanes per atom twice as many waves of ~0.55 the length.  Whichever needs the cheaper whole number
+  // of rounds wins -- measured at 63 k / 126 k / 170 k / 200 k / 250 k / 300 k grains: 2 / either / 1 / 2 / 2 / 1 lanes,
+  // up to 10 % apart (profiles/r03_README.md)
+  static const int slots = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus * 4 * 3;
+  }();
+  const double r = (double)nwork / 64.0 / (double)slots;
+  return 0.55 * std::ceil(2.0 * r) < std::ceil(r) ? 2 : 1;
 }
 
 void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)

@@ -62,6 +62,12 @@ Measured and dropped: the old-list look-up inside the walk against after it (equ
 cutoff instead of half (`SF_SUB=1`: walk 228 -> 184 us on the loose bed, but the sub-step kernel 191 -> 330 us on the
 lattice and 180 -> 250 us on dense jittered beds: the finer cells are what orders the atoms for its gathers).
 
+Lanes per atom between 20 k and 300 k grains (the sizes an 8 / 4 / 2-GPU split of the 1 M bed leaves per GPU), whole-run
+µs per sub-step, same box (`tests/ab_persist.sh`, `SF_LPA=1` / `SF_LPA=2` / the policy of `DemEngine::lanes_per_atom` =
+the cheaper whole number of rounds of resident waves):
+63 k 23.5 / 19.7 / 19.5; 126 k 29.8 / 29.8 / 30.0; 170 k 35.8 / 36.7 / 35.5; 200 k 45.0 / 42.7 / 42.4;
+250 k 50.4 / 48.9 / 48.7; 300 k 55.2 / 58.1 / 55.9 (round 2's fixed threshold at 150 k picked the slower one at 200-295 k).
+
 Loose disordered ("fluidised") bed, the `fluidised_bed` object of the line: {f['mean_kernel_us']:.0f} us per sub-step kernel at K_half {f['k_half']}
 = {f['roofline_frac']:.2f} of the roofline (236 us / 0.26-0.28 with the round-2 slot order on the same boxes), {f['value'] / 1e9:.2f}e9
 particle-sub-steps/s whole-run with {f['neighbor_rebuilds_in_run']} rebuilds in 250 sub-steps (2.9e9 before).
