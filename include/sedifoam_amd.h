@@ -118,6 +118,9 @@ int sf_dem_device_view_get(void *ptr, sf_dem_device_view *out);
  * (events recorded on the engine's stream): number of launches and their summed duration */
 int sf_dem_set_profiling(void *ptr, int on);
 int sf_dem_get_profile(void *ptr, long long *launches, double *kernel_ms);
+/* neighbour rebuilds ([3P] Neighbor::build + the re-sort, ghosts and history carry-over around it) that sf_dem_step /
+ * lammps_step ran while profiling was on: how many, and their summed host-clock duration (synchronised) */
+int sf_dem_get_rebuild_profile(void *ptr, long long *rebuilds, double *ms);
 /* forces/torques of owned atoms to host AoS (3n each, engine order) with tags */
 int sf_dem_get_forces(void *ptr, double *f, double *torque, double *omega, int *tag);
 /* touching pairs (tag_i < tag_j, shear oriented i->j) ; returns count or <0 */

@@ -107,6 +107,7 @@ _SIGS = {
     "sf_dem_device_view_get": (C.c_int, [vp, C.POINTER(DemDeviceView)]),
     "sf_dem_set_profiling": (C.c_int, [vp, C.c_int]),
     "sf_dem_get_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "sf_dem_get_rebuild_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "sf_dem_get_forces": (C.c_int, [vp, dp, dp, dp, ip]),
     "sf_dem_get_history": (C.c_longlong, [vp, C.c_longlong, ip, ip, dp]),
     "sf_dem_get_wall_shear": (C.c_int, [vp, C.c_int, dp]),

@@ -448,6 +448,9 @@ class DemEngine {
   // per-launch HIP-event timing of the fused sub-step kernel (bench.py roofline leg)
   void set_profiling(bool on);
   void get_profile(long long* launches, double* kernel_ms);
+  // neighbour rebuilds inside runs while profiling was on: how many, and their summed duration on the host clock, from
+  // the trigger read to the end of the last kernel of the rebuild (synchronised: only while profiling)
+  void get_rebuild_profile(long long* rebuilds, double* ms);
 
  private:
   void ensure_capacity(size_t need);
@@ -637,6 +640,8 @@ private:
   long long nsend_[2] = {0, 0};
   int recv_first_[2] = {0, 0}, recv_count_[2] = {0, 0};
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  long long prof_rebuilds_ = 0;
+  double prof_rebuild_ms_ = 0.0;
   hipEvent_t ev_flags_ = nullptr;   // "the flag words have reached the host" (bin_and_build)
   bool profiling_ = false;
   std::vector<hipEvent_t> prof_ev_;   // pairs (start, stop) of launches not yet harvested

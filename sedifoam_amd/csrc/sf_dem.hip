@@ -5,6 +5,7 @@
 #include "sf_dem.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -896,6 +897,8 @@ void DemEngine::set_profiling(bool on)
   profiling_ = on;
   prof_launches_ = 0;
   prof_ms_ = 0.0;
+  prof_rebuilds_ = 0;
+  prof_rebuild_ms_ = 0.0;
 }
 
 void DemEngine::harvest_profile(int last_step)
@@ -919,6 +922,12 @@ void DemEngine::get_profile(long long* launches, double* kernel_ms)
   prof_used_ = 0;
   *launches = prof_launches_;
   *kernel_ms = prof_ms_;
+}
+
+void DemEngine::get_rebuild_profile(long long* rebuilds, double* ms)
+{
+  *rebuilds = prof_rebuilds_;
+  *ms = prof_rebuild_ms_;
 }
 
 void DemEngine::launch_ghost_forward(int buf, int kstep, int phase, int trig_word, hipStream_t s)
@@ -1690,7 +1699,13 @@ void DemEngine::run(int nsteps)
       cur_ = (base + done) & 1;
       k = trig + 1;
       in_run_ = true;
+      const auto t_rb = std::chrono::steady_clock::now();   // (the stream is idle: read_flags above synchronised)
       rebuild();
+      if (profiling_) {
+        sync();
+        prof_rebuild_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rb).count();
+        prof_rebuilds_++;
+      }
       in_run_ = false;
       predict_.rebuilt(run_base_step_ + k);
     }

@@ -533,6 +533,13 @@ int sf_dem_get_profile(void* ptr, long long* launches, double* kernel_ms)
   SF_API_END(0)
 }
 
+int sf_dem_get_rebuild_profile(void* ptr, long long* rebuilds, double* ms)
+{
+  SF_API_BEGIN
+  H(ptr)->eng.get_rebuild_profile(rebuilds, ms);
+  SF_API_END(0)
+}
+
 int sf_dem_get_forces(void* ptr, double* f, double* torque, double* omega, int* tag)
 {
   SF_API_BEGIN

@@ -144,6 +144,12 @@ class Lammps:
         check(self.L.sf_dem_get_profile(self.ptr, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def get_rebuild_profile(self):
+        """(neighbour rebuilds inside runs while profiling was on, their summed host-clock milliseconds)"""
+        n = C.c_longlong(); ms = C.c_double()
+        check(self.L.sf_dem_get_rebuild_profile(self.ptr, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def get_state(self):
         """x, v, omega, f, torque of the owned atoms sorted by tag."""
         n = self.get_local_n()

@@ -50,7 +50,8 @@ What overlapping consecutive sub-steps could add, and why it was not built: `r03
 Neighbour rebuild (1 M grains): `k_build_neigh` {avg('k_build_neigh'):.0f} us on this lattice (candidate order kept, look-ups coalesced in
 the second sweep), 440-480 us on the loose bed where the touching neighbours are placed first; whole rebuild of the loose
 bed 1.02-1.12 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.18 before the
-last batch of the round, 1.37 at its start).  That batch, library against library on the same box
+last batch of the round, 1.37 at its start); on the host clock of an un-traced run, synchronised at both ends
+(`neighbor_rebuild_ms` of the bench line): {d['config'].get('neighbor_rebuild_ms', float('nan')):.2f} ms on the lattice, {f.get('neighbor_rebuild_ms', float('nan')):.2f} ms on the loose bed.  That batch, library against library on the same box
 (`tests/ab_rebuild.sh`, rocprofv3 per-kernel averages over the 34 rebuilds of a loose-bed run): every per-atom array
 re-ordered by ONE kernel (`k_permute_all` 60-69 us instead of 14 launches summing to ~115), periodic ghosts of two
 dimensions made without a host round trip in between, the host's look at the list counts overlapped with
