@@ -70,7 +70,7 @@ def test_cell_owner_bit_exact_1m():
 
 
 def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=50e-6, bed=None, mesh_n=(4, 5, 4),
-                  walls=None, cfg_extra=None, inlet=None):
+                  walls=None, cfg_extra=None, inlet=None, tol=None):
     """Coupled cloud + DEM, HIP vs oracle.  Default: a 1 792-grain bed on a 4x5x4 mesh (the small case every force
     switch runs on); BASELINE configs C2 (10 k grains, 32^3 mesh) and C3 (100 k grains, 50 sub-steps per CFD step)
     pass their own bed / mesh."""
@@ -139,6 +139,8 @@ def _coupled_case(drag_name, flags, sub_cycles=2, n_cfd=3, smooth=None, deltaT=5
     g0 = cloud.gamma()
     assert gamma.max() < 0.85   # alpha >= 1 would make every closure return inf (as in the reference)
     tol_s = 1e-9 if smooth else 1e-12      # two different CG solvers of the same system
+    if tol is not None:
+        tol_s = max(tol_s, tol)
     # Ue = (smoothed sum of Vol U) / (smoothed gamma): far from every grain both are round-off of the linear solve
     # (1e-17 and below, in the reference's PCG just as here), their ratio means nothing -- compare Ue where the smoothed
     # void fraction is a number (the unsmoothed case has exact zeros there and compares everywhere)
