@@ -262,11 +262,12 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
                          [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "hertz", True),
                           ((3, 1, 2), (9, 5, 8), "hertz", True), ((1, 1, 2), (6, 5, 8), "hertz", True),
                           ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False),
-                          ((2, 2, 2), (8, 8, 8), "loose", True), ((2, 2, 2), (20, 20, 20), "hertz", True)])
+                          ((2, 2, 2), (8, 8, 8), "loose", True), ((2, 2, 2), (20, 20, 20), "hertz", True),
+                          ((4, 1, 2), (12, 5, 8), "hertz", True)])
 def test_cxx_brick_driver_on_a_processor_grid(tmp_path, grid, ncells, physics, periodic_x):
     """The brick driver (sf_brick_init + sf_slab_setup / _step / _rebuild): a 3-D processor grid -- 2 x 1 x 2 and
     2 x 2 x 2 (BASELINE config C4's 8 GPUs; the y cut crosses the wall dimension, the end bricks have a face without a
-    neighbour), 3 x 1 x 2 (left and right neighbour differ), 1 x 1 x 2 (x keeps its images local), 2 x 2 x 1 with
+    neighbour), 4 x 1 x 2 (the grid `bench.py --gpus 8` picks for the headline bed), 3 x 1 x 2 (left and right neighbour differ), 1 x 1 x 2 (x keeps its images local), 2 x 2 x 1 with
     config C5's physics (cohesion + lubricate/poly: global particle volume and radius over the bricks), x between
     walls -- against the single-domain run: staged migration through faces, edges and corners, ghosts sent straight
     to the up to 26 neighbour bricks, one grouped exchange per sub-step, the rebuild vote in the chunk headers.  The
