@@ -19,7 +19,8 @@
  *     SyamlalOBrien, the drag assembly of enhancedCloud and the sub-cycling rule.
  *   "parity unpinned" (no golden vector, known-answer test or runnable build of the reference
  *   exists for them -- the reference needs LAMMPS + OpenFOAM headers that this image lacks):
- *     - gran/hertzFix/history, fix cohesive, pair lubricate/poly, ErgunWenYu.
+ *     - gran/hertzFix/history, fix cohesive, pair lubricate/poly, ErgunWenYu, the plain Hookean law
+ *       (gran/hooke [3P] and FixWallGranFix::hooke).
  *     These are restated line by line and checked by hand-derived known answers only.
  *
  * Layout convention: AoS like LAMMPS (double x[n][3] flattened to 3*n), int32 ids.
