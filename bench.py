@@ -334,9 +334,7 @@ def main():
         except Exception as ex:   # noqa: BLE001  (a side measurement: the headline above stands)
             side["weak_scaling"] = {"error": str(ex)[:300]}
     exchange_us[0], rebuild_ms[0] = main_exchange_us, main_rebuild_ms
-    if world > 1:
-        pass
-    elif world == 1 and args.slab_driver:
+    if world == 1 and args.slab_driver:
         lmp = make_driver("from_bed", bed)
         elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
     elif world == 1:
