@@ -640,6 +640,7 @@ private:
   long long nsend_[2] = {0, 0};
   int recv_first_[2] = {0, 0}, recv_count_[2] = {0, 0};
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  bool hist_clean_ = false;   // the cell histograms of cell_start_ are all zero (their users count them back down)
   long long prof_rebuilds_ = 0;
   double prof_rebuild_ms_ = 0.0;
   hipEvent_t ev_flags_ = nullptr;   // "the flag words have reached the host" (bin_and_build)

@@ -980,6 +980,7 @@ void DemEngine::compute_grid()
     if (cell_start_) SF_HIP(hipFree(cell_start_));
     cell_alloc_ = (size_t)grid_.nbins + grid_.nbins / 8 + 16;
     SF_HIP(hipMalloc(&cell_start_, sizeof(int) * 4 * cell_alloc_));
+    hist_clean_ = false;
   }
 }
 
@@ -1100,20 +1101,24 @@ void DemEngine::rebuild_sort()
     pb.wrap[k] = periodic_[k] && !ext_[k];
   }
   const int nb = div_up(nlocal_, 256);
-  k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
-                                      perm_.as<int>(), d_flags_);
-  // Plain keys (no tiles, no LDS staging): counting sort.  cell_start_ = [0] counts, then cursors | [1] first sorted
-  // position of every cell (owned) | [2] counts of the ghosts | [3] first position in the ghost order
+  // Plain keys (no tiles, no LDS staging): counting sort.  cell_start_ = [0] histogram of the owned atoms | [1] first
+  // sorted position of every cell (owned) | [2] histogram of the ghosts | [3] first position in the ghost order.  The
+  // histograms are counted back down to zero by the kernels that use them: cleared only when the table is new.
   row_tables_ = grid_.tile <= 1 && !opt_lds_;
+  int* count = row_tables_ ? cell_start_ : nullptr;
+  if (row_tables_ && !hist_clean_) {
+    SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * cell_alloc_, stream_));
+    SF_HIP(hipMemsetAsync(cell_start_ + 2 * cell_alloc_, 0, sizeof(int) * cell_alloc_, stream_));
+  }
+  hist_clean_ = false;   // (until the kernels below have run: an error in between leaves it dirty)
+  k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
+                                      perm_.as<int>(), d_flags_, count);
   if (row_tables_) {
     const int ne = grid_.nbins + 1;
-    int* count = cell_start_;
     int* first = cell_start_ + cell_alloc_;
-    SF_HIP(hipMemsetAsync(count, 0, sizeof(int) * ne, stream_));
-    k_key_count<unsigned><<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, 0, count);
     exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, first, ne, stream_);
-    SF_HIP(hipMemcpyAsync(count, first, sizeof(int) * ne, hipMemcpyDeviceToDevice, stream_));   // cursors
-    k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, perm_.as<int>());
+    k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, first, perm_.as<int>());
+    hist_clean_ = true;
     k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), tag_.as<int>(),
                                         perm_alt_.as<int>());
     permute_locals(perm_alt_.as<int>(), nlocal_, /*rows=*/false);
@@ -1126,6 +1131,7 @@ void DemEngine::rebuild_sort()
     permute_locals(perm_alt_.as<int>(), nlocal_);
     mark_frozen();
     // sorted bin keys -> cell ranges of owned atoms
+    hist_clean_ = false;
     SF_HIP(hipMemsetAsync(cell_start_, 0, sizeof(int) * 4 * cell_alloc_, stream_));
     k_cell_bounds<unsigned><<<nb, 256, 0, stream_>>>(keys_alt_.as<unsigned>(), nlocal_, 0, cell_start_,
                                                      cell_start_ + 1, 4);
@@ -1269,10 +1275,13 @@ void DemEngine::bin_and_build()
     if (row_tables_) {
       const int ne = grid_.nbins + 1;
       int* count = cell_start_ + 2 * cell_alloc_;
-      SF_HIP(hipMemsetAsync(count, 0, sizeof(int) * ne, stream_));
+      hist_clean_ = false;
       k_key_count<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-          keys64_alt_.as<unsigned long long>(), nghost_, 32, count);
+          keys64_alt_.as<unsigned long long>(), nghost_, 32, count, 1);
       exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, cell_start_ + 3 * cell_alloc_, ne, stream_);
+      k_key_count<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
+          keys64_alt_.as<unsigned long long>(), nghost_, 32, count, -1);   // (back to zero for the next rebuild)
+      hist_clean_ = true;
     } else {
       k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
           keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
@@ -1308,7 +1317,6 @@ void DemEngine::bin_and_build()
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
         have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), neigh_.as<int>(),
         numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
-    k_max_int<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(numneigh_old_.as<int>(), nlocal_, d_flags_ + F_MAXNEIGH);
     // the host looks at the counts (overflow, widest row) while the partner-slot pass below is already running: it
     // needs nothing but the list, and a list that overflowed -- rare -- is built again and the pass repeated
     SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));

@@ -984,8 +984,9 @@ __global__ __launch_bounds__(1024) void k_count_layers(const double4* xr, int nl
 }
 
 // [3P] Domain::pbc for owned atoms + bin key
+// (count: the counting sort's histogram, filled in the same pass; nullptr on the radix-sort path)
 __global__ __launch_bounds__(256) void k_pbc_keys(double4* xr, int nlocal, PbcParams pb, BinGrid g,
-                                                  unsigned* keys, int* perm, int* flags)
+                                                  unsigned* keys, int* perm, int* flags, int* count)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
@@ -1012,8 +1013,10 @@ __global__ __launch_bounds__(256) void k_pbc_keys(double4* xr, int nlocal, PbcPa
     xr[i] = x;
   }
   int lost = 0;
-  keys[i] = (unsigned)bin_of(x, g, lost);
+  const unsigned key = (unsigned)bin_of(x, g, lost);
+  keys[i] = key;
   perm[i] = i;
+  if (count) atomicAdd(&count[key], 1);
   if (lost) flags[F_LOST] = 1;
 }
 
@@ -1223,19 +1226,22 @@ struct BuildParams {
 
 // ---- counting sort of the owned atoms by cell key (plain keys): a by-product is first[b], the first sorted position
 // of EVERY cell b (with or without atoms), which the list build reads instead of per-cell ranges ----
+// (delta -1 after the scan has used the counts: the histogram is zero again for the next rebuild -- no 16 MB memset)
 template <class K>
-__global__ __launch_bounds__(256) void k_key_count(const K* keys, int n, int shift, int* count)
+__global__ __launch_bounds__(256) void k_key_count(const K* keys, int n, int shift, int* count, int delta)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  atomicAdd(&count[(int)(keys[i] >> shift)], 1);
+  atomicAdd(&count[(int)(keys[i] >> shift)], delta);
 }
-// slots inside a cell are handed out in arrival order ...
-__global__ __launch_bounds__(256) void k_key_place(const unsigned* keys, int n, int* cursor, int* arrival)
+// slots inside a cell are handed out in arrival order, counting the cell's histogram entry back down to zero (the
+// array needs no clearing before the next rebuild and no copy as a cursor) ...
+__global__ __launch_bounds__(256) void k_key_place(const unsigned* keys, int n, int* count, const int* first, int* arrival)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  arrival[atomicAdd(&cursor[keys[i]], 1)] = i;
+  const unsigned b = keys[i];
+  arrival[first[b] + atomicSub(&count[b], 1) - 1] = i;
 }
 // ... and then put into ascending TAG inside every cell (tags are unique): perm[new] = old.  The order of the owned
 // atoms -- like that of the ghosts, (cell, tag) -- then depends on nothing but the particles themselves: the same
@@ -1502,7 +1508,17 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     atomicMax(&flags[F_NEIGH_OVER], n);
     n = B.M;
   }
-  numneigh[i] = n;   // F_MAXNEIGH: k_max_int over numneigh afterwards (a same-address atomic per atom costs ~11 ns each)
+  numneigh[i] = n;
+  // F_MAXNEIGH: one atomic per wave (a same-address atomic costs ~11 ns at the memory side: per atom that would be
+  // 11 ms, per wave it is 0.17 ms spread over the kernel's 0.3-0.45 ms and behind other work)
+  int m = n;
+  const unsigned long long act = __ballot(1);   // (the last wave: lanes past the last atom have left)
+  const int lane = threadIdx.x & 63;
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(m, off, 64);
+    if ((act >> (lane ^ off)) & 1ull) m = max(m, o);
+  }
+  if (lane == __ffsll((long long)act) - 1) atomicMax(&flags[F_MAXNEIGH], m);
 }
 
 // ---- LDS staging tables: which atoms a tile's workgroup copies into LDS, bin by bin ----
