@@ -1120,7 +1120,7 @@ void DemEngine::rebuild_sort()
     k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, first, perm_.as<int>());
     hist_clean_ = true;
     k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), tag_.as<int>(),
-                                        perm_alt_.as<int>());
+                                        perm_alt_.as<int>(), 0);
     permute_locals(perm_alt_.as<int>(), nlocal_, /*rows=*/false);
     mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   } else {
@@ -1265,27 +1265,29 @@ void DemEngine::bin_and_build()
   int* cellLE = cell_start_ + 1;
   int* cellGS = cell_start_ + 2;
   int* cellGE = cell_start_ + 3;
-  if (nghost_) {
+  if (nghost_ && row_tables_) {
+    // ghosts in (cell, tag) order by the same counting sort as the owned atoms; its scan IS the table of first
+    // ghost-order positions per cell that the list build reads
+    const int ne = grid_.nbins + 1, ng = div_up(nghost_, 256);
+    int* count = cell_start_ + 2 * cell_alloc_;
+    int* first = cell_start_ + 3 * cell_alloc_;
+    hist_clean_ = false;
+    k_ghost_cells<<<ng, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, nghost_, grid_, keys_.as<unsigned>(), count,
+                                           d_flags_);
+    exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, first, ne, stream_);
+    k_key_place<<<ng, 256, 0, stream_>>>(keys_.as<unsigned>(), nghost_, count, first, perm_.as<int>());
+    k_key_rank<<<ng, 256, 0, stream_>>>(keys_.as<unsigned>(), nghost_, first, perm_.as<int>(), tag_.as<int>(),
+                                        perm_alt_.as<int>(), nlocal_);
+    hist_clean_ = true;
+  } else if (nghost_) {
     k_ghost_keys<<<div_up(nghost_, 256), 256, 0, stream_>>>(xr_[cur_].as<double4>(), tag_.as<int>(), nlocal_,
                                                             nghost_, grid_, keys64_.as<unsigned long long>(),
                                                             perm_.as<int>(), d_flags_);
     sort_pairs_u64(sort_tmp_, sort_tmp_bytes_, keys64_.as<unsigned long long>(),
                    keys64_alt_.as<unsigned long long>(), perm_.as<int>(), perm_alt_.as<int>(), nghost_, 64,
                    stream_);
-    if (row_tables_) {
-      const int ne = grid_.nbins + 1;
-      int* count = cell_start_ + 2 * cell_alloc_;
-      hist_clean_ = false;
-      k_key_count<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-          keys64_alt_.as<unsigned long long>(), nghost_, 32, count, 1);
-      exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, cell_start_ + 3 * cell_alloc_, ne, stream_);
-      k_key_count<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-          keys64_alt_.as<unsigned long long>(), nghost_, 32, count, -1);   // (back to zero for the next rebuild)
-      hist_clean_ = true;
-    } else {
-      k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
-          keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
-    }
+    k_cell_bounds<unsigned long long><<<div_up(nghost_, 256), 256, 0, stream_>>>(
+        keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
   }
   build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {

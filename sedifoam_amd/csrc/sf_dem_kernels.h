@@ -1246,17 +1246,38 @@ __global__ __launch_bounds__(256) void k_key_place(const unsigned* keys, int n, 
 // ... and then put into ascending TAG inside every cell (tags are unique): perm[new] = old.  The order of the owned
 // atoms -- like that of the ghosts, (cell, tag) -- then depends on nothing but the particles themselves: the same
 // system fed in another order, or arriving through another history of rebuilds, gives the same lists and the same bits.
+// (base: 0 for the owned atoms; nlocal for the ghosts, whose keys / arrival entries count from the first ghost.  Two
+// ghosts of one cell never carry the same tag -- images of an atom lie a box length apart -- the index breaks the tie
+// all the same.)
 __global__ __launch_bounds__(256) void k_key_rank(const unsigned* keys, int n, const int* first, const int* arrival,
-                                                  const int* tag, int* perm)
+                                                  const int* tag, int* perm, int base)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned b = keys[i];
   const int s = first[b], e = first[b + 1];
-  const int ti = tag[i];
+  const int ti = tag[base + i];
   int r = 0;
-  for (int k = s; k < e; k++) r += tag[arrival[k]] < ti ? 1 : 0;
-  perm[s + r] = i;
+  for (int k = s; k < e; k++) {
+    const int a = arrival[k], ta = tag[base + a];
+    r += (ta < ti || (ta == ti && a < i)) ? 1 : 0;
+  }
+  perm[s + r] = base + i;
+}
+
+// counting sort of the ghosts by cell (row path): cell of every ghost + the histogram the scan turns into the first
+// ghost-order position of every cell, which the list build needs anyway -- k_key_place / k_key_rank then order the
+// ghosts by (cell, tag) like the owned atoms, instead of a 64-bit radix sort (7 launches) of (cell, tag) keys
+__global__ __launch_bounds__(256) void k_ghost_cells(const double4* xr, int nlocal, int nghost, BinGrid g,
+                                                     unsigned* keys, int* count, int* flags)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nghost) return;
+  int lost = 0;
+  const unsigned b = (unsigned)bin_of(xr[nlocal + k], g, lost);
+  keys[k] = b;
+  atomicAdd(&count[b], 1);
+  if (lost) flags[F_LOST] = 1;
 }
 
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear

@@ -49,7 +49,7 @@ What overlapping consecutive sub-steps could add, and why it was not built: `r03
 
 Neighbour rebuild (1 M grains): `k_build_neigh` {avg('k_build_neigh'):.0f} us on this lattice (candidate order kept, look-ups coalesced in
 the second sweep), 440-480 us on the loose bed where the touching neighbours are placed first; whole rebuild of the loose
-bed 1.02-1.12 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.18 before the
+bed 0.98-1.12 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.18 before the
 last batch of the round, 1.37 at its start); on the host clock of an un-traced run, synchronised at both ends
 (`neighbor_rebuild_ms` of the bench line): {d['config'].get('neighbor_rebuild_ms', float('nan')):.2f} ms on the lattice, {f.get('neighbor_rebuild_ms', float('nan')):.2f} ms on the loose bed.  That batch, library against library on the same box
 (`tests/ab_rebuild.sh`, rocprofv3 per-kernel averages over the 34 rebuilds of a loose-bed run): every per-atom array
@@ -58,6 +58,10 @@ dimensions made without a host round trip in between, the host's look at the lis
 `k_back_slots`, history of non-touching slots no longer zero-filled, candidate walk rewritten (unconditional 16-byte
 record loads, running row keys and scratch pointer: 270 -> 128 instructions per four candidates) and given the XCD-
 contiguous block order of the sub-step kernel: `k_build_neigh` 505-524 -> 437-465 us, loose-bed throughput +5-7 %.
+After that, on the un-traced host clock (same box, library against library): the cell histograms counted back to zero
+by the kernels that use them (no 16 MB memsets, no cursor copy), the owned histogram filled by `k_pbc_keys`, the
+widest row found inside the list build (0.953 -> 0.927 ms), and the ghosts ordered by the same counting sort as the
+owned atoms, sharing its scan with the list build's ghost table, instead of a 64-bit radix sort (0.923 -> 0.877 ms).
 Measured and dropped: the old-list look-up inside the walk against after it (equal), the walk as its own kernel at
 5 / 6 / 8 waves per SIMD (249 / 243 / 234 us against ~238 inside the fused kernel: not latency-bound), cells of the full
 cutoff instead of half (`SF_SUB=1`: walk 228 -> 184 us on the loose bed, but the sub-step kernel 191 -> 330 us on the
