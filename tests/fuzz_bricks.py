@@ -1,0 +1,36 @@
+"""Random processor grids and beds through tests/test_halo_gpu.py::test_cxx_brick_driver_on_a_processor_grid (C++ brick
+driver over the stand-in wire against the single-domain run); development helper, GPU box.
+usage: python tests/fuzz_bricks.py [seed] [cases]   (42 cases run on the final code of round 3, none failing)"""
+import os, sys, tempfile, pathlib, traceback
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import test_halo_gpu as th
+
+
+def main():
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    grids = [(2, 1, 1), (3, 1, 1), (2, 1, 2), (1, 1, 2), (1, 1, 3), (2, 2, 1), (1, 2, 1), (2, 2, 2), (3, 1, 2), (4, 1, 1), (2, 1, 3)]
+    bad = 0
+    for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
+        g = grids[int(rng.integers(len(grids)))]
+        # every brick at least 3 lattice cells (4 d) wide along a cut dimension
+        nc = tuple(int(g[d] * rng.integers(3, 6)) if g[d] > 1 else int(rng.integers(4, 8)) for d in range(3))
+        physics = str(rng.choice(["hertz", "hertz", "loose", "c5"]))
+        if physics == "c5" and g[1] > 1:
+            physics = "hertz"
+        px = bool(rng.random() < 0.8) or physics != "hertz"
+        c = (g, nc, physics, px)
+        with tempfile.TemporaryDirectory() as d:
+            try:
+                th.test_cxx_brick_driver_on_a_processor_grid(pathlib.Path(d), *c)
+                print("ok", c, flush=True)
+            except Exception as ex:
+                bad += 1
+                print("FAILED", c, str(ex)[:300], flush=True)
+                traceback.print_exc(limit=4)
+    print(bad, "failed")
+
+
+if __name__ == "__main__":
+    main()
