@@ -978,7 +978,7 @@ void DemEngine::compute_grid()
   }
   if ((size_t)grid_.nbins > cell_alloc_) {
     if (cell_start_) SF_HIP(hipFree(cell_start_));
-    cell_alloc_ = (size_t)grid_.nbins + grid_.nbins / 8 + 16;
+    cell_alloc_ = ((size_t)grid_.nbins + grid_.nbins / 8 + 16 + 3) & ~(size_t)3;   // (the four tables stay 16-byte aligned)
     SF_HIP(hipMalloc(&cell_start_, sizeof(int) * 4 * cell_alloc_));
     hist_clean_ = false;
   }

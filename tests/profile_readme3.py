@@ -61,7 +61,8 @@ contiguous block order of the sub-step kernel: `k_build_neigh` 505-524 -> 437-46
 After that, on the un-traced host clock (same box, library against library): the cell histograms counted back to zero
 by the kernels that use them (no 16 MB memsets, no cursor copy), the owned histogram filled by `k_pbc_keys`, the
 widest row found inside the list build (0.953 -> 0.927 ms), and the ghosts ordered by the same counting sort as the
-owned atoms, sharing its scan with the list build's ghost table, instead of a 64-bit radix sort (0.923 -> 0.877 ms).
+owned atoms, sharing its scan with the list build's ghost table, instead of a 64-bit radix sort (0.923 -> 0.877 ms); the two scans over the 4 M cell histograms by a three-launch
+tile scan instead of rocPRIM's (0.893 -> 0.868 ms).
 Measured and dropped: the old-list look-up inside the walk against after it (equal), the walk as its own kernel at
 5 / 6 / 8 waves per SIMD (249 / 243 / 234 us against ~238 inside the fused kernel: not latency-bound), cells of the full
 cutoff instead of half (`SF_SUB=1`: walk 228 -> 184 us on the loose bed, but the sub-step kernel 191 -> 330 us on the
