@@ -1291,7 +1291,7 @@ void DemEngine::bin_and_build()
   }
   build_stage_tables();
   for (int attempt = 0; attempt < 3; attempt++) {
-    set_flags3(F_NEIGH_OVER, 0, F_MAXNEIGH, 0, F_MAXNEIGH, 0);
+    set_flags3(F_NEIGH_OVER, 0, F_MAXNEIGH, 0, F_MAXNEIGH, 0);   // (two flags: the third pair repeats the second)
     BuildParams B;
     B.nlocal = nlocal_;
     B.M = M_;
