@@ -1344,7 +1344,9 @@ void DemEngine::bin_and_build()
   // the new list's history was built into shear_[hist_buf_ ^ 1]: that buffer is the one the next sub-step reads
   if ((hist_buf_ ^ 1) != cur_) std::swap(shear_[0].ptr, shear_[1].ptr);
   hist_indirect_ = false;   // the old rows are gone with the old list
-  measure_list();
+  // (the statistics steer slow choices behind hysteresis -- history copies, slot order, cache policy: the first lists
+  // and then every fourth one are measured; the counters keep their last values in between)
+  if (nbuilds_ < 4 || (nbuilds_ & 3) == 0) measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
   nbuilds_++;
