@@ -227,6 +227,13 @@ struct RebuildPredictor {
   long long last = 0;      // absolute sub-step index of the last rebuild
   double interval = 0.0;   // sub-steps between rebuilds (mean of the last two estimates); 0: no history yet
   bool on = true;
+  // Queue THROUGH the predicted trigger instead of stopping short of it.  On a large single domain a sub-step queued
+  // behind a trigger is one early-exit launch (~5 us) while every piece ends in a host read (~25 us of idle GPU): a hot
+  // bed that rebuilds every ~10 sub-steps paid two or three reads per rebuild for stopping short and creeping up in
+  // small pieces.  Not on small systems, where an early-exit launch costs a whole launch period (10 k grains: -5 %),
+  // not on a decomposed domain, where the sub-step behind a trigger still runs its halo exchange, and not when rebuilds
+  // are rare (interval > 32: the pieces around the trigger are 16 long, as dear as the reads they would save).
+  bool overshoot = false;
   void rebuilt(long long step)
   {
     if (step > last) {
@@ -247,6 +254,8 @@ struct RebuildPredictor {
     const double left = interval - (double)(step - last);   // predicted sub-steps until the trigger
     int c;
     if (left >= (double)(remaining + small)) c = remaining;           // not expected within this run
+    else if (overshoot && interval <= 32.0 && left >= -(double)small)
+      c = (int)(left > 0.0 ? left : 0.0) + small;                     // hot bed: run through it
     else if (left > 2.0 * small) c = (int)left - small;               // stop short of it
     else if (left >= -(double)small) c = small;                       // around it: small pieces
     else c = (int)(-left / 2.0) > small ? (int)(-left / 2.0) : small; // overdue (the bed calmed down): lengthen again

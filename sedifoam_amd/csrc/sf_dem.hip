@@ -1670,6 +1670,7 @@ void DemEngine::run(int nsteps)
     const int base = cur_;
     prof_used_ = 0;
     // queue up to where the next rebuild is expected (RebuildPredictor), not blindly to the end of the run
+    predict_.overshoot = nlocal_ >= 200000 && !(getenv("SF_QUEUE_OVERSHOOT") && !atoi(getenv("SF_QUEUE_OVERSHOOT")));
     const int end = k + predict_.chunk(run_base_step_ + k, nsteps - k);
 #if SF_EXP_PERSIST_NOWAIT
     static const int pn = getenv("SF_PERSIST_NOWAIT") ? atoi(getenv("SF_PERSIST_NOWAIT")) : 0;

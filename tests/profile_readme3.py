@@ -49,7 +49,7 @@ What overlapping consecutive sub-steps could add, and why it was not built: `r03
 
 Neighbour rebuild (1 M grains): `k_build_neigh` {avg('k_build_neigh'):.0f} us on this lattice (candidate order kept, look-ups coalesced in
 the second sweep), 440-480 us on the loose bed where the touching neighbours are placed first; whole rebuild of the loose
-bed 0.98-1.12 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.18 before the
+bed 0.95-1.12 ms from the last sub-step before to the first after (`{tag}_rebuild_trace_fluidised.txt`; 1.18 before the
 last batch of the round, 1.37 at its start); on the host clock of an un-traced run, synchronised at both ends
 (`neighbor_rebuild_ms` of the bench line): {d['config'].get('neighbor_rebuild_ms', float('nan')):.2f} ms on the lattice, {f.get('neighbor_rebuild_ms', float('nan')):.2f} ms on the loose bed.  That batch, library against library on the same box
 (`tests/ab_rebuild.sh`, rocprofv3 per-kernel averages over the 34 rebuilds of a loose-bed run): every per-atom array
@@ -62,7 +62,9 @@ After that, on the un-traced host clock (same box, library against library): the
 by the kernels that use them (no 16 MB memsets, no cursor copy), the owned histogram filled by `k_pbc_keys`, the
 widest row found inside the list build (0.953 -> 0.927 ms), and the ghosts ordered by the same counting sort as the
 owned atoms, sharing its scan with the list build's ghost table, instead of a 64-bit radix sort (0.923 -> 0.877 ms); the two scans over the 4 M cell histograms by a three-launch
-tile scan instead of rocPRIM's (0.893 -> 0.868 ms).
+tile scan instead of rocPRIM's (0.893 -> 0.868 ms); list statistics on the first lists and every fourth one after
+(-25 us); hot beds (a rebuild at least every 32 sub-steps, >= 200 k grains, single domain) queue through the predicted
+trigger instead of stopping short of it: one host read per rebuild instead of two or three (+0.6-1 % at 1 M, +4.7 % at 300 k).
 Measured and dropped: the old-list look-up inside the walk against after it (equal), the walk as its own kernel at
 5 / 6 / 8 waves per SIMD (249 / 243 / 234 us against ~238 inside the fused kernel: not latency-bound), cells of the full
 cutoff instead of half (`SF_SUB=1`: walk 228 -> 184 us on the loose bed, but the sub-step kernel 191 -> 330 us on the
