@@ -77,11 +77,37 @@ class LAMMPS {
  public:
   Input* input;      /* lmp_->input->one(line), softParticleCloud.C:106 */
   void* sf_handle;   /* the engine behind it (sf_lammps_* handle) */
+#ifdef MPI_VERSION
+  MPI_Comm world;    /* [3P] LAMMPS::world, the communicator the object lives on (library.cpp:84 MPI_Barrier) */
+#endif
 
+  /* `mpirun -np N lammpsFoam -parallel`: the object is created on a duplicate of the world communicator
+   * (softParticleCloud.C:60-62) and LAMMPS decomposes itself over its N ranks.  The engine library links no MPI;
+   * the three things it needs from the application's MPI happen HERE, with the application's own mpi.h: this
+   * rank, the number of ranks, and the broadcast of rank 0's RCCL communicator id.  Everything after that (the
+   * bricks of `processors px py pz`, the ghost halo, the collective counts of library.cpp:94-131) runs inside the
+   * library over RCCL. */
   template <class Comm>
   LAMMPS(int narg, char** arg, Comm communicator) : input(NULL), sf_handle(NULL)
   {
-    if (sf_lammps_open(narg, arg, sedifoam_shim::comm_handle(communicator), &sf_handle) != 0 || !sf_handle)
+    int rank = 0, size = 1;
+    char id[128];
+    std::memset(id, 0, sizeof id);
+#ifdef MPI_VERSION
+    world = communicator;
+    int mpi_up = 0;
+    MPI_Initialized(&mpi_up);
+    if (mpi_up) {
+      MPI_Comm_rank(communicator, &rank);
+      MPI_Comm_size(communicator, &size);
+      if (size > 1) {
+        if (rank == 0 && sf_dem_comm_unique_id(id) != 0) sedifoam_shim::die("LAMMPS::LAMMPS (RCCL id)");
+        MPI_Bcast(id, 128, MPI_CHAR, 0, communicator);
+      }
+    }
+#endif
+    if (sf_lammps_open_world(narg, arg, sedifoam_shim::comm_handle(communicator), rank, size, id, &sf_handle) != 0 ||
+        !sf_handle)
       sedifoam_shim::die("LAMMPS::LAMMPS");
     input = new Input(sf_handle);
   }
@@ -114,7 +140,15 @@ inline void lammps_file(void* ptr, char* str)
   if (sf_lammps_file(sedifoam_shim::h(ptr), str) != 0) sedifoam_shim::die("lammps_file");
 }
 inline char* lammps_command(void* ptr, char* str) { return static_cast<LAMMPS_NS::LAMMPS*>(ptr)->input->one(str); }
-inline void lammps_sync(void* ptr) { sf_lammps_sync(sedifoam_shim::h(ptr)); }
+inline void lammps_sync(void* ptr)   /* library.cpp:80-85: MPI_Barrier(lammps->world) */
+{
+  sf_lammps_sync(sedifoam_shim::h(ptr));
+#ifdef MPI_VERSION
+  int mpi_up = 0;
+  MPI_Initialized(&mpi_up);
+  if (mpi_up) MPI_Barrier(static_cast<LAMMPS_NS::LAMMPS*>(ptr)->world);
+#endif
+}
 inline int lammps_get_global_n(void* ptr) { return sf_lammps_get_global_n(sedifoam_shim::h(ptr)); }
 inline void lammps_get_initial_np(void* ptr, int* np_) { sf_lammps_get_initial_np(sedifoam_shim::h(ptr), np_); }
 inline void lammps_get_initial_info(void* ptr, double* coords, double* velos, double* diam, double* rho_, int* tag_,

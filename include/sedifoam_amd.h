@@ -45,6 +45,16 @@ const char *sf_version(void);
 /* library.h:29 lammps_open(int, char**, MPI_Comm, void**): `comm` is carried opaquely (this
  * library needs no MPI: one engine per process, ranks are wired up by sf_dem_* below). */
 int sf_lammps_open(int argc, char **argv, intptr_t comm, void **ptr);
+/* The same on rank `rank` of `world` ranks: what `new LAMMPS(0, NULL, commLammps)` is when lammpsFoam runs
+ * `mpirun -np N lammpsFoam -parallel` (lammpsFoam/softParticleCloud.C:60-62).  The library links no MPI, so the
+ * caller -- include/lammps_shim/sedifoam_lammps_shim.h does it with the application's own mpi.h -- passes its rank,
+ * the size and a 128-byte communicator id (sf_dem_comm_unique_id on rank 0, MPI_Bcast).  With world > 1 the engine
+ * decomposes itself as LAMMPS does: `processors px py pz` (default: the grid of least surface area, [3P]
+ * ProcMap::onelevel_grid) cuts the box into bricks when read_data creates it, every rank keeps the atoms of its
+ * brick, and sf_lammps_step / _get_global_n / _get_initial_np / _create_particle / _delete_particle become
+ * collective exactly where interfaceToLammps/library.cpp:94-131,372-386,470-473 is.  One process per GPU: the device
+ * is rank % (visible devices) unless SF_DEVICE names one. */
+int sf_lammps_open_world(int argc, char **argv, intptr_t comm, int rank, int world, const char *id128, void **ptr);
 /* library.h:30 */
 int sf_lammps_close(void *ptr);
 /* library.h:31  run every line of an input script (library.cpp:63-67) */
@@ -245,7 +255,15 @@ int sf_brick_pattern(int rank, int px, int py, int pz, const int *periodic, int 
 int sf_slab_setup(void *ptr);
 int sf_slab_rebuild(void *ptr);
 int sf_slab_step(void *ptr, int n);
+/* 1 when sf_slab_init / sf_brick_init has made this engine one domain of a decomposed run: sf_lammps_step(ptr, n)
+ * and the `run` command then ARE sf_slab_step(ptr, n) (interfaceToLammps/library.cpp:372-386 is the same call on
+ * one rank and on N) */
+int sf_slab_active(void *ptr);
 long long sf_slab_rebuild_count(void *ptr);
+/* values[0..n) summed over the ranks of the engine's communicator, in place on the host (MPI_Allreduce(MPI_SUM) of
+ * interfaceToLammps/library.cpp:112-131,470-473; counts stay exact below 2^53).  Collective; after sf_slab_init /
+ * sf_brick_init. */
+int sf_slab_allreduce_sum(void *ptr, double *values, int n);
 /* the communicator behind this engine: ranks as RCCL counts them (ncclCommCount), ncclGetVersion, and the shared
  * object the nccl* symbols were loaded from */
 int sf_slab_comm_info(void *ptr, int *comm_ranks, int *rccl_version, char *lib_path, int lib_path_len);

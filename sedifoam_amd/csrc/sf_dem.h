@@ -340,6 +340,22 @@ class DemEngine {
   void rebuild_sort();
   void rebuild_finish();
   void set_in_run(bool on) { in_run_ = on; }   // the driver's stepping loop brackets its rebuilds with it
+  // ... through this guard: a rebuild that throws (lost atoms, list overflow, an RCCL error) must not leave the engine
+  // marked "inside a run" -- later out-of-run rebuilds would skip the force / torque permutation
+  struct InRunGuard {
+    explicit InRunGuard(DemEngine& e) : e_(&e) { e.in_run_ = true; }
+    ~InRunGuard() { release(); }
+    void release()
+    {
+      if (e_) e_->in_run_ = false;
+      e_ = nullptr;
+    }
+    InRunGuard(const InRunGuard&) = delete;
+    InRunGuard& operator=(const InRunGuard&) = delete;
+
+   private:
+    DemEngine* e_;
+  };
 
   // ---- data exchange ----
   int nlocal() const { return nlocal_; }
@@ -578,6 +594,7 @@ private:
   RebuildPredictor predict_;                 // single-domain run(): how far to queue (SF_QUEUE_PREDICT=0: everything)
   int nt_policy_ = 2, nt_policy_env_ = -1;   // non-temporal policy of the row streams (sf_dem_kernels.h, NTP)
   void measure_list();     // queue k_partner_coalescing on the current list (results with the next flag read)
+  bool list_stats_near_a_threshold() const;
   long long list_sampled_ = 0;   // atoms the last measure_list looked at
   void choose_kernel();    // pick touch_prefetch_ from the last measurement
   DevArray nloc_;                      // [M][cap] uint16 (see DemPtrs::nloc)

@@ -123,6 +123,7 @@ DemEngine::~DemEngine()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevArray* a : per_atom_) a->release();
+  bslot_.release();   // (not in per_atom_: allocated by the first brick rebuild, re-allocated when the capacity moves)
   if (cell_start_) (void)hipFree(cell_start_);
   if (tile_tab_) (void)hipFree(tile_tab_);
   if (bsend_list_) (void)hipFree(bsend_list_);
@@ -811,6 +812,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   if (tx_ready_ && mode == 0 && !lds_active_) S.tx_nhdr = tx_nhdr_;
   if (tx_ready_ && brick_ && mode == 0 && part == 0 && !lds_active_) {
     S.tx_fused = 2;
+    if (bslot_.cap != cap_) fail("launch_substep: the record-slot table has stride %zu, the engine %zu", bslot_.cap, cap_);
     const double cut = cutneighmax() + skin_;   // (an atom is within skin/2 of where the send lists were made)
     for (int k = 0; k < 3; k++) {
       S.tx_lo3[k] = ext_[k] ? sublo_[k] + cut : -1.0e300;
@@ -1344,12 +1346,32 @@ void DemEngine::bin_and_build()
   // the new list's history was built into shear_[hist_buf_ ^ 1]: that buffer is the one the next sub-step reads
   if ((hist_buf_ ^ 1) != cur_) std::swap(shear_[0].ptr, shear_[1].ptr);
   hist_indirect_ = false;   // the old rows are gone with the old list
-  // (the statistics steer slow choices behind hysteresis -- history copies, slot order, cache policy: the first lists
-  // and then every fourth one are measured; the counters keep their last values in between)
-  if (nbuilds_ < 4 || (nbuilds_ & 3) == 0) measure_list();
+  // (the statistics steer slow choices behind hysteresis -- history copies, slot order, v / omega prefetch, cache
+  // policy.  A list is measured whenever the last measured fractions lie within 0.08 of a band a decision switches
+  // on -- so the decisions are those of measuring EVERY list as long as a fraction does not jump a whole margin
+  // between two lists, whatever the count or the chunking of the rebuilds -- and otherwise on the first lists and
+  // every fourth one, which only refreshes numbers no decision is near; the counters keep their values in between)
+  if (nbuilds_ < 4 || (nbuilds_ & 3) == 0 || list_stats_near_a_threshold()) measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
   nbuilds_++;
+}
+
+// true when a decision taken from the list statistics could change with the next measurement: a fraction within
+// 0.08 of the hysteresis band of the history copies (0.45 / 0.60), the slot order (0.40 / 0.50) or the v, omega
+// prefetch (0.70 / 0.85)
+bool DemEngine::list_stats_near_a_threshold() const
+{
+  const double m = 0.08;
+  if (h_flags_[F_PART_SLOTS] > 0) {
+    const double c = (double)h_flags_[F_PART_COAL] / (double)h_flags_[F_PART_SLOTS];
+    if (c > 0.45 - m && c < 0.60 + m) return true;
+  }
+  if (h_flags_[F_LIST_SLOTS] > 0) {
+    const double t = (double)h_flags_[F_LIST_TOUCH] / (double)h_flags_[F_LIST_SLOTS];
+    if ((t > 0.40 - m && t < 0.50 + m) || (t > 0.70 - m && t < 0.85 + m)) return true;
+  }
+  return false;
 }
 
 // List statistics that pick the kernel variant and the history layout (read back with the flags at the next
@@ -1658,7 +1680,8 @@ void DemEngine::run(int nsteps)
 {
   if (!setup_done_) setup();
   if (nsteps <= 0) return;
-  if (have_subdomain_) fail("sf_lammps_step on a decomposed domain: drive the sub-steps through sf_dem_*");
+  // (an engine the SCRIPT decomposed never gets here: sf_lammps_step routes it to sf_slab_step, sf_lammps_api.hip)
+  if (have_subdomain_) fail("DemEngine::run on a sub-domain set by sf_dem_set_subdomain / sf_slab_init / sf_brick_init: step it with sf_slab_step (or the sf_dem_* pieces)");
   run_base_step_ = nsteps_;
   choose_kernel();
   reset_flag(F_TRIGGER, INT_MAX);
@@ -1711,7 +1734,7 @@ void DemEngine::run(int nsteps)
       const int done = trig + 1 - k;
       cur_ = (base + done) & 1;
       k = trig + 1;
-      in_run_ = true;
+      InRunGuard guard(*this);   // (a rebuild that throws must not leave the engine marked "inside a run")
       const auto t_rb = std::chrono::steady_clock::now();   // (the stream is idle: read_flags above synchronised)
       rebuild();
       if (profiling_) {
@@ -1719,7 +1742,7 @@ void DemEngine::run(int nsteps)
         prof_rebuild_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rb).count();
         prof_rebuilds_++;
       }
-      in_run_ = false;
+      guard.release();
       predict_.rebuilt(run_base_step_ + k);
     }
   }

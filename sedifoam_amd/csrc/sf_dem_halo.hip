@@ -570,9 +570,12 @@ long long DemEngine::migrate_pack_dim(int dim, int side, double xshift, double* 
   }
   migrate_leavers_ += n;
   read_flags();
-  if (h_flags_[F_MIG_TRUNC])
+  if (h_flags_[F_MIG_TRUNC]) {
+    const int listed = h_flags_[F_MIG_TRUNC];
+    reset_flag(F_MIG_TRUNC, 0);   // (not sticky: the caller may widen the record and try again)
     fail("migrate_pack: an atom lists %d neighbours but the migrate record carries %d history slots (call "
-         "sf_dem_migrate_set_slots with the maximum of max_neigh_used over ALL ranks)", h_flags_[F_MIG_TRUNC], mrec_);
+         "sf_dem_migrate_set_slots with the maximum of max_neigh_used over ALL ranks)", listed, mrec_);
+  }
   return (long long)n * rec;
 }
 
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(256) void k_brick_slots(const int* list, DemEngine:
   if (k >= blk.first[blk.n]) return;
   const int q = block_of(blk, k);
   const int i = list[k];
-  const int s = atomicAdd(&cursor[i], 1);
+  const int s = atomicAdd(&cursor[i], 1);   // (< kBrickSlots: brick_set_forward_tx refuses thinner bricks)
   if (s < kBrickSlots) slots[(size_t)s * cap + i] = (int)(blk.off[q] + (long long)(k - blk.first[q]) * kForwardDoubles);
 }
 
@@ -768,7 +771,14 @@ void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, co
   static const bool off = getenv("SF_HALO_FUSED_PACK") && !atoi(getenv("SF_HALO_FUSED_PACK"));
   tx_ready_ = tx_written_ = false;
   if (off || !nlocal_) return;
-  if (bslot_.cap < cap_) bslot_.alloc(sizeof(int), kBrickSlots + 1, cap_, stream_);
+  // A brick thinner than twice the ghost cutoff in an external dimension has atoms that are ghosts of BOTH neighbours
+  // along it: three choices in that dimension instead of two, up to 3 * 2 * 2 - 1 = 11 (17, 26) send directions per
+  // atom -- more than the kBrickSlots = 7 records the sub-step kernel writes itself.  Such a rank keeps the stand-alone
+  // pack kernel in front of every exchange (same send buffer; the neighbours cannot tell).
+  const double cut = cutneighmax();
+  for (int d = 0; d < 3; d++)
+    if (ext_[d] && subhi_[d] - sublo_[d] < 2.0 * cut) return;
+  if (bslot_.cap != cap_) bslot_.alloc(sizeof(int), kBrickSlots + 1, cap_, stream_);   // (row stride = P.cap)
   SF_HIP(hipMemsetAsync(bslot_.ptr, 0xFF, sizeof(int) * kBrickSlots * bslot_.cap, stream_));
   int* cursor = bslot_.as<int>() + (size_t)kBrickSlots * bslot_.cap;
   SF_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * bslot_.cap, stream_));

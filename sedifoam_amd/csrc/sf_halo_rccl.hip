@@ -457,9 +457,10 @@ static void slab_step(SfLammps& S, HaloComm& hc, int n)
     }
     k = trig + 1;   // sub-steps k..trig ran (trig = -1: the list was stale for sub-step 0)
     hc.pre_exchanged = false;
-    e.set_in_run(true);
-    slab_rebuild(S, hc);
-    e.set_in_run(false);
+    {
+      DemEngine::InRunGuard guard(e);
+      slab_rebuild(S, hc);
+    }
     hc.predict.rebuilt(e.nsteps());
     if (e.overlap()) e.overlap_begin();
   }
@@ -859,9 +860,10 @@ static void brick_step(SfLammps& S, HaloComm& hc, int n)
     }
     k = trig + 1;
     hc.pre_exchanged = false;
-    e.set_in_run(true);
-    brick_rebuild(S, hc);
-    e.set_in_run(false);
+    {
+      DemEngine::InRunGuard guard(e);
+      brick_rebuild(S, hc);
+    }
     hc.predict.rebuilt(e.nsteps());
   }
 }
@@ -1286,6 +1288,33 @@ int sf_slab_comm_info(void* ptr, int* comm_ranks, int* rccl_version, char* lib_p
   if (comm_ranks) *comm_ranks = n;
   if (rccl_version) *rccl_version = v;
   if (lib_path && lib_path_len > 0) snprintf(lib_path, (size_t)lib_path_len, "%s", a.path);
+  SF_API_END(0)
+}
+
+int sf_slab_active(void* ptr)
+{
+  SF_API_BEGIN
+  auto* hc = static_cast<sf::HaloComm*>(H(ptr)->halo);
+  const int on = hc && hc->slab ? 1 : 0;
+  SF_API_END(on)
+}
+
+int sf_slab_allreduce_sum(void* ptr, double* values, int n)
+{
+  SF_API_BEGIN
+  SfLammps* L = H(ptr);
+  auto* hc = static_cast<sf::HaloComm*>(L->halo);
+  if (!hc || !hc->comm) sf::fail("sf_slab_allreduce_sum: no communicator (sf_slab_init / sf_brick_init first)");
+  if (n < 0 || (n && !values)) sf::fail("sf_slab_allreduce_sum: bad arguments");
+  if (hc->world > 1 && n > 0) {
+    hipStream_t st = L->eng.stream();
+    sf::GrowBuf buf;
+    double* d = buf.need(2 * (size_t)n);
+    SF_HIP(hipMemcpyAsync(d, values, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    SF_NCCL(sf::rccl().AllReduce(d, d + n, (size_t)n, ncclDouble, ncclSum, hc->comm, st));
+    SF_HIP(hipMemcpyAsync(values, d + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+  }
   SF_API_END(0)
 }
 

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -47,6 +48,100 @@ int inum(const std::string& s)
   return (int)v;
 }
 
+// [3P] LAMMPS 1Feb14 ProcMap::onelevel_grid -> factor / cull_user / best_factors: of all px py pz with product N that
+// agree with the non-`*` entries of the `processors` command, the one with the least sub-domain surface
+//   xprd yprd / (px py) + xprd zprd / (px pz) + yprd zprd / (py pz);
+// factorisations are visited with px slowest and the first strictly smaller surface wins.
+void choose_procgrid(const SfLammps& L, int P[3])
+{
+  double lo[3], hi[3];
+  int per[3];
+  L.eng.box(lo, hi, per);
+  const double xprd = hi[0] - lo[0], yprd = hi[1] - lo[1], zprd = hi[2] - lo[2];
+  const double area[3] = {xprd * yprd, xprd * zprd, yprd * zprd};
+  const int n = L.world_size;
+  double best = 2.0 * (area[0] + area[1] + area[2]);
+  P[0] = P[1] = P[2] = 0;
+  for (int i = 1; i <= n; i++) {
+    if (n % i) continue;
+    const int nyz = n / i;
+    for (int j = 1; j <= nyz; j++) {
+      if (nyz % j) continue;
+      const int k = nyz / j;
+      if ((L.procgrid[0] && L.procgrid[0] != i) || (L.procgrid[1] && L.procgrid[1] != j) ||
+          (L.procgrid[2] && L.procgrid[2] != k))
+        continue;
+      const double surf = area[0] / i / j + area[1] / i / k + area[2] / j / k;
+      if (surf < best) {
+        best = surf;
+        P[0] = i; P[1] = j; P[2] = k;
+      }
+    }
+  }
+  if (!P[0]) sf::fail("Bad grid of processors");   // [3P] the text of Comm::set_proc_grid
+}
+
+// the processor grid exists once the box does ([3P] read_data / create_box call Comm::set_proc_grid): one brick per rank
+void decompose(SfLammps& L)
+{
+  if (L.world_size <= 1 || L.decomposed) return;
+  if (L.halo) sf::fail("the engine was decomposed by sf_slab_init / sf_brick_init before the script created its box");
+  int P[3];
+  choose_procgrid(L, P);
+  if (sf_brick_init(&L, L.comm_id, L.world_rank, L.world_size, P[0], P[1], P[2]) != 0)
+    sf::fail("%s", sf::last_error().c_str());
+  L.procgrid[0] = P[0]; L.procgrid[1] = P[1]; L.procgrid[2] = P[2];
+  L.decomposed = true;
+}
+
+// rank that owns a point: brick (cx, cy, cz) with the bounds sf_brick_init computes, lo + c w (the last one ends at the
+// box face); a point outside the box in a wall dimension belongs to the end brick, a periodic coordinate is wrapped
+int brick_owner(const SfLammps& L, const double* x)
+{
+  double lo[3], hi[3];
+  int per[3], c[3];
+  L.eng.box(lo, hi, per);
+  for (int k = 0; k < 3; k++) {
+    const int Pk = L.procgrid[k];
+    const double len = hi[k] - lo[k], w = len / Pk;
+    double xk = x[k];
+    if (per[k]) {
+      while (xk < lo[k]) xk += len;
+      while (xk >= hi[k]) xk -= len;
+    }
+    int ck = (int)std::floor((xk - lo[k]) / w);
+    ck = ck < 0 ? 0 : (ck >= Pk ? Pk - 1 : ck);
+    while (ck > 0 && xk < lo[k] + ck * w) ck--;
+    while (ck < Pk - 1 && xk >= lo[k] + (ck + 1) * w) ck++;
+    c[k] = ck;
+  }
+  return c[0] + L.procgrid[0] * (c[1] + L.procgrid[1] * c[2]);
+}
+
+// "run n pre no post no" on whatever the engine is: one domain, or the bricks of a -parallel run (library.cpp:372-386
+// is collective there: Verlet::run with its forward communication and the reneighbouring vote)
+void run_steps(SfLammps& L, int n)
+{
+  if (!L.decomposed && sf_slab_active(&L) != 1) {   // (a host may also have set the domains up itself: sf_slab_init)
+    L.eng.run(n);
+    return;
+  }
+  if (L.pending_rebuild) {
+    // atoms were created / deleted since the last list (next_reneighbor = ntimestep + 1, library.cpp:482-486)
+    L.pending_rebuild = false;
+    if (L.eng.is_setup() && sf_slab_rebuild(&L) != 0) sf::fail("%s", sf::last_error().c_str());
+  }
+  if (sf_slab_step(&L, n) != 0) sf::fail("%s", sf::last_error().c_str());
+}
+
+// atom->natoms after atoms came or went: the sum of nlocal over the ranks (library.cpp:470-473)
+void recount_atoms(SfLammps& L)
+{
+  double n = (double)L.eng.nlocal();
+  if (L.decomposed && sf_slab_allreduce_sum(&L, &n, 1) != 0) sf::fail("%s", sf::last_error().c_str());
+  L.natoms = (long long)n;
+}
+
 void read_data(SfLammps& L, const std::string& path)
 {
   // [3P] read_data for atom_style sphere: "N atoms", "lo hi xlo xhi" ..., section "Atoms":
@@ -83,6 +178,25 @@ void read_data(SfLammps& L, const std::string& path)
   }
   if (natoms >= 0 && (long)tag.size() != natoms) sf::fail("Did not assign all atoms correctly");
   L.eng.set_box(lo, hi);
+  L.natoms = (long long)tag.size();
+  if (L.world_size > 1) {
+    // [3P] read_data on N ranks: every rank reads the file, the box is cut by the processor grid, a rank keeps the
+    // atoms of its sub-domain (Comm::set_proc_grid, then sublo <= x < subhi in Atom::data_atoms)
+    decompose(L);
+    double dom[6];
+    L.eng.sublo_hi(dom);
+    size_t keep = 0;
+    for (size_t i = 0; i < tag.size(); i++) {
+      if (brick_owner(L, &x[3 * i]) != L.world_rank) continue;
+      tag[keep] = tag[i];
+      type[keep] = type[i];
+      diam[keep] = diam[i];
+      dens[keep] = dens[i];
+      for (int k = 0; k < 3; k++) x[3 * keep + k] = x[3 * i + k];
+      keep++;
+    }
+    tag.resize(keep);
+  }
   L.eng.create_atoms((int)tag.size(), x.data(), nullptr, nullptr, diam.data(), dens.data(), tag.data(),
                      type.data());
 }
@@ -255,6 +369,7 @@ void command(SfLammps& L, const std::string& line)
     if (w.size() != 4) sf::fail("Illegal boundary command");
     int p[3];
     for (int k = 0; k < 3; k++) p[k] = (w[k + 1] == "p" || w[k + 1] == "pp");
+    if (L.decomposed) sf::fail("Boundary command after simulation box is defined");   // [3P] the text of Domain::set_boundary
     L.eng.set_periodic(p[0], p[1], p[2]);
   } else if (c == "read_data") {
     if (w.size() < 2) sf::fail("Illegal read_data command");
@@ -289,8 +404,19 @@ void command(SfLammps& L, const std::string& line)
     cmd_fix(L, w);
   } else if (c == "run") {
     if (w.size() < 2) sf::fail("Illegal run command");
-    L.eng.run(inum(w[1]));
-  } else if (c == "pair_coeff" || c == "atom_modify" || c == "processors" || c == "thermo" ||
+    run_steps(L, inum(w[1]));
+  } else if (c == "processors") {
+    // [3P] processors px py pz (`*` = chosen by LAMMPS); must come before the box is created, like in LAMMPS
+    if (w.size() < 4) sf::fail("Illegal processors command");
+    if (L.decomposed) sf::fail("Processors command after simulation box is defined");
+    for (int k = 0; k < 3; k++) {
+      L.procgrid[k] = w[k + 1] == "*" ? 0 : inum(w[k + 1]);
+      if (L.procgrid[k] < 0) sf::fail("Illegal processors command");
+    }
+    if (L.procgrid[0] && L.procgrid[1] && L.procgrid[2] &&
+        L.procgrid[0] * L.procgrid[1] * L.procgrid[2] != L.world_size && L.world_size > 1)
+      sf::fail("Specified processors != physical processors");   // [3P] Comm::set_proc_grid
+  } else if (c == "pair_coeff" || c == "atom_modify" || c == "thermo" ||
              c == "thermo_style" || c == "thermo_modify" || c == "dump" || c == "dump_modify" ||
              c == "restart" || c == "echo" || c == "log" || c == "dimension") {
     // accepted, nothing to do on this path
@@ -327,6 +453,26 @@ int sf_lammps_open(int, char**, intptr_t comm, void** ptr)
   SF_API_BEGIN
   SfLammps* L = new SfLammps();
   L->comm = comm;
+  *ptr = L;
+  SF_API_END(0)
+}
+
+int sf_lammps_open_world(int, char**, intptr_t comm, int rank, int world, const char* id128, void** ptr)
+{
+  SF_API_BEGIN
+  if (world < 1 || rank < 0 || rank >= world) sf::fail("sf_lammps_open_world: rank %d of %d", rank, world);
+  if (world > 1 && !id128) sf::fail("sf_lammps_open_world: %d ranks need the communicator id of rank 0", world);
+  // one process per GPU: choose the device BEFORE the engine creates its stream and buffers
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 1 && world > 1) {
+    const char* want = getenv("SF_DEVICE");
+    SF_HIP(hipSetDevice(want ? atoi(want) : rank % ndev));
+  }
+  SfLammps* L = new SfLammps();
+  L->comm = comm;
+  L->world_rank = rank;
+  L->world_size = world;
+  if (id128) memcpy(L->comm_id, id128, 128);
   *ptr = L;
   SF_API_END(0)
 }
@@ -369,16 +515,24 @@ int sf_lammps_sync(void* ptr)
 int sf_lammps_get_global_n(void* ptr)
 {
   SF_API_BEGIN
-  const int n = H(ptr)->eng.nlocal();
+  // library.cpp:94-98: atom->natoms, the GLOBAL count (cached like LAMMPS' own; not a collective)
+  SfLammps* L = H(ptr);
+  if (L->decomposed && L->natoms < 0) recount_atoms(*L);   // (atoms handed over by sf_dem_create_atoms: counted once)
+  const int n = L->decomposed ? (int)L->natoms : L->eng.nlocal();
   SF_API_END(n)
 }
 
 int sf_lammps_get_initial_np(void* ptr, int* np_)
 {
   SF_API_BEGIN
-  DemEngine& e = H(ptr)->eng;
-  for (int r = 0; r < e.nranks(); r++) np_[r] = 0;
-  np_[e.rank()] = e.nlocal();
+  // library.cpp:112-131: every rank's nlocal in its slot, MPI_Allreduce(MPI_SUM) over the LAMMPS world
+  SfLammps* L = H(ptr);
+  DemEngine& e = L->eng;
+  const int W = std::max(e.nranks(), L->world_size);
+  std::vector<double> cnt(W, 0.0);
+  cnt[L->decomposed ? L->world_rank : e.rank()] = (double)e.nlocal();
+  if (L->decomposed && sf_slab_allreduce_sum(ptr, cnt.data(), W) != 0) sf::fail("%s", sf::last_error().c_str());
+  for (int r = 0; r < W; r++) np_[r] = (int)cnt[r];
   SF_API_END(0)
 }
 
@@ -431,7 +585,7 @@ int sf_lammps_step(void* ptr, int n)
 {
   SF_API_BEGIN
   sf::Range r("lammps");
-  H(ptr)->eng.run(n);
+  run_steps(*H(ptr), n);
   SF_API_END(0)
 }
 
@@ -456,14 +610,24 @@ int sf_lammps_create_particle(void* ptr, int npAdd, const double* position, cons
                               double rho, int type, const double* vel)
 {
   SF_API_BEGIN
-  H(ptr)->eng.create_particles(npAdd, position, tag, diameter, rho, type, vel);
+  SfLammps* L = H(ptr);
+  L->eng.create_particles(npAdd, position, tag, diameter, rho, type, vel);
+  if (L->decomposed) {   // library.cpp:470-473 (collective: every rank calls, possibly with npAdd = 0)
+    recount_atoms(*L);
+    L->pending_rebuild = true;
+  }
   SF_API_END(0)
 }
 
 int sf_lammps_delete_particle(void* ptr, const int* deleteList, int nDelete)
 {
   SF_API_BEGIN
-  H(ptr)->eng.delete_particles(deleteList, nDelete);
+  SfLammps* L = H(ptr);
+  L->eng.delete_particles(deleteList, nDelete);
+  if (L->decomposed) {   // library.cpp:527-537: collective counts; every rank deletes the listed atoms it owns
+    recount_atoms(*L);
+    L->pending_rebuild = true;
+  }
   SF_API_END(0)
 }
 

@@ -94,24 +94,28 @@ def test_lammps_object_shim_compiles_against_a_real_mpi(tmp_path):
     _build_shim_real_mpich(tmp_path)
 
 
-def _bed_script(tmp_path):
+def _bed_script(tmp_path, nx=6, nz=6, processors=None, velocity=None):
     d = 5.0e-4
     pts = [(0.5 * d + ix * 1.02 * d, 0.5 * d + iy * 1.02 * d, 0.5 * d + iz * 1.02 * d)
-           for iy in range(4) for ix in range(6) for iz in range(6)]
+           for iy in range(4) for ix in range(nx) for iz in range(nz)]
     data = tmp_path / "bed.in"
     with open(data, "w") as f:
         f.write(" sphere data\n\n %d atoms\n 1 atom types\n\n 0.0 %g xlo xhi\n 0.0 %g ylo yhi\n 0.0 %g zlo zhi\n\nAtoms\n\n"
-                % (len(pts), 6.12 * d, 8.0 * d, 6.12 * d))
+                % (len(pts), 1.02 * nx * d, 8.0 * d, 1.02 * nz * d))
         for k, p in enumerate(pts):
             f.write(" %d 1 %g 2650 %.12g %.12g %.12g\n" % (k + 1, d, p[0], p[1], p[2]))
     script = tmp_path / "in.lammps"
     with open(script, "w") as f:
         f.write("# bed of the reference's kind, read line by line through lmp->input->one\n"
-                "atom_style sphere\nboundary pp ff pp\nnewton off\ncommunicate single vel yes\n"
-                "read_data %s\n\nneighbor 1.0e-4 bin\nneigh_modify delay 0\n"
-                "pair_style gran/hertzFix/history 1.0e7 NULL 0.5 NULL 0.4 1\npair_coeff * *\ntimestep 1e-6\n"
-                "fix 1 all nve/sphere\nfix 2 all gravity 9.8 vector 0 -1 0\nfix 3 all fdrag\n"
-                "fix ywall all wall/granFix 1.0e7 NULL 0.5 NULL 0.4 1 yplane 0.0 0.004\nthermo 1000\n" % data)
+                "atom_style sphere\nboundary pp ff pp\nnewton off\ncommunicate single vel yes\n")
+        if processors:
+            f.write("processors %s\n" % processors)   # (xiaocase1/in.lammps:7 `processors 2 1 1`)
+        f.write("read_data %s\n\nneighbor 1.0e-4 bin\nneigh_modify delay 0\n"
+                "pair_style gran/hertzFix/history 1.0e7 NULL 0.5 NULL 0.4 1\npair_coeff * *\ntimestep 1e-6\n" % data)
+        if velocity:
+            f.write("velocity all set %s\n" % velocity)
+        f.write("fix 1 all nve/sphere\nfix 2 all gravity 9.8 vector 0 -1 0\nfix 3 all fdrag\n"
+                "fix ywall all wall/granFix 1.0e7 NULL 0.5 NULL 0.4 1 yplane 0.0 0.004\nthermo 1000\n")
     return script, len(pts)
 
 
@@ -147,3 +151,38 @@ def test_lammps_object_shim_aborts_like_lammps_on_a_bad_script_line(tmp_path):
     exe = _build_shim(tmp_path, "c++98", "int")
     r = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "pair_style" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,processors,nx,nz", [(2, None, 12, 12), (2, "2 1 1", 12, 12), (4, "2 1 2", 12, 12),
+                                                    (4, "* 1 *", 12, 12), (3, "1 1 3", 6, 9), (4, "4 1 1", 6, 6)])
+def test_lammps_object_shim_runs_in_parallel_from_the_reference_calls_alone(tmp_path, world, processors, nx, nz):
+    """`mpirun -np N lammpsFoam -parallel` as the reference does it (softParticleCloud.C:60-62,106,119-201,893-914): N
+    ranks each create `new LAMMPS(0, NULL, comm)` on the duplicated world communicator and feed it the SAME script
+    lines; the engine decomposes itself from `processors px py pz` (or chooses the grid like LAMMPS), every rank keeps
+    the atoms of its brick of the `read_data` file, lammps_get_global_n / _get_initial_np are the global / per-rank
+    counts of library.cpp:94-131, lammps_step is collective, atoms migrate between the ranks (the bed is thrown
+    sideways through the periodic faces: ~10 rebuilds in the 65 sub-steps), create / delete are collective.  The
+    driver (tests/c_abi/shim_driver.cpp, the image's real MPICH) contains no sf_* call; its N-rank result must equal
+    its 1-rank result.  The ranks share the box's one GPU, the wire is the stand-in (tests/c_abi/standin_rccl.cpp).
+    `4 1 1` on the narrow bed: bricks thinner than twice the ghost cutoff (an atom is a ghost of BOTH x-neighbours:
+    more send directions than the sub-step kernel writes itself -> the pack kernel stays in the loop)."""
+    import shutil
+    from test_halo_gpu import _standin_rccl
+    script, n = _bed_script(tmp_path, nx=nx, nz=nz, processors=processors, velocity="8.0 0.0 5.0")
+    exe = _build_shim_real_mpich(tmp_path)
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    one = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and one.stdout.strip().splitlines()[-1].startswith("OK"), one.stdout + one.stderr
+    ref = one.stdout.strip().splitlines()[-1].split()
+    env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path))
+    r = subprocess.run([mpirun, "-np", str(world), exe, str(script)], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ok = [ln for ln in r.stdout.splitlines() if ln.startswith("OK")]
+    assert len(ok) == 1, r.stdout[-3000:]
+    tok = ok[0].split()
+    assert int(tok[1]) == int(ref[1]) == n and int(tok[4]) == int(ref[4]) == n + 1 - 2 and int(tok[7]) == world
+    assert float(tok[2]) == pytest.approx(float(ref[2]), rel=1e-12)
+    for k in (3, 5, 6):        # mean height, tag-weighted checksums of positions and velocities
+        assert float(tok[k]) == pytest.approx(float(ref[k]), rel=1e-9), (k, tok, ref)
