@@ -7,7 +7,8 @@
 // -std=c++98 and -std=c++17, run on the GPU.  It is written for N ranks the way initLammps is (`npArray = new
 // int[nprocs]`, `nLocal = npArray[myrank]`, :122-132): under `mpirun -np N` every rank runs it, LAMMPS -- here the
 // engine -- decomposes itself from the script's `processors` line, and NOT ONE sf_* call appears below.
-// Rank 0 prints "OK <nGlobal> <ymean_before> <ymean_after> <n_after_create_delete> <checksum_x> <checksum_v> <ranks>".
+// Rank 0 prints "OK <nGlobal> <ymean_before> <ymean_after> <n_after_create_delete> <checksum_x> <checksum_v> <ranks>
+// <atoms that changed rank>".
 #include "mpi.h"
 #include "lammps.h"
 #include "input.h"
@@ -73,6 +74,7 @@ int main(int argc, char** argv)
       return 1;
     }
 
+  const std::vector<int> tag0(tag.begin(), tag.begin() + n);
   lammps_step(lmp, 0);
   double box[6];
   lammps_get_local_domain(lmp, box);
@@ -123,6 +125,14 @@ int main(int argc, char** argv)
     tag.resize(nLocal + 1); lmpCpuId.resize(nLocal + 1); foamCpuId.resize(nLocal + 1);
     lammps_get_local_info(lmp, &x[0], &v[0], &foamCpuId[0], &lmpCpuId[0], &tag[0]);
   }
+  // atoms that changed their rank since lammps_get_initial_info (Comm::exchange at the rebuilds)
+  int movedLocal = 0, moved = 0;
+  {
+    std::vector<char> wasMine(nGlobal + 2, 0);
+    for (int i = 0; i < n; i++) wasMine[tag0[i]] = 1;
+    for (int i = 0; i < nLocal; i++) movedLocal += wasMine[tag[i]] ? 0 : 1;
+    MPI_Allreduce(&movedLocal, &moved, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+  }
   // mean height and a tag-weighted checksum of positions and velocities over ALL ranks
   double loc[3] = {0.0, 0.0, 0.0}, glob[3] = {0.0, 0.0, 0.0};
   for (int i = 0; i < nLocal; i++) {
@@ -167,6 +177,6 @@ int main(int argc, char** argv)
   MPI_Finalize();
 #endif
   if (myrank == 0)
-    std::printf("OK %d %.12g %.12g %d %.15g %.15g %d\n", nGlobal, y0, y1, nAfter, glob[1], glob[2], nprocs);
+    std::printf("OK %d %.12g %.12g %d %.15g %.15g %d %d\n", nGlobal, y0, y1, nAfter, glob[1], glob[2], nprocs, moved);
   return 0;
 }

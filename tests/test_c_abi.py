@@ -168,7 +168,7 @@ def test_lammps_object_shim_runs_in_parallel_from_the_reference_calls_alone(tmp_
     `4 1 1` on the narrow bed: bricks thinner than twice the ghost cutoff (an atom is a ghost of BOTH x-neighbours:
     more send directions than the sub-step kernel writes itself -> the pack kernel stays in the loop)."""
     import shutil
-    from test_halo_gpu import _standin_rccl
+    from tests.test_halo_gpu import _standin_rccl
     script, n = _bed_script(tmp_path, nx=nx, nz=nz, processors=processors, velocity="8.0 0.0 5.0")
     exe = _build_shim_real_mpich(tmp_path)
     mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
@@ -183,6 +183,7 @@ def test_lammps_object_shim_runs_in_parallel_from_the_reference_calls_alone(tmp_
     assert len(ok) == 1, r.stdout[-3000:]
     tok = ok[0].split()
     assert int(tok[1]) == int(ref[1]) == n and int(tok[4]) == int(ref[4]) == n + 1 - 2 and int(tok[7]) == world
+    assert int(tok[8]) >= 10, "no atom changed its rank: the run did not exercise the migration"
     assert float(tok[2]) == pytest.approx(float(ref[2]), rel=1e-12)
     for k in (3, 5, 6):        # mean height, tag-weighted checksums of positions and velocities
         assert float(tok[k]) == pytest.approx(float(ref[k]), rel=1e-9), (k, tok, ref)
