@@ -85,6 +85,7 @@ _SIGS = {
     "sf_device_check": (C.c_int, []),
     "sf_version": (C.c_char_p, []),
     "sf_lammps_open": (C.c_int, [C.c_int, vp, C.c_ssize_t, C.POINTER(vp)]),
+    "sf_lammps_open_world": (C.c_int, [C.c_int, vp, C.c_ssize_t, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
     "sf_lammps_close": (C.c_int, [vp]),
     "sf_lammps_file": (C.c_int, [vp, C.c_char_p]),
     "sf_lammps_command": (C.c_char_p, [vp, C.c_char_p]),
@@ -150,6 +151,8 @@ _SIGS = {
     "sf_slab_setup": (C.c_int, [vp]),
     "sf_slab_rebuild": (C.c_int, [vp]),
     "sf_slab_step": (C.c_int, [vp, C.c_int]),
+    "sf_slab_active": (C.c_int, [vp]),
+    "sf_slab_allreduce_sum": (C.c_int, [vp, dp, C.c_int]),
     "sf_slab_rebuild_count": (C.c_longlong, [vp]),
     "sf_slab_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "sf_slab_exchange_profile": (C.c_int, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

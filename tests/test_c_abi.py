@@ -109,7 +109,7 @@ def _bed_script(tmp_path, nx=6, nz=6, processors=None, velocity=None):
         f.write("# bed of the reference's kind, read line by line through lmp->input->one\n"
                 "atom_style sphere\nboundary pp ff pp\nnewton off\ncommunicate single vel yes\n")
         if processors:
-            f.write("processors %s\n" % processors)   # (xiaocase1/in.lammps:7 `processors 2 1 1`)
+            f.write("processors %s\n" % processors)   # (expMueller09/in.lammps:7 `processors  2 1 1`)
         f.write("read_data %s\n\nneighbor 1.0e-4 bin\nneigh_modify delay 0\n"
                 "pair_style gran/hertzFix/history 1.0e7 NULL 0.5 NULL 0.4 1\npair_coeff * *\ntimestep 1e-6\n" % data)
         if velocity:
