@@ -156,7 +156,10 @@ struct StepParams {
   LubParams lub;
   int nwalls;
   int stage_cap;   // LDS slots per workgroup in k_substep_lds
-  int xcd_remap;   // blockIdx -> contiguous chunk per XCD (8 XCDs, block b runs on XCD b % 8)
+  int xcd_remap;   // blockIdx -> contiguous chunk per XCD (8 XCDs, block b runs on XCD b % 8); 2: chunks of UNEQUAL
+                   // size -- XCD x works on the xcd_count[x] blocks from xcd_first[x], the grid is 8 x the largest count
+                   // and a workgroup beyond its XCD's count exits at once
+  int xcd_first[8], xcd_count[8];
   WallParams wall[kMaxWalls];
   int have_gravity;
   double gacc[3];
@@ -535,6 +538,9 @@ private:
   // environment overrides, all measured: SF_SUB sort cells per cutoff length, SF_TILE tile-major
   // sort, SF_XCD_REMAP contiguous block range per XCD, SF_LDS the LDS-staged kernel
   int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
+  double xcd_weight_[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // share of the sorted range each XCD works on (launch_substep)
+  bool xcd_weighted_ = false;
+  size_t stamp_last_grid_ = 0;   // workgroups of the last k_substep launch (SF_EXP_STAMP variant builds)
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;
   int migrate_leavers_ = 0;        // atoms packed by migrate_pack since the last compaction

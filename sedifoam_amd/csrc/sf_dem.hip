@@ -99,6 +99,13 @@ DemEngine::DemEngine()
   SF_HIP(hipEventCreateWithFlags(&ev_flags_, hipEventDisableTiming));
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
+  if (const char* e = getenv("SF_XCD_WEIGHTS")) {   // eight relative shares, comma separated
+    double w[8];
+    if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", &w[0], &w[1], &w[2], &w[3], &w[4], &w[5], &w[6], &w[7]) == 8) {
+      for (int x = 0; x < 8; x++) xcd_weight_[x] = w[x] > 0.0 ? w[x] : 1.0;
+      xcd_weighted_ = true;
+    }
+  }
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
   roots_ = !opt_lds_;
   if (const char* e = getenv("SF_SUB")) opt_sub_ = std::max(1, atoi(e));
@@ -880,7 +887,28 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     // one wave per workgroup: the dispatcher then balances single waves (a 256-thread workgroup holds its CU slots
     // until its slowest wave is done); measured 207.0 -> 203.2 us per sub-step at 1 M atoms, never slower below
     const int block = block_env ? block_env : 64;
-    const dim3 grid((unsigned)((lanes + block - 1) / block));
+    dim3 grid((unsigned)((lanes + block - 1) / block));
+    // The XCDs do not finish together when each gets the same number of workgroups: the two that hold the ends of the
+    // sorted range gather across the periodic face from lines no neighbour of theirs has pulled into their L2, and run
+    // ~5 % longer (workgroup timeline, profiles/r04_*).  xcd_weight_[x]: relative share of XCD x.
+    if (part == 0 && S.xcd_remap == 1 && xcd_weighted_ && grid.x >= 64) {
+      const int nb = (int)grid.x;
+      double wsum = 0.0;
+      for (int x = 0; x < 8; x++) wsum += xcd_weight_[x];
+      int first = 0, most = 0;
+      double acc = 0.0;
+      for (int x = 0; x < 8; x++) {
+        acc += xcd_weight_[x];
+        const int end = x == 7 ? nb : std::min(nb, (int)std::llround(nb * acc / wsum));
+        S.xcd_first[x] = first;
+        S.xcd_count[x] = std::max(0, end - first);
+        most = std::max(most, S.xcd_count[x]);
+        first = std::max(first, end);
+      }
+      S.xcd_remap = 2;
+      grid = dim3((unsigned)(8 * most));
+    }
+    stamp_last_grid_ = grid.x;
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
       case 3:
@@ -890,6 +918,40 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   }
   SF_HIP(hipGetLastError());
   if (e1) SF_HIP(hipEventRecord(e1, stream_));
+#if SF_EXP_STAMP
+  // SF_STAMP_FILE=<path> [SF_STAMP_AT=<n>]: the n-th full-size launch (default 60) is recorded workgroup by workgroup
+  static const char* stamp_file = getenv("SF_STAMP_FILE");
+  static const int stamp_at = getenv("SF_STAMP_AT") ? atoi(getenv("SF_STAMP_AT")) : 60;
+  static int stamp_seen = 0;
+  static unsigned long long* stamp_buf = nullptr;
+  static size_t stamp_blocks = 0, stamp_grid = 0;
+  if (stamp_buf && stamp_file && !lds_active_ && part == 0 && mode == 0) stamp_grid = stamp_last_grid_;
+  if (stamp_file && !lds_active_ && part == 0 && mode == 0) {
+    stamp_seen++;
+    if (stamp_seen == stamp_at) {   // arm: the NEXT launch records
+      const int lpa = lanes_per_atom(nlocal_);
+      stamp_blocks = ((size_t)nlocal_ * lpa + 63) / 64 + 8192;   // (a weighted XCD split launches a few more)
+      SF_HIP(hipMalloc(&stamp_buf, sizeof(unsigned long long) * 36 * stamp_blocks));   // (+ 32 phase marks each)
+      SF_HIP(hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * 36 * stamp_blocks, stream_));
+      SF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stamp), &stamp_buf, sizeof(stamp_buf), 0, hipMemcpyHostToDevice, stream_));
+    } else if (stamp_seen == stamp_at + 1 && stamp_buf) {
+      unsigned long long* none = nullptr;
+      SF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stamp), &none, sizeof(none), 0, hipMemcpyHostToDevice, stream_));
+      // [4 x grid] stamps, then [32 x grid] phase marks (SF_EXP_PHASE); the file starts with the grid size
+      std::vector<unsigned long long> h(36 * stamp_blocks);
+      SF_HIP(hipMemcpyAsync(h.data(), stamp_buf, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, stream_));
+      SF_HIP(hipStreamSynchronize(stream_));
+      if (FILE* f = fopen(stamp_file, "wb")) {
+        const unsigned long long g = stamp_grid;
+        fwrite(&g, sizeof(g), 1, f);
+        fwrite(h.data(), sizeof(unsigned long long), (size_t)36 * stamp_grid, f);
+        fclose(f);
+      }
+      (void)hipFree(stamp_buf);
+      stamp_buf = nullptr;
+    }
+  }
+#endif
 }
 
 void DemEngine::set_profiling(bool on)

@@ -41,7 +41,8 @@
 // They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
 // SF_VARIANT_BUILD); the shipped library never carries them.
 #if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT) || defined(SF_EXP_SC1_GATHER) || \
-     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ)) && !defined(SF_VARIANT_BUILD)
+     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ) || defined(SF_EXP_STAMP) || defined(SF_EXP_PHASE)) &&          \
+    !defined(SF_VARIANT_BUILD)
 #error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
 #endif
 #ifndef SF_EXP_NOSHLD
@@ -63,6 +64,10 @@
 #ifndef SF_EXP_ACQ
 #define SF_EXP_ACQ 0          // an agent-scope acquire (vector-L1 invalidate) at the start of every wave
 #endif
+#ifndef SF_EXP_STAMP
+#define SF_EXP_STAMP 0        // every workgroup of one chosen launch records {XCC_ID, HW_ID, start, end} (100 MHz clock):
+                              // the fill / drain timeline per XCD (tests/micro/stamp_timeline.py; valid results)
+#endif
 #ifndef SF_EXP_PERSIST_NOWAIT
 #define SF_EXP_PERSIST_NOWAIT 0   // upper bound of a persistent kernel: n sub-steps in one launch, NO dependency waits
                                   // (every sub-step recomputes the same in -> out: valid inputs, timing only)
@@ -71,6 +76,29 @@
 namespace sf {
 
 __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
+
+#if SF_EXP_STAMP
+__device__ unsigned long long* g_stamp = nullptr;   // [4 * workgroups] of the launch being recorded, else null
+#endif
+#ifndef SF_EXP_PHASE
+#define SF_EXP_PHASE 0        // with SF_EXP_STAMP: lane 0 of every wave also stores the clock at the phases of its life
+                              // (entry, every slot of the neighbour loop, fixes, stores): [32 * workgroups] after the stamps
+#endif
+#if SF_EXP_PHASE
+// (kept in LDS while the wave runs -- a global store per mark would sit in the in-order vmcnt queue of the loads it is
+// meant to observe: measured +25 % -- and copied out by the StampEnd destructor of k_substep)
+__device__ __forceinline__ unsigned long long* sf_phase_slots()
+{
+  __shared__ unsigned long long ph[32];
+  return ph;
+}
+#define SF_PH(k)                                                                                              \
+  do {                                                                                                        \
+    if ((threadIdx.x & 63) == 0) sf_phase_slots()[(k)] = (unsigned long long)wall_clock64();                  \
+  } while (0)
+#else
+#define SF_PH(k) do { } while (0)
+#endif
 
 // agent-coherent (sc1) accesses to a record array through a raw buffer descriptor: they bypass the CU's vector L1
 // (loads) / write through the XCD's L2 (stores); the compiler counts them like any other memory operation
@@ -158,6 +186,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   constexpr bool NT_LD = NTP != 0, NT_ST = NTP == 1 || NTP == 2, NT_HIST = NTP == 2;
   __builtin_assume(i >= 0 && i < (1 << kIdxBits));
 
+  SF_PH(0);
   const double4 xi4 = P.xr_in[i];   // also a gather target of the neighbours: keep it cached
   const double4 vi4 = P.vm_in[i];
   const double4 wi4 = P.om_in[i];
@@ -196,10 +225,12 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       sh.y = ldh(&(hin + cap)[i]);
       sh.z = ldh(&(hin + 2 * cap)[i]);
     } else {
+      // (the owner's value, NOT yet negated: flipping the sign here would make the wave wait for these loads on the
+      // spot -- the prefetch of the next slot's history would be no prefetch at all; the consumer flips it)
       const double* src = P.shear_in + (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + (size_t)(jraw & kIdxMask);
-      sh.x = -ldh(src);
-      sh.y = -ldh(src + cap);
-      sh.z = -ldh(src + 2 * cap);
+      sh.x = ldh(src);
+      sh.y = ldh(src + cap);
+      sh.z = ldh(src + 2 * cap);
     }
   };
   // The contact law needs the neighbour's v and omega only if the pair touches, and a pair that touches now almost
@@ -248,6 +279,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
   auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more, const bool uniform_s) {
+    SF_PH(2 + (s < 24 ? s : 24));
     // the list slot this iteration works on; with one lane per atom and inside the (convergent) loop it is the same in
     // every active lane of the wave -- NOT in the tail call after the loop, where lanes with different neighbour
     // counts arrive with different s
@@ -258,6 +290,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const bool own = (jraw & kOwnBit) != 0;
     Vec3 sh = cur.sh;
     if (!SF_HIST_PREFETCH) load_history(jraw, sl, sh);
+    // the pair seen from the partner's side (a pair that did not touch starts from +0.0 on both sides, as before)
+    if (STYLE != 0 && !own && (jraw & kTouchBit)) sh = {-sh.x, -sh.y, -sh.z};
     jraw_n1 = jraw_n2;
     if (s + 2 < nn) jraw_n2 = ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
     if (more) {
@@ -391,6 +425,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     }
   };
   // unrolled by two so that the prefetch ping-pongs between RA and RB without register copies
+  SF_PH(1);
   int s = 0;
 #if SF_UNROLL2
   for (; s + 1 < nn; s += 2) {
@@ -404,6 +439,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     RA = RB;
   }
 #endif
+  SF_PH(27);
   if (LPA > 1) {
     // fixed tree: (q0 + q1) [+ (q2 + q3)] -- the same bits on every run
     for (int off = 1; off < LPA; off <<= 1) {
@@ -514,6 +550,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (wt_new != wt) P.wtouch[i] = (unsigned char)wt_new;
   }
 
+  SF_PH(28);
   // ---- integrate: final(k) [+ initial(k+1)]  ([3P] FixNVESphere, dtf = dt/2, INERTIA = 0.4) ----
   // [3P] fix freeze: force and torque of the group's atoms are zeroed where the fix stands in the script
   if (mk & S.freeze_bit) {
@@ -565,6 +602,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (txk0 >= 0) put(P.tx[0] + txk0, (size_t)S.tx_n[0], S.tx_shift[0]);
     if (txk1 >= 0) put(P.tx[1] + txk1, (size_t)S.tx_n[1], S.tx_shift[1]);
   }
+  SF_PH(29);
 #if SF_ST_SHUFFLE
   // A 32-byte record per lane is two 16-byte stores at a 32-byte stride: each store instruction covers only half
   // of every cache line it touches.  When the whole wave holds consecutive atoms the halves are exchanged between
@@ -603,6 +641,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     P.force[i] = {F.x, F.y, F.z, 0.0};
     P.torque[i] = {T.x, T.y, T.z, 0.0};
   }
+  SF_PH(30);
 }
 
 // Registers: the plain contact kernel needs 169 VGPRs when left alone -- one more than three waves per SIMD allow
@@ -631,11 +670,41 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
   if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
+#if SF_EXP_STAMP
+  unsigned long long* const stamp = g_stamp;
+  const unsigned long long stamp_t0 = stamp ? wall_clock64() : 0ull;
+#if SF_EXP_PHASE
+  if (threadIdx.x < 32) sf_phase_slots()[threadIdx.x] = 0ull;
+#endif
+  struct StampEnd {
+    unsigned long long* s;
+    unsigned long long t0;
+    __device__ ~StampEnd()
+    {
+      if (!s) return;
+      __builtin_amdgcn_s_waitcnt(0);   // (the stores of this wave have been issued and acknowledged)
+#if SF_EXP_PHASE
+      if (threadIdx.x < 32) s[4 * (size_t)gridDim.x + 32 * (size_t)blockIdx.x + threadIdx.x] = sf_phase_slots()[threadIdx.x];
+#endif
+      if (threadIdx.x == 0) {
+        unsigned long long* q = s + 4 * (size_t)blockIdx.x;
+        q[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);     // HW_REG_XCC_ID[3:0]
+        q[1] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID
+        q[2] = t0;
+        q[3] = wall_clock64();
+      }
+    }
+  } stamp_end{stamp, stamp_t0};
+#endif
   // The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
   int bid = blockIdx.x;
-  if (S.xcd_remap) {
+  if (S.xcd_remap == 2) {
+    const int xcd = bid & 7, loc = bid >> 3;
+    if (loc >= S.xcd_count[xcd]) return;
+    bid = S.xcd_first[xcd] + loc;
+  } else if (S.xcd_remap) {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
