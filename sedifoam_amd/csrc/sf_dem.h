@@ -131,6 +131,7 @@ struct DemPtrs {
   const int* bslot;             // brick driver (tx_fused == 2): [kBrickSlots][cap] where an atom's forward records go, in
                                 // doubles from tx_sendbuf (-1: no further direction sends this atom)
   const int* tx_hdr_off;
+  int* xcd_time;                // StepParams::xcd_time: [64 x + 0] first start, [64 x + 32] last end of XCD x (100 MHz clock)
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -142,6 +143,7 @@ struct DemPtrs {
 struct StepParams {
   int nlocal, cap, mode;   // mode 0: force + final + next initial ; 1: last (force + final, store f) ; 2: setup
   int kstep;
+  int nslots;        // rows of the slot-major list arrays (M)
   int roots;         // neighbour words hold (root, image code), see kIdxMask
   double prd[3];     // box lengths (image shift = code component * prd)
   int part, nb;      // 0: every owned atom ; 1: interior atoms [n_lo, n_hi) ; 2: boundary atoms [0, n_lo) + [n_hi, nlocal)
@@ -160,6 +162,8 @@ struct StepParams {
                    // size -- XCD x works on the xcd_count[x] blocks from xcd_first[x], the grid is 8 x the largest count
                    // and a workgroup beyond its XCD's count exits at once
   int xcd_first[8], xcd_count[8];
+  int sweep_rev;   // walk each XCD's range backwards (every other sub-step)
+  int xcd_time;    // this launch records when each XCD starts and ends (DemPtrs::xcd_time): the engine balances the shares
   WallParams wall[kMaxWalls];
   int have_gravity;
   double gacc[3];
@@ -540,6 +544,14 @@ private:
   int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
   double xcd_weight_[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // share of the sorted range each XCD works on (launch_substep)
   bool xcd_weighted_ = false;
+  // XCD balance: a launch a few sub-steps after every list build is timed per XCD (two atomics per wave), and the shares
+  // follow the measured rates.  Placement only: results do not depend on it.
+  bool xcd_auto_ = true;
+  int xcd_countdown_ = 0;          // launches until the next timed one (0: none pending)
+  bool xcd_sample_pending_ = false;
+  int* d_xcd_time_ = nullptr;      // [512 + 512]: the sample (two words per XCD, a cache line apart), then its initial values
+  int* h_xcd_time_ = nullptr;      // pinned
+  void apply_xcd_sample();
   size_t stamp_last_grid_ = 0;   // workgroups of the last k_substep launch (SF_EXP_STAMP variant builds)
   int mrec_ = 0;                   // history slots per migrating atom (global max over ranks)
   bool migrate_pending_ = false;

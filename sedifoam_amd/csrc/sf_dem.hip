@@ -99,11 +99,17 @@ DemEngine::DemEngine()
   SF_HIP(hipEventCreateWithFlags(&ev_flags_, hipEventDisableTiming));
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
-  if (const char* e = getenv("SF_XCD_WEIGHTS")) {   // eight relative shares, comma separated
+  SF_HIP(hipMalloc(&d_xcd_time_, sizeof(int) * 1024));
+  SF_HIP(hipHostMalloc(&h_xcd_time_, sizeof(int) * 1024));
+  for (int k = 0; k < 512; k++) h_xcd_time_[512 + k] = (k & 63) == 0 ? INT_MAX : 0;   // start: atomicMin, end: atomicMax
+  SF_HIP(hipMemcpyAsync(d_xcd_time_ + 512, h_xcd_time_ + 512, sizeof(int) * 512, hipMemcpyHostToDevice, stream_));
+  if (const char* e = getenv("SF_XCD_BALANCE")) xcd_auto_ = atoi(e) != 0;
+  if (const char* e = getenv("SF_XCD_WEIGHTS")) {   // eight relative shares, comma separated: pins them
     double w[8];
     if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", &w[0], &w[1], &w[2], &w[3], &w[4], &w[5], &w[6], &w[7]) == 8) {
       for (int x = 0; x < 8; x++) xcd_weight_[x] = w[x] > 0.0 ? w[x] : 1.0;
       xcd_weighted_ = true;
+      xcd_auto_ = false;
     }
   }
   if (const char* e = getenv("SF_LDS")) opt_lds_ = atoi(e);
@@ -130,6 +136,8 @@ DemEngine::~DemEngine()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevArray* a : per_atom_) a->release();
+  if (d_xcd_time_) (void)hipFree(d_xcd_time_);
+  if (h_xcd_time_) (void)hipHostFree(h_xcd_time_);
   bslot_.release();   // (not in per_atom_: allocated by the first brick rebuild, re-allocated when the capacity moves)
   if (cell_start_) (void)hipFree(cell_start_);
   if (tile_tab_) (void)hipFree(tile_tab_);
@@ -621,6 +629,39 @@ void DemEngine::read_flags()
 {
   SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
   sync();
+  if (xcd_sample_pending_) apply_xcd_sample();
+}
+
+// The shares of the eight XCDs follow what the timed launch measured: XCD x took T_x for its share, so its rate is
+// share / T_x; the new shares are proportional to the rates (damped, bounded).  An XCD is slower when its range is
+// harder -- the ends of the sorted range gather across the periodic face, a bed that does not fill the box has rows of
+// different lengths -- not because of anything in the results, which no placement can change.
+void DemEngine::apply_xcd_sample()
+{
+  xcd_sample_pending_ = false;
+  static const bool dbg = getenv("SF_DEBUG_XCD") != nullptr;
+  int t0 = INT_MAX;
+  for (int x = 0; x < 8; x++) t0 = std::min(t0, h_xcd_time_[64 * x]);
+  double T[8], mean = 0.0;
+  for (int x = 0; x < 8; x++) {
+    T[x] = (double)(h_xcd_time_[64 * x + 32] - t0);   // 10 ns units
+    if (h_xcd_time_[64 * x] == INT_MAX || T[x] <= 100.0 || T[x] > 1.0e7) return;   // (an early-exit launch, or the clock wrapped)
+    mean += T[x] / 8.0;
+  }
+  double w[8], wsum = 0.0;
+  for (int x = 0; x < 8; x++) {
+    w[x] = xcd_weight_[x] * std::pow(mean / T[x], 0.7);
+    wsum += w[x] / 8.0;
+  }
+  for (int x = 0; x < 8; x++) xcd_weight_[x] = std::min(1.2, std::max(0.8, w[x] / wsum));
+  xcd_weighted_ = true;
+  if (dbg) {
+    fprintf(stderr, "[sedifoam_amd] XCD times [us]");
+    for (int x = 0; x < 8; x++) fprintf(stderr, " %.1f", T[x] * 0.01);
+    fprintf(stderr, "  -> shares");
+    for (int x = 0; x < 8; x++) fprintf(stderr, " %.3f", xcd_weight_[x]);
+    fprintf(stderr, "\n");
+  }
 }
 
 DemPtrs DemEngine::ptrs(int in_buf) const
@@ -656,6 +697,7 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.tx_sendbuf = tx_sendbuf_;
   P.bslot = bslot_.as<int>();
   P.tx_hdr_off = tx_hdr_off_;
+  P.xcd_time = d_xcd_time_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
   P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
   P.stage_idx = stage_idx_;
@@ -670,6 +712,7 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.cap = (int)cap_;
   S.mode = mode;
   S.kstep = kstep;
+  S.nslots = M_;
   S.dt = dt_;
   S.trigger_sq = (0.5 * skin_) * (0.5 * skin_);
   S.roots = roots_ ? 1 : 0;
@@ -685,6 +728,8 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.lub = lub_;
   S.nwalls = nwalls_;
   S.xcd_remap = opt_xcd_remap_;
+  static const int sweep_env = getenv("SF_SWEEP_REVERSE") ? atoi(getenv("SF_SWEEP_REVERSE")) : 1;
+  S.sweep_rev = (sweep_env && mode != 2) ? (int)((run_base_step_ + kstep) & 1) : 0;
   S.stage_cap = stage_cap_;
   // wall positions / velocities of the LAMMPS step this launch evaluates: post_force of step n sees ntimestep = n,
   // the setup evaluation sees the value the run starts from (fix_wall_granFix.cpp:255-264)
@@ -891,6 +936,11 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     // The XCDs do not finish together when each gets the same number of workgroups: the two that hold the ends of the
     // sorted range gather across the periodic face from lines no neighbour of theirs has pulled into their L2, and run
     // ~5 % longer (workgroup timeline, profiles/r04_*).  xcd_weight_[x]: relative share of XCD x.
+    const bool xcd_can = part == 0 && S.xcd_remap == 1 && grid.x >= 2048 && mode == 0;
+    if (xcd_can && xcd_auto_ && xcd_countdown_ > 0 && --xcd_countdown_ == 0 && !xcd_sample_pending_) {
+      SF_HIP(hipMemcpyAsync(d_xcd_time_, d_xcd_time_ + 512, sizeof(int) * 512, hipMemcpyDeviceToDevice, stream_));
+      S.xcd_time = 1;
+    }
     if (part == 0 && S.xcd_remap == 1 && xcd_weighted_ && grid.x >= 64) {
       const int nb = (int)grid.x;
       double wsum = 0.0;
@@ -918,6 +968,10 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   }
   SF_HIP(hipGetLastError());
   if (e1) SF_HIP(hipEventRecord(e1, stream_));
+  if (S.xcd_time) {   // read with the next synchronisation of the stepping loop (read_flags)
+    SF_HIP(hipMemcpyAsync(h_xcd_time_, d_xcd_time_, sizeof(int) * 512, hipMemcpyDeviceToHost, stream_));
+    xcd_sample_pending_ = true;
+  }
 #if SF_EXP_STAMP
   // SF_STAMP_FILE=<path> [SF_STAMP_AT=<n>]: the n-th full-size launch (default 60) is recorded workgroup by workgroup
   static const char* stamp_file = getenv("SF_STAMP_FILE");
@@ -1417,6 +1471,7 @@ void DemEngine::bin_and_build()
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
   nbuilds_++;
+  if (xcd_auto_ && xcd_countdown_ == 0) xcd_countdown_ = 3;   // the third full launch on the new list is timed per XCD
 }
 
 // true when a decision taken from the list statistics could change with the next measurement: a fraction within

@@ -41,7 +41,7 @@
 // They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
 // SF_VARIANT_BUILD); the shipped library never carries them.
 #if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT) || defined(SF_EXP_SC1_GATHER) || \
-     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ) || defined(SF_EXP_STAMP) || defined(SF_EXP_PHASE)) &&          \
+     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ) || defined(SF_EXP_STAMP) || defined(SF_EXP_PHASE)) && \
     !defined(SF_VARIANT_BUILD)
 #error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
 #endif
@@ -194,9 +194,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const double radi = xi4.w, mi = vi4.w;
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
+  const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
   const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
-  const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
@@ -265,8 +265,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   };
   // rows of the slot-major arrays are addressed as (row pointer)[i]: with one lane per atom the slot -- hence the row
   // pointer -- is wave-uniform (scalar registers), the element offset 32 bits
-  int jraw_n1 = nn > 0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
-  int jraw_n2 = nn > 1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)(q + LPA) * cap)[i]) : 0;
+  // (the first two words are requested whatever the count says -- rows q and q + LPA exist -- so that they travel
+  // together with numneigh and the atom's own records instead of one memory round trip behind them)
+  const int row1 = q + LPA < S.nslots ? q + LPA : S.nslots - 1;
+  const int w_first = ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]);
+  const int w_second = ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]);
+  int jraw_n1 = nn > 0 ? w_first : 0;
+  int jraw_n2 = nn > 1 ? w_second : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
   // owner's slot; the five image-code bits of a partner-side word hold that slot (a partner-side neighbour is never
   // a periodic image, see k_back_slots).
@@ -457,6 +462,17 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     }
   }
 
+  // the rows the fixes and the integration read, requested TOGETHER here (one memory round trip instead of one per fix)
+  const bool use_fd = S.have_fdrag && (mk & S.fdrag_bit);   // fix_fluid_drag.cpp:145
+  Vec3 fd_in = {0.0, 0.0, 0.0}, xh_in = {0.0, 0.0, 0.0};
+  unsigned wt_in = 0;
+  if (S.have_fdrag) {
+    const size_t k = use_fd ? (size_t)i : 0;   // (a lane outside the group reads a valid element and drops it)
+    fd_in = {P.fdrag[k], P.fdrag[cap + k], P.fdrag[2 * cap + k]};
+  }
+  if (S.mode == 0 && S.have_nve)
+    xh_in = {ld_stream<NT_LD>(&P.xhold[i]), ld_stream<NT_LD>(&P.xhold[cap + i]), ld_stream<NT_LD>(&P.xhold[2 * cap + i])};
+  if (S.nwalls) wt_in = P.wtouch[i];
   // (fused forward pack: the send slots of a border atom, requested here so that they have arrived by the end)
   int txk0 = -1, txk1 = -1;
   if (S.tx_fused == 1 && (xi.x < S.tx_xlo || xi.x >= S.tx_xhi)) {
@@ -478,8 +494,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     F = F + g;
     if (any_post && (S.post_freeze & 1)) Fa = Fa + g;
   }
-  if (S.have_fdrag && (mk & S.fdrag_bit)) {   // fix_fluid_drag.cpp:145
-    Vec3 fd = {P.fdrag[i], P.fdrag[cap + i], P.fdrag[2 * cap + i]};
+  if (use_fd) {
+    Vec3 fd = fd_in;
     if (S.carrier_rho != 0.0) {
       const double rho = 3.0 * mi / (4.0 * kPiTypo * radi * radi * radi);
       const Vec3 vo = {P.vOld[i], P.vOld[cap + i], P.vOld[2 * cap + i]};
@@ -496,7 +512,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     if (any_post && (S.post_freeze & 2)) Fa = Fa + fd;
   }
   if (S.nwalls) {
-    unsigned wt = P.wtouch[i], wt_new = 0;
+    unsigned wt = wt_in, wt_new = 0;
     for (int w = 0; w < S.nwalls; w++) {
       const WallParams& W = S.wall[w];
       if (!(mk & W.bit)) continue;   // fix_wall_granFix.cpp:290
@@ -568,8 +584,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       vn = vn + dtfm * F;
       xn = xn + S.dt * vn;
       wn = wn + dtirot * T;
-      const double dx = xn.x - ld_stream<NT_LD>(&P.xhold[i]), dy = xn.y - ld_stream<NT_LD>(&P.xhold[cap + i]),
-                   dz = xn.z - ld_stream<NT_LD>(&P.xhold[2 * cap + i]);
+      const double dx = xn.x - xh_in.x, dy = xn.y - xh_in.y, dz = xn.z - xh_in.z;
       if (dx * dx + dy * dy + dz * dz > S.trigger_sq) {
         atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
         // (fused forward pack: no kernel will copy the trigger word into the vote headers before the exchange)
@@ -700,13 +715,17 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
   int bid = blockIdx.x;
+  // S.sweep_rev: every other sub-step walks each XCD's range from its END.  A sub-step touches ~3 x the 256 MB of the
+  // memory-side cache; sweeping always in the same direction it finds nothing of the previous sub-step there (cyclic
+  // access, LRU), sweeping back and forth the first third of what it needs is what the previous sub-step touched last.
   if (S.xcd_remap == 2) {
     const int xcd = bid & 7, loc = bid >> 3;
     if (loc >= S.xcd_count[xcd]) return;
-    bid = S.xcd_first[xcd] + loc;
+    bid = S.xcd_first[xcd] + (S.sweep_rev ? S.xcd_count[xcd] - 1 - loc : loc);
   } else if (S.xcd_remap) {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int cnt = xcd < r ? q + 1 : q, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (S.sweep_rev ? cnt - 1 - loc : loc);
   }
   const int tid = bid * blockDim.x + threadIdx.x;
   int i = tid / LPA;          // LPA consecutive lanes share an atom
@@ -721,7 +740,14 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     return;
   }
   if (SF_EXP_ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // a timed launch (one in a few hundred): when did this XCD start, when did it finish?  (the engine evens the shares out)
+  // (each XCD's two words on a cache line of their own, the end stamped by one workgroup in eight: atomics on one line
+  // are resolved one after the other at the memory side, ~11 ns each -- 31 k of them doubled the launch)
+  const int xq = (int)(blockIdx.x & 7) * 64;
+  if (S.xcd_time && threadIdx.x == 0 && (blockIdx.x >> 3) == 0) atomicMin(&P.xcd_time[xq], (int)(wall_clock64() & 0x3fffffff));
   substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
+  if (S.xcd_time && threadIdx.x == 0 && ((blockIdx.x >> 3) & 7) == 0)
+    atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
 }
 
 #if SF_EXP_PERSIST_NOWAIT
