@@ -728,7 +728,7 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   S.lub = lub_;
   S.nwalls = nwalls_;
   S.xcd_remap = opt_xcd_remap_;
-  static const int sweep_env = getenv("SF_SWEEP_REVERSE") ? atoi(getenv("SF_SWEEP_REVERSE")) : 1;
+  static const int sweep_env = getenv("SF_SWEEP_REVERSE") ? atoi(getenv("SF_SWEEP_REVERSE")) : 0;   // (measured neutral at 1 M grains: off)
   S.sweep_rev = (sweep_env && mode != 2) ? (int)((run_base_step_ + kstep) & 1) : 0;
   S.stage_cap = stage_cap_;
   // wall positions / velocities of the LAMMPS step this launch evaluates: post_force of step n sees ntimestep = n,

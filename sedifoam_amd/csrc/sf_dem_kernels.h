@@ -231,6 +231,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       sh.x = ldh(src);
       sh.y = ldh(src + cap);
       sh.z = ldh(src + 2 * cap);
+      if (LPA > 1) sh = {-sh.x, -sh.y, -sh.z};   // (several lanes per atom: registers are tighter than time, flip at once)
     }
   };
   // The contact law needs the neighbour's v and omega only if the pair touches, and a pair that touches now almost
@@ -268,8 +269,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // (the first two words are requested whatever the count says -- rows q and q + LPA exist -- so that they travel
   // together with numneigh and the atom's own records instead of one memory round trip behind them)
   const int row1 = q + LPA < S.nslots ? q + LPA : S.nslots - 1;
-  const int w_first = ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]);
-  const int w_second = ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]);
+  // (one lane per atom only: with several lanes per atom the two extra live registers spill)
+  const bool ld0 = LPA == 1 || nn > 0, ld1 = LPA == 1 || nn > 1;
+  const int w_first = ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
+  const int w_second = ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0;
   int jraw_n1 = nn > 0 ? w_first : 0;
   int jraw_n2 = nn > 1 ? w_second : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
@@ -296,7 +299,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     Vec3 sh = cur.sh;
     if (!SF_HIST_PREFETCH) load_history(jraw, sl, sh);
     // the pair seen from the partner's side (a pair that did not touch starts from +0.0 on both sides, as before)
-    if (STYLE != 0 && !own && (jraw & kTouchBit)) sh = {-sh.x, -sh.y, -sh.z};
+    if (STYLE != 0 && LPA == 1 && !own && (jraw & kTouchBit)) sh = {-sh.x, -sh.y, -sh.z};
     jraw_n1 = jraw_n2;
     if (s + 2 < nn) jraw_n2 = ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
     if (more) {
