@@ -1,0 +1,139 @@
+"""The HIP kernels against numbers computed by the reference's own source lines (tests/golden/reference_pins.json, see
+tests/test_reference_pins.py for the CPU half): the stand-alone PairStyle / FixStyle / dragModel entry points (sfk_*) run
+on exactly the LAMMPS-shaped inputs the reference's loops were executed on.  Tolerance: 1e-12 of the largest component
+(the kernels re-associate a few products and use the hardware's reciprocal / rsqrt seeds)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import dem_cases as dc
+from tests.test_reference_pins import LUB_KEY, PINS, csr, unhex
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+@pytest.mark.parametrize("k", range(len(PINS["pair_gran_hertzFix_history.cpp:109-286"])))
+def test_hip_hertzfix_history_equals_the_reference_lines(k):
+    import torch
+    import sedifoam_amd
+    from sedifoam_amd._lib import GranParams
+    S = sedifoam_amd.lib()
+    c = PINS["pair_gran_hertzFix_history.cpp:109-286"][k]
+    I, O = c["inp"], c["out"]
+    pg = GranParams()
+    assert S.sfk_gran_settings(C.byref(pg), I["kn"], 0, I["kt"], I["gamman"], 1, 0.0, I["xmu"], 1, 1.0) == 0
+    n, nlocal = I["n"], I["nlocal"]
+    first, jl = csr(I["firstneigh"], nlocal)
+    touch = np.array([t for i in range(nlocal) for t in I["touch"][i]] or [0], dtype=np.int32)
+    shear = np.array([s for i in range(nlocal) for s in I["shear"][i]] or [0.0]).reshape(-1, 3)
+    d = dict(x=_t(I["x"], np.float64), v=_t(I["v"], np.float64), w=_t(I["omega"], np.float64),
+             r=_t(I["radius"], np.float64), m=_t(I["rmass"], np.float64), mask=_t(I["mask"], np.int32),
+             ilist=_t(np.arange(nlocal), np.int32))
+    dfirst, djl, dtouch, dshear = _t(first), _t(jl), _t(touch), _t(shear)
+    df = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    dtq = torch.zeros_like(df)
+    assert S.sfk_pair_gran_history_compute(1, C.byref(pg), I["dt"], I["shearupdate"], nlocal, nlocal,
+                                           d["ilist"].data_ptr(), dfirst.data_ptr(), djl.data_ptr(), dtouch.data_ptr(),
+                                           dshear.data_ptr(), d["x"].data_ptr(), d["v"].data_ptr(), d["w"].data_ptr(),
+                                           d["r"].data_ptr(), d["m"].data_ptr(), d["mask"].data_ptr(),
+                                           I["freeze_group_bit"], df.data_ptr(), dtq.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    ref_touch = np.array([t for i in range(nlocal) for t in O["touch"][i]], dtype=np.int32)
+    ref_shear = np.array([float.fromhex(s) for i in range(nlocal) for s in O["shear"][i]]).reshape(-1, 3)
+    assert np.array_equal(dtouch.cpu().numpy()[:ref_touch.size], ref_touch)
+    assert dc.rel_err(dshear.cpu().numpy()[:len(ref_shear)], ref_shear) <= 1e-12
+    assert dc.rel_err(df.cpu().numpy(), unhex(O["f"])) <= 1e-12
+    assert dc.rel_err(dtq.cpu().numpy(), unhex(O["torque"])) <= 1e-12
+
+
+@pytest.mark.parametrize("k", range(len(PINS["fix_cohesive.cpp:161-262"])))
+def test_hip_fix_cohesive_equals_the_reference_lines(k):
+    import torch
+    import sedifoam_amd
+    S = sedifoam_amd.lib()
+    c = PINS["fix_cohesive.cpp:161-262"][k]
+    I, O = c["inp"], c["out"]
+    n, nlocal = I["n"], I["nlocal"]
+    first, jl = csr(I["firstneigh"], nlocal)
+    df = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    dx, dr, dmask, dil = _t(I["x"], np.float64), _t(I["radius"], np.float64), _t(I["mask"], np.int32), \
+        _t(np.arange(nlocal), np.int32)
+    dfirst, djl = _t(first), _t(jl)
+    assert S.sfk_fix_cohesive_post_force(I["ah"], I["lam"], I["smin"], I["smax"], I["opt"], nlocal, I["newton_pair"],
+                                         dil.data_ptr(), dfirst.data_ptr(), djl.data_ptr(), dx.data_ptr(), dr.data_ptr(),
+                                         dmask.data_ptr(), I["groupbit"], df.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert dc.rel_err(df.cpu().numpy(), unhex(O["f"])) <= 1e-12
+
+
+@pytest.mark.parametrize("k", range(len(PINS[LUB_KEY])))
+def test_hip_lubricate_poly_equals_the_reference_lines(k):
+    import torch
+    import sedifoam_amd
+    from sedifoam_amd._lib import LubParams
+    S = sedifoam_amd.lib()
+    c = PINS[LUB_KEY][k]
+    I, O = c["inp"], c["out"]
+    n, nlocal = I["n"], I["nlocal"]
+    lp = LubParams(I["mu"], I["flaglog"], I["flagfld"], I["flagHI"], I["flagVF"], I["cut_inner"], I["cut_global"],
+                   float.fromhex(O["R0"]), float.fromhex(O["RT0"]), float.fromhex(O["RS0"]), 1.0)
+    first, jl = csr(I["firstneigh"], nlocal)
+    d = dict(x=_t(I["x"], np.float64), v=_t(I["v"], np.float64), w=_t(I["omega"], np.float64),
+             r=_t(I["radius"], np.float64), ilist=_t(np.arange(nlocal), np.int32))
+    dfirst, djl = _t(first), _t(jl)
+    df = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    dtq = torch.zeros_like(df)
+    assert S.sfk_pair_lubricate_poly_compute(C.byref(lp), nlocal, d["ilist"].data_ptr(), dfirst.data_ptr(),
+                                             djl.data_ptr(), d["x"].data_ptr(), d["v"].data_ptr(), d["w"].data_ptr(),
+                                             d["r"].data_ptr(), df.data_ptr(), dtq.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert dc.rel_err(df.cpu().numpy(), unhex(O["f"])) <= 1e-11
+    assert dc.rel_err(dtq.cpu().numpy(), unhex(O["torque"])) <= 1e-11
+
+
+@pytest.mark.parametrize("k", range(len(PINS["fix_fluid_drag.cpp:143-163"])))
+def test_hip_fix_fluid_drag_equals_the_reference_lines(k):
+    import torch
+    import sedifoam_amd
+    S = sedifoam_amd.lib()
+    c = PINS["fix_fluid_drag.cpp:143-163"][k]
+    I, O = c["inp"], c["out"]
+    n = I["n"]
+    dv, dm, dr, dmask = _t(I["v"], np.float64), _t(I["rmass"], np.float64), _t(I["radius"], np.float64), \
+        _t(I["mask"], np.int32)
+    dfd, ddu, dvo, df = _t(I["ffluiddrag"], np.float64), _t(I["DuDt"], np.float64), _t(I["vOld"], np.float64), \
+        _t(I["f"], np.float64)
+    assert S.sfk_fix_fluid_drag_post_force(n, I["dt"], I["carrier_rho"], dv.data_ptr(), dm.data_ptr(), dr.data_ptr(),
+                                           dmask.data_ptr(), I["groupbit"], dfd.data_ptr(), ddu.data_ptr(),
+                                           dvo.data_ptr(), df.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert dc.rel_err(df.cpu().numpy(), unhex(O["f"])) <= 1e-13
+    assert np.array_equal(dvo.cpu().numpy(), unhex(O["vOld"]))
+
+
+@pytest.mark.parametrize("key,model", [("ErgunWenYu.C:104-132", 0), ("SyamlalOBrien.C:105-143", 1)])
+def test_hip_drag_model_jd_equals_the_reference_lines(key, model):
+    import torch
+    import sedifoam_amd
+    S = sedifoam_amd.lib()
+    for c in PINS[key]:
+        I, O = c["inp"], c["out"]
+        n = I["n"]
+        dU, da, dp_ = _t(I["Ur"], np.float64), _t(I["alpha"], np.float64), _t(I["pd"], np.float64)
+        djd = torch.zeros(n, dtype=torch.float64, device="cuda")
+        assert S.sfk_drag_model_jd(model, n, dU.data_ptr(), da.data_ptr(), dp_.data_ptr(), I["nuf"], I["rhof"],
+                                   djd.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        ref, got = unhex(O["Jd"]), djd.cpu().numpy()
+        # per element: the values span 30 decades (Re clamps to ROOTVSMALL for a particle at rest)
+        ok = np.abs(got - ref) <= 1e-9 * np.abs(ref) if model == 1 else np.abs(got - ref) <= 1e-12 * np.abs(ref)
+        assert ok.all(), (key, np.max(np.abs(got - ref) / np.abs(ref)))
