@@ -17,11 +17,23 @@
  *     - cases/auto-testing/test-cases/multiParticlesCollideRho/data/origin/p[1-4].dat
  *     which exercise fix fdrag, nve/sphere, gravity, wall/gran hooke_history, gran/hooke/history,
  *     SyamlalOBrien, the drag assembly of enhancedCloud and the sub-cycling rule.
- *   "parity unpinned" (no golden vector, known-answer test or runnable build of the reference
- *   exists for them -- the reference needs LAMMPS + OpenFOAM headers that this image lacks):
- *     - gran/hertzFix/history, fix cohesive, pair lubricate/poly, ErgunWenYu, the plain Hookean law
- *       (gran/hooke [3P] and FixWallGranFix::hooke).
- *     These are restated line by line and checked by hand-derived known answers only.
+ *   pinned by numbers computed by THE REFERENCE'S OWN SOURCE LINES (tests/golden/reference_pins.json, generated in the
+ *   build container by tests/golden/make_reference_pins.py, which reads the line ranges below from the reference at
+ *   generation time, transliterates them statement by statement and executes them on seeded LAMMPS-shaped inputs;
+ *   tests/test_reference_pins.py: the oracle equals them BIT FOR BIT, tests/test_reference_pins_gpu.py: the HIP styles
+ *   to 1e-12):
+ *     - gran/hertzFix/history   pair_gran_hertzFix_history.cpp:109-286 (the ii / jj loop of compute)
+ *     - fix cohesive            fix_cohesive.cpp:161-262 (opt 0 and 1)
+ *     - fix fdrag               fix_fluid_drag.cpp:143-163
+ *     - fix wall/granFix        fix_wall_granFix.cpp:286-344 + hooke :361-436, hooke_history :446-553,
+ *                               hertz_history :563-678
+ *     - pair lubricate/poly     pair_lubricate_poly.cpp:193-407 (compute loop) + :539-559 (init_style constants)
+ *     - ErgunWenYu / SyamlalOBrien   ErgunWenYu.C:104-132, SyamlalOBrien.C:105-143
+ *     The reference itself still cannot be BUILT here (LAMMPS / OpenFOAM headers are not in the image): what is pinned
+ *     is the arithmetic of those lines, not their integration into LAMMPS' Verlet loop or OpenFOAM's cloud.
+ *   "parity unpinned" (restated from the published upstream algorithm or the linear system the reference assembles, and
+ *   checked by hand-derived known answers only): the [3P] LAMMPS 1Feb14 machinery (neighbour list, FixShearHistory,
+ *   nve/sphere beyond what the golden curves exercise, gran/hooke) and smoothField's implicit diffusion solve.
  *
  * Layout convention: AoS like LAMMPS (double x[n][3] flattened to 3*n), int32 ids.
  */
