@@ -49,7 +49,8 @@ def _synthetic():
 
 def cpu_baseline(ncells, script_kw, substeps, seed=12345 + 3, keep_state=False):
     """Oracle (CPU port of the reference algorithm) on the same kind of bed: particle-substeps/s.  keep_state: also the
-    oracle's x, v, omega (sorted by tag) after those sub-steps -- the parity leg compares them with the GPU's."""
+    oracle's x, v, omega (sorted by tag) after those sub-steps -- the parity leg compares them with the GPU's -- and the
+    oracle itself with its bed (the coupled CPU step continues from there)."""
     from oracle import binding as ob
     synthetic = _synthetic()
     bed = synthetic.fcc_bed(ncells, seed=seed)
@@ -68,8 +69,71 @@ def cpu_baseline(ncells, script_kw, substeps, seed=12345 + 3, keep_state=False):
     dem.run(substeps)
     dt = time.perf_counter() - t0
     if keep_state:
-        return bed["n"] * substeps / dt, bed["n"], dt, dem.get()
+        return bed["n"] * substeps / dt, bed["n"], dt, dem.get(), dem, bed
     return bed["n"] * substeps / dt, bed["n"], dt
+
+
+def cpu_coupled_step(dem, bed, mesh_n, substeps, band, steps):
+    """ONE coupled CFD-DEM step of the reference's algorithm on the CPU (oracle/orc_cloud.c + the oracle's DEM loop), the
+    same step the GPU's `coupled_steps_per_s` times -- enhancedCloud::evolve() with subCycles 1 (UfSmoothed, drag closure
+    + assembly, lammps_put_local_info, `substeps` DEM sub-steps, cell owner, particle -> Eulerian scatter with diffusion
+    smoothing) and calcTcFields() -- with the wall clock split into the reference's buckets (writeCPUTime.H:1-19)."""
+    import ctypes as C
+    from oracle import binding as ob
+    L = ob.lib()
+    mesh_n = np.array(mesh_n, np.int32)
+    origin = np.array(bed["boxlo"], np.float64)
+    dxm = (np.array(bed["boxhi"], np.float64) - origin) / mesh_n
+    ncells = int(np.prod(mesh_n))
+    sm = ob.Smooth()
+    sm.n = (C.c_int * 3)(*[int(k) for k in mesh_n]); sm.dx = (C.c_double * 3)(*dxm); sm.D = (C.c_double * 3)(1.0, 1.0, 1.0)
+    sm.band = band; sm.steps = steps; sm.UfSmooth = sm.UpSmooth = sm.dragSmooth = sm.alphaSmooth = 1
+    smp = C.byref(sm)
+    fl = ob.CloudFlags()
+    fl.particleDrag = 1; fl.particlePressureGrad = 1
+    fl.gravity = (C.c_double * 3)(0.0, -9.81, 0.0); fl.rhob = 1000.0; fl.nub = 1.0e-6; fl.deltaT = substeps * KW["dt"]
+    st = dem.get()
+    n = st["x"].shape[0]
+    d = np.ascontiguousarray(bed["diameter"], np.float64)
+    V = np.full(ncells, float(np.prod(dxm)))
+    Uf = np.tile([0.0, 0.05, 0.0], (ncells, 1)); gradp = np.tile([0.0, -9810.0, 0.0], (ncells, 1))
+    zc = np.zeros((ncells, 3))
+    gamma = np.zeros(ncells); Ue = np.zeros((ncells, 3)); cell = np.zeros(n, np.int32); UfS = np.zeros((ncells, 3))
+    L.orc_cell_owner(n, ob.P(st["x"]), ob.P(origin), ob.P(dxm), ob.P(mesh_n), ob.P(cell))
+    L.orc_particle_to_eulerian_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), smp, ob.P(gamma), ob.P(Ue))
+    tb = {}
+
+    def lap(name, t):
+        tb[name] = tb.get(name, 0.0) + time.perf_counter() - t
+    t_ev = time.perf_counter()
+    t = time.perf_counter()
+    L.orc_uf_smoothed(ncells, ob.P(Uf), ob.P(gamma), smp, ob.P(UfS))                  # enhancedCloud.C:675-690
+    Uri = np.zeros((n, 3)); mag = np.zeros(n); Jd = np.zeros(n); pDrag = np.zeros((n, 3)); pDuDt = np.zeros((n, 3))
+    sumFb = np.zeros((n, 3)); n0 = np.zeros(n)
+    L.orc_drag_on_particles_hist(C.byref(fl), 0, n, ob.P(cell), ob.P(st["x"]), ob.P(d), ob.P(st["v"]), ob.P(st["v"]),
+                                 ob.P(gamma), ob.P(UfS), ob.P(gradp), ob.P(zc), ob.P(zc), -1, ob.P(UfS), ob.P(sumFb),
+                                 ob.P(n0), ob.P(Uri), ob.P(mag), ob.P(Jd), ob.P(pDrag), ob.P(pDuDt))
+    dem.put_fdrag(pDrag, st["tag"])
+    lap("foam->lammps (drag closure + assembly)", t)
+    t = time.perf_counter()
+    dem.run(substeps)
+    lap("lammps (%d sub-steps)" % substeps, t)
+    t = time.perf_counter()
+    st = dem.get()
+    L.orc_cell_owner(n, ob.P(st["x"]), ob.P(origin), ob.P(dxm), ob.P(mesh_n), ob.P(cell))
+    L.orc_particle_to_eulerian_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ncells, ob.P(V), smp, ob.P(gamma), ob.P(Ue))
+    lap("particle move (cell owner + scatter + smoothing)", t)
+    tb["evolve"] = time.perf_counter() - t_ev
+    t = time.perf_counter()
+    gcap = np.minimum(gamma, 0.65)                                                     # liftDragCoeffs.H:6-14
+    Ur = np.linalg.norm(UfS[cell] - st["v"], axis=1)
+    L.orc_ergun_wenyu_jd(n, ob.P(Ur), ob.P(np.ascontiguousarray(gcap[cell])), ob.P(d), 1.0e-6, 1000.0, ob.P(Jd))
+    Asrc = np.zeros((ncells, 3)); Omega = np.ones(ncells)
+    L.orc_calc_tc_fields_smooth(n, ob.P(cell), ob.P(d), ob.P(st["v"]), ob.P(Jd), ncells, ob.P(V), ob.P(gcap), ob.P(UfS),
+                                smp, ob.P(Asrc), ob.P(Omega))
+    lap("calcTcField", t)
+    total = tb["evolve"] + tb["calcTcField"]
+    return total, {k: 1e3 * v for k, v in tb.items()}
 
 
 KW = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
@@ -358,7 +422,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if is_strong else "weak",
+        # (one workload for every N of a --scaling both / strong series: the SAME --particles bed, in one domain at N = 1)
+        "scaling": "weak" if args.scaling == "weak" else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -544,10 +609,59 @@ def main():
         out["fluidised_bed"] = fo
         args.steps, args.warmup = keep
         del flmp, fbed
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (the CPU baseline is an N = 1 measurement)
+    # N > 1: the decomposed engine proves itself -- the SAME global bed through setup + 50 sub-steps on the N domains (the
+    # headline's decomposition and transport) and on ONE domain (rank 0's GPU); the line carries the difference, and the
+    # run fails (rc 1) when they disagree
+    parity_ok = True
+    if world > 1 and not args.no_parity and args.scaling != "weak":
+        sub = 50
+        gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
+        pdrv = make_driver("from_global_bed", gbed)
+        pdrv.setup()
+        pdrv.step(sub)
+        mine = pdrv.e.lmp.get_state()
+        mine_builds = int(pdrv.n_rebuilds)
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object({k: mine[k] for k in ("tag", "x", "v", "omega")}, parts, dst=0)
+        del pdrv
+        if rank == 0:
+            one = build_engine(gbed, synthetic.hertz_script(gbed, **kw))
+            one.setup()
+            one.step(sub)
+            ref = one.get_state()
+            one_builds = int(one.info().nbuilds)
+            del one
+            tag = np.concatenate([q["tag"] for q in parts])
+            o = np.argsort(tag, kind="stable")
+            same = bool(len(tag) == len(ref["tag"]) and np.array_equal(tag[o], ref["tag"]))
+            d = float(np.max(gbed["diameter"]))
+            L3 = np.array(gbed["boxhi"]) - np.array(gbed["boxlo"])
+
+            def rel(a, b):
+                sc = float(np.max(np.abs(b)))
+                return float(np.max(np.abs(a - b)) / (sc if sc > 0 else 1.0))
+            par = {"against": "the same %d-particle bed on ONE domain (rank 0's GPU), setup + %d sub-steps from the same "
+                              "start; the %d domains gathered by tag" % (len(ref["tag"]), sub, world),
+                   "n": int(len(ref["tag"])), "substeps": sub, "tags_identical": same}
+            if same:
+                dx = np.concatenate([q["x"] for q in parts])[o] - ref["x"]
+                per = np.array(gbed["periodic"], bool)
+                dx[:, per] -= L3[per] * np.round(dx[:, per] / L3[per])   # (an atom is wrapped when its owner reneighbours)
+                par.update(max_abs_dx_over_d=float(np.max(np.abs(dx)) / d),
+                           max_rel_v=rel(np.concatenate([q["v"] for q in parts])[o], ref["v"]),
+                           max_rel_omega=rel(np.concatenate([q["omega"] for q in parts])[o], ref["omega"]))
+            par["rebuilds_decomposed_rank0"] = mine_builds
+            par["rebuilds_single_domain"] = one_builds
+            par["tolerance"] = "x 1e-9 d, v / omega 1e-9 of max (SURVEY.md 8d)"
+            par["ok"] = bool(same and par["max_abs_dx_over_d"] <= 1e-9 and par["max_rel_v"] <= 1e-9
+                             and par["max_rel_omega"] <= 1e-9)
+            out["parity"] = par
+            parity_ok = par["ok"]
+        del gbed
+    if rank == 0 and not args.no_cpu_baseline:   # (on rank 0's host cores; at N > 1 the other ranks are done)
         sample_n = args.cpu_sample or 1000000
         sub = 50
-        do_parity = (not args.no_parity and not args.slab_driver and sample_n == args.particles and not bed_kw)
+        do_parity = (world == 1 and not args.no_parity and not args.slab_driver and sample_n == args.particles and not bed_kw)
         gpu_state = None
         if do_parity:
             # the SAME bed from the SAME start through the product path: setup + `sub` sub-steps, outside the timed region
@@ -557,12 +671,24 @@ def main():
             gpu_state = plmp.get_state()
             p_builds = int(plmp.info().nbuilds)
             del plmp
-        res = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub, keep_state=do_parity)
+        res = cpu_baseline(synthetic.fcc_cells_for(sample_n), kw, sub, keep_state=True)
         v, n_s, secs = res[:3]
         out["cpu_baseline"] = {"value": v, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
                                "buckets_ms_per_step": {"lammps (%d sub-steps)" % sub: 1e3 * secs},
                                "sample": "%d-particle bed of the same packing, %d sub-steps, %.1f s, "
                                          "oracle/ (C, gcc -O2) single thread" % (n_s, sub, secs)}
+        if not args.no_coupled:
+            # BASELINE.json's second metric on the CPU: ONE coupled CFD-DEM step of the same kind the GPU's
+            # `coupled_steps_per_s` times, continued from the oracle state above, in the reference's timer buckets
+            cbed = res[5]
+            cmesh = np.clip(((cbed["boxhi"] - cbed["boxlo"]) / 3.0e-3).astype(int), 1, 32)
+            csecs, cb = cpu_coupled_step(res[4], cbed, cmesh, sub, 0.006, 6)
+            out["cpu_baseline"]["coupled_steps_per_s"] = 1.0 / csecs
+            out["cpu_baseline"]["coupled_buckets_ms"] = cb
+            out["cpu_baseline"]["coupled_sample"] = ("one coupled step (ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc + "
+                                                     "diffusion smoothing b = 6 mm, 6 steps; %dx%dx%d mesh) of the same %d-"
+                                                     "particle bed, %.1f s, oracle/ single thread"
+                                                     % (sub, cmesh[0], cmesh[1], cmesh[2], n_s, csecs))
         if do_parity:
             o = res[3]
             d = float(np.max(bed["diameter"]))
@@ -582,6 +708,8 @@ def main():
                              "gpu_rebuilds": p_builds}
             out["parity"]["ok"] = bool(same and out["parity"]["max_abs_dx_over_d"] <= 1e-9
                                        and out["parity"]["max_rel_v"] <= 1e-9 and out["parity"]["max_rel_omega"] <= 1e-9)
+            parity_ok = out["parity"]["ok"]
+        del res
         allc = cpu_baseline_all_cores(args.cpu_all_particles, 20) if args.cpu_all_particles > 0 else None
         if allc:
             out["cpu_baseline_all_cores"] = allc
@@ -589,6 +717,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and not parity_ok:
+        sys.stderr.write("bench.py: the parity leg FAILED (see the `parity` object of the line)\n")
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":
