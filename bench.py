@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--substeps", type=int, default=50, help="DEM sub-steps per step (per CFD step)")
     ap.add_argument("--jitter", type=float, default=None, help="sensitivity runs: uniform position jitter / d (default 0.005)")
     ap.add_argument("--spacing", type=float, default=None, help="sensitivity runs: lattice spacing / d (default 0.98)")
+    ap.add_argument("--skin", type=float, default=None, help="sensitivity runs: neighbour skin / d (default 0.25)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coupled", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true",
@@ -265,7 +266,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sedifoam_amd import synthetic
-    kw = KW
+    kw = dict(KW, skin_d=args.skin) if args.skin is not None else KW
     ncells = synthetic.fcc_cells_for(args.particles)
     bed_kw = {}
     if args.bed == "fluidised":

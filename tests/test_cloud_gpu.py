@@ -520,6 +520,24 @@ def test_config_c3_100k_coupled_50_substeps():
                   mesh_n=(11, 16, 13))
 
 
+def test_config_c3_loose_100k_coupled():
+    """Config C3 as a FLUIDISED bed: 100 k grains on FCC sites at spacing 1.1 d with 0.3 d jitter (deep initial overlaps:
+    a hot, loose, disordered bed -- 8 listed neighbours per grain, 2-3 of them touching, touching neighbours first in
+    their rows, two history copies), 50 DEM sub-steps per CFD step with SEVERAL neighbour rebuilds inside each (the
+    cloud's per-particle rows -- previous velocity, Basset sums -- are permuted by every re-sort), added mass and the
+    Basset history force on, ErgunWenYu drag, scatter and Asrc against the oracle over two CFD steps."""
+    from sedifoam_amd import synthetic
+    bed = synthetic.fcc_bed(synthetic.fcc_cells_for(100000), seed=12345 + 2, spacing=1.1, jitter=0.3)
+    assert bed["n"] >= 100000
+    mesh_n = np.clip(((bed["boxhi"] - bed["boxlo"]) / 3.3e-3).astype(int), 1, 32)
+    cloud = _coupled_case("ErgunWenYu", dict(particleBuoyancy=True, particleAddedMass=True, particleHistoryForce=True),
+                          sub_cycles=1, n_cfd=2, deltaT=50e-6, bed=bed, mesh_n=tuple(int(k) for k in mesh_n), tol=1e-10)
+    # (1e-10 on Jd / pDrag / gamma / Ue: the grains fly apart at metres per second, round-off differences of the two
+    # force sums reach 1e-13 of the velocities within the first CFD step; north star: fields within 1e-6)
+    builds = int(cloud.lmp.info().nbuilds)
+    assert builds >= 1 + 2 * 3, "only %d list builds: the bed is not hot enough to rebuild inside a CFD step" % builds
+
+
 def test_coupled_with_carrier_rho_fdrag_sees_zero_DuDt():
     """`fix fdrag 1000` (in-LAMMPS added mass, fix_fluid_drag.cpp:152-156) under the coupled cloud: the reference's
     lammps_put_local_info drops the DuDt the cloud computes (library.cpp:314-367), so the fix uses DuDt = 0 -- the
