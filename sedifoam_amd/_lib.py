@@ -152,6 +152,7 @@ _SIGS = {
     "sf_slab_rebuild": (C.c_int, [vp]),
     "sf_slab_step": (C.c_int, [vp, C.c_int]),
     "sf_slab_active": (C.c_int, [vp]),
+    "sf_slab_direct_halo": (C.c_int, [vp]),
     "sf_slab_allreduce_sum": (C.c_int, [vp, dp, C.c_int]),
     "sf_slab_rebuild_count": (C.c_longlong, [vp]),
     "sf_slab_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),

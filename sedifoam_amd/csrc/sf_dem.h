@@ -73,6 +73,8 @@ enum Flag {
   F_MIG_TRUNC,      // a migrating atom had more history slots than the migrate record carries (an error, never truncated)
   F_GHOST_BEFORE,   // + dim: ghosts that existed before the images of periodic dimension `dim` were made (3 words)
   F_GHOST_BEFORE_Z = F_GHOST_BEFORE + 2,
+  F_HALO_TIMEOUT,   // direct ghost writes: a peer's "exchange done" flag did not arrive in time (an error, never a hang)
+  F_HALO_TIMEOUT_PEER,   // ... which rank's, and the value its flag had
   F_NFLAGS = 32
 };
 
@@ -97,6 +99,8 @@ struct WallMotion {
 
 constexpr int kForwardDoubles = 9;   // forward halo record: x | v | omega
 constexpr int kBrickSlots = 7;       // directions that can send one atom (3 faces + 3 edges + 1 corner)
+constexpr int kBlkShift = 26;        // record slot = (block << kBlkShift) | offset in doubles inside the block
+constexpr int kBlkMask = (1 << kBlkShift) - 1;
 // the rebuild vote in the one-double header of a forward chunk: an int in the slot's first four bytes (so that the
 // kernel that finds an atom beyond skin/2 can lower it with an integer atomicMin)
 __host__ __device__ inline int* header_vote_ptr(double* slot) { return reinterpret_cast<int*>(slot); }
@@ -128,8 +132,12 @@ struct DemPtrs {
   const int* sendslot[2];
   double* tx[2];
   double* tx_sendbuf;           // vote headers: the 8-byte slot at tx_sendbuf + tx_hdr_off[p] holds an int (header_vote)
-  const int* bslot;             // brick driver (tx_fused == 2): [kBrickSlots][cap] where an atom's forward records go, in
-                                // doubles from tx_sendbuf (-1: no further direction sends this atom)
+  const int* bslot;             // brick driver (tx_fused == 2): [kBrickSlots][cap] where an atom's forward records go:
+                                // (send block q << kBlkShift) | doubles from the start of that block (-1: no further
+                                // direction sends this atom)
+  double* const* tx_blkptr;     // [directions] where block q of the exchange that follows this sub-step starts: in the
+                                // local send buffer, or -- direct ghost writes -- in the NEIGHBOUR's receive area (an
+                                // IPC mapping; two areas, used alternately)
   const int* tx_hdr_off;
   int* xcd_time;                // StepParams::xcd_time: [64 x + 0] first start, [64 x + 32] last end of XCD x (100 MHz clock)
   // LDS-staged tiles (k_substep_lds)
@@ -428,9 +436,28 @@ class DemEngine {
   void brick_ghost_unpack(const double* buf, long long natoms);   // border records -> external ghosts (appended)
   void brick_forward_pack(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr);
   // the sub-step kernel writes the forward records itself from now on (until the next rebuild): record positions of
-  // every sent atom from the blocks' offsets in the send buffer
-  void brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr);
+  // every sent atom from the blocks' offsets in the send buffer.  direct_blk != null: [2][kMaxDirs] block starts in the
+  // neighbours' receive areas (parity of the exchange), the vote headers are then not the kernel's business
+  void brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr,
+                            double* const* direct_blk = nullptr);
   void brick_forward_unpack(const BrickBlocks& rcv, const double* recvbuf, const int* hdr_off, int nhdr);
+  // direct ghost writes (sf_halo_rccl.hip): which of the two receive areas the exchange after the next sub-step uses
+  void set_tx_parity(int par) { tx_par_ = par & 1; }
+  bool tx_direct() const { return tx_direct_; }
+  int halo_timeout() const { return h_flags_[F_HALO_TIMEOUT]; }   // (after a synchronising flag read: batch_end)
+  int halo_timeout_peer() const { return h_flags_[F_HALO_TIMEOUT_PEER]; }
+  // one kernel instead of {RCCL send/recv, unpack}: tell every rank "my records of exchange `seq` are in your area"
+  // (vote first, then the flag, system-scope release), wait for the same word from every rank (bounded: F_HALO_TIMEOUT),
+  // lower the trigger word to the smallest vote and move the received records into the ghost slots
+  static constexpr int kSyncStride = 32;   // ints: one 128-byte line per sending rank
+  struct DirectSync {
+    int world, rank, seq, par;
+    int* my_sync;          // this rank's area (fine-grained): for sender r the line [kSyncStride r]: flag, vote[2]
+    int* peer_sync[32];    // every rank's area, mapped (own entry unused)
+    long long max_ticks;   // 100 MHz clock
+  };
+  void brick_direct_unpack(const BrickBlocks& rcv, const double* recvarea, const DirectSync& D);
+  void brick_direct_probe(const BrickBlocks& none, const DirectSync& D);   // bring-up: one flag round, no records; synchronises
   const BrickBlocks& brick_send_blocks() const { return bsend_blocks_; }
   long long migrate_count3();      // owned atoms outside the brick in any external dimension
   long long migrate_pack_dim(int dim, int side, double shift, double* buf, long long max_doubles);
@@ -661,6 +688,9 @@ private:
   const int* tx_hdr_off_ = nullptr;
   int tx_nhdr_ = 0, tx_n_[2] = {0, 0};
   bool tx_ready_ = false, tx_written_ = false;
+  bool tx_direct_ = false;             // records go straight into the neighbours' receive areas
+  int tx_par_ = 0;
+  double** d_blkptr_ = nullptr;        // [2][kMaxDirs] device table of block starts (both rows equal unless tx_direct_)
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
   // brick decomposition: directions, face masks of the owned atoms, concatenated send lists
   int bndir_ = 0;

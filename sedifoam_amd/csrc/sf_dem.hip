@@ -136,6 +136,7 @@ DemEngine::~DemEngine()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevArray* a : per_atom_) a->release();
+  if (d_blkptr_) (void)hipFree(d_blkptr_);
   if (d_xcd_time_) (void)hipFree(d_xcd_time_);
   if (h_xcd_time_) (void)hipHostFree(h_xcd_time_);
   bslot_.release();   // (not in per_atom_: allocated by the first brick rebuild, re-allocated when the capacity moves)
@@ -696,6 +697,7 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   }
   P.tx_sendbuf = tx_sendbuf_;
   P.bslot = bslot_.as<int>();
+  P.tx_blkptr = d_blkptr_ ? d_blkptr_ + (size_t)tx_par_ * kMaxDirs : nullptr;
   P.tx_hdr_off = tx_hdr_off_;
   P.xcd_time = d_xcd_time_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
@@ -861,7 +863,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   }
   // the forward halo of the exchange that follows: written by the kernel that integrates the border atoms
   if (part != 1) tx_written_ = false;   // (the interior part sends nothing: what the boundary part wrote stands)
-  if (tx_ready_ && mode == 0 && !lds_active_) S.tx_nhdr = tx_nhdr_;
+  if (tx_ready_ && mode == 0 && !lds_active_) S.tx_nhdr = tx_direct_ ? 0 : tx_nhdr_;   // (direct: votes travel with the flags)
   if (tx_ready_ && brick_ && mode == 0 && part == 0 && !lds_active_) {
     S.tx_fused = 2;
     if (bslot_.cap != cap_) fail("launch_substep: the record-slot table has stride %zu, the engine %zu", bslot_.cap, cap_);

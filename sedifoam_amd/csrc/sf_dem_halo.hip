@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void k_brick_border_pack(const int* list, DemE
 __global__ __launch_bounds__(256) void k_brick_forward_pack(const int* list, DemEngine::BrickBlocks blk,
                                                             const int* hdr_off, int nhdr, double* sendbuf,
                                                             const int* trig_word, const double4* xr, const double4* vm,
-                                                            const double4* om)
+                                                            const double4* om, double* const* blkptr)
 {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int tot = blk.first[blk.n];
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void k_brick_forward_pack(const int* list, Dem
   const int q = block_of(blk, k);
   const int i = list[k];
   const double4 x = xr[i], v = vm[i], w = om[i];
-  double* b = sendbuf + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  double* b = blkptr[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
   // (unshifted, like the records the sub-step kernel writes itself: the receiver adds the block's periodic shift)
   b[0] = x.x; b[1] = x.y; b[2] = x.z;
   b[3] = v.x; b[4] = v.y; b[5] = v.z;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void k_brick_slots(const int* list, DemEngine:
   const int q = block_of(blk, k);
   const int i = list[k];
   const int s = atomicAdd(&cursor[i], 1);   // (< kBrickSlots: brick_set_forward_tx refuses thinner bricks)
-  if (s < kBrickSlots) slots[(size_t)s * cap + i] = (int)(blk.off[q] + (long long)(k - blk.first[q]) * kForwardDoubles);
+  if (s < kBrickSlots) slots[(size_t)s * cap + i] = (q << kBlkShift) | ((k - blk.first[q]) * kForwardDoubles);
 }
 
 __global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBlocks blk, const int* hdr_off, int nhdr,
@@ -766,10 +766,28 @@ __global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBl
   om[g] = {b[6], b[7], b[8], om[g].w};
 }
 
-void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr)
+void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr,
+                                     double* const* direct_blk)
 {
   static const bool off = getenv("SF_HALO_FUSED_PACK") && !atoi(getenv("SF_HALO_FUSED_PACK"));
   tx_ready_ = tx_written_ = false;
+  // where the blocks of an exchange start: the local send buffer, or the neighbours' receive areas (two of them)
+  tx_direct_ = direct_blk != nullptr;
+  tx_sendbuf_ = sendbuf;
+  tx_hdr_off_ = hdr_off;
+  tx_nhdr_ = nhdr;
+  {
+    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 2 * kMaxDirs));
+    double* h[2 * kMaxDirs];
+    for (int par = 0; par < 2; par++)
+      for (int q = 0; q < kMaxDirs; q++)
+        h[par * kMaxDirs + q] = q >= snd.n ? nullptr : (direct_blk ? direct_blk[par * kMaxDirs + q] : sendbuf + snd.off[q]);
+    SF_HIP(hipMemcpyAsync(d_blkptr_, h, sizeof(h), hipMemcpyHostToDevice, stream_));
+    SF_HIP(hipStreamSynchronize(stream_));   // (h is on the stack)
+  }
+  for (int q = 0; q < snd.n; q++)
+    if ((long long)(snd.first[q + 1] - snd.first[q]) * kForwardDoubles > (long long)kBlkMask)
+      fail("brick_set_forward_tx: a send block of %d atoms does not fit the record slot encoding", snd.first[q + 1] - snd.first[q]);
   if (off || !nlocal_) return;
   // A brick thinner than twice the ghost cutoff in an external dimension has atoms that are ghosts of BOTH neighbours
   // along it: three choices in that dimension instead of two, up to 3 * 2 * 2 - 1 = 11 (17, 26) send directions per
@@ -786,9 +804,6 @@ void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, co
   if (snd.n && (size_t)(snd.off[snd.n - 1] + (long long)tot * kForwardDoubles) >= (size_t)INT_MAX)
     fail("brick_set_forward_tx: send buffer beyond 2^31 doubles");
   if (tot) k_brick_slots<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, snd, bslot_.as<int>(), cursor, bslot_.cap);
-  tx_sendbuf_ = sendbuf;
-  tx_hdr_off_ = hdr_off;
-  tx_nhdr_ = nhdr;
   tx_ready_ = true;
 }
 
@@ -875,11 +890,97 @@ void DemEngine::brick_ghost_unpack(const double* buf, long long natoms)
 
 void DemEngine::brick_forward_pack(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr)
 {
+  if (tx_direct_) nhdr = 0;   // (the votes travel with the flags of brick_direct_unpack)
   const int tot = snd.first[snd.n] + nhdr;
   if (tot)
     k_brick_forward_pack<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, snd, hdr_off, nhdr, sendbuf,
                                                                d_flags_ + F_TRIGGER, xr_[cur_].as<double4>(),
-                                                               vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+                                                               vm_[cur_].as<double4>(), om_[cur_].as<double4>(),
+                                                               d_blkptr_ + (size_t)tx_par_ * kMaxDirs);
+}
+
+// Direct ghost writes: the records of this exchange were written into the receive areas by the NEIGHBOURS' sub-step
+// kernels (IPC mappings; sf_halo_rccl.hip).  This kernel is everything that stands between two sub-step kernels:
+//   1. workgroup 0 tells every rank that this rank's records and vote of exchange `seq` are in place: the vote into
+//      the peer's vote[par][me], then seq into its flag[me] with a system-scope release (the sub-step kernel that wrote
+//      the records is complete: stream order);
+//   2. every workgroup waits (acquire, bounded by max_ticks) until all ranks have said the same here;
+//   3. trigger word <- min of the votes; received records -> ghost slots (+ the block's periodic shift).
+__global__ __launch_bounds__(256) void k_brick_direct_unpack(DemEngine::BrickBlocks blk, const double* recvarea,
+                                                             DemEngine::DirectSync D, int* flags, int nlocal, double4* xr,
+                                                             double4* vm, double4* om)
+{
+  __shared__ int ok;
+  const int W = D.world;
+  if (blockIdx.x == 0 && (int)threadIdx.x < W && (int)threadIdx.x != D.rank) {
+    // (every sender has a 128-byte line of its own in the receiver's area: {flag, vote[2]}.  Eight ranks' words on ONE
+    // line went wrong on eight XCDs: a flag was seen at 61 and later at 57 -- the per-XCD L2s are not coherent with each
+    // other, a line has to have one writer)
+    int* peer = D.peer_sync[threadIdx.x] + DemEngine::kSyncStride * D.rank;
+    __hip_atomic_store(&peer[1 + D.par], __atomic_load_n(&flags[F_TRIGGER], __ATOMIC_RELAXED), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&peer[0], D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  if ((int)threadIdx.x < W && (int)threadIdx.x != D.rank) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < D.seq) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > D.max_ticks) {
+        ok = 0;
+        flags[F_HALO_TIMEOUT_PEER] = (int)threadIdx.x * 1000000 +
+                                     __hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * threadIdx.x], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (!ok) {
+    if (threadIdx.x == 0) flags[F_HALO_TIMEOUT] = D.seq;
+    return;
+  }
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tot = blk.first[blk.n];
+  if (k >= tot) {
+    k -= tot;
+    if (k < W && k != D.rank)
+      atomicMin(&flags[F_TRIGGER], __hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * k + 1 + D.par], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_SYSTEM));
+    return;
+  }
+  const int q = block_of(blk, k);
+  const double* b = recvarea + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  const int g = nlocal + k;
+  double4 x = xr[g], v = vm[g];
+  x.x = b[0] + blk.shift[q][0]; x.y = b[1] + blk.shift[q][1]; x.z = b[2] + blk.shift[q][2];
+  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  xr[g] = x;
+  vm[g] = v;
+  om[g] = {b[6], b[7], b[8], om[g].w};
+}
+
+void DemEngine::brick_direct_unpack(const BrickBlocks& rcv, const double* recvarea, const DirectSync& D)
+{
+  if (rcv.first[rcv.n] != next_ghost_)
+    fail("brick_direct_unpack: %d ghosts in the layout, the border exchange set up %d", rcv.first[rcv.n], next_ghost_);
+  if (D.world > 32) fail("brick_direct_unpack: %d ranks (at most 32)", D.world);
+  const int tot = rcv.first[rcv.n] + D.world;
+  k_brick_direct_unpack<<<div_up(tot, 256), 256, 0, stream_>>>(rcv, recvarea, D, d_flags_, nlocal_,
+                                                              xr_[cur_].as<double4>(), vm_[cur_].as<double4>(),
+                                                              om_[cur_].as<double4>());
+  launch_ghost_forward(cur_, INT_MIN);   // (index mode only: local images of everything, received ghosts included)
+}
+
+void DemEngine::brick_direct_probe(const BrickBlocks& none, const DirectSync& D)
+{
+  read_flags();
+  const int keep = h_flags_[F_TRIGGER];
+  reset_flag(F_HALO_TIMEOUT, 0);
+  k_brick_direct_unpack<<<1, 256, 0, stream_>>>(none, nullptr, D, d_flags_, 0, nullptr, nullptr, nullptr);
+  read_flags();
+  reset_flag(F_TRIGGER, keep);   // (the probe's votes carried whatever the word held: put it back)
 }
 
 void DemEngine::brick_forward_unpack(const BrickBlocks& rcv, const double* recvbuf, const int* hdr_off, int nhdr)

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/sedifoam_amd.h"
@@ -135,9 +136,47 @@ struct BrickState {
   }
 };
 
+// ---- direct ghost writes (brick driver): the sub-step kernel of a rank writes the forward records of its border atoms
+// straight into the receive area of the neighbour's process -- an IPC mapping of fine-grained device memory -- and one
+// kernel per exchange publishes / awaits a flag word per rank (DemEngine::brick_direct_unpack).  No RCCL kernel, no
+// separate pack or unpack pass between two sub-steps.  RCCL still carries everything rare: the rebuild-time migration
+// and border exchange, the reductions, and the IPC handles themselves.
+struct DirectHalo {
+  bool on = false;
+  int* my_sync = nullptr;               // one 128-byte line per sending rank: {flag, vote[2]}; peers write, this rank polls
+  std::vector<int*> peer_sync;          // every rank's area as mapped here
+  double* rx[2] = {nullptr, nullptr};   // receive areas (exchange parity); neighbours write, this rank unpacks
+  size_t rx_cap = 0;
+  long long rx_gen = 0;                 // bumped when the areas are re-allocated: the neighbours re-open their mappings
+  struct Peer {
+    long long gen_seen = -1;
+    void* map[2] = {nullptr, nullptr};  // that rank's receive areas as mapped here
+    long long remote_off = 0;           // where this rank's chunk starts in them (doubles)
+  };
+  std::vector<Peer> peers;
+  long long xseq = 0;                   // exchanges done so far (the same number on every rank)
+  long long* d_msg = nullptr;           // [2][world][kMsg] handle / offset messages (device, for the RCCL exchange)
+  long long* h_msg = nullptr;
+  static constexpr int kMsg = 18;       // generation, two 64-byte IPC handles, chunk offset
+  ~DirectHalo()
+  {
+    for (Peer& p : peers)
+      for (void* m : p.map)
+        if (m) (void)hipIpcCloseMemHandle(m);
+    for (size_t r = 0; r < peer_sync.size(); r++)
+      if (peer_sync[r] && peer_sync[r] != my_sync) (void)hipIpcCloseMemHandle(peer_sync[r]);
+    if (my_sync) (void)hipFree(my_sync);
+    for (double* b : rx)
+      if (b) (void)hipFree(b);
+    if (d_msg) (void)hipFree(d_msg);
+    if (h_msg) (void)hipHostFree(h_msg);
+  }
+};
+
 struct HaloComm {
   ncclComm_t comm = nullptr;
   BrickState* brick = nullptr;
+  DirectHalo* direct = nullptr;
   int rank = 0, world = 1;
   hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
   // ---- the slab driver (sf_slab_*): what sedifoam_amd/halo.py SlabDriver does, in C++ ----
@@ -180,6 +219,7 @@ struct HaloComm {
   }
   ~HaloComm()
   {
+    delete direct;
     delete brick;
     if (comm) (void)rccl().CommDestroy(comm);
     if (ev_boundary) (void)hipEventDestroy(ev_boundary);
@@ -656,6 +696,191 @@ static void brick_segments(HaloComm& hc, hipStream_t st, const T* send, const st
   SF_NCCL(a.GroupEnd());
 }
 
+// ------------------------------------------------------------------------------------------------
+// direct ghost writes: bring-up, rebuild-time handle exchange
+// ------------------------------------------------------------------------------------------------
+static void* alloc_fine_grained(size_t bytes)
+{
+  void* p = nullptr;
+  SF_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+  SF_HIP(hipMemset(p, 0, bytes));
+  return p;
+}
+
+static DemEngine::DirectSync direct_sync(const HaloComm& hc, int seq, int par)
+{
+  const DirectHalo& D = *hc.direct;
+  DemEngine::DirectSync s;
+  s.world = hc.world;
+  s.rank = hc.rank;
+  s.seq = seq;
+  s.par = par;
+  s.my_sync = D.my_sync;
+  for (int p = 0; p < 32; p++) s.peer_sync[p] = p < hc.world ? D.peer_sync[p] : nullptr;
+  static const double secs = getenv("SF_HALO_DIRECT_TIMEOUT") ? atof(getenv("SF_HALO_DIRECT_TIMEOUT")) : 20.0;
+  s.max_ticks = (long long)(secs * 1.0e8);   // wall_clock64: 100 MHz
+  return s;
+}
+
+// every rank's message for every other rank (kMsg int64 each; cnt[p] = 0: nothing for / from rank p) over RCCL
+static void direct_messages(HaloComm& hc, hipStream_t st, const std::vector<int>& with)
+{
+  DirectHalo& D = *hc.direct;
+  const int W = hc.world, K = DirectHalo::kMsg;
+  std::vector<long long> off(W), cnt(W);
+  for (int p = 0; p < W; p++) {
+    off[p] = (long long)p * K;
+    cnt[p] = with[p] ? K : 0;
+  }
+  SF_HIP(hipMemcpyAsync(D.d_msg, D.h_msg, sizeof(long long) * W * K, hipMemcpyHostToDevice, st));
+  brick_segments<long long>(hc, st, D.d_msg, off, cnt, D.d_msg + (size_t)W * K, off, cnt, ncclInt64);
+  SF_HIP(hipMemcpyAsync(D.h_msg + (size_t)W * K, D.d_msg + (size_t)W * K, sizeof(long long) * W * K, hipMemcpyDeviceToHost, st));
+  SF_HIP(hipStreamSynchronize(st));
+}
+
+// SF_HALO_DIRECT: unset / 0 = the RCCL exchange; "auto" = try, and fall back to the RCCL exchange when anything in the
+// bring-up fails on any rank; 1 = must come up (an error otherwise).  Bring-up: the flag / vote areas of all ranks are
+// mapped into each other and a first round of {vote, flag} goes through them before a single ghost depends on it.
+// (bench.py --gpus N asks for "auto" and proves the decomposed result against a single-domain run before it times
+// anything; a library default of "auto" would put an unproven transport under every host.)
+static void direct_init(SfLammps& S, HaloComm& hc)
+{
+  const char* env = getenv("SF_HALO_DIRECT");
+  const int want = !env ? 0 : (!strcmp(env, "auto") ? -1 : atoi(env));
+  if (want == 0 || hc.world < 2) return;
+  if (hc.world > 32) {
+    if (want == 1) fail("SF_HALO_DIRECT=1: %d ranks (at most 32)", hc.world);
+    return;
+  }
+  DemEngine& e = S.eng;
+  hipStream_t st = e.stream();
+  const int W = hc.world, K = DirectHalo::kMsg;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle = 8 int64");
+  hc.direct = new DirectHalo();
+  DirectHalo& D = *hc.direct;
+  double ok = 1.0;
+  std::string why;
+  D.peer_sync.assign(W, nullptr);
+  D.peers.assign(W, DirectHalo::Peer());
+  SF_HIP(hipMalloc(&D.d_msg, sizeof(long long) * 2 * W * K));
+  SF_HIP(hipHostMalloc(&D.h_msg, sizeof(long long) * 2 * W * K));
+  memset(D.h_msg, 0, sizeof(long long) * 2 * W * K);
+  try {
+    D.my_sync = static_cast<int*>(alloc_fine_grained(sizeof(int) * DemEngine::kSyncStride * 32));
+    hipIpcMemHandle_t h;
+    SF_HIP(hipIpcGetMemHandle(&h, D.my_sync));
+    for (int p = 0; p < W; p++) memcpy(D.h_msg + (size_t)p * K + 1, &h, 64);
+  } catch (const std::exception& ex) {
+    ok = 0.0;
+    why = ex.what();
+  }
+  // (collective from here on: every rank takes part whatever happened to it)
+  std::vector<int> all(W, 1);
+  all[hc.rank] = 0;
+  direct_messages(hc, st, all);
+  if (ok != 0.0) {
+    try {
+      for (int p = 0; p < W; p++) {
+        if (p == hc.rank) {
+          D.peer_sync[p] = D.my_sync;
+          continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, D.h_msg + (size_t)(W + p) * K + 1, 64);
+        void* m = nullptr;
+        SF_HIP(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+        D.peer_sync[p] = static_cast<int*>(m);
+      }
+    } catch (const std::exception& ex) {
+      ok = 0.0;
+      why = ex.what();
+    }
+  }
+  ok = slab_allreduce(hc, st, ok, ncclMin);
+  if (ok != 0.0) {
+    // the first round: vote + flag to every rank, every rank's flag awaited (no records yet)
+    DemEngine::BrickBlocks none{};
+    DemEngine::DirectSync s = direct_sync(hc, 1, 0);
+    s.max_ticks = 500000000LL;   // 5 s
+    e.brick_direct_probe(none, s);
+    ok = e.halo_timeout() ? 0.0 : 1.0;
+    if (ok == 0.0) why = "the first flag round timed out";
+    ok = slab_allreduce(hc, st, ok, ncclMin);
+    D.xseq = 1;
+  }
+  if (ok == 0.0) {
+    delete hc.direct;
+    hc.direct = nullptr;
+    if (want == 1) fail("SF_HALO_DIRECT=1: direct ghost writes did not come up on every rank (%s)", why.empty() ? "another rank" : why.c_str());
+    if (getenv("SF_DEBUG_HALO")) fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes off, RCCL exchange (%s)\n", hc.rank, why.empty() ? "another rank failed" : why.c_str());
+    return;
+  }
+  D.on = true;
+  if (getenv("SF_DEBUG_HALO")) fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes on (%d ranks)\n", hc.rank, W);
+}
+
+// after a rebuild fixed the chunk layout: the receive areas (grown if need be), their handles and this rank's chunk
+// offsets to every neighbour, the neighbours' to this rank; returns the [2][kMaxDirs] table of block starts
+static void direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2)
+{
+  DirectHalo& D = *hc.direct;
+  BrickState& B = *hc.brick;
+  DemEngine& e = S.eng;
+  hipStream_t st = e.stream();
+  const int W = hc.world, K = DirectHalo::kMsg;
+  const size_t need = (size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1;
+  if (need > D.rx_cap) {
+    SF_HIP(hipStreamSynchronize(st));
+    for (double*& b : D.rx) {
+      if (b) SF_HIP(hipFree(b));
+      b = nullptr;
+    }
+    D.rx_cap = need + need / 2 + 4096;
+    for (double*& b : D.rx) b = static_cast<double*>(alloc_fine_grained(sizeof(double) * D.rx_cap));
+    D.rx_gen++;
+  }
+  std::vector<int> nbr(W, 0);
+  for (const auto& sd : B.sdirs) nbr[sd.peer] = 1;
+  hipIpcMemHandle_t h0, h1;
+  SF_HIP(hipIpcGetMemHandle(&h0, D.rx[0]));
+  SF_HIP(hipIpcGetMemHandle(&h1, D.rx[1]));
+  for (int p = 0; p < W; p++) {
+    long long* m = D.h_msg + (size_t)p * K;
+    m[0] = D.rx_gen;
+    memcpy(m + 1, &h0, 64);
+    memcpy(m + 9, &h1, 64);
+    m[17] = hc.recv_off[p];   // where rank p's chunk starts in this rank's areas
+  }
+  direct_messages(hc, st, nbr);
+  for (int p = 0; p < W; p++) {
+    if (!nbr[p]) continue;
+    const long long* m = D.h_msg + (size_t)(W + p) * K;
+    DirectHalo::Peer& P = D.peers[p];
+    if (m[0] != P.gen_seen) {
+      for (void*& mm : P.map) {
+        if (mm) SF_HIP(hipIpcCloseMemHandle(mm));
+        mm = nullptr;
+      }
+      hipIpcMemHandle_t a, b;
+      memcpy(&a, m + 1, 64);
+      memcpy(&b, m + 9, 64);
+      SF_HIP(hipIpcOpenMemHandle(&P.map[0], a, hipIpcMemLazyEnablePeerAccess));
+      SF_HIP(hipIpcOpenMemHandle(&P.map[1], b, hipIpcMemLazyEnablePeerAccess));
+      P.gen_seen = m[0];
+    }
+    P.remote_off = m[17];
+  }
+  // block q of this rank's chunk for peer p sits where it sits in the local send buffer, relative to the chunk's start
+  for (int par = 0; par < 2; par++)
+    for (int q = 0; q < DemEngine::kMaxDirs; q++) {
+      blk2[par * DemEngine::kMaxDirs + q] = nullptr;
+      if (q >= (int)B.sdirs.size()) continue;
+      const int p = B.sdirs[q].peer;
+      blk2[par * DemEngine::kMaxDirs + q] =
+          static_cast<double*>(D.peers[p].map[par]) + D.peers[p].remote_off + (B.snd.off[q] - hc.send_off[p]);
+    }
+}
+
 static void brick_rebuild(SfLammps& S, HaloComm& hc)
 {
   Range r("neighbor rebuild");
@@ -742,7 +967,9 @@ static void brick_rebuild(SfLammps& S, HaloComm& hc)
   hc.recv_off.assign(W, 0);
   for (int p = 1; p < W; p++) {
     hc.send_off[p] = hc.send_off[p - 1] + hc.send_cnt[p - 1];
-    hc.recv_off[p] = hc.recv_off[p - 1] + hc.recv_cnt[p - 1];
+    // (a sender's chunk starts on a 128-byte line of its own: with direct ghost writes the chunks of one receive area
+    // are written by different processes, and a cache line must have ONE writer)
+    hc.recv_off[p] = (hc.recv_off[p - 1] + hc.recv_cnt[p - 1] + 15) / 16 * 16;
   }
   B.snd = e.brick_send_blocks();
   // the shift of a received block: what its sender -- the brick at offset -d of the block's direction d, seen from
@@ -792,7 +1019,14 @@ static void brick_rebuild(SfLammps& S, HaloComm& hc)
   L.dev_tx = hc.a2a_tx.need((size_t)(hc.send_off[W - 1] + hc.send_cnt[W - 1]) + 1);
   L.dev_rx = hc.a2a_rx.need((size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1);
   hc.lay_valid = true;
-  e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1);
+  if (hc.direct && hc.direct->on) {
+    double* blk2[2 * DemEngine::kMaxDirs];
+    direct_rebuild(S, hc, blk2);
+    e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1, blk2);
+    e.set_tx_parity((int)(hc.direct->xseq & 1));
+  } else {
+    e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1);
+  }
   hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -809,6 +1043,15 @@ static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int
     // (the sub-step kernel that integrated the border atoms has written their records and the vote headers itself;
     // the pack kernel runs only in front of the first sub-step after a rebuild / at the start of a run)
     if (!e.forward_tx_written()) e.brick_forward_pack(B.snd, hc.lay.dev_tx, hc.lay.dev_shdr, nh);
+    if (hc.direct && hc.direct->on) {
+      // the records are already in the neighbours' receive areas: one kernel publishes, waits and unpacks
+      DirectHalo& D = *hc.direct;
+      const int par = (int)(D.xseq & 1);
+      e.brick_direct_unpack(B.rcv, D.rx[par], direct_sync(hc, (int)(D.xseq + 1), par));
+      D.xseq++;
+      e.set_tx_parity((int)(D.xseq & 1));
+      return;
+    }
     hc.all_to_all(hc.lay, main);
     e.brick_forward_unpack(B.rcv, hc.lay.dev_rx, hc.lay.dev_rhdr, nh);
   };
@@ -840,6 +1083,10 @@ static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int
     hc.pre_exchanged = true;
   }
   const int trigger = e.batch_end(first_k, end_k - first_k);
+  if (e.halo_timeout())
+    fail("direct ghost writes: rank %d waited for exchange %d, rank %d had confirmed %d when the wait ran out (a peer "
+         "died, or the ranks disagree about the exchanges they run); SF_HALO_DIRECT=0 selects the RCCL exchange",
+         hc.rank, e.halo_timeout(), e.halo_timeout_peer() / 1000000, e.halo_timeout_peer() % 1000000);
   hc.harvest_exchange_profile();
   return trigger;
 }
@@ -1137,6 +1384,7 @@ int sf_brick_init(void* ptr, const char* id128, int rank, int world, int px, int
   sf::slab_scratch(*hc);
   sf::brick_topology(*hc, L->eng);
   if (const char* q = getenv("SF_QUEUE_PREDICT")) hc->predict.on = atoi(q) != 0;
+  sf::direct_init(*L, *hc);
   SF_API_END(0)
 }
 
@@ -1296,6 +1544,14 @@ int sf_slab_active(void* ptr)
   SF_API_BEGIN
   auto* hc = static_cast<sf::HaloComm*>(H(ptr)->halo);
   const int on = hc && hc->slab ? 1 : 0;
+  SF_API_END(on)
+}
+
+int sf_slab_direct_halo(void* ptr)
+{
+  SF_API_BEGIN
+  auto* hc = static_cast<sf::HaloComm*>(H(ptr)->halo);
+  const int on = hc && hc->direct && hc->direct->on ? 1 : 0;
   SF_API_END(on)
 }
 

@@ -142,7 +142,8 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
         drv.step(n)
     st = lmp.get_state()
     h = lmp.history()
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), rebuilds=drv.n_rebuilds,
+    direct = int(lmp.L.sf_slab_direct_halo(lmp.ptr)) if grid is not None else 0
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), rebuilds=drv.n_rebuilds, direct=direct,
              hk=np.array(sorted(h), dtype=np.int64).reshape(-1, 2), hv=np.array([h[k] for k in sorted(h)]).reshape(-1, 3),
              **st)
     dist.barrier()
@@ -258,22 +259,35 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
     assert set(hb) == set(ha)
 
 
-@pytest.mark.parametrize("grid,ncells,physics,periodic_x",
-                         [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "hertz", True),
-                          ((3, 1, 2), (9, 5, 8), "hertz", True), ((1, 1, 2), (6, 5, 8), "hertz", True),
-                          ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False),
-                          ((2, 2, 2), (8, 8, 8), "loose", True), ((2, 2, 2), (20, 20, 20), "hertz", True),
-                          ((4, 1, 2), (12, 5, 8), "hertz", True)])
-def test_cxx_brick_driver_on_a_processor_grid(tmp_path, grid, ncells, physics, periodic_x):
+_BRICK_CASES = [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "hertz", True),
+                ((3, 1, 2), (9, 5, 8), "hertz", True), ((1, 1, 2), (6, 5, 8), "hertz", True),
+                ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False),
+                ((2, 2, 2), (8, 8, 8), "loose", True), ((2, 2, 2), (20, 20, 20), "hertz", True),
+                ((4, 1, 2), (12, 5, 8), "hertz", True)]
+
+
+# every grid over the wire (direct "0"); with direct ghost writes every grid of up to 6 ranks and two of the 8-rank ones
+# (eight processes that all spin on flags time-slice the ONE GPU of the box: correct, but tens of seconds per case)
+@pytest.mark.parametrize("grid,ncells,physics,periodic_x,direct",
+                         [c + ("0",) for c in _BRICK_CASES] +
+                         [c + ("1",) for c in _BRICK_CASES if c[0][0] * c[0][1] * c[0][2] <= 6 or c[1] in ((8, 8, 8), (12, 5, 8))
+                          and c[2] == "hertz"])
+def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncells, physics, periodic_x, direct):
     """The brick driver (sf_brick_init + sf_slab_setup / _step / _rebuild): a 3-D processor grid -- 2 x 1 x 2 and
     2 x 2 x 2 (BASELINE config C4's 8 GPUs; the y cut crosses the wall dimension, the end bricks have a face without a
     neighbour), 4 x 1 x 2 (the grid `bench.py --gpus 8` picks for the headline bed), 3 x 1 x 2 (left and right neighbour differ), 1 x 1 x 2 (x keeps its images local), 2 x 2 x 1 with
     config C5's physics (cohesion + lubricate/poly: global particle volume and radius over the bricks), x between
     walls -- against the single-domain run: staged migration through faces, edges and corners, ghosts sent straight
     to the up to 26 neighbour bricks, one grouped exchange per sub-step, the rebuild vote in the chunk headers.  The
-    ranks share the one GPU of the box over the stand-in wire (tests/c_abi/standin_rccl.cpp)."""
+    ranks share the one GPU of the box over the stand-in wire (tests/c_abi/standin_rccl.cpp).
+    direct = "1": the forward halo by DIRECT GHOST WRITES (SF_HALO_DIRECT=1: required to come up) -- every rank's sub-step
+    kernel writes its border records through IPC mappings into the receive areas of the neighbours' processes, one kernel
+    per exchange publishes / awaits the per-rank flags and votes; "0": one grouped send / receive per sub-step over the
+    wire.  Both must reproduce the single-domain run."""
     import socket
     import torch.multiprocessing as mp
+    monkeypatch.setenv("SF_HALO_DIRECT", direct)
+    monkeypatch.setenv("SF_HALO_DIRECT_TIMEOUT", "120")   # (ranks sharing one GPU wait for each other's time slices)
     lib = _standin_rccl(tmp_path)
     world = grid[0] * grid[1] * grid[2]
     steps = {"hertz": (50, 50), "c5": (40, 40), "loose": (20, 20)}[physics]
@@ -298,6 +312,7 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, grid, ncells, physics, p
     mp.spawn(_two_rank_worker, args=(world, port, out, steps, False, physics, "rccl", lib, ncells, periodic_x, grid),
              nprocs=world, join=True)
     parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+    assert all(int(p["direct"]) == int(direct) for p in parts)      # the transport that was asked for carried the run
     tag = np.concatenate([p["tag"] for p in parts])
     assert len(tag) == bed["n"] and len(np.unique(tag)) == bed["n"]
     assert sum(1 for p in parts if len(p["tag"])) == world          # every brick owns atoms
