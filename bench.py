@@ -248,6 +248,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     if args.one_gpu:
         local_rank = 0
+        os.environ.setdefault("SF_HALO_DIRECT_TIMEOUT", "120")   # (ranks sharing ONE GPU wait for each other's time slices)
     torch.cuda.set_device(local_rank)
     dist = None
     # --one-gpu: gloo through host memory from Python, or -- with SF_RCCL_LIB pointing at tests/c_abi/standin_rccl.cpp
@@ -372,6 +373,90 @@ def main():
             o["rank0_kernel_us"] = 1e3 * kernel_ms_ / launches_
             o["rank0_roofline_frac"] = (284.0 + 52.0 * kh) * info_.nlocal / (1e-3 * kernel_ms_ / launches_) / 1e9 / HBM_PEAK_GBS
         return o
+
+    def all_ok(flag):
+        """True only if `flag` is true on every rank"""
+        if dist is None or world == 1:
+            return bool(flag)
+        t = torch.tensor([0.0 if flag else 1.0], dtype=torch.float64, device="cpu" if args.one_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item() == 0.0
+
+    def decomposed_parity():
+        """N > 1: the decomposed engine proves itself -- the SAME global bed through setup + 50 sub-steps on the N domains
+        (the headline's decomposition and halo transport) and on ONE domain (rank 0's GPU).  Returns (parity dict on rank
+        0 / None elsewhere, True if the leg ran through on every rank and agreed)."""
+        sub = 50
+        gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
+        mine, mine_builds, direct_on, err = None, 0, 0, None
+        try:
+            pdrv = make_driver("from_global_bed", gbed)
+            pdrv.setup()
+            pdrv.step(sub)
+            mine = pdrv.e.lmp.get_state()
+            mine_builds = int(pdrv.n_rebuilds)
+            direct_on = int(pdrv.e.lmp.L.sf_slab_direct_halo(pdrv.e.lmp.ptr)) if grid_used[0] else 0
+            del pdrv
+        except Exception as ex:   # noqa: BLE001  (e.g. a bounded flag wait of the direct ghost writes ran out)
+            err = ex
+            sys.stderr.write("bench.py rank %d: the decomposed parity leg failed: %s\n" % (rank, str(ex)[:300]))
+        if not all_ok(err is None):
+            return None, False, direct_on
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object({k: mine[k] for k in ("tag", "x", "v", "omega")}, parts, dst=0)
+        par, ok = None, True
+        if rank == 0:
+            one = build_engine(gbed, synthetic.hertz_script(gbed, **kw))
+            one.setup()
+            one.step(sub)
+            ref = one.get_state()
+            one_builds = int(one.info().nbuilds)
+            del one
+            tag = np.concatenate([q["tag"] for q in parts])
+            o = np.argsort(tag, kind="stable")
+            same = bool(len(tag) == len(ref["tag"]) and np.array_equal(tag[o], ref["tag"]))
+            d = float(np.max(gbed["diameter"]))
+            L3 = np.array(gbed["boxhi"]) - np.array(gbed["boxlo"])
+
+            def rel(a, b):
+                sc = float(np.max(np.abs(b)))
+                return float(np.max(np.abs(a - b)) / (sc if sc > 0 else 1.0))
+            par = {"against": "the same %d-particle bed on ONE domain (rank 0's GPU), setup + %d sub-steps from the same "
+                              "start; the %d domains gathered by tag" % (len(ref["tag"]), sub, world),
+                   "n": int(len(ref["tag"])), "substeps": sub, "tags_identical": same,
+                   "halo": "direct ghost writes" if direct_on else "RCCL exchange"}
+            if same:
+                dx = np.concatenate([q["x"] for q in parts])[o] - ref["x"]
+                per = np.array(gbed["periodic"], bool)
+                dx[:, per] -= L3[per] * np.round(dx[:, per] / L3[per])   # (an atom is wrapped when its owner reneighbours)
+                par.update(max_abs_dx_over_d=float(np.max(np.abs(dx)) / d),
+                           max_rel_v=rel(np.concatenate([q["v"] for q in parts])[o], ref["v"]),
+                           max_rel_omega=rel(np.concatenate([q["omega"] for q in parts])[o], ref["omega"]))
+            par["rebuilds_decomposed_rank0"] = mine_builds
+            par["rebuilds_single_domain"] = one_builds
+            par["tolerance"] = "x 1e-9 d, v / omega 1e-9 of max (SURVEY.md 8d)"
+            par["ok"] = bool(same and par["max_abs_dx_over_d"] <= 1e-9 and par["max_rel_v"] <= 1e-9
+                             and par["max_rel_omega"] <= 1e-9)
+            ok = par["ok"]
+        return par, all_ok(ok), direct_on
+
+    # N > 1, before anything is timed: the parity leg, first with the direct ghost writes (SF_HALO_DIRECT=auto: bricks whose
+    # sub-step kernels write their border records straight into the neighbours' receive areas), and -- should that
+    # transport not come up, run out of time or disagree with the single-domain run on this node -- once more over RCCL,
+    # which then also carries the timed runs.  The line says which one it was.
+    parity_first, halo_note = None, None
+    parity_ok = True
+    if world > 1 and not args.no_parity and args.scaling != "weak":
+        asked = os.environ.get("SF_HALO_DIRECT")
+        if asked is None:
+            os.environ["SF_HALO_DIRECT"] = "auto"
+        parity_first, ok_all, was_direct = decomposed_parity()
+        if not ok_all and os.environ.get("SF_HALO_DIRECT") != "0":
+            os.environ["SF_HALO_DIRECT"] = "0"
+            halo_note = ("direct ghost writes were tried first and %s; the RCCL exchange carried the run"
+                         % ("disagreed with the single-domain run" if parity_first is not None else "did not run through"))
+            parity_first, ok_all, was_direct = decomposed_parity()
+        parity_ok = ok_all
 
     # N > 1: BASELINE config C4 -- ONE --particles bed split into `world` spatial domains -- is the headline (`value`,
     # scaling "strong"); the weak-scaling run (every rank one --particles slab) is the side object `weak_scaling`
@@ -610,55 +695,18 @@ def main():
         out["fluidised_bed"] = fo
         args.steps, args.warmup = keep
         del flmp, fbed
-    # N > 1: the decomposed engine proves itself -- the SAME global bed through setup + 50 sub-steps on the N domains (the
-    # headline's decomposition and transport) and on ONE domain (rank 0's GPU); the line carries the difference, and the
-    # run fails (rc 1) when they disagree
-    parity_ok = True
-    if world > 1 and not args.no_parity and args.scaling != "weak":
-        sub = 50
-        gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
-        pdrv = make_driver("from_global_bed", gbed)
-        pdrv.setup()
-        pdrv.step(sub)
-        mine = pdrv.e.lmp.get_state()
-        mine_builds = int(pdrv.n_rebuilds)
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object({k: mine[k] for k in ("tag", "x", "v", "omega")}, parts, dst=0)
-        del pdrv
-        if rank == 0:
-            one = build_engine(gbed, synthetic.hertz_script(gbed, **kw))
-            one.setup()
-            one.step(sub)
-            ref = one.get_state()
-            one_builds = int(one.info().nbuilds)
-            del one
-            tag = np.concatenate([q["tag"] for q in parts])
-            o = np.argsort(tag, kind="stable")
-            same = bool(len(tag) == len(ref["tag"]) and np.array_equal(tag[o], ref["tag"]))
-            d = float(np.max(gbed["diameter"]))
-            L3 = np.array(gbed["boxhi"]) - np.array(gbed["boxlo"])
-
-            def rel(a, b):
-                sc = float(np.max(np.abs(b)))
-                return float(np.max(np.abs(a - b)) / (sc if sc > 0 else 1.0))
-            par = {"against": "the same %d-particle bed on ONE domain (rank 0's GPU), setup + %d sub-steps from the same "
-                              "start; the %d domains gathered by tag" % (len(ref["tag"]), sub, world),
-                   "n": int(len(ref["tag"])), "substeps": sub, "tags_identical": same}
-            if same:
-                dx = np.concatenate([q["x"] for q in parts])[o] - ref["x"]
-                per = np.array(gbed["periodic"], bool)
-                dx[:, per] -= L3[per] * np.round(dx[:, per] / L3[per])   # (an atom is wrapped when its owner reneighbours)
-                par.update(max_abs_dx_over_d=float(np.max(np.abs(dx)) / d),
-                           max_rel_v=rel(np.concatenate([q["v"] for q in parts])[o], ref["v"]),
-                           max_rel_omega=rel(np.concatenate([q["omega"] for q in parts])[o], ref["omega"]))
-            par["rebuilds_decomposed_rank0"] = mine_builds
-            par["rebuilds_single_domain"] = one_builds
-            par["tolerance"] = "x 1e-9 d, v / omega 1e-9 of max (SURVEY.md 8d)"
-            par["ok"] = bool(same and par["max_abs_dx_over_d"] <= 1e-9 and par["max_rel_v"] <= 1e-9
-                             and par["max_rel_omega"] <= 1e-9)
-            out["parity"] = par
-            parity_ok = par["ok"]
-        del gbed
+    if world > 1 and rank == 0:
+        if parity_first is not None:
+            out["parity"] = parity_first
+        try:
+            direct_on = bool(grid_used[0]) and int(lmp.e.lmp.L.sf_slab_direct_halo(lmp.e.lmp.ptr)) == 1
+        except Exception:   # noqa: BLE001
+            direct_on = False
+        out["config"]["halo"] = ("direct ghost writes: the sub-step kernel writes the border records into the neighbours' "
+                                 "IPC-mapped receive areas, one kernel per exchange publishes / awaits the ranks' flags"
+                                 if direct_on else "one grouped ncclSend/ncclRecv per sub-step + unpack kernel")
+        if halo_note:
+            out["config"]["halo_note"] = halo_note
     if rank == 0 and not args.no_cpu_baseline:   # (on rank 0's host cores; at N > 1 the other ranks are done)
         sample_n = args.cpu_sample or 1000000
         sub = 50

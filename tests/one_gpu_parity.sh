@@ -13,6 +13,7 @@ for line in sys.stdin:
     if line.startswith('{'):
         d = json.loads(line)
         print('N', d['n_gpus'], 'value %.3e' % d['value'], 'scaling', d['scaling'], '|', d['config']['decomposition'][:60])
+        print('   halo:', d['config'].get('halo', '')[:60], '|', d['config'].get('halo_note'), '| exchange us', d['config'].get('halo_exchange_us_per_substep'))
         print('   parity:', json.dumps(d.get('parity')))
 "
   echo "   rc=$? $(grep -c Traceback gpurun_out/ogp_$w.err) tracebacks"; grep -A8 Traceback gpurun_out/ogp_$w.err | tail -12
