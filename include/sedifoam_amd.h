@@ -55,6 +55,10 @@ int sf_lammps_open(int argc, char **argv, intptr_t comm, void **ptr);
  * collective exactly where interfaceToLammps/library.cpp:94-131,372-386,470-473 is.  One process per GPU: the device
  * is rank % (visible devices) unless SF_DEVICE names one. */
 int sf_lammps_open_world(int argc, char **argv, intptr_t comm, int rank, int world, const char *id128, void **ptr);
+/* the processor grid a `processors px py pz` line (user[k] = 0 for `*`) resolves to on `world` ranks for a box [lo, hi):
+ * [3P] LAMMPS 1Feb14 ProcMap::onelevel_grid -- of the factorisations that agree with the given entries, visited with px
+ * slowest, the first of least sub-domain surface xy / (px py) + xz / (px pz) + yz / (py pz).  Host logic only. */
+int sf_procgrid_choose(int world, const double lo[3], const double hi[3], const int user[3], int out[3]);
 /* library.h:30 */
 int sf_lammps_close(void *ptr);
 /* library.h:31  run every line of an input script (library.cpp:63-67) */

@@ -86,6 +86,7 @@ _SIGS = {
     "sf_version": (C.c_char_p, []),
     "sf_lammps_open": (C.c_int, [C.c_int, vp, C.c_ssize_t, C.POINTER(vp)]),
     "sf_lammps_open_world": (C.c_int, [C.c_int, vp, C.c_ssize_t, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
+    "sf_procgrid_choose": (C.c_int, [C.c_int, dp, dp, ip, ip]),
     "sf_lammps_close": (C.c_int, [vp]),
     "sf_lammps_file": (C.c_int, [vp, C.c_char_p]),
     "sf_lammps_command": (C.c_char_p, [vp, C.c_char_p]),

@@ -52,14 +52,10 @@ int inum(const std::string& s)
 // agree with the non-`*` entries of the `processors` command, the one with the least sub-domain surface
 //   xprd yprd / (px py) + xprd zprd / (px pz) + yprd zprd / (py pz);
 // factorisations are visited with px slowest and the first strictly smaller surface wins.
-void choose_procgrid(const SfLammps& L, int P[3])
+bool procgrid_rule(int n, const double lo[3], const double hi[3], const int user[3], int P[3])
 {
-  double lo[3], hi[3];
-  int per[3];
-  L.eng.box(lo, hi, per);
   const double xprd = hi[0] - lo[0], yprd = hi[1] - lo[1], zprd = hi[2] - lo[2];
   const double area[3] = {xprd * yprd, xprd * zprd, yprd * zprd};
-  const int n = L.world_size;
   double best = 2.0 * (area[0] + area[1] + area[2]);
   P[0] = P[1] = P[2] = 0;
   for (int i = 1; i <= n; i++) {
@@ -68,9 +64,7 @@ void choose_procgrid(const SfLammps& L, int P[3])
     for (int j = 1; j <= nyz; j++) {
       if (nyz % j) continue;
       const int k = nyz / j;
-      if ((L.procgrid[0] && L.procgrid[0] != i) || (L.procgrid[1] && L.procgrid[1] != j) ||
-          (L.procgrid[2] && L.procgrid[2] != k))
-        continue;
+      if ((user[0] && user[0] != i) || (user[1] && user[1] != j) || (user[2] && user[2] != k)) continue;
       const double surf = area[0] / i / j + area[1] / i / k + area[2] / j / k;
       if (surf < best) {
         best = surf;
@@ -78,7 +72,15 @@ void choose_procgrid(const SfLammps& L, int P[3])
       }
     }
   }
-  if (!P[0]) sf::fail("Bad grid of processors");   // [3P] the text of Comm::set_proc_grid
+  return P[0] != 0;
+}
+
+void choose_procgrid(const SfLammps& L, int P[3])
+{
+  double lo[3], hi[3];
+  int per[3];
+  L.eng.box(lo, hi, per);
+  if (!procgrid_rule(L.world_size, lo, hi, L.procgrid, P)) sf::fail("Bad grid of processors");   // [3P] Comm::set_proc_grid
 }
 
 // the processor grid exists once the box does ([3P] read_data / create_box call Comm::set_proc_grid): one brick per rank
@@ -474,6 +476,16 @@ int sf_lammps_open_world(int, char**, intptr_t comm, int rank, int world, const 
   L->world_size = world;
   if (id128) memcpy(L->comm_id, id128, 128);
   *ptr = L;
+  SF_API_END(0)
+}
+
+// the grid `processors px py pz` resolves to on `world` ranks (0 = `*`), host logic only (no device): 0, or -1 when no
+// factorisation fits ("Bad grid of processors")
+int sf_procgrid_choose(int world, const double lo[3], const double hi[3], const int user[3], int out[3])
+{
+  SF_API_BEGIN
+  if (world < 1 || !lo || !hi || !user || !out) sf::fail("sf_procgrid_choose: bad arguments");
+  if (!procgrid_rule(world, lo, hi, user, out)) sf::fail("Bad grid of processors");
   SF_API_END(0)
 }
 

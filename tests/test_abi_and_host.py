@@ -163,3 +163,30 @@ def test_brick_exchange_pattern_is_consistent_between_every_pair_of_ranks(grid, 
     # a fully periodic 2 x 2 x 2 grid: every rank exchanges with all 7 others (26 blocks)
     if grid == (2, 2, 2) and periodic == (1, 1, 1):
         assert all(len(p["send"]) == 26 and len({q for q, _ in p["send"]}) == 7 for p in pat)
+
+
+def test_processors_line_resolves_like_lammps():
+    """`processors px py pz` with `*` entries: [3P] ProcMap::onelevel_grid's rule (least sub-domain surface, px slowest,
+    first of equals) -- host logic of the -parallel bring-up, no device needed"""
+    import ctypes as C
+    import sedifoam_amd
+    L = sedifoam_amd.lib()
+
+    def grid(world, box, user=(0, 0, 0)):
+        lo = (C.c_double * 3)(0.0, 0.0, 0.0)
+        hi = (C.c_double * 3)(*box)
+        u = (C.c_int * 3)(*user)
+        out = (C.c_int * 3)()
+        rc = L.sf_procgrid_choose(world, lo, hi, u, out)
+        return tuple(out) if rc == 0 else None
+
+    assert grid(8, (1.0, 1.0, 1.0)) == (2, 2, 2)
+    assert grid(8, (8.0, 1.0, 1.0)) == (8, 1, 1)
+    assert grid(4, (1.0, 1.0, 1.0)) == (1, 2, 2)              # three equal surfaces: the first visited (px slowest)
+    assert grid(4, (2.0, 2.0, 1.0)) == (2, 2, 1)
+    assert grid(6, (3.0, 2.0, 1.0)) == (3, 2, 1)
+    assert grid(8, (1.0, 1.0, 1.0), (0, 1, 0)) == (2, 1, 4)   # `* 1 *`: 2 1 4 before the equal 4 1 2
+    assert grid(8, (4.0, 1.0, 2.0), (0, 1, 0)) == (4, 1, 2)
+    assert grid(2, (1.0, 3.0, 1.0)) == (1, 2, 1)
+    assert grid(7, (1.0, 1.0, 1.0), (2, 0, 0)) is None        # Bad grid of processors
+    assert grid(1, (1.0, 1.0, 1.0)) == (1, 1, 1)
