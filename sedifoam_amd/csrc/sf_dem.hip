@@ -1498,6 +1498,23 @@ bool DemEngine::list_stats_near_a_threshold() const
 void DemEngine::measure_list()
 {
   if (!nlocal_ || !roots_) return;
+  static const bool dbg_lines = getenv("SF_DEBUG_LINES") != nullptr;
+  if (dbg_lines) {
+    unsigned long long* d = nullptr;
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    SF_HIP(hipMalloc(&d, sizeof h));
+    SF_HIP(hipMemsetAsync(d, 0, sizeof h, stream_));
+    const int nw = div_up(nlocal_, 64), st = nw > 4096 ? 16 : 1;
+    k_gather_lines<<<div_up(nw, st), 64, 0, stream_>>>(neigh_.as<int>(), numneigh_.as<int>(), nlocal_, cap_, st, d);
+    SF_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, stream_));
+    SF_HIP(hipStreamSynchronize(stream_));
+    SF_HIP(hipFree(d));
+    if (h[0])
+      fprintf(stderr, "[sedifoam_amd] gather lines per wave-level slot (%llu sampled): %.1f active lanes; 128-B lines %.1f "
+              "(x 2 halves = %.1f accesses per record gather); lane pairs sharing a record: %.1f + %.1f = %.1f; 64-B half "
+              "lines %.1f\n", h[0], (double)h[1] / h[0], (double)h[2] / h[0], 2.0 * h[2] / h[0], (double)h[3] / h[0],
+              (double)h[4] / h[0], (double)(h[3] + h[4]) / h[0], (double)h[5] / h[0]);
+  }
   static_assert(F_PART_COAL == F_PART_SLOTS + 1 && F_LIST_SLOTS == F_PART_SLOTS + 2 && F_LIST_TOUCH == F_PART_SLOTS + 3,
                 "adjacent counters");
   reset_flags(F_PART_SLOTS, 4, 0);

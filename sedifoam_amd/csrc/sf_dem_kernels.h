@@ -41,7 +41,7 @@
 // They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
 // SF_VARIANT_BUILD); the shipped library never carries them.
 #if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT) || defined(SF_EXP_SC1_GATHER) || \
-     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ) || defined(SF_EXP_STAMP) || defined(SF_EXP_PHASE)) && \
+     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ) || defined(SF_EXP_STAMP) || defined(SF_EXP_PHASE) || defined(SF_EXP_DMA)) && \
     !defined(SF_VARIANT_BUILD)
 #error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
 #endif
@@ -67,6 +67,11 @@
 #ifndef SF_EXP_STAMP
 #define SF_EXP_STAMP 0        // every workgroup of one chosen launch records {XCC_ID, HW_ID, start, end} (100 MHz clock):
                               // the fill / drain timeline per XCD (tests/micro/stamp_timeline.py; valid results)
+#endif
+#ifndef SF_EXP_DMA
+#define SF_EXP_DMA 0          // the wave's list words (12 rows) and own-side history rows (six slots) streamed into LDS by
+                              // global_load_lds_dwordx4 at the start of the wave: 3 + 9 instructions of 1 KB instead of 12 + 18
+                              // of 256 / 512 B, no VGPRs, in flight while the first slots run (valid results)
 #endif
 #ifndef SF_EXP_PERSIST_NOWAIT
 #define SF_EXP_PERSIST_NOWAIT 0   // upper bound of a persistent kernel: n sub-steps in one launch, NO dependency waits
@@ -175,7 +180,8 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
 template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP>
 __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
-                                                 const double4* lx, const double4* lv, const double* lw)
+                                                 const double4* lx, const double4* lv, const double* lw,
+                                                 __attribute__((address_space(3))) char* dma = nullptr)
 {
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
@@ -198,6 +204,56 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
   const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
+#if SF_EXP_DMA
+  // LDS of the (one-wave) workgroup: [12 rows of list words: 3 KB][18 history rows (six slots from `dma_s0`): 9 KB]
+  typedef __attribute__((address_space(3))) char* LdsPtr;
+  constexpr int kDmaWords = 12, kDmaSlots = 6;
+  const int lane = threadIdx.x & 63;
+  // (wave-uniform: a full wave of consecutive atoms whose first one is 64-aligned)
+  const bool dma_ok = !LDS && LPA == 1 && dma != nullptr && S.part == 0 && blockDim.x == 64 && __ballot(1) == ~0ull &&
+                      (i & 63) == lane;
+  unsigned dma_hist = 0;   // slots whose own-side history rows are (being) copied into LDS
+  int dma_s0 = 0;
+  // (issued through inline assembly: the compiler makes every later LDS read wait for ALL outstanding copies it knows of
+  // -- vmcnt(0) in every slot; this way it sees ordinary LDS reads, and the code below orders them itself)
+  auto dma16 = [&](const void* g, LdsPtr l) {
+    const unsigned off = (unsigned)(__UINTPTR_TYPE__)l;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(off) : "memory", "m0");
+  };
+  auto lds_word = [&](int sl) {
+    return *reinterpret_cast<__attribute__((address_space(3))) const int*>(dma + (sl * 64 + lane) * 4);
+  };
+  if (dma_ok) {
+    const int base = i - lane;
+    for (int k = 0; k < kDmaWords / 4; k++) {
+      const int row = 4 * k + (lane >> 4);
+      if (row < S.nslots) {
+        const int* src = P.neigh + (size_t)row * cap + base + (lane & 15) * 4;
+        dma16(src, dma + k * 1024);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int nmax = nn_all;
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    nmax = __builtin_amdgcn_readfirstlane(nmax < kDmaWords ? nmax : kDmaWords);
+    unsigned need = 0;
+    for (int sl = 0; sl < nmax; sl++) {
+      const int w = sl < nn_all ? lds_word(sl) : 0;
+      if (__ballot(STYLE != 0 && (w & kOwnBit) && (w & kTouchBit)) != 0ull) need |= 1u << sl;
+    }
+    if (need && SF_EXP_DMA != 2) {   // (2: the list words only)
+      dma_s0 = __builtin_ctz(need);
+      dma_hist = need & (((1u << kDmaSlots) - 1u) << dma_s0);
+      for (int m = 0; m < 3 * kDmaSlots / 2; m++) {
+        const int t = 2 * m + (lane >> 5), sl = dma_s0 + t / 3, c = t - 3 * (t / 3);
+        if ((dma_hist >> sl) & 1u) {
+          const double* src = P.shear_in + (size_t)(3 * sl + c) * cap + base + (lane & 31) * 2;
+          dma16(src, dma + kDmaWords * 256 + m * 1024);
+        }
+      }
+    }
+  }
+#endif
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
   // Software pipeline: the index of slot s+2 and the x, v, omega records of slot s+1 are requested before the
@@ -220,6 +276,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const bool own = (jraw & kOwnBit) != 0;
     auto ldh = [&](const double* p) { return SF_EXP_SC1_GATHER ? ld_f64_sc1(p) : ld_stream<NT_HIST>(p); };
     if (own) {
+#if SF_EXP_DMA
+      if ((dma_hist >> slotrow) & 1u) return;   // (in LDS: read where it is consumed)
+#endif
       const double* const hin = P.shear_in + (size_t)(3 * slotrow) * cap;
       sh.x = ldh(&hin[i]);
       sh.y = ldh(&(hin + cap)[i]);
@@ -271,8 +330,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const int row1 = q + LPA < S.nslots ? q + LPA : S.nslots - 1;
   // (one lane per atom only: with several lanes per atom the two extra live registers spill)
   const bool ld0 = LPA == 1 || nn > 0, ld1 = LPA == 1 || nn > 1;
+#if SF_EXP_DMA
+  const int w_first = dma_ok ? lds_word(0) : (ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0);
+  const int w_second = dma_ok ? lds_word(row1) : (ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0);
+#else
   const int w_first = ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
   const int w_second = ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0;
+#endif
   int jraw_n1 = nn > 0 ? w_first : 0;
   int jraw_n2 = nn > 1 ? w_second : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
@@ -298,10 +362,26 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const bool own = (jraw & kOwnBit) != 0;
     Vec3 sh = cur.sh;
     if (!SF_HIST_PREFETCH) load_history(jraw, sl, sh);
+#if SF_EXP_DMA
+    if (STYLE != 0 && own && (jraw & kTouchBit) && ((dma_hist >> sl) & 1u)) {
+      // the copy was issued before this slot's records: once THEY have arrived (in-order return) it is complete --
+      // the address is made to depend on the record so that the read cannot be scheduled above that wait
+      unsigned a = (unsigned)(kDmaWords * 256 + (sl - dma_s0) * 1536 + lane * 8);
+      asm volatile("" : "+v"(a) : "v"(cur.x.x));
+      const __attribute__((address_space(3))) char* hp = dma + a;
+      sh.x = *reinterpret_cast<const __attribute__((address_space(3)) ) double*>(hp);
+      sh.y = *reinterpret_cast<const __attribute__((address_space(3)) ) double*>(hp + 512);
+      sh.z = *reinterpret_cast<const __attribute__((address_space(3)) ) double*>(hp + 1024);
+    }
+#endif
     // the pair seen from the partner's side (a pair that did not touch starts from +0.0 on both sides, as before)
     if (STYLE != 0 && LPA == 1 && !own && (jraw & kTouchBit)) sh = {-sh.x, -sh.y, -sh.z};
     jraw_n1 = jraw_n2;
+#if SF_EXP_DMA
+    if (s + 2 < nn) jraw_n2 = (dma_ok && sl + 2 < kDmaWords) ? lds_word(sl + 2) : ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
+#else
     if (s + 2 < nn) jraw_n2 = ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
+#endif
     if (more) {
       bool reuse = false;
 #if SF_GATHER_SHUFFLE
@@ -748,7 +828,13 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // are resolved one after the other at the memory side, ~11 ns each -- 31 k of them doubled the launch)
   const int xq = (int)(blockIdx.x & 7) * 64;
   if (S.xcd_time && threadIdx.x == 0 && (blockIdx.x >> 3) == 0) atomicMin(&P.xcd_time[xq], (int)(wall_clock64() & 0x3fffffff));
+#if SF_EXP_DMA
+  __shared__ __attribute__((aligned(16))) char dma_lds[12 * 256 + 18 * 512];
+  substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr,
+                                                          (__attribute__((address_space(3))) char*)dma_lds);
+#else
   substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
+#endif
   if (S.xcd_time && threadIdx.x == 0 && ((blockIdx.x >> 3) & 7) == 0)
     atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
 }
@@ -1021,6 +1107,52 @@ __global__ __launch_bounds__(1024) void k_partner_coalescing(const int* neigh, c
     atomicAdd(&counters[1], c);
     atomicAdd(&counters[2], l);
     atomicAdd(&counters[3], u);
+  }
+}
+
+// Debug statistic (SF_DEBUG_LINES=1): how many 128-byte lines one gather instruction of the sub-step kernel touches.
+// One wave = 64 consecutive atoms, slot s: lane l reads 16 bytes of the 32-byte record of its neighbour j(l), twice
+// (the two halves) -> 2 x [distinct lines among all 64 lanes]; if lanes 2k, 2k + 1 read the 32 bytes of ONE record
+// together (first j(2k), then j(2k + 1)) -> [distinct among even lanes] + [distinct among odd lanes].
+// out: {instructions (slots with an active lane), active lanes, distinct lines all, distinct even, distinct odd,
+//       distinct 64-byte half lines all}
+__global__ __launch_bounds__(64) void k_gather_lines(const int* neigh, const int* numneigh, int nlocal, size_t cap,
+                                                     int stride, unsigned long long* out)
+{
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * stride * 64 + lane;
+  const int nn = i < nlocal ? numneigh[i] : 0;
+  int nmax = nn;
+  for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+  unsigned long long instr = 0, act = 0, all = 0, ev = 0, od = 0, half = 0;
+  for (int s = 0; s < nmax; s++) {
+    const int j = s < nn ? (neigh[(size_t)s * cap + i] & kIdxMask) : -1;
+    const int line = j < 0 ? -1 : j >> 2, hl = j < 0 ? -1 : j >> 1;
+    bool first_all = line >= 0, first_par = line >= 0, first_half = hl >= 0;
+    for (int k = 1; k < 64; k++) {
+      const int src = (lane + 64 - k) & 63;
+      const int ol = __shfl(line, src, 64), oh = __shfl(hl, src, 64);
+      if (src < lane) {
+        if (ol == line) {
+          first_all = false;
+          if (((src ^ lane) & 1) == 0) first_par = false;
+        }
+        if (oh == hl) first_half = false;
+      }
+    }
+    const unsigned long long a = __ballot(line >= 0), fa = __ballot(first_all), fp = __ballot(first_par),
+                             fh = __ballot(first_half);
+    const unsigned long long evens = 0x5555555555555555ull;
+    instr += 1;
+    act += __popcll(a);
+    all += __popcll(fa);
+    ev += __popcll(fp & evens);
+    od += __popcll(fp & ~evens);
+    half += __popcll(fh);
+  }
+  if (lane == 0 && nmax) {
+    atomicAdd(&out[0], instr); atomicAdd(&out[1], act); atomicAdd(&out[2], all);
+    atomicAdd(&out[3], ev); atomicAdd(&out[4], od); atomicAdd(&out[5], half);
   }
 }
 

@@ -13,7 +13,7 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int BYTES>
+template <int BYTES, int ALT = 16>
 __global__ __launch_bounds__(256) void k_gather(const char* base, const int* idx, int stride, int iters, double* out)
 {
   const int lane = threadIdx.x & 63;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_gather(const char* base, const int* idx
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const char* q = p + ((it + u) & 1) * 16;   // (alternate the two halves of a 32-byte record: defeats hoisting)
+      const char* q = p + ((it + u) & 1) * ALT;   // (alternate the two halves of a 32-byte record: defeats hoisting)
       if (BYTES == 16) { d2 v = *reinterpret_cast<const volatile d2*>(q); acc += v.x + v.y; }
       else if (BYTES == 8) { double v = *reinterpret_cast<const volatile double*>(q); acc += v; }
       else { float v = *reinterpret_cast<const volatile float*>(q); acc += v; }
@@ -32,16 +32,16 @@ __global__ __launch_bounds__(256) void k_gather(const char* base, const int* idx
   if (acc == 1.2345e300) out[0] = acc;
 }
 
-template <int BYTES>
+template <int BYTES, int ALT = 16>
 void run(const char* name, const char* base, const int* d_idx, int stride, int blocks)
 {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   double* out; CK(hipMalloc(&out, 8));
   const int iters = 2000;
-  k_gather<BYTES><<<blocks, 256>>>(base, d_idx, stride, 10, out);
+  k_gather<BYTES, ALT><<<blocks, 256>>>(base, d_idx, stride, 10, out);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
-  k_gather<BYTES><<<blocks, 256>>>(base, d_idx, stride, iters, out);
+  k_gather<BYTES, ALT><<<blocks, 256>>>(base, d_idx, stride, iters, out);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   int clk_khz = 0; CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0));
@@ -69,6 +69,28 @@ int main()
   run<16>("16 B/lane, stride 16, lanes permuted in the window", base, d_perm, 16, blocks);
   run<16>("16 B/lane, stride 16, adjacent lanes swapped", base, d_pairs, 16, blocks);
   run<16>("16 B/lane, stride 96 (AoS 96-byte records)", base, d_lin, 96, blocks);
+  // scattered gathers: every lane in a 128-byte line of its own (64 lines per instruction) against lane pairs reading the 32
+  // bytes of ONE record together (32 lines per instruction, the two instructions cover 64 records)
+  run<16>("16 B/lane, stride 128: every lane its own line (64 lines)", base, d_lin, 128, blocks);
+  {
+    std::vector<int> off(64);
+    int* d_off; CK(hipMalloc(&d_off, 256));
+    for (int l = 0; l < 64; l++) off[l] = (l >> 1) * 128 + (l & 1) * 16;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16, 32>("16 B/lane, lane PAIRS share a 32-B record, 128 B apart (32 lines)", base, d_off, 1, blocks);
+    for (int l = 0; l < 64; l++) off[l] = (l >> 1) * 64 + (l & 1) * 16;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16, 32>("16 B/lane, lane pairs share a record, 64 B apart (16 lines)", base, d_off, 1, blocks);
+    for (int l = 0; l < 64; l++) off[l] = (l >> 1) * 32 + (l & 1) * 16;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16, 1024>("16 B/lane, lane pairs share a record, consecutive records (8 lines)", base, d_off, 1, blocks);
+    for (int l = 0; l < 64; l++) off[l] = (l >> 2) * 128 + (l & 3) * 32;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16>("16 B/lane, four lanes per line, own records (16 lines)", base, d_off, 1, blocks);
+    for (int l = 0; l < 64; l++) off[l] = (l >> 1) * 128 + (l & 1) * 32;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16>("16 B/lane, two lanes per line, own records (32 lines)", base, d_off, 1, blocks);
+  }
   run<8>(" 8 B/lane, lane-linear (stride 8: 512 B contiguous)", base, d_lin, 8, blocks);
   run<8>(" 8 B/lane, stride 32", base, d_lin, 32, blocks);
   run<8>(" 8 B/lane, stride 8, lanes permuted", base, d_perm, 8, blocks);
