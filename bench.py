@@ -484,7 +484,12 @@ def main():
         except Exception as ex:   # noqa: BLE001  (a side measurement: the headline above stands)
             side["weak_scaling"] = {"error": str(ex)[:300]}
     exchange_us[0], rebuild_ms[0] = main_exchange_us, main_rebuild_ms
-    if world == 1 and args.slab_driver:
+    if world == 1 and args.slab_driver and args.decomposition == "bricks":
+        # (development: one brick exchanging with itself, SF_HALO_SELF_COMM=1 -- tests/trace_selfcomm.sh)
+        from sedifoam_amd.halo import BrickDriver
+        lmp = BrickDriver.from_global_bed(bed, script, dist, 0, 1, (1, 1, 1))
+        elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
+    elif world == 1 and args.slab_driver:
         lmp = make_driver("from_bed", bed)
         elapsed, n_total, launches, kernel_ms, info, _info_after = timed_run(lmp)
     elif world == 1:

@@ -133,11 +133,15 @@ struct DemPtrs {
   double* tx[2];
   double* tx_sendbuf;           // vote headers: the 8-byte slot at tx_sendbuf + tx_hdr_off[p] holds an int (header_vote)
   const int* bslot;             // brick driver (tx_fused == 2): [kBrickSlots][cap] where an atom's forward records go:
-                                // (send block q << kBlkShift) | doubles from the start of that block (-1: no further
+                                // (send block q << kBlkShift) | index of the record in that block (-1: no further
                                 // direction sends this atom)
   double* const* tx_blkptr;     // [directions] where block q of the exchange that follows this sub-step starts: in the
                                 // local send buffer, or -- direct ghost writes -- in the NEIGHBOUR's receive area (an
                                 // IPC mapping; two areas, used alternately)
+  const size_t* tx_blkcnt;      // [directions] records in block q.  A block is component-major, [kForwardDoubles][count]:
+                                // consecutive border atoms of a wave write consecutive doubles -- whole 64-byte lines
+                                // instead of one 8-byte word per 72-byte record, which is what a write over xGMI into a
+                                // neighbour's uncached area is made of
   const int* tx_hdr_off;
   int* xcd_time;                // StepParams::xcd_time: [64 x + 0] first start, [64 x + 32] last end of XCD x (100 MHz clock)
   // LDS-staged tiles (k_substep_lds)
@@ -690,7 +694,8 @@ private:
   bool tx_ready_ = false, tx_written_ = false;
   bool tx_direct_ = false;             // records go straight into the neighbours' receive areas
   int tx_par_ = 0;
-  double** d_blkptr_ = nullptr;        // [2][kMaxDirs] device table of block starts (both rows equal unless tx_direct_)
+  double** d_blkptr_ = nullptr;        // [2][kMaxDirs] device table of block starts (both rows equal unless tx_direct_),
+                                       // then [kMaxDirs] records per block (size_t)
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
   // brick decomposition: directions, face masks of the owned atoms, concatenated send lists
   int bndir_ = 0;

@@ -698,6 +698,8 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.tx_sendbuf = tx_sendbuf_;
   P.bslot = bslot_.as<int>();
   P.tx_blkptr = d_blkptr_ ? d_blkptr_ + (size_t)tx_par_ * kMaxDirs : nullptr;
+  static_assert(sizeof(size_t) == sizeof(double*), "the count row of the block table");
+  P.tx_blkcnt = d_blkptr_ ? reinterpret_cast<const size_t*>(d_blkptr_ + 2 * (size_t)kMaxDirs) : nullptr;
   P.tx_hdr_off = tx_hdr_off_;
   P.xcd_time = d_xcd_time_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;

@@ -725,11 +725,12 @@ __global__ __launch_bounds__(256) void k_brick_forward_pack(const int* list, Dem
   const int q = block_of(blk, k);
   const int i = list[k];
   const double4 x = xr[i], v = vm[i], w = om[i];
-  double* b = blkptr[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  double* b = blkptr[q] + (size_t)(k - blk.first[q]);
+  const size_t n = (size_t)(blk.first[q + 1] - blk.first[q]);   // (component-major block: [kForwardDoubles][n])
   // (unshifted, like the records the sub-step kernel writes itself: the receiver adds the block's periodic shift)
-  b[0] = x.x; b[1] = x.y; b[2] = x.z;
-  b[3] = v.x; b[4] = v.y; b[5] = v.z;
-  b[6] = w.x; b[7] = w.y; b[8] = w.z;
+  b[0] = x.x; b[n] = x.y; b[2 * n] = x.z;
+  b[3 * n] = v.x; b[4 * n] = v.y; b[5 * n] = v.z;
+  b[6 * n] = w.x; b[7 * n] = w.y; b[8 * n] = w.z;
 }
 
 // where the forward records of a sent atom go: slot s of atom i <- position of its record in block q (arrival order)
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256) void k_brick_slots(const int* list, DemEngine:
   const int q = block_of(blk, k);
   const int i = list[k];
   const int s = atomicAdd(&cursor[i], 1);   // (< kBrickSlots: brick_set_forward_tx refuses thinner bricks)
-  if (s < kBrickSlots) slots[(size_t)s * cap + i] = (q << kBlkShift) | ((k - blk.first[q]) * kForwardDoubles);
+  if (s < kBrickSlots) slots[(size_t)s * cap + i] = (q << kBlkShift) | (k - blk.first[q]);
 }
 
 __global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBlocks blk, const int* hdr_off, int nhdr,
@@ -756,14 +757,15 @@ __global__ __launch_bounds__(256) void k_brick_forward_unpack(DemEngine::BrickBl
     return;
   }
   const int q = block_of(blk, k);
-  const double* b = recvbuf + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  const double* b = recvbuf + blk.off[q] + (size_t)(k - blk.first[q]);
+  const size_t n = (size_t)(blk.first[q + 1] - blk.first[q]);
   const int g = nlocal + k;
   double4 x = xr[g], v = vm[g];
-  x.x = b[0] + blk.shift[q][0]; x.y = b[1] + blk.shift[q][1]; x.z = b[2] + blk.shift[q][2];
-  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  x.x = b[0] + blk.shift[q][0]; x.y = b[n] + blk.shift[q][1]; x.z = b[2 * n] + blk.shift[q][2];
+  v.x = b[3 * n]; v.y = b[4 * n]; v.z = b[5 * n];
   xr[g] = x;   // radius / mass (.w) were set by the border exchange
   vm[g] = v;
-  om[g] = {b[6], b[7], b[8], om[g].w};
+  om[g] = {b[6 * n], b[7 * n], b[8 * n], om[g].w};
 }
 
 void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, const int* hdr_off, int nhdr,
@@ -777,16 +779,18 @@ void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, co
   tx_hdr_off_ = hdr_off;
   tx_nhdr_ = nhdr;
   {
-    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 2 * kMaxDirs));
-    double* h[2 * kMaxDirs];
+    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 3 * kMaxDirs));
+    double* h[3 * kMaxDirs];
     for (int par = 0; par < 2; par++)
       for (int q = 0; q < kMaxDirs; q++)
         h[par * kMaxDirs + q] = q >= snd.n ? nullptr : (direct_blk ? direct_blk[par * kMaxDirs + q] : sendbuf + snd.off[q]);
+    for (int q = 0; q < kMaxDirs; q++)   // (third row: records per block)
+      reinterpret_cast<size_t*>(h)[2 * kMaxDirs + q] = q >= snd.n ? 0 : (size_t)(snd.first[q + 1] - snd.first[q]);
     SF_HIP(hipMemcpyAsync(d_blkptr_, h, sizeof(h), hipMemcpyHostToDevice, stream_));
     SF_HIP(hipStreamSynchronize(stream_));   // (h is on the stack)
   }
   for (int q = 0; q < snd.n; q++)
-    if ((long long)(snd.first[q + 1] - snd.first[q]) * kForwardDoubles > (long long)kBlkMask)
+    if ((long long)(snd.first[q + 1] - snd.first[q]) > (long long)kBlkMask)
       fail("brick_set_forward_tx: a send block of %d atoms does not fit the record slot encoding", snd.first[q + 1] - snd.first[q]);
   if (off || !nlocal_) return;
   // A brick thinner than twice the ghost cutoff in an external dimension has atoms that are ghosts of BOTH neighbours
@@ -951,14 +955,15 @@ __global__ __launch_bounds__(256) void k_brick_direct_unpack(DemEngine::BrickBlo
     return;
   }
   const int q = block_of(blk, k);
-  const double* b = recvarea + blk.off[q] + (size_t)(k - blk.first[q]) * kForwardDoubles;
+  const double* b = recvarea + blk.off[q] + (size_t)(k - blk.first[q]);
+  const size_t n = (size_t)(blk.first[q + 1] - blk.first[q]);
   const int g = nlocal + k;
   double4 x = xr[g], v = vm[g];
-  x.x = b[0] + blk.shift[q][0]; x.y = b[1] + blk.shift[q][1]; x.z = b[2] + blk.shift[q][2];
-  v.x = b[3]; v.y = b[4]; v.z = b[5];
+  x.x = b[0] + blk.shift[q][0]; x.y = b[n] + blk.shift[q][1]; x.z = b[2 * n] + blk.shift[q][2];
+  v.x = b[3 * n]; v.y = b[4 * n]; v.z = b[5 * n];
   xr[g] = x;
   vm[g] = v;
-  om[g] = {b[6], b[7], b[8], om[g].w};
+  om[g] = {b[6 * n], b[7 * n], b[8 * n], om[g].w};
 }
 
 void DemEngine::brick_direct_unpack(const BrickBlocks& rcv, const double* recvarea, const DirectSync& D)

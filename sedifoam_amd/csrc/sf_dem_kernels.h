@@ -685,10 +685,12 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     for (int k = 0; k < kBrickSlots; k++) {
       const int off = P.bslot[(size_t)k * cap + i];
       if (off < 0) break;
-      double* b = P.tx_blkptr[off >> kBlkShift] + (off & kBlkMask);
-      b[0] = xn.x; b[1] = xn.y; b[2] = xn.z;
-      b[3] = vn.x; b[4] = vn.y; b[5] = vn.z;
-      b[6] = wn.x; b[7] = wn.y; b[8] = wn.z;
+      const int bq = off >> kBlkShift;
+      double* b = P.tx_blkptr[bq] + (off & kBlkMask);
+      const size_t n = P.tx_blkcnt[bq];   // (component-major block: [kForwardDoubles][n])
+      b[0] = xn.x; b[n] = xn.y; b[2 * n] = xn.z;
+      b[3 * n] = vn.x; b[4 * n] = vn.y; b[5 * n] = vn.z;
+      b[6 * n] = wn.x; b[7 * n] = wn.y; b[8 * n] = wn.z;
     }
   }
   if (S.tx_fused == 1) {

@@ -162,7 +162,7 @@ struct DirectHalo {
   {
     for (Peer& p : peers)
       for (void* m : p.map)
-        if (m) (void)hipIpcCloseMemHandle(m);
+        if (m && m != rx[0] && m != rx[1]) (void)hipIpcCloseMemHandle(m);
     for (size_t r = 0; r < peer_sync.size(); r++)
       if (peer_sync[r] && peer_sync[r] != my_sync) (void)hipIpcCloseMemHandle(peer_sync[r]);
     if (my_sync) (void)hipFree(my_sync);
@@ -747,7 +747,8 @@ static void direct_init(SfLammps& S, HaloComm& hc)
 {
   const char* env = getenv("SF_HALO_DIRECT");
   const int want = !env ? 0 : (!strcmp(env, "auto") ? -1 : atoi(env));
-  if (want == 0 || hc.world < 2) return;
+  const bool self_only = hc.world == 1 && hc.brick && (hc.brick->ext[0] || hc.brick->ext[1] || hc.brick->ext[2]);
+  if (want == 0 || (hc.world < 2 && !self_only)) return;
   if (hc.world > 32) {
     if (want == 1) fail("SF_HALO_DIRECT=1: %d ranks (at most 32)", hc.world);
     return;
@@ -851,11 +852,21 @@ static void direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2)
     memcpy(m + 9, &h1, 64);
     m[17] = hc.recv_off[p];   // where rank p's chunk starts in this rank's areas
   }
-  direct_messages(hc, st, nbr);
+  {
+    std::vector<int> with = nbr;
+    with[hc.rank] = 0;
+    direct_messages(hc, st, with);
+  }
   for (int p = 0; p < W; p++) {
     if (!nbr[p]) continue;
     const long long* m = D.h_msg + (size_t)(W + p) * K;
     DirectHalo::Peer& P = D.peers[p];
+    if (p == hc.rank) {   // (SF_HALO_SELF_COMM: this rank's own areas, no handle)
+      P.map[0] = D.rx[0];
+      P.map[1] = D.rx[1];
+      P.remote_off = hc.recv_off[p];
+      continue;
+    }
     if (m[0] != P.gen_seen) {
       for (void*& mm : P.map) {
         if (mm) SF_HIP(hipIpcCloseMemHandle(mm));
@@ -1373,8 +1384,12 @@ int sf_brick_init(void* ptr, const char* id128, int rank, int world, int px, int
   L->eng.box(B.lo, B.hi, B.periodic);
   double lo[3], hi[3];
   int ext[3];
+  // SF_HALO_SELF_COMM=1 (development, one rank): the periodic dimensions are external too -- the rank exchanges border
+  // records and migrating atoms with ITSELF through the same code as with a neighbour (what the exchange costs next to
+  // the sub-step kernel without another process' kernels on the GPU: tests/trace_selfcomm.sh)
+  const bool self_comm = world == 1 && getenv("SF_HALO_SELF_COMM") && atoi(getenv("SF_HALO_SELF_COMM")) != 0;
   for (int k = 0; k < 3; k++) {
-    B.ext[k] = B.P[k] > 1;
+    B.ext[k] = B.P[k] > 1 || (self_comm && B.periodic[k]);
     ext[k] = B.ext[k] ? 1 : 0;
     const double w = (B.hi[k] - B.lo[k]) / B.P[k];
     lo[k] = B.lo[k] + B.c[k] * w;

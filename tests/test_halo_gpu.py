@@ -263,7 +263,9 @@ _BRICK_CASES = [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "h
                 ((3, 1, 2), (9, 5, 8), "hertz", True), ((1, 1, 2), (6, 5, 8), "hertz", True),
                 ((2, 2, 1), (8, 8, 5), "c5", True), ((2, 1, 2), (8, 5, 8), "hertz", False),
                 ((2, 2, 2), (8, 8, 8), "loose", True), ((2, 2, 2), (20, 20, 20), "hertz", True),
-                ((4, 1, 2), (12, 5, 8), "hertz", True)]
+                ((4, 1, 2), (12, 5, 8), "hertz", True),
+                # one rank that exchanges with ITSELF (SF_HALO_SELF_COMM=1: the periodic dimensions external) over the real RCCL
+                ((1, 1, 1), (8, 5, 8), "hertz", True)]
 
 
 # every grid over the wire (direct "0"); with direct ghost writes every grid of up to 6 ranks and two of the 8-rank ones
@@ -288,8 +290,12 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncell
     import torch.multiprocessing as mp
     monkeypatch.setenv("SF_HALO_DIRECT", direct)
     monkeypatch.setenv("SF_HALO_DIRECT_TIMEOUT", "120")   # (ranks sharing one GPU wait for each other's time slices)
-    lib = _standin_rccl(tmp_path)
     world = grid[0] * grid[1] * grid[2]
+    if world == 1:
+        monkeypatch.setenv("SF_HALO_SELF_COMM", "1")
+        lib = None                     # (RCCL itself: one rank on one device is what it accepts)
+    else:
+        lib = _standin_rccl(tmp_path)
     steps = {"hertz": (50, 50), "c5": (40, 40), "loose": (20, 20)}[physics]
     if physics == "c5":
         bed, cfg = _c5_case(ncells)

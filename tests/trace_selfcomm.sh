@@ -1,12 +1,14 @@
 #!/bin/bash
 # development helper (GPU box): kernel trace of the halo loop with one rank exchanging with its own periodic images
 # over RCCL (SF_HALO_SELF_COMM=1): what the forward exchange costs per sub-step next to k_substep.
-# usage: tests/trace_selfcomm.sh TAG PARTICLES
+# usage: [BENCH_EXTRA="--decomposition bricks"] [SF_HALO_DIRECT=1] tests/trace_selfcomm.sh TAG PARTICLES
+#   (--decomposition bricks: ONE brick whose periodic dimensions are external -- the brick driver's exchange, over RCCL or,
+#    with SF_HALO_DIRECT=1, by direct ghost writes into its own receive areas)
 tag=$1; n=${2:-125000}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 SF_HALO_SELF_COMM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/kt_$tag -o p -- \
-  python $root/bench.py --slab-driver --particles $n --steps 4 --warmup 1 --no-cpu-baseline --no-coupled --no-kernel-profile > $root/gpurun_out/kt_$tag.log 2>&1
+  python $root/bench.py --slab-driver --particles $n --steps 4 --warmup 1 --no-cpu-baseline --no-coupled --no-kernel-profile $BENCH_EXTRA > $root/gpurun_out/kt_$tag.log 2>&1
 cd $root
 tail -1 gpurun_out/kt_$tag.log | cut -c1-300
 f=$(ls gpurun_out/kt_$tag/*/*kernel_stats.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(ls gpurun_out/kt_$tag/*kernel_stats.csv | head -1)
