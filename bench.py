@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--coupled-multi", action="store_true",
                     help="with --gpus N > 1 also time coupled steps: enhancedCloud over the decomposed particles, "
                          "whole mesh on every rank, per-cell sums all-reduced")
+    ap.add_argument("--watchdog", type=float, default=None,
+                    help="N > 1: seconds after which a rank that is still running ends the job with rc 124 (a collective "
+                         "that never completes must not hold the node forever; default 1500, 0 = off)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -242,6 +245,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
+
+    wd = args.watchdog if args.watchdog is not None else (1500.0 if world > 1 else 0.0)
+    if wd > 0:
+        import threading
+
+        def _expired():
+            sys.stderr.write("bench.py: rank %d still running after %.0f s (--watchdog): a collective or a halo exchange "
+                             "never completed -- ending the job, rc 124\n" % (rank, wd))
+            sys.stderr.flush()
+            os._exit(124)
+        t = threading.Timer(wd, _expired)
+        t.daemon = True
+        t.start()
 
     import torch
     if not torch.cuda.is_available():
