@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--decomposition", choices=["auto", "slabs", "bricks"], default="auto",
                     help="N > 1, strong scaling: x-slabs, or bricks of a 3-D processor grid (sedifoam_amd.halo.brick_grid: "
                          "periodic dimensions first, as cubic as N allows: 8 -> 4x1x2, 4 -> 2x1x2 on the channel bed); "
-                         "auto = bricks from 4 ranks on (half the bytes per face, two to three links busy at once)")
+                         "auto = bricks for every N (2 -> 2x1x1: the driver with the direct ghost writes; from 4 ranks on half the bytes per face, two to three links busy at once)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: if the C++ RCCL driver cannot come up, measure the Python loop over torch.distributed "
                          "instead of exiting non-zero (config.decomposition says so)")
@@ -353,13 +353,20 @@ def main():
         from sedifoam_amd.halo import brick_grid
         err = None
         kw_grid = {}
-        if factory == "from_global_bed" and (args.decomposition == "bricks" or (args.decomposition == "auto" and world >= 4)):
+        # (auto: bricks for every N -- 2 x 1 x 1 are the two slabs, cut by the driver that also has the direct ghost writes;
+        # the slab driver stays behind --decomposition slabs, and under --one-gpu without the stand-in wire)
+        if factory == "from_global_bed" and (args.decomposition == "bricks" or (args.decomposition == "auto" and world >= 2
+                                                                                   and not (args.one_gpu and transport != "rccl"))):
             if args.one_gpu and transport != "rccl":
                 raise SystemExit("bench.py --one-gpu with bricks needs SF_RCCL_LIB (the brick driver is C++ only)")
             kw_grid = {"grid": brick_grid(world, the_bed)}
             grid_used[0] = kw_grid["grid"]
         try:
-            drv = getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport=transport, **kw_grid)
+            if kw_grid:
+                from sedifoam_amd.halo import BrickDriver
+                drv = BrickDriver.from_global_bed(the_bed, script, dist, rank, world, kw_grid["grid"])
+            else:
+                drv = getattr(SlabDriver, factory)(the_bed, script, dist, rank, world, transport=transport)
         except Exception as ex:   # noqa: BLE001
             drv, err = None, ex
         if dist is not None and world > 1:
