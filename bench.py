@@ -259,6 +259,10 @@ def main():
         t.daemon = True
         t.start()
 
+    # every 16th sub-step kernel of the timed region sits between a HIP event pair (`roofline.achieved`): a pair costs the run
+    # ~12 us of launch gaps (kernel trace), i.e. 0.4 % of the whole-run value at this stride
+    os.environ.setdefault("SF_PROF_STRIDE", "16")
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
