@@ -7,7 +7,8 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 od=$root/sedifoam_amd/csrc/_obj/var_$name; mkdir -p $od
 for f in $root/sedifoam_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DSF_VARIANT_BUILD "$@" -c $f -o $od/$b.o &
+  extra=""; [ "$b" == "sf_dem" ] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"   # (like sedifoam_amd/build.py FILE_FLAGS)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DSF_VARIANT_BUILD $extra "$@" -c $f -o $od/$b.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/sedifoam_amd/libsedifoam_amd_$name.so $od/*.o

@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+       "-mllvm", "-amdgpu-sched-strategy=max-ilp",   # (sedifoam_amd/build.py FILE_FLAGS for this file)
        "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(ROOT, "sedifoam_amd", "csrc", "sf_dem.hip"),
        "-o", "/tmp/_kr.o"] + sys.argv[1:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
