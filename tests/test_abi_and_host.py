@@ -190,3 +190,14 @@ def test_processors_line_resolves_like_lammps():
     assert grid(2, (1.0, 3.0, 1.0)) == (1, 2, 1)
     assert grid(7, (1.0, 1.0, 1.0), (2, 0, 0)) is None        # Bad grid of processors
     assert grid(1, (1.0, 1.0, 1.0)) == (1, 1, 1)
+
+
+def test_bench_watchdog_ends_a_job_that_does_not_finish():
+    """bench.py --watchdog: a rank still running after the given time ends the job with rc 124 (an N > 1 run whose collective
+    never completes must not hold the node); started before anything that could block, so it fires here without a GPU"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--watchdog", "0.2"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 124 and "--watchdog" in r.stderr
