@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void k_lubricate_csr(LubParams p, int inum, co
       const Vec3 del = xi - ld3(x, j);
       const double rsq = dot(del, del);
       if (!(rsq < cutsq)) continue;
-      lubricate_poly_pair(p, del, rsq, radi, radius[j], vi, ld3(v, j), wi, ld3(omega, j), F, T);
+      double r, rinv;
+      sf_sqrt_rsqrt(rsq, r, rinv);
+      lubricate_poly_pair(p, del, r, rinv, radi, radius[j], vi, ld3(v, j), wi, ld3(omega, j), F, T);
     }
   }
   atomic_add3(f, i, F);

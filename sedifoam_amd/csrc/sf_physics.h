@@ -95,6 +95,38 @@ __device__ __forceinline__ double sf_sqrt(double x)
 #endif
 }
 
+// natural logarithm of a positive, finite, normal x: frexp, (m - 1) / (m + 1) and the odd atanh series to s^21 -- ~30
+// instructions against the ~100 of the library's log with its special cases; within 1-2 ulp of it (the lubrication
+// series takes one per listed pair: pair_lubricate_poly.cpp:311-333)
+__device__ __forceinline__ double sf_log(double x)
+{
+#if SF_FAST_MATH
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);               // [0.5, 1)
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;                                     // [sqrt(1/2), sqrt(2))
+  e = low ? e - 1 : e;
+  const double s = (m - 1.0) * sf_rcp(m + 1.0);            // |s| <= 0.1716
+  const double z = s * s;
+  double p = 2.0 / 21.0;
+  p = fma(p, z, 2.0 / 19.0);
+  p = fma(p, z, 2.0 / 17.0);
+  p = fma(p, z, 2.0 / 15.0);
+  p = fma(p, z, 2.0 / 13.0);
+  p = fma(p, z, 2.0 / 11.0);
+  p = fma(p, z, 2.0 / 9.0);
+  p = fma(p, z, 2.0 / 7.0);
+  p = fma(p, z, 2.0 / 5.0);
+  p = fma(p, z, 2.0 / 3.0);
+  p = p * z;                                               // log(m) = 2 s + s p
+  const double de = (double)e;
+  // e ln2 in two pieces (the high one exact for |e| < 2^11), smallest terms first
+  return fma(de, 0.693147180369123816490, fma(s, p, fma(de, 1.90821492927058770002e-10, s + s)));
+#else
+  return log(x);
+#endif
+}
+
 struct ContactIn {
   Vec3 del;        // from partner (or wall) to the particle
   double rsq;
@@ -289,12 +321,11 @@ struct LubParams {
 // lubrication force/torque on i from neighbour j (full list: only i is updated), Ef = 0.
 // Same algebra as pair_lubricate_poly.cpp:241-399; its ~25 divisions are four reciprocals (1/r, 1/radi, 1/beta1,
 // 1/h_sep) and products, the constant divisors are folded.
-__device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del, double rsq, double radi,
+// (r, rinv = sf_sqrt_rsqrt of the pair's squared distance: the fused kernel shares them between its arms)
+__device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del, double r, double rinv, double radi,
                                                     double radj, Vec3 vi0, Vec3 vj0, Vec3 wi, Vec3 wj,
                                                     Vec3& F, Vec3& T)
 {
-  double r, rinv;
-  sf_sqrt_rsqrt(rsq, r, rinv);
   const Vec3 n = {del.x * rinv, del.y * rinv, del.z * rinv};
   const Vec3 xl = {-n.x * radi, -n.y * radi, -n.z * radi};
   const Vec3 jl = {-n.x * radj, -n.y * radj, -n.z * radj};
@@ -316,7 +347,7 @@ __device__ __forceinline__ void lubricate_poly_pair(const LubParams& p, Vec3 del
   if (p.flaglog) {
     const double b03 = b02 * beta0, b04 = b02 * b02;
     const double ib13 = ib12 * ib1, ib14 = ib12 * ib12;
-    const double lg = log(ih);             // log(1 / h_sep)
+    const double lg = -sf_log(h_sep);      // log(1 / h_sep)
     const double hl = h_sep * lg;
     a_sq = b02 * ib12 * ih + (1.0 + 7.0 * beta0 + b02) * (0.2 * ib13) * lg;
     a_sq += (1.0 + 18.0 * beta0 - 29.0 * b02 + 18.0 * b03 + b04) * ((1.0 / 21.0) * ib14) * hl;

@@ -28,11 +28,13 @@ for _ in range(2):
     lmp.step(50)
 lmp.set_profiling(True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-steps = 8
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 for _ in range(steps):
     lmp.step(50)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 launches, ms = lmp.get_profile()
-print(mode, "N %d  pairs/atom (full list) %.2f  kernel %.1f us  %.3e particle-substeps/s  rebuilds %d" % (
+kh = info.npairs_full / 2.0 / info.nlocal
+balg = 284.0 + 52.0 * kh   # SURVEY.md 8d, as bench.py
+print(mode, "N %d  pairs/atom (full list) %.2f  kernel %.1f us  %.3e particle-substeps/s  rebuilds %d  frac(kernel) %.3f of 8 TB/s on %.0f B/particle-substep" % (
     info.nlocal, info.npairs_full / info.nlocal, 1e3 * ms / launches, info.nlocal * 50 * steps / el,
-    lmp.info().nbuilds - info.nbuilds))
+    lmp.info().nbuilds - info.nbuilds, balg * info.nlocal / (1e-3 * ms / launches) / 8e12, balg))
