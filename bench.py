@@ -137,6 +137,15 @@ def cpu_coupled_step(dem, bed, mesh_n, substeps, band, steps):
 
 
 KW = dict(kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9.81)
+STAGE = ["start"]   # what the run was doing, for the `error` line of a run that does not come up (N > 1 above all)
+
+
+def error_line(args_gpus, steps, warmup, msg):
+    """the ONE JSON line of a run that failed before it had a number: same keys, value null, what failed and where"""
+    return json.dumps({"metric": "particle-DEM-substeps/sec", "value": None, "unit": "particle-substeps/s", "n_gpus": args_gpus,
+                       "steps": steps, "warmup": warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                       "vs_baseline": None, "dtype": "f64", "data": "synthetic", "error": str(msg)[:600], "stage": STAGE[0],
+                       "rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1"))})
 FLUIDISED = dict(jitter=0.3, spacing=1.1)   # --bed fluidised
 
 
@@ -187,6 +196,77 @@ def cpu_baseline_all_cores(npart, sub):
                                       "slowest %.1f s; no halo exchange between them" % (len(res), res[0]["n"], sub, slowest)}
 
 
+# ---- BASELINE.json configs[1], [2], [4] (C2, C3, C5) next to the headline (configs[3] = C4): the `configs` object ----
+C5_LUB = (1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)        # pair lubricate/poly mu flaglog flagfld cut_inner cut_global flagHI flagVF
+C5_COHESIVE = (1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1)     # fix cohesive ah lam smin smax opt
+
+
+def config_cases(synthetic):
+    """name -> (bed, cfg, coupled mesh or None, label).  cfg is the dictionary tests/dem_cases.py turns into the oracle's
+    set-up; config_script() below writes the same thing as in.lammps lines for the GPU engine."""
+    out = {}
+    # C2: 10 k monodisperse spheres standing free on the floor of a closed (32 x 3.5 d)^3 box, 32^3 mesh
+    nc = synthetic.fcc_cells_for(10000)
+    bed = synthetic.fcc_bed(nc, seed=12345 + 1, vmax=0.01)
+    box = 32 * 3.5e-3
+    bed["x"][:, 0] += 0.5 * (box - nc[0] * bed["edge"])
+    bed["x"][:, 2] += 0.5 * (box - nc[2] * bed["edge"])
+    bed["periodic"] = (0, 0, 0)
+    bed["boxhi"] = np.array([box, box, box])
+    cfg = dict(kn=KW["kn"], gamman=KW["gamman"], xmu=KW["xmu"], g=KW["g"], dt=KW["dt"], skin=KW["skin_d"] * 1.0e-3,
+               walls=[(1, 0.0, box), (0, 0.0, box), (2, 0.0, box)])
+    out["C2"] = (bed, cfg, (32, 32, 32), "%d monodisperse spheres, Hertz history + ErgunWenYu drag, 32^3 mesh (closed box, "
+                                          "three wall pairs), 50 DEM sub-steps per CFD step" % bed["n"])
+    # C3: 100 k-grain fluidised (loose, disordered) bed, 50 sub-steps per CFD step
+    bed = synthetic.fcc_bed(synthetic.fcc_cells_for(100000), seed=12345 + 2, **FLUIDISED)
+    cfg = dict(kn=KW["kn"], gamman=KW["gamman"], xmu=KW["xmu"], g=KW["g"], dt=KW["dt"], skin=KW["skin_d"] * 1.0e-3,
+               walls=[(1, float(bed["boxlo"][1]), float(bed["boxhi"][1]))])
+    mesh = tuple(int(k) for k in np.clip(((bed["boxhi"] - bed["boxlo"]) / 3.3e-3).astype(int), 1, 32))
+    out["C3"] = (bed, cfg, mesh, "%d-grain fluidised bed (FCC sites at spacing 1.1 d, jitter 0.3 d), Hertz history + ErgunWenYu "
+                                 "drag, %dx%dx%d mesh, 50 DEM sub-steps per CFD step" % ((bed["n"],) + mesh))
+    # C5: 500 k polydisperse grains, hybrid/overlay gran/hertzFix/history + lubricate/poly, fix cohesive (periodic box)
+    nc = synthetic.fcc_cells_for(500000)
+    bed = synthetic.fcc_bed(nc, seed=15, vmax=0.05, poly=(0.85e-3, 1.0e-3), spacing=0.95)
+    bed["boxhi"][1] = nc[1] * bed["edge"]
+    bed["x"][:, 1] %= bed["boxhi"][1]
+    bed["periodic"] = (1, 1, 1)
+    cfg = dict(kn=KW["kn"], gamman=KW["gamman"], xmu=KW["xmu"], g=0.0, dt=KW["dt"], skin=0.06e-3, walls=[],
+               cohesive=C5_COHESIVE, lub=C5_LUB)
+    out["C5"] = (bed, cfg, None, "%d polydisperse grains (d = 0.85-1.0 mm), pair hybrid/overlay gran/hertzFix/history + "
+                                 "lubricate/poly, fix cohesive, periodic box, 50 DEM sub-steps per step" % bed["n"])
+    return out
+
+
+def config_script(bed, cfg):
+    gran = "gran/hertzFix/history %.17g NULL %.17g NULL %.17g 1" % (cfg["kn"], cfg["gamman"], cfg["xmu"])
+    pair = gran if not cfg.get("lub") else ("hybrid/overlay %s lubricate/poly %.17g %d %d %.17g %.17g %d %d"
+                                            % ((gran,) + tuple(cfg["lub"])))
+    lines = ["atom_style sphere", "boundary %s %s %s" % tuple("p" if q else "f" for q in bed["periodic"]), "newton off",
+             "communicate single vel yes", "neighbor %.17g bin" % cfg["skin"], "neigh_modify delay 0",
+             "pair_style " + pair, "pair_coeff * *", "timestep %.17g" % cfg["dt"], "fix 1 all nve/sphere",
+             "fix 2 all gravity %.17g vector 0 -1 0" % cfg["g"], "fix 3 all fdrag"]
+    for k, (dim, lo, hi) in enumerate(cfg["walls"]):
+        lines.append("fix w%d all wall/granFix %.17g NULL %.17g NULL %.17g 1 %splane %.17g %.17g"
+                     % (k, cfg["kn"], cfg["gamman"], cfg["xmu"], "xyz"[dim], lo, hi))
+    if cfg.get("cohesive"):
+        lines.append("fix coh all cohesive %.17g %.17g %.17g %.17g %d" % tuple(cfg["cohesive"]))
+    return lines
+
+
+def config_cpu_leg(bed, cfg, substeps):
+    """the oracle on the same bed and script (tests/dem_cases.py builds it from the same dictionary), `substeps` DEM sub-steps
+    after setup, single thread: the bounded CPU baseline of one named configuration"""
+    from tests import dem_cases as dc
+    orc = dc.make_oracle(bed, dict(cfg, pair="hertz"))
+    orc.setup()
+    t0 = time.perf_counter()
+    orc.run(substeps)
+    secs = time.perf_counter() - t0
+    return {"value": bed["n"] * substeps / secs, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
+            "sample": "the same %d-particle bed and script, %d sub-steps after setup, %.2f s, oracle/ (C, gcc -O2) single "
+                      "thread" % (bed["n"], substeps, secs)}
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2:])
@@ -223,6 +303,9 @@ def main():
                     help="packed = the lattice bed of BASELINE's headline; fluidised = a loose disordered bed (jitter 0.3 d, "
                          "spacing 1.1 d: K_half ~4, a third of the listed neighbours touch, a rebuild every ~11 sub-steps)")
     ap.add_argument("--no-fluidised", action="store_true", help="N = 1: skip the `fluidised_bed` side measurement")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1: skip the `configs` object (BASELINE configs C2, C3, C5 next to the headline) and the 2 M bed "
+                         "of `roofline.frac_2m`")
     ap.add_argument("--no-parity", action="store_true", help="N = 1: skip the GPU-vs-oracle comparison of the final state")
     ap.add_argument("--one-gpu", action="store_true",
                     help="development: all ranks share GPU 0, halo over gloo through host memory (RCCL refuses two "
@@ -254,6 +337,10 @@ def main():
             sys.stderr.write("bench.py: rank %d still running after %.0f s (--watchdog): a collective or a halo exchange "
                              "never completed -- ending the job, rc 124\n" % (rank, wd))
             sys.stderr.flush()
+            if rank == 0:   # (the line the driver parses says what hung and where)
+                sys.stdout.write(error_line(args.gpus, args.steps, args.warmup,
+                                            "watchdog: still running after %.0f s in stage '%s'" % (wd, STAGE[0])) + "\n")
+                sys.stdout.flush()
             os._exit(124)
         t = threading.Timer(wd, _expired)
         t.daemon = True
@@ -281,10 +368,17 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_mod
         dist = dist_mod
+        STAGE[0] = "torch.distributed.init_process_group (%s, %s:%s)" % ("gloo" if args.one_gpu else "nccl = RCCL",
+                                                                          os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))
         if args.one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # (the first collective brings the RCCL communicator up: fail here, with this stage name, rather than inside a driver)
+            STAGE[0] = "first RCCL all-reduce over %d ranks" % world
+            t_ = torch.ones(1, device="cuda")
+            dist.all_reduce(t_)
+            torch.cuda.synchronize()
 
     from sedifoam_amd import synthetic
     kw = dict(KW, skin_d=args.skin) if args.skin is not None else KW
@@ -311,7 +405,9 @@ def main():
     def timed_run(lmp):
         """W warm-up + K timed steps of `lammps_step(S)`; returns (elapsed max over ranks, total particles, launches,
         kernel ms, info before, info after)"""
+        STAGE[0] = "setup (first list build, halo bring-up) of %s" % type(lmp).__name__
         lmp.setup()
+        STAGE[0] = "stepping %s" % type(lmp).__name__
         info0 = lmp.info()
         for _ in range(args.warmup):
             lmp.step(args.substeps)
@@ -357,6 +453,7 @@ def main():
         from sedifoam_amd.halo import brick_grid
         err = None
         kw_grid = {}
+        STAGE[0] = "creating the C++ halo driver (%s)" % factory
         # (auto: bricks for every N -- 2 x 1 x 1 are the two slabs, cut by the driver that also has the direct ghost writes;
         # the slab driver stays behind --decomposition slabs, and under --one-gpu without the stand-in wire)
         if factory == "from_global_bed" and (args.decomposition == "bricks" or (args.decomposition == "auto" and world >= 2
@@ -414,6 +511,7 @@ def main():
         (the headline's decomposition and halo transport) and on ONE domain (rank 0's GPU).  Returns (parity dict on rank
         0 / None elsewhere, True if the leg ran through on every rank and agreed)."""
         sub = 50
+        STAGE[0] = "parity leg (decomposed vs one domain), SF_HALO_DIRECT=%s" % os.environ.get("SF_HALO_DIRECT")
         gbed = synthetic.fcc_bed(ncells, seed=12345 + 3, **bed_kw)
         mine, mine_builds, direct_on, err = None, 0, 0, None
         try:
@@ -727,6 +825,69 @@ def main():
         out["fluidised_bed"] = fo
         args.steps, args.warmup = keep
         del flmp, fbed
+    # N = 1: the kernel's roofline fraction on a 2 M-grain bed of the same packing next to the 1 M one (the 1 M launch is
+    # five rounds of resident waves: its fill and drain weigh ~9 % of it, half that at 2 M), and BASELINE.json's other
+    # single-GPU configurations -- C2 (10 k grains, 32^3 mesh), C3 (100 k fluidised), C5 (500 k polydisperse + cohesive +
+    # lubricate/poly) -- each through the same engine path and timing rules, with its coupled step where it has a mesh
+    cfg_cases = None
+    if (world == 1 and not args.slab_driver and not args.no_configs and args.bed == "packed" and not bed_kw
+            and args.particles == 1000000):
+        keep = (args.steps, args.warmup)
+        b2 = synthetic.fcc_bed(synthetic.fcc_cells_for(2000000), seed=12345 + 3)
+        l2 = build_engine(b2, synthetic.hertz_script(b2, **kw))
+        args.steps, args.warmup = max(2, keep[0] // 3), 1
+        el2, n2, la2, km2, i2, i2b = timed_run(l2)
+        if la2:
+            kh2 = i2b.npairs_full / 2.0 / max(i2b.nlocal, 1)
+            out["roofline"]["frac_2m"] = (284.0 + 52.0 * kh2) * i2b.nlocal / (1e-3 * km2 / la2) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["mean_kernel_us_2m"] = 1e3 * km2 / la2
+            out["roofline"]["particles_2m"] = int(n2)
+            out["roofline"]["value_2m"] = n2 * args.substeps * args.steps / el2
+        del l2, b2
+        cfg_cases = config_cases(synthetic)
+        out["configs"] = {}
+        for name, (cbed, ccfg, cmesh, label) in cfg_cases.items():
+            try:
+                clmp = build_engine(cbed, config_script(cbed, ccfg))
+                args.steps, args.warmup = {"C2": (keep[0], 2), "C3": (max(2, keep[0] // 2), 1), "C5": (max(2, keep[0] // 3), 1)}[name]
+                el_c, n_c, l_c, k_c, i_c, i_c1 = timed_run(clmp)
+                kh_c = i_c1.npairs_full / 2.0 / max(i_c1.nlocal, 1)
+                o = {"workload": label, "value": n_c * args.substeps * args.steps / el_c, "unit": "particle-substeps/s",
+                     "ms_per_step": 1e3 * el_c / args.steps, "steps": args.steps, "warmup": args.warmup,
+                     "particles": int(n_c), "k_half": round(kh_c, 3),
+                     "neighbor_rebuilds_in_run": int(i_c1.nbuilds - i_c.nbuilds),
+                     "algorithmic_bytes_per_particle_substep": 284.0 + 52.0 * kh_c}
+                if l_c:
+                    o["mean_kernel_us"] = 1e3 * k_c / l_c
+                    o["roofline_frac"] = (284.0 + 52.0 * kh_c) * i_c1.nlocal / (1e-3 * k_c / l_c) / 1e9 / HBM_PEAK_GBS
+                    o["roofline_frac_whole_run"] = (284.0 + 52.0 * kh_c) * o["value"] / 1e9 / HBM_PEAK_GBS
+                if cmesh is not None and not args.no_coupled:
+                    from sedifoam_amd import enhancedCloud
+                    mesh_n = np.array(cmesh, np.int32)
+                    dxm = (cbed["boxhi"] - cbed["boxlo"]) / mesh_n
+                    ncm = int(np.prod(mesh_n))
+                    cloud = enhancedCloud(clmp, cbed["boxlo"], dxm, mesh_n,
+                                          dict(dragModel="ErgunWenYu", subCycles=1, maxPossibleAlpha=0.65,
+                                               diffusionBandWidth=0.006, diffusionSteps=6),
+                                          dict(rhob=1000.0, nub=1.0e-6), deltaT=args.substeps * kw["dt"])
+                    cloud.setFluid(Uf=np.tile([0.0, 0.05, 0.0], (ncm, 1)), gradp=np.tile([0.0, -9810.0, 0.0], (ncm, 1)))
+                    cloud.calcTcFields()
+                    cloud.evolve(); cloud.calcTcFields()
+                    barrier()
+                    t1 = time.perf_counter()
+                    ncpl = max(3, args.steps)
+                    for _ in range(ncpl):
+                        cloud.evolve(); cloud.calcTcFields()
+                    barrier()
+                    o["coupled_steps_per_s"] = ncpl / (time.perf_counter() - t1)
+                    o["coupled_step"] = ("ErgunWenYu drag + %d DEM sub-steps + scatter + Asrc + diffusion smoothing (b = 6 mm, "
+                                         "6 steps), %dx%dx%d mesh" % ((args.substeps,) + tuple(int(k) for k in mesh_n)))
+                    cloud.close()
+                out["configs"][name] = o
+                del clmp
+            except Exception as ex:   # noqa: BLE001  (a side measurement: the headline stands)
+                out["configs"][name] = {"workload": label, "error": str(ex)[:300]}
+        args.steps, args.warmup = keep
     if world > 1 and rank == 0:
         if parity_first is not None:
             out["parity"] = parity_first
@@ -791,6 +952,16 @@ def main():
                                        and out["parity"]["max_rel_v"] <= 1e-9 and out["parity"]["max_rel_omega"] <= 1e-9)
             parity_ok = out["parity"]["ok"]
         del res
+        if cfg_cases is not None:
+            # the named configurations on the CPU: the oracle on the same bed and script, a bounded number of sub-steps
+            # (200 / 50 / 10 for 10 k / 100 k / 500 k grains: 0.5-20 s each)
+            for name, (cbed, ccfg, cmesh, label) in cfg_cases.items():
+                if name in out.get("configs", {}):
+                    try:
+                        out["configs"][name]["cpu_baseline"] = config_cpu_leg(cbed, ccfg, {"C2": 200, "C3": 50}.get(name, 10))
+                    except Exception as ex:   # noqa: BLE001
+                        out["configs"][name]["cpu_baseline"] = {"error": str(ex)[:300]}
+            cfg_cases = None
         allc = cpu_baseline_all_cores(args.cpu_all_particles, 20) if args.cpu_all_particles > 0 else None
         if allc:
             out["cpu_baseline_all_cores"] = allc
@@ -804,4 +975,21 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    def _arg(name, default):
+        a = sys.argv[1:]
+        return int(a[a.index(name) + 1]) if name in a and a.index(name) + 1 < len(a) else default
+    try:
+        main()
+    except SystemExit as ex:
+        # (SystemExit with a message = the run refused to start -- no GPU, wrong launcher: say so in the line as well)
+        if isinstance(ex.code, str) and int(os.environ.get("RANK", "0")) == 0 and "--cpu-worker" not in sys.argv:
+            print(error_line(_arg("--gpus", 1), _arg("--steps", 10), _arg("--warmup", 2), ex.code))
+            sys.stdout.flush()
+        raise
+    except BaseException as ex:   # noqa: BLE001  -- a run that dies before its line still prints ONE parseable line (rank 0) ...
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(error_line(_arg("--gpus", 1), _arg("--steps", 10), _arg("--warmup", 2), "%s: %s" % (type(ex).__name__, ex)))
+            sys.stdout.flush()
+        os._exit(1)   # ... and does not wait in a destructor for ranks that are stuck in a collective

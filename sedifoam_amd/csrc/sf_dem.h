@@ -174,9 +174,6 @@ struct StepParams {
                    // size -- XCD x works on the xcd_count[x] blocks from xcd_first[x], the grid is 8 x the largest count
                    // and a workgroup beyond its XCD's count exits at once
   int xcd_first[8], xcd_count[8];
-  int xcd_two[8];  // xcd_remap 2: that many of XCD x's xcd_count[x] tiles are run by two-lane workgroups (two per tile; the
-                   // grid then covers xcd_count + xcd_two blocks per XCD) -- the launch tail, see k_substep
-  int tail_pos;    // 0: the two-lane tiles are the LAST of the XCD's range (dispatched last), 1: the first
   int sweep_rev;   // walk each XCD's range backwards (every other sub-step)
   int xcd_time;    // this launch records when each XCD starts and ends (DemPtrs::xcd_time): the engine balances the shares
   WallParams wall[kMaxWalls];
@@ -578,8 +575,6 @@ private:
   int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
   double xcd_weight_[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // share of the sorted range each XCD works on (launch_substep)
   bool xcd_weighted_ = false;
-  double tail_frac_ = 0.0;   // share of every XCD's tiles run two-lane at the end of the launch (SF_TAIL_FRAC)
-  int tail_pos_ = 0;         // SF_TAIL_POS
   // XCD balance: a launch a few sub-steps after every list build is timed per XCD (two atomics per wave), and the shares
   // follow the measured rates.  Placement only: results do not depend on it.
   bool xcd_auto_ = true;

@@ -99,8 +99,6 @@ DemEngine::DemEngine()
   SF_HIP(hipEventCreateWithFlags(&ev_flags_, hipEventDisableTiming));
   if (const char* e = getenv("SF_TILE")) opt_tile_ = atoi(e);
   if (const char* e = getenv("SF_XCD_REMAP")) opt_xcd_remap_ = atoi(e);
-  if (const char* e = getenv("SF_TAIL_FRAC")) tail_frac_ = std::min(0.5, std::max(0.0, atof(e)));
-  if (const char* e = getenv("SF_TAIL_POS")) tail_pos_ = atoi(e) ? 1 : 0;
   SF_HIP(hipMalloc(&d_xcd_time_, sizeof(int) * 1024));
   SF_HIP(hipHostMalloc(&h_xcd_time_, sizeof(int) * 1024));
   for (int k = 0; k < 512; k++) h_xcd_time_[512 + k] = (k & 63) == 0 ? INT_MAX : 0;   // start: atomicMin, end: atomicMax
@@ -947,8 +945,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
       SF_HIP(hipMemcpyAsync(d_xcd_time_, d_xcd_time_ + 512, sizeof(int) * 512, hipMemcpyDeviceToDevice, stream_));
       S.xcd_time = 1;
     }
-    const bool tail = tail_frac_ > 0.0 && block == 64 && part == 0 && S.xcd_remap == 1 && lpa == 1 && !cohe && !lub && mode == 0 && grid.x >= 2048;
-    if (part == 0 && S.xcd_remap == 1 && (xcd_weighted_ || tail) && grid.x >= 64) {
+    if (part == 0 && S.xcd_remap == 1 && xcd_weighted_ && grid.x >= 64) {
       const int nb = (int)grid.x;
       double wsum = 0.0;
       for (int x = 0; x < 8; x++) wsum += xcd_weight_[x];
@@ -959,11 +956,9 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
         const int end = x == 7 ? nb : std::min(nb, (int)std::llround(nb * acc / wsum));
         S.xcd_first[x] = first;
         S.xcd_count[x] = std::max(0, end - first);
-        S.xcd_two[x] = tail ? (int)(tail_frac_ * S.xcd_count[x]) : 0;
-        most = std::max(most, S.xcd_count[x] + S.xcd_two[x]);
+        most = std::max(most, S.xcd_count[x]);
         first = std::max(first, end);
       }
-      S.tail_pos = tail_pos_;
       S.xcd_remap = 2;
       grid = dim3((unsigned)(8 * most));
     }

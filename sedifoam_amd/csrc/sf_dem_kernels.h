@@ -34,9 +34,6 @@
 #endif
 // (whether v, omega of a neighbour are prefetched always or only when the pair touched one sub-step ago is the template
 // parameter TP of k_substep, chosen per list from the fraction of listed neighbours that touch)
-#ifndef SF_TAIL_KERNEL
-#define SF_TAIL_KERNEL 1      // the one-lane contact kernels carry the two-lane tail path (StepParams::xcd_two)
-#endif
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
@@ -84,6 +81,13 @@
 namespace sf {
 
 __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
+
+// one lane per atom with exactly one of the cohesive / lubrication arms: the lean loop at three waves per SIMD (see
+// substep_particle); the kernels of small systems (several lanes per atom) and the one with both arms stay as they were
+#ifndef SF_LEAN_VARIANTS
+#define SF_LEAN_VARIANTS 1
+#endif
+constexpr bool sf_lean_variant(bool cohe, bool lub, int lpa) { return SF_LEAN_VARIANTS && lpa == 1 && cohe != lub; }
 
 #if SF_EXP_STAMP
 __device__ unsigned long long* g_stamp = nullptr;   // [4 * workgroups] of the launch being recorded, else null
@@ -181,12 +185,7 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // LPA lanes per atom (1, 2 or 4): lane q of an atom's group handles the slots q, q + LPA, ...; the partial force and
 // torque sums are combined with a fixed shuffle tree and lane 0 integrates.  Small systems (< ~3 waves per SIMD at
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
-// CHAIN (two lanes per atom only): the two lanes of an atom add their contacts' forces to ONE running sum in slot order --
-// after every pair of slots they exchange their contact's force and torque (two row-adjacent lanes: DPP moves) and both
-// add them, even slot first.  The sums are then bit for bit those of the one-lane kernel, so waves of this kind can be
-// mixed into a one-lane launch wherever shorter waves pay (the launch tail, k_substep) without anything in the results
-// depending on where they were placed.
-template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP, bool CHAIN = false>
+template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP>
 __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw,
                                                  __attribute__((address_space(3))) char* dma = nullptr)
@@ -211,8 +210,6 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
   const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
-  static_assert(!CHAIN || (LPA == 2 && !COHE && !LUB && !LDS), "chained sums: two lanes per atom, contact law only");
-  const int nnp = CHAIN ? (nn_all + 1) / 2 : nn;   // CHAIN: trips of the slot loop, the same in both lanes of an atom
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 #if SF_EXP_DMA
   // LDS of the (one-wave) workgroup: [12 rows of list words: 3 KB][18 history rows (six slots from `dma_s0`): 9 KB]
@@ -272,7 +269,12 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // retires in order, so the contact law only waits for them and the prefetch stays in flight.  Measured at 1 M
   // atoms: 249 -> 224 us.  Prefetching the shear history as well costs 10 VGPRs (3 waves/SIMD) and loses 10 %.
   constexpr bool NEED_VW = (STYLE != 0) || LUB;
-  constexpr bool HIST_PF = SF_HIST_PREFETCH && !CHAIN;   // (chained two-lane waves: the registers are needed elsewhere)
+  // The kernels that carry ONE of the cohesive / lubrication arms run leaner -- one register set (no unroll by two), the
+  // history requested where it is consumed -- and fit three waves per SIMD that way: measured on the 500 k polydisperse
+  // bed against the two-wave form, cohesive 134.0 -> 120.6 us, lubricate/poly 176.8 -> 164.7 us; the kernel with both arms
+  // spills at three waves and gains nothing (192.3 / 198.7 -> 191.9 us), it keeps two (profiles/r05_c5_README.md)
+  constexpr bool LEAN = sf_lean_variant(COHE, LUB, LPA);
+  constexpr bool HIST_PF = SF_HIST_PREFETCH && !LEAN;
   struct Rec {
     double4 x, v, w;
     Vec3 sh; // the pair's history as THIS side sees it (SF_HIST_PREFETCH)
@@ -369,12 +371,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const int sl = (LPA == 1 && uniform_s) ? __builtin_amdgcn_readfirstlane(s) : q + LPA * s;
     int* const nrow = P.neigh + (size_t)sl * cap;                       // this slot's row of the list
     double* const hout = P.shear_out + (size_t)(3 * sl) * cap;
-    const bool valid = !CHAIN || s < nn;   // (CHAIN: the odd lane of an atom with an odd count idles in the last trip)
-    const int jraw = valid ? jraw_n1 : 0;
+    const int jraw = jraw_n1;
     const bool own = (jraw & kOwnBit) != 0;
     Vec3 sh = cur.sh;
-    bool ch_has = false;                   // CHAIN: this lane's slot gave a contact force
-    Vec3 ch_F = {0.0, 0.0, 0.0}, ch_tor = {0.0, 0.0, 0.0};
     if (!HIST_PF) load_history(jraw, sl, sh);
 #if SF_EXP_DMA
     if (STYLE != 0 && own && (jraw & kTouchBit) && ((dma_hist >> sl) & 1u)) {
@@ -461,7 +460,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     // own: three 19-instruction sequences per pair); the plain contact kernel takes them only for a touching pair
     double r_pair = 0.0, rinv_pair = 0.0;
     if (COHE || LUB) sf_sqrt_rsqrt(rsq, r_pair, rinv_pair);
-    if (STYLE != 0 && valid) {
+    if (STYLE != 0) {
       if (rsq >= radsum * radsum) {
         // unset non-touching neighbours (:131-139); the stale shear is ignored once the bit is clear
         if (jraw & kTouchBit) nrow[i] = jraw & ~kTouchBit;
@@ -515,44 +514,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         if (sh.x == 1.2345) hout[i] = sh.y + sh.z;
 #endif
         if (!(jraw & kTouchBit)) nrow[i] = jraw | kTouchBit;
-        if (CHAIN) {
-          ch_has = true;
-          ch_F = o.F;
-          ch_tor = o.tor;
-        } else {
-          F = F + o.F;
-          T = T - radi * o.tor;
-        }
-      }
-    }
-    if (CHAIN) {
-      // the running sums pass through the atom's two lanes in slot order: the even lane adds its contact, hands the sums
-      // to the odd lane, which adds its own and hands them back -- the additions (and their order) of the one-lane kernel
-      // (lane ^ 1 within a quad: a DPP move per dword, no LDS crossbar)
-      auto other1 = [](double v) {
-        const long long b = __builtin_bit_cast(long long, v);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, false);          // quad_perm:[1,0,3,2]
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, false);
-        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-      };
-      auto other = [&](Vec3 v) { return Vec3{other1(v.x), other1(v.y), other1(v.z)}; };
-      if (q == 0 && ch_has) {
-        F = F + ch_F;
-        T = T - radi * ch_tor;
-      }
-      const Vec3 Fe = other(F), Te = other(T);
-      if (q == 1) {
-        F = Fe;
-        T = Te;
-        if (ch_has) {
-          F = F + ch_F;
-          T = T - radi * ch_tor;
-        }
-      }
-      const Vec3 Fo = other(F), To = other(T);
-      if (q == 0) {
-        F = Fo;
-        T = To;
+        F = F + o.F;
+        T = T - radi * o.tor;
       }
     }
     if (COHE) {
@@ -572,30 +535,20 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // unrolled by two so that the prefetch ping-pongs between RA and RB without register copies
   SF_PH(1);
   int s = 0;
-#if SF_UNROLL2
-  if constexpr (CHAIN) {
-    // (one register set: these waves are few and short, what they must not do is push the kernel over its register budget)
-    for (; s < nnp; s++) {
-      slot_body(s, RA, RB, s + 1 < nn, false);
-      RA = RB;
-    }
-  } else {
+  if constexpr (SF_UNROLL2 && !LEAN) {
     for (; s + 1 < nn; s += 2) {
       slot_body(s, RA, RB, true, true);
       slot_body(s + 1, RB, RA, s + 2 < nn, true);
     }
     if (s < nn) slot_body(s, RA, RB, false, false);
+  } else {
+    for (; s < nn; s++) {
+      slot_body(s, RA, RB, s + 1 < nn, true);
+      RA = RB;
+    }
   }
-#else
-  for (; s < nn; s++) {
-    slot_body(s, RA, RB, s + 1 < nn, true);
-    RA = RB;
-  }
-#endif
   SF_PH(27);
-  if (LPA > 1 && CHAIN) {
-    if (q != 0) return;   // (both lanes hold the same sums)
-  } else if (LPA > 1) {
+  if (LPA > 1) {
     // fixed tree: (q0 + q1) [+ (q2 + q3)] -- the same bits on every run
     for (int off = 1; off < LPA; off <<= 1) {
       F.x += __shfl_xor(F.x, off, 64); F.y += __shfl_xor(F.y, off, 64); F.z += __shfl_xor(F.z, off, 64);
@@ -813,11 +766,12 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
 
 // Registers: the plain contact kernel needs 169 VGPRs when left alone -- one more than three waves per SIMD allow
 // (512 / 3, granule 8 = 168), and at two waves per SIMD it is 30 % slower (latency bound).  Asked for three waves the
-// compiler finds 167 without spilling.  The cohesive / lubrication variants would spill at three waves: left alone.
+// compiler finds 167 without spilling.  With ONE of the cohesive / lubrication arms the lean loop (sf_lean_variant) fits
+// three waves (154 VGPRs / 168 with 12 bytes of scratch); with both arms the kernel needs 223 and stays at two.
 #ifdef SF_WAVES_PER_EU
 #define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu(SF_WAVES_PER_EU, SF_WAVES_PER_EU)))
 #else
-#define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu((COHE || LUB) ? 1 : 3)))
+#define SF_SUBSTEP_ATTR __attribute__((amdgpu_waves_per_eu((COHE || LUB) && !sf_lean_variant(COHE, LUB, LPA) ? 1 : 3)))
 #endif
 // The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by bin, so giving
 // every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of the XCD that gathers them
@@ -837,7 +791,6 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
   if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
-  constexpr bool TAIL = SF_TAIL_KERNEL && LPA == 1 && !COHE && !LUB;   // (xcd_two[] all zero: the plain one-lane launch)
 #if SF_EXP_STAMP
   unsigned long long* const stamp = g_stamp;
   const unsigned long long stamp_t0 = stamp ? wall_clock64() : 0ull;
@@ -872,43 +825,9 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // memory-side cache; sweeping always in the same direction it finds nothing of the previous sub-step there (cyclic
   // access, LRU), sweeping back and forth the first third of what it needs is what the previous sub-step touched last.
   if (S.xcd_remap == 2) {
-    const int xcd = bid & 7;
-    int loc = bid >> 3;
-    // Launch tail: the last (tail_pos 0) or first (1) xcd_two[x] tiles of XCD x's range are run by TWO workgroups each, two
-    // lanes per atom with chained sums (substep_particle<CHAIN>: bit for bit the one-lane result) -- waves that live
-    // ~0.6 x as long, so that the launch drains in the time of a short wave instead of a long one
-    if constexpr (TAIL) {
-      const int n2 = S.xcd_two[xcd], n1 = S.xcd_count[xcd] - n2;
-      if (loc >= n1 + 2 * n2) return;
-      const int h = S.tail_pos ? loc : loc - n1;   // half-tile index when this workgroup is a two-lane one
-      if (n2 > 0 && h >= 0 && h < 2 * n2) {
-        const int tile = S.xcd_first[xcd] + (S.tail_pos ? 0 : n1) + (h >> 1);
-        const int i2 = tile * 64 + 32 * (h & 1) + (int)(threadIdx.x >> 1);
-        if (i2 >= S.nlocal) return;
-        const int xq2 = xcd * 64;
-        if (S.xcd_time && threadIdx.x == 0 && loc == 0) atomicMin(&P.xcd_time[xq2], (int)(wall_clock64() & 0x3fffffff));
-        // (the parameter blocks through laundered constant-address-space pointers: left to itself the compiler hoists the
-        // scalar loads of BOTH paths' parameters above this branch and spills ~50 SGPRs)
-        typedef const __attribute__((address_space(4))) DemPtrs* CP;
-        typedef const __attribute__((address_space(4))) StepParams* CS;
-        // (the kernel's argument segment holds P at offset 0 and S behind it at its natural alignment)
-        typedef const __attribute__((address_space(4))) char* CB;
-        CB kargs = (CB)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kargs));
-        constexpr size_t s_off = (sizeof(DemPtrs) + alignof(StepParams) - 1) / alignof(StepParams) * alignof(StepParams);
-        CP Pp = (CP)kargs;
-        CS Sp = (CS)(kargs + s_off);
-        substep_particle<STYLE, COHE, LUB, false, 2, TP, NTP, true>(*(const DemPtrs*)Pp, *(const StepParams*)Sp, i2,
-                                                                    (int)(threadIdx.x & 1), nullptr, nullptr, nullptr);
-        if (S.xcd_time && threadIdx.x == 0 && (loc & 7) == 0) atomicMax(&P.xcd_time[xq2 + 32], (int)(wall_clock64() & 0x3fffffff));
-        return;
-      }
-      if (S.tail_pos) loc -= 2 * n2;
-      bid = S.xcd_first[xcd] + (S.tail_pos ? n2 : 0) + loc;
-    } else {
-      if (loc >= S.xcd_count[xcd]) return;
-      bid = S.xcd_first[xcd] + (S.sweep_rev ? S.xcd_count[xcd] - 1 - loc : loc);
-    }
+    const int xcd = bid & 7, loc = bid >> 3;
+    if (loc >= S.xcd_count[xcd]) return;
+    bid = S.xcd_first[xcd] + (S.sweep_rev ? S.xcd_count[xcd] - 1 - loc : loc);
   } else if (S.xcd_remap) {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     const int cnt = xcd < r ? q + 1 : q, loc = bid >> 3;
@@ -937,19 +856,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr,
                                                           (__attribute__((address_space(3))) char*)dma_lds);
 #else
-  if constexpr (TAIL) {
-    // (as in the two-lane path above: each path loads its own parameters)
-    typedef const __attribute__((address_space(4))) DemPtrs* CP;
-    typedef const __attribute__((address_space(4))) StepParams* CS;
-    typedef const __attribute__((address_space(4))) char* CB;
-    CB kargs = (CB)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kargs));
-    constexpr size_t s_off = (sizeof(DemPtrs) + alignof(StepParams) - 1) / alignof(StepParams) * alignof(StepParams);
-    substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(*(const DemPtrs*)(CP)kargs, *(const StepParams*)(CS)(kargs + s_off), i, q,
-                                                            nullptr, nullptr, nullptr);
-  } else {
-    substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
-  }
+  substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
 #endif
   if (S.xcd_time && threadIdx.x == 0 && ((blockIdx.x >> 3) & 7) == 0)
     atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));

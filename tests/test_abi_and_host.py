@@ -201,3 +201,23 @@ def test_bench_watchdog_ends_a_job_that_does_not_finish():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--watchdog", "0.2"], capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 124 and "--watchdog" in r.stderr
+    # ... and rank 0 still prints ONE parseable line that says what hung and where
+    import json
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and "watchdog" in line["error"] and line["stage"] and line["n_gpus"] == 1
+
+
+def test_bench_prints_an_error_line_when_a_multi_gpu_run_cannot_come_up():
+    """bench.py --gpus 2 as one rank of a world of 2 whose rendezvous never completes (nobody listens, short timeout): the run
+    fails BEFORE it has a number and still prints one JSON line with `error` and the failing `stage` (a first hardware
+    N > 1 record that does not come up must be diagnosable from the driver's record alone)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 3 and line["error"] and line["stage"]
