@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_SUMMARIES = ("r04_pmc_summary.json", "r03_pmc_summary.json")   # committed PMC passes, newest first (tests/profile_round.sh)
+PMC_SUMMARIES = ("r05_pmc_summary.json", "r04_pmc_summary.json")   # committed PMC passes, newest first (tests/profile_round.sh)
 
 
 def build_engine(bed, script):

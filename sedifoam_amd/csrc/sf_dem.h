@@ -74,7 +74,8 @@ enum Flag {
   F_GHOST_BEFORE,   // + dim: ghosts that existed before the images of periodic dimension `dim` were made (3 words)
   F_GHOST_BEFORE_Z = F_GHOST_BEFORE + 2,
   F_HALO_TIMEOUT,   // direct ghost writes: a peer's "exchange done" flag did not arrive in time (an error, never a hang)
-  F_HALO_TIMEOUT_PEER,   // ... which rank's, and the value its flag had
+  F_HALO_TIMEOUT_PEER,   // ... which rank's ...
+  F_HALO_TIMEOUT_SEEN,   // ... and the value its flag had (adjacent words: brick_direct_probe clears the three together)
   F_NFLAGS = 32
 };
 
@@ -450,18 +451,20 @@ class DemEngine {
   bool tx_direct() const { return tx_direct_; }
   int halo_timeout() const { return h_flags_[F_HALO_TIMEOUT]; }   // (after a synchronising flag read: batch_end)
   int halo_timeout_peer() const { return h_flags_[F_HALO_TIMEOUT_PEER]; }
+  int halo_timeout_seen() const { return h_flags_[F_HALO_TIMEOUT_SEEN]; }
   // one kernel instead of {RCCL send/recv, unpack}: tell every rank "my records of exchange `seq` are in your area"
   // (vote first, then the flag, system-scope release), wait for the same word from every rank (bounded: F_HALO_TIMEOUT),
   // lower the trigger word to the smallest vote and move the received records into the ghost slots
   static constexpr int kSyncStride = 32;   // ints: one 128-byte line per sending rank
   struct DirectSync {
-    int world, rank, seq, par;
+    int world, rank, seq, par;   // (seq: the exchange number as the flag words hold it -- 32 bits, compared as such)
     int* my_sync;          // this rank's area (fine-grained): for sender r the line [kSyncStride r]: flag, vote[2]
     int* peer_sync[32];    // every rank's area, mapped (own entry unused)
     long long max_ticks;   // 100 MHz clock
   };
   void brick_direct_unpack(const BrickBlocks& rcv, const double* recvarea, const DirectSync& D);
-  void brick_direct_probe(const BrickBlocks& none, const DirectSync& D);   // bring-up: one flag round, no records; synchronises
+  bool brick_direct_probe(const BrickBlocks& none, const DirectSync& D);   // bring-up: one flag round, no records; synchronises;
+                                                                            // false = a peer's flag did not arrive in time
   const BrickBlocks& brick_send_blocks() const { return bsend_blocks_; }
   long long migrate_count3();      // owned atoms outside the brick in any external dimension
   long long migrate_pack_dim(int dim, int side, double shift, double* buf, long long max_doubles);

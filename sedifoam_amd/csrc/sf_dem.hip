@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "sf_dem_kernels.h"
+#include "sf_dem_lds_kernel.h"
 #include "sf_roctx.h"
 
 namespace sf {
@@ -1833,26 +1834,6 @@ void DemEngine::run(int nsteps)
     // queue up to where the next rebuild is expected (RebuildPredictor), not blindly to the end of the run
     predict_.overshoot = nlocal_ >= 200000 && !(getenv("SF_QUEUE_OVERSHOOT") && !atoi(getenv("SF_QUEUE_OVERSHOOT")));
     const int end = k + predict_.chunk(run_base_step_ + k, nsteps - k);
-#if SF_EXP_PERSIST_NOWAIT
-    static const int pn = getenv("SF_PERSIST_NOWAIT") ? atoi(getenv("SF_PERSIST_NOWAIT")) : 0;
-    if (pn && gran_.style == 2 && !cohe_.enabled && !lub_.enabled && end - k > 1) {
-      // timing experiment: one launch for the whole piece (results are not those of end - k sub-steps)
-      PersistArgs A;
-      A.P = ptrs(base);
-      A.S = step_params(0, k);
-      SF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_persist), &A, sizeof(A), 0, hipMemcpyHostToDevice, stream_));
-      SF_HIP(hipStreamSynchronize(stream_));   // (A is on the stack)
-      const int lpa = nlocal_ < 20 * 1024 ? 4 : (nlocal_ < 150 * 1024 ? 2 : 1);
-      const dim3 grid(8 * pn);
-      const int ns = end - k;
-      if (lpa == 4) k_substep_persist_nowait<2, false, false, 4, false, 0><<<grid, 64, 0, stream_>>>(0, ns);
-      else if (lpa == 2) k_substep_persist_nowait<2, false, false, 2, false, 0><<<grid, 64, 0, stream_>>>(0, ns);
-      else if (nt_policy_ == 0) k_substep_persist_nowait<2, false, false, 1, false, 0><<<grid, 64, 0, stream_>>>(0, ns);
-      else if (nt_policy_ == 3) k_substep_persist_nowait<2, false, false, 1, false, 3><<<grid, 64, 0, stream_>>>(0, ns);
-      else k_substep_persist_nowait<2, false, false, 1, false, 1><<<grid, 64, 0, stream_>>>(0, ns);
-      SF_HIP(hipGetLastError());
-    } else
-#endif
     for (int s = k; s < end; s++) {
       const int in_buf = (base + (s - k)) & 1;
       launch_substep(in_buf, (s == nsteps - 1) ? 1 : 0, s);

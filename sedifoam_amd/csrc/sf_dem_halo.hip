@@ -933,8 +933,9 @@ __global__ __launch_bounds__(256) void k_brick_direct_unpack(DemEngine::BrickBlo
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > D.max_ticks) {
         ok = 0;
-        flags[F_HALO_TIMEOUT_PEER] = (int)threadIdx.x * 1000000 +
-                                     __hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * threadIdx.x], __ATOMIC_RELAXED,
+        // (which rank's flag was missing and the value it had: two words, the exchange number outgrows any packing)
+        flags[F_HALO_TIMEOUT_PEER] = (int)threadIdx.x;
+        flags[F_HALO_TIMEOUT_SEEN] = __hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * threadIdx.x], __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -978,14 +979,19 @@ void DemEngine::brick_direct_unpack(const BrickBlocks& rcv, const double* recvar
   launch_ghost_forward(cur_, INT_MIN);   // (index mode only: local images of everything, received ghosts included)
 }
 
-void DemEngine::brick_direct_probe(const BrickBlocks& none, const DirectSync& D)
+// returns false when a peer's flag did not arrive in time; the timeout words are cleared again either way (a probe that
+// failed makes the caller fall back to RCCL: the stepping loop must not find a stale F_HALO_TIMEOUT afterwards)
+bool DemEngine::brick_direct_probe(const BrickBlocks& none, const DirectSync& D)
 {
   read_flags();
   const int keep = h_flags_[F_TRIGGER];
   reset_flag(F_HALO_TIMEOUT, 0);
   k_brick_direct_unpack<<<1, 256, 0, stream_>>>(none, nullptr, D, d_flags_, 0, nullptr, nullptr, nullptr);
   read_flags();
-  reset_flag(F_TRIGGER, keep);   // (the probe's votes carried whatever the word held: put it back)
+  const bool timed_out = h_flags_[F_HALO_TIMEOUT] != 0;
+  reset_flags(F_HALO_TIMEOUT, 3, 0);   // F_HALO_TIMEOUT, _PEER, _SEEN
+  reset_flag(F_TRIGGER, keep);         // (the probe's votes carried whatever the word held: put it back)
+  return !timed_out;
 }
 
 void DemEngine::brick_forward_unpack(const BrickBlocks& rcv, const double* recvbuf, const int* hdr_off, int nhdr)

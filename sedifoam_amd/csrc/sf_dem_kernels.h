@@ -27,56 +27,16 @@
 #ifndef SF_ST_SHUFFLE
 #define SF_ST_SHUFFLE 1       // output records exchanged between lanes so that every store covers whole cache lines
 #endif
-#ifndef SF_GATHER_SHUFFLE
-#define SF_GATHER_SHUFFLE 0   // neighbour records taken from the next lane's registers when it holds them: -20 % L2 read
-                              // requests, +50 shuffle / select instructions per slot -- a gain while the kernel ran four
-                              // waves per SIMD (round 1), a loss of 1-3 % since it is as much issue- as memory-bound
-#endif
 // (whether v, omega of a neighbour are prefetched always or only when the pair touched one sub-step ago is the template
 // parameter TP of k_substep, chosen per list from the fraction of listed neighbours that touch)
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
-// Measurement only -- these produce WRONG results and exist to price the history traffic (profiles/r01_f_README.md).
-// They can only be switched on in a variant library built next to the shipped one (tests/build_variant.sh defines
-// SF_VARIANT_BUILD); the shipped library never carries them.
-#if (defined(SF_EXP_NOSHLD) || defined(SF_EXP_NOSHST) || defined(SF_EXP_PERSIST_NOWAIT) || defined(SF_EXP_SC1_GATHER) || \
-     defined(SF_EXP_SC1_RECST) || defined(SF_EXP_SC1_SHST) || defined(SF_EXP_ACQ) || defined(SF_EXP_STAMP) || defined(SF_EXP_PHASE) || defined(SF_EXP_DMA)) && \
-    !defined(SF_VARIANT_BUILD)
-#error "SF_EXP_* arms break results: variant builds only (tests/build_variant.sh)"
-#endif
-#ifndef SF_EXP_NOSHLD
-#define SF_EXP_NOSHLD 0       // skip the shear-history loads
-#endif
-#ifndef SF_EXP_NOSHST
-#define SF_EXP_NOSHST 0       // skip the shear-history stores
-#endif
-// pricing of the agent-coherent access forms a persistent multi-sub-step kernel would need (valid results):
-#ifndef SF_EXP_SC1_GATHER
-#define SF_EXP_SC1_GATHER 0   // neighbour records and partner-side history gathered with sc1 loads (bypass the vector L1)
-#endif
-#ifndef SF_EXP_SC1_RECST
-#define SF_EXP_SC1_RECST 0    // output records stored write-through (sc1)
-#endif
-#ifndef SF_EXP_SC1_SHST
-#define SF_EXP_SC1_SHST 0     // shear-history stores write-through (sc1, 8 bytes per lane)
-#endif
-#ifndef SF_EXP_ACQ
-#define SF_EXP_ACQ 0          // an agent-scope acquire (vector-L1 invalidate) at the start of every wave
-#endif
-#ifndef SF_EXP_STAMP
-#define SF_EXP_STAMP 0        // every workgroup of one chosen launch records {XCC_ID, HW_ID, start, end} (100 MHz clock):
-                              // the fill / drain timeline per XCD (tests/micro/stamp_timeline.py; valid results)
-#endif
-#ifndef SF_EXP_DMA
-#define SF_EXP_DMA 0          // the wave's list words (12 rows) and own-side history rows (six slots) streamed into LDS by
-                              // global_load_lds_dwordx4 at the start of the wave: 3 + 9 instructions of 1 KB instead of 12 + 18
-                              // of 256 / 512 B, no VGPRs, in flight while the first slots run (valid results)
-#endif
-#ifndef SF_EXP_PERSIST_NOWAIT
-#define SF_EXP_PERSIST_NOWAIT 0   // upper bound of a persistent kernel: n sub-steps in one launch, NO dependency waits
-                                  // (every sub-step recomputes the same in -> out: valid inputs, timing only)
-#endif
+// Instrumentation of variant builds (tests/build_variant.sh): SF_EXP_STAMP / SF_EXP_PHASE, the workgroup timeline of one
+// launch -- sf_dem_variants.h.  The pricing arms of rounds 1-4 (history traffic off, agent-coherent access forms, LDS-DMA
+// row streams, the no-wait persistent kernel, neighbour records by lane shuffle, the two-lane launch tail) were measured,
+// written up (docs/history_r01_r03.md, profiles/r04_README.md, profiles/r05_README.md) and removed from this file.
+#include "sf_dem_variants.h"
 
 namespace sf {
 
@@ -88,58 +48,6 @@ __device__ __forceinline__ Vec3 v3(const double4& a) { return {a.x, a.y, a.z}; }
 #define SF_LEAN_VARIANTS 1
 #endif
 constexpr bool sf_lean_variant(bool cohe, bool lub, int lpa) { return SF_LEAN_VARIANTS && lpa == 1 && cohe != lub; }
-
-#if SF_EXP_STAMP
-__device__ unsigned long long* g_stamp = nullptr;   // [4 * workgroups] of the launch being recorded, else null
-#endif
-#ifndef SF_EXP_PHASE
-#define SF_EXP_PHASE 0        // with SF_EXP_STAMP: lane 0 of every wave also stores the clock at the phases of its life
-                              // (entry, every slot of the neighbour loop, fixes, stores): [32 * workgroups] after the stamps
-#endif
-#if SF_EXP_PHASE
-// (kept in LDS while the wave runs -- a global store per mark would sit in the in-order vmcnt queue of the loads it is
-// meant to observe: measured +25 % -- and copied out by the StampEnd destructor of k_substep)
-__device__ __forceinline__ unsigned long long* sf_phase_slots()
-{
-  __shared__ unsigned long long ph[32];
-  return ph;
-}
-#define SF_PH(k)                                                                                              \
-  do {                                                                                                        \
-    if ((threadIdx.x & 63) == 0) sf_phase_slots()[(k)] = (unsigned long long)wall_clock64();                  \
-  } while (0)
-#else
-#define SF_PH(k) do { } while (0)
-#endif
-
-// agent-coherent (sc1) accesses to a record array through a raw buffer descriptor: they bypass the CU's vector L1
-// (loads) / write through the XCD's L2 (stores); the compiler counts them like any other memory operation
-typedef int sf_v4i __attribute__((ext_vector_type(4)));
-typedef double sf_v2d __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rec_rsrc(const void* base)
-{
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00027000);
-}
-__device__ __forceinline__ double4 ld_rec_sc1(const double4* base, int j)
-{
-  const __amdgpu_buffer_rsrc_t r = rec_rsrc(base);
-  const sf_v2d a = __builtin_bit_cast(sf_v2d, __builtin_amdgcn_raw_buffer_load_b128(r, j * 32, 0, 16));
-  const sf_v2d b = __builtin_bit_cast(sf_v2d, __builtin_amdgcn_raw_buffer_load_b128(r, j * 32 + 16, 0, 16));
-  return {a.x, a.y, b.x, b.y};
-}
-__device__ __forceinline__ void st_half_sc1(double4* base, int half_index, double2 v)
-{
-  const sf_v2d t = {v.x, v.y};
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_v4i, t), rec_rsrc(base), half_index * 16, 0, 16);
-}
-__device__ __forceinline__ double ld_f64_sc1(const double* p)
-{
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_f64_sc1(double* p, double v)
-{
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // Streamed (read-once / write-once per sub-step) rows can be marked non-temporal so that they do not evict the
 // neighbour records the gathers want to find again in the 32 KB vector L1 and the 4 MB L2 of the XCD.  Whether that
@@ -187,8 +95,7 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
 template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP>
 __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
-                                                 const double4* lx, const double4* lv, const double* lw,
-                                                 __attribute__((address_space(3))) char* dma = nullptr)
+                                                 const double4* lx, const double4* lv, const double* lw)
 {
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
@@ -211,56 +118,6 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
   const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
-#if SF_EXP_DMA
-  // LDS of the (one-wave) workgroup: [12 rows of list words: 3 KB][18 history rows (six slots from `dma_s0`): 9 KB]
-  typedef __attribute__((address_space(3))) char* LdsPtr;
-  constexpr int kDmaWords = 12, kDmaSlots = 6;
-  const int lane = threadIdx.x & 63;
-  // (wave-uniform: a full wave of consecutive atoms whose first one is 64-aligned)
-  const bool dma_ok = !LDS && LPA == 1 && dma != nullptr && S.part == 0 && blockDim.x == 64 && __ballot(1) == ~0ull &&
-                      (i & 63) == lane;
-  unsigned dma_hist = 0;   // slots whose own-side history rows are (being) copied into LDS
-  int dma_s0 = 0;
-  // (issued through inline assembly: the compiler makes every later LDS read wait for ALL outstanding copies it knows of
-  // -- vmcnt(0) in every slot; this way it sees ordinary LDS reads, and the code below orders them itself)
-  auto dma16 = [&](const void* g, LdsPtr l) {
-    const unsigned off = (unsigned)(__UINTPTR_TYPE__)l;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(off) : "memory", "m0");
-  };
-  auto lds_word = [&](int sl) {
-    return *reinterpret_cast<__attribute__((address_space(3))) const int*>(dma + (sl * 64 + lane) * 4);
-  };
-  if (dma_ok) {
-    const int base = i - lane;
-    for (int k = 0; k < kDmaWords / 4; k++) {
-      const int row = 4 * k + (lane >> 4);
-      if (row < S.nslots) {
-        const int* src = P.neigh + (size_t)row * cap + base + (lane & 15) * 4;
-        dma16(src, dma + k * 1024);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int nmax = nn_all;
-    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-    nmax = __builtin_amdgcn_readfirstlane(nmax < kDmaWords ? nmax : kDmaWords);
-    unsigned need = 0;
-    for (int sl = 0; sl < nmax; sl++) {
-      const int w = sl < nn_all ? lds_word(sl) : 0;
-      if (__ballot(STYLE != 0 && (w & kOwnBit) && (w & kTouchBit)) != 0ull) need |= 1u << sl;
-    }
-    if (need && SF_EXP_DMA != 2) {   // (2: the list words only)
-      dma_s0 = __builtin_ctz(need);
-      dma_hist = need & (((1u << kDmaSlots) - 1u) << dma_s0);
-      for (int m = 0; m < 3 * kDmaSlots / 2; m++) {
-        const int t = 2 * m + (lane >> 5), sl = dma_s0 + t / 3, c = t - 3 * (t / 3);
-        if ((dma_hist >> sl) & 1u) {
-          const double* src = P.shear_in + (size_t)(3 * sl + c) * cap + base + (lane & 31) * 2;
-          dma16(src, dma + kDmaWords * 256 + m * 1024);
-        }
-      }
-    }
-  }
-#endif
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
   // Software pipeline: the index of slot s+2 and the x, v, omega records of slot s+1 are requested before the
@@ -285,13 +142,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   // partner the owner's row, the pair seen from the other side
   auto load_history = [&](const int jraw, const int slotrow, Vec3& sh) {
     sh = {0.0, 0.0, 0.0};
-    if (STYLE == 0 || !(jraw & kTouchBit) || (SF_EXP_NOSHLD && S.kstep >= 0)) return;
+    if (STYLE == 0 || !(jraw & kTouchBit)) return;
     const bool own = (jraw & kOwnBit) != 0;
-    auto ldh = [&](const double* p) { return SF_EXP_SC1_GATHER ? ld_f64_sc1(p) : ld_stream<NT_HIST>(p); };
+    auto ldh = [&](const double* p) { return ld_stream<NT_HIST>(p); };
     if (own) {
-#if SF_EXP_DMA
-      if ((dma_hist >> slotrow) & 1u) return;   // (in LDS: read where it is consumed)
-#endif
       const double* const hin = P.shear_in + (size_t)(3 * slotrow) * cap;
       sh.x = ldh(&hin[i]);
       sh.y = ldh(&(hin + cap)[i]);
@@ -320,18 +174,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       const int j = neigh_index(jraw, ROOTS);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.vw = wants_vw(jraw);
-      if (SF_EXP_SC1_GATHER) {
-        R.x = ld_rec_sc1(P.xr_in, j);
-        if (R.vw) {
-          R.v = ld_rec_sc1(P.vm_in, j);
-          R.w = ld_rec_sc1(P.om_in, j);
-        }
-      } else {
-        R.x = P.xr_in[j];
-        if (R.vw) {
-          R.v = P.vm_in[j];
-          R.w = P.om_in[j];
-        }
+      R.x = P.xr_in[j];
+      if (R.vw) {
+        R.v = P.vm_in[j];
+        R.w = P.om_in[j];
       }
     }
     if (HIST_PF) load_history(jraw, slotrow, R.sh);
@@ -343,13 +189,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   const int row1 = q + LPA < S.nslots ? q + LPA : S.nslots - 1;
   // (one lane per atom only: with several lanes per atom the two extra live registers spill)
   const bool ld0 = LPA == 1 || nn > 0, ld1 = LPA == 1 || nn > 1;
-#if SF_EXP_DMA
-  const int w_first = dma_ok ? lds_word(0) : (ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0);
-  const int w_second = dma_ok ? lds_word(row1) : (ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0);
-#else
   const int w_first = ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
   const int w_second = ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0;
-#endif
   int jraw_n1 = nn > 0 ? w_first : 0;
   int jraw_n2 = nn > 1 ? w_second : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
@@ -375,61 +216,12 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     const bool own = (jraw & kOwnBit) != 0;
     Vec3 sh = cur.sh;
     if (!HIST_PF) load_history(jraw, sl, sh);
-#if SF_EXP_DMA
-    if (STYLE != 0 && own && (jraw & kTouchBit) && ((dma_hist >> sl) & 1u)) {
-      // the copy was issued before this slot's records: once THEY have arrived (in-order return) it is complete --
-      // the address is made to depend on the record so that the read cannot be scheduled above that wait
-      unsigned a = (unsigned)(kDmaWords * 256 + (sl - dma_s0) * 1536 + lane * 8);
-      asm volatile("" : "+v"(a) : "v"(cur.x.x));
-      const __attribute__((address_space(3))) char* hp = dma + a;
-      sh.x = *reinterpret_cast<const __attribute__((address_space(3)) ) double*>(hp);
-      sh.y = *reinterpret_cast<const __attribute__((address_space(3)) ) double*>(hp + 512);
-      sh.z = *reinterpret_cast<const __attribute__((address_space(3)) ) double*>(hp + 1024);
-    }
-#endif
     // the pair seen from the partner's side (a pair that did not touch starts from +0.0 on both sides, as before)
     if (STYLE != 0 && LPA == 1 && !own && (jraw & kTouchBit)) sh = {-sh.x, -sh.y, -sh.z};
     jraw_n1 = jraw_n2;
-#if SF_EXP_DMA
-    if (s + 2 < nn) jraw_n2 = (dma_ok && sl + 2 < kDmaWords) ? lds_word(sl + 2) : ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
-#else
     if (s + 2 < nn) jraw_n2 = ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
-#endif
     if (more) {
       bool reuse = false;
-#if SF_GATHER_SHUFFLE
-      // In the sorted order the next neighbour of lane l is very often the CURRENT neighbour of lane l+1 (two
-      // adjacent atoms of a row see the same row of neighbours, shifted by one).  Its three records are then already
-      // in lane l+1's registers: take them by shuffle instead of gathering them from L2 again.  Checked per lane on
-      // the root index, so it is only a shortcut, never a different result.
-      if (!LDS && LPA == 1) {
-        const int jn = neigh_index(jraw_n1, ROOTS);
-        const unsigned long long act = __ballot(1);
-        const int lane = threadIdx.x & 63;
-        const int jdn = __shfl_down(cur.l, 1, 64);
-        Rec t;
-        t.x = {__shfl_down(cur.x.x, 1, 64), __shfl_down(cur.x.y, 1, 64), __shfl_down(cur.x.z, 1, 64),
-               __shfl_down(cur.x.w, 1, 64)};
-        if (NEED_VW) {
-          t.v = {__shfl_down(cur.v.x, 1, 64), __shfl_down(cur.v.y, 1, 64), __shfl_down(cur.v.z, 1, 64),
-                 __shfl_down(cur.v.w, 1, 64)};
-          t.w = {__shfl_down(cur.w.x, 1, 64), __shfl_down(cur.w.y, 1, 64), __shfl_down(cur.w.z, 1, 64),
-                 __shfl_down(cur.w.w, 1, 64)};
-        }
-        const bool donor_vw = __shfl_down((int)cur.vw, 1, 64) != 0;
-        reuse = lane < 63 && ((act >> (lane + 1)) & 1ull) && jdn == jn && (donor_vw || !wants_vw(jraw_n1));
-        if (reuse) {
-          nxt.x = t.x;
-          if (NEED_VW) {
-            nxt.v = t.v;
-            nxt.w = t.w;
-          }
-          nxt.l = jn;
-          nxt.vw = donor_vw;
-          if (HIST_PF) load_history(jraw_n1, sl + LPA, nxt.sh);
-        }
-      }
-#endif
       if (!reuse) fetch(jraw_n1, sl + LPA, nxt);
     }
     double4 xj4 = cur.x, vj4 = cur.v, wj4 = cur.w;
@@ -498,21 +290,11 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         }
         ContactOut o;
         gran_history_law<STYLE>(S.gran, S.dt, shearupdate, c, sh, o);
-#if !SF_EXP_NOSHST
         if (own) {
-          if (SF_EXP_SC1_SHST) {
-            st_f64_sc1(&hout[i], sh.x);
-            st_f64_sc1(&(hout + cap)[i], sh.y);
-            st_f64_sc1(&(hout + 2 * cap)[i], sh.z);
-          } else {
-            st_stream<NT_ST>(&hout[i], sh.x);
-            st_stream<NT_ST>(&(hout + cap)[i], sh.y);
-            st_stream<NT_ST>(&(hout + 2 * cap)[i], sh.z);
-          }
+          st_stream<NT_ST>(&hout[i], sh.x);
+          st_stream<NT_ST>(&(hout + cap)[i], sh.y);
+          st_stream<NT_ST>(&(hout + 2 * cap)[i], sh.z);
         }
-#else
-        if (sh.x == 1.2345) hout[i] = sh.y + sh.z;
-#endif
         if (!(jraw & kTouchBit)) nrow[i] = jraw | kTouchBit;
         F = F + o.F;
         T = T - radi * o.tor;
@@ -737,8 +519,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         const double b0 = __shfl(a0, src, 64), b1 = __shfl(a1, src, 64);
         const double b2 = __shfl(a2, src, 64), b3 = __shfl(a3, src, 64);
         const double2 val = (lane & 1) ? double2{b2, b3} : double2{b0, b1};
-        if (SF_EXP_SC1_RECST) st_half_sc1(arr, 2 * base + 64 * half + lane, val);
-        else dst[64 * half + lane] = val;
+        dst[64 * half + lane] = val;
       }
     };
     store_shuffled(P.xr_out, xn.x, xn.y, xn.z, radi);
@@ -791,32 +572,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
   if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
-#if SF_EXP_STAMP
-  unsigned long long* const stamp = g_stamp;
-  const unsigned long long stamp_t0 = stamp ? wall_clock64() : 0ull;
-#if SF_EXP_PHASE
-  if (threadIdx.x < 32) sf_phase_slots()[threadIdx.x] = 0ull;
-#endif
-  struct StampEnd {
-    unsigned long long* s;
-    unsigned long long t0;
-    __device__ ~StampEnd()
-    {
-      if (!s) return;
-      __builtin_amdgcn_s_waitcnt(0);   // (the stores of this wave have been issued and acknowledged)
-#if SF_EXP_PHASE
-      if (threadIdx.x < 32) s[4 * (size_t)gridDim.x + 32 * (size_t)blockIdx.x + threadIdx.x] = sf_phase_slots()[threadIdx.x];
-#endif
-      if (threadIdx.x == 0) {
-        unsigned long long* q = s + 4 * (size_t)blockIdx.x;
-        q[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);     // HW_REG_XCC_ID[3:0]
-        q[1] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID
-        q[2] = t0;
-        q[3] = wall_clock64();
-      }
-    }
-  } stamp_end{stamp, stamp_t0};
-#endif
+  SF_STAMP_WORKGROUP();   // (variant builds: this workgroup's start / end and phase marks, sf_dem_variants.h)
   // The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
@@ -845,97 +601,19 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   } else if (i >= S.nlocal) {
     return;
   }
-  if (SF_EXP_ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // a timed launch (one in a few hundred): when did this XCD start, when did it finish?  (the engine evens the shares out)
   // (each XCD's two words on a cache line of their own, the end stamped by one workgroup in eight: atomics on one line
   // are resolved one after the other at the memory side, ~11 ns each -- 31 k of them doubled the launch)
   const int xq = (int)(blockIdx.x & 7) * 64;
   if (S.xcd_time && threadIdx.x == 0 && (blockIdx.x >> 3) == 0) atomicMin(&P.xcd_time[xq], (int)(wall_clock64() & 0x3fffffff));
-#if SF_EXP_DMA
-  __shared__ __attribute__((aligned(16))) char dma_lds[12 * 256 + 18 * 512];
-  substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr,
-                                                          (__attribute__((address_space(3))) char*)dma_lds);
-#else
   substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
-#endif
   if (S.xcd_time && threadIdx.x == 0 && ((blockIdx.x >> 3) & 7) == 0)
     atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
 }
 
-#if SF_EXP_PERSIST_NOWAIT
-// Upper bound of what a persistent multi-sub-step kernel can gain (measurement only): `nsub` sub-steps in ONE launch,
-// one wave per workgroup, as many workgroups as the chip holds at once; XCD x walks the tiles (64 / LPA atoms) of its
-// contiguous eighth of the atoms, sub-step after sub-step, its waves taking the items round-robin.  No dependency
-// waits and every sub-step reads the SAME input buffer (so that the inputs stay valid): this prices the per-launch
-// fill / drain that the real kernel pays, nothing else.
-// The parameters live in constant memory and are re-read (scalar loads) per tile through a laundered pointer: passed by
-// value the compiler hoists every field out of the tile loop and spills ~120 SGPRs.
-struct PersistArgs {
-  DemPtrs P;
-  StepParams S;
-};
-__constant__ PersistArgs c_persist[4];
-template <int STYLE, bool COHE, bool LUB, int LPA, bool TP, int NTP>
-__global__ __launch_bounds__(64) SF_SUBSTEP_ATTR void k_substep_persist_nowait(int slot, int nsub)
-{
-  const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3, Wx = gridDim.x >> 3;
-  constexpr int APT = 64 / LPA;
-  const int nlocal = c_persist[slot].S.nlocal;
-  const int ntiles = (nlocal + APT - 1) / APT;
-  const int per = (ntiles + 7) / 8;
-  const int t0 = xcd * per, t1 = min(ntiles, t0 + per), cnt = max(0, t1 - t0);
-  const int total = cnt * nsub;
-  for (int p = r; p < total; p += Wx) {
-    const int k = p / cnt;
-    const int t = t0 + (p - k * cnt);
-    const int i = t * APT + (int)threadIdx.x / LPA;
-    const int q = (int)threadIdx.x % LPA;
-    typedef const __attribute__((address_space(4))) PersistArgs* CArgs;
-    CArgs A = (CArgs)&c_persist[slot];
-    asm volatile("" : "+s"(A));   // (not loop-invariant for the compiler)
-    if (i < nlocal)
-      substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(*(const DemPtrs*)&A->P, *(const StepParams*)&A->S, i, q,
-                                                              nullptr, nullptr, nullptr);
-  }
-}
-#endif
 
-// LDS-staged cell bins: one workgroup per tile of T x T x T bins.  The x/v/omega records of every atom in
-// the tile and in the one-bin shell around it (owned and ghost) are copied ONCE into LDS with mostly
-// sequential loads (atoms are sorted tile by tile, bin by bin); the 12-odd neighbour look-ups per atom then
-// hit LDS (ds_read_b128) instead of issuing 6 scattered 16-byte global loads each, which is what saturates
-// the vector-memory address pipe of a CU in k_substep.  nloc[slot][i] is the neighbour's position in that
-// staged copy, written when the list is built.
-template <int STYLE, bool COHE, bool LUB>
-__global__ __launch_bounds__(1024) void k_substep_lds(DemPtrs P, StepParams S)
-{
-  extern __shared__ double4 lds4[];
-  if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
-  int tile = blockIdx.x;
-  if (S.xcd_remap) {
-    const int nb = gridDim.x, xcd = tile & 7, q = nb >> 3, r = nb & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
-  }
-  const int first = P.tile_first[tile], last = P.tile_last[tile];
-  if (first >= last) return;
-  const int s0 = P.stage_start[tile], ns = P.stage_start[tile + 1] - s0;
-  double4* lx = lds4;
-  double4* lv = lds4 + S.stage_cap;
-  double* lw = reinterpret_cast<double*>(lds4 + 2 * (size_t)S.stage_cap);
-  for (int k = threadIdx.x; k < ns; k += blockDim.x) {
-    const int g = P.stage_idx[s0 + k];
-    lx[k] = P.xr_in[g];
-    lv[k] = P.vm_in[g];
-    const double4 w = P.om_in[g];
-    lw[3 * k] = w.x;
-    lw[3 * k + 1] = w.y;
-    lw[3 * k + 2] = w.z;
-  }
-  __syncthreads();
-  for (int i = first + threadIdx.x; i < last; i += blockDim.x)
-    substep_particle<STYLE, COHE, LUB, true, 1, true, 2>(P, S, i, 0, lx, lv, lw);
-}
-
+// (the LDS-staged cell-bin kernel, k_substep_lds -- the same substep_particle on a tile's staged copy -- is in
+// sf_dem_lds_kernel.h)
 // first half-kick of a run with the forces stored by the previous run's last sub-step
 __global__ __launch_bounds__(256) void k_initial_integrate(double4* xr, double4* vm, double4* om,
                                                            const double4* force, const double4* torque,

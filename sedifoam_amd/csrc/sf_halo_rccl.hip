@@ -802,9 +802,10 @@ static void direct_init(SfLammps& S, HaloComm& hc)
     // the first round: vote + flag to every rank, every rank's flag awaited (no records yet)
     DemEngine::BrickBlocks none{};
     DemEngine::DirectSync s = direct_sync(hc, 1, 0);
-    s.max_ticks = 500000000LL;   // 5 s
-    e.brick_direct_probe(none, s);
-    ok = e.halo_timeout() ? 0.0 : 1.0;
+    // (the wait of SF_HALO_DIRECT_TIMEOUT -- direct_sync -- capped at 5 s unless the variable asks for more: ranks that share
+    // one GPU time-slice it and need longer)
+    if (!getenv("SF_HALO_DIRECT_TIMEOUT") && s.max_ticks > 500000000LL) s.max_ticks = 500000000LL;
+    ok = e.brick_direct_probe(none, s) ? 1.0 : 0.0;
     if (ok == 0.0) why = "the first flag round timed out";
     ok = slab_allreduce(hc, st, ok, ncclMin);
     D.xseq = 1;
@@ -1094,10 +1095,10 @@ static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int
     hc.pre_exchanged = true;
   }
   const int trigger = e.batch_end(first_k, end_k - first_k);
-  if (e.halo_timeout())
+  if (hc.direct && hc.direct->on && e.halo_timeout())
     fail("direct ghost writes: rank %d waited for exchange %d, rank %d had confirmed %d when the wait ran out (a peer "
          "died, or the ranks disagree about the exchanges they run); SF_HALO_DIRECT=0 selects the RCCL exchange",
-         hc.rank, e.halo_timeout(), e.halo_timeout_peer() / 1000000, e.halo_timeout_peer() % 1000000);
+         hc.rank, e.halo_timeout(), e.halo_timeout_peer(), e.halo_timeout_seen());
   hc.harvest_exchange_profile();
   return trigger;
 }

@@ -7,9 +7,9 @@ i=0
 for v in "$@"; do
   i=$((i+1))
   echo "== $v"
-  ( cd $root; env $v python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-coupled 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('   kernel_us %.1f frac %.3f value %.3e'%(d['roofline']['mean_kernel_us'],d['roofline']['frac'],d['value']))" )
+  ( cd $root; env $v python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-coupled --no-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('   kernel_us %.1f frac %.3f value %.3e'%(d['roofline']['mean_kernel_us'],d['roofline']['frac'],d['value']))" )
   for set in ${AB_FETCH_SETS:-TCC_HIT_sum,TCC_MISS_sum}; do
-    ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/abf; env $v timeout 100 rocprofv3 --pmc ${set//,/ } --kernel-trace --output-format csv -d /tmp/abf -o p -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-coupled > /tmp/abf.log 2>&1
+    ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/abf; env $v timeout 100 rocprofv3 --pmc ${set//,/ } --kernel-trace --output-format csv -d /tmp/abf -o p -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-coupled --no-configs > /tmp/abf.log 2>&1
       python - <<'PY'
 import csv, collections
 agg=collections.defaultdict(list)

@@ -10,7 +10,7 @@ for spec in "$@"; do
   cd /tmp && export TMPDIR=/tmp
   rm -rf $root/gpurun_out/abr_$v
   timeout 300 env $envs rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/abr_$v -o p -- \
-    python $root/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-coupled --no-fluidised --no-parity $args > $root/gpurun_out/abr_$v.log 2>&1
+    python $root/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-coupled --no-configs --no-fluidised --no-parity $args > $root/gpurun_out/abr_$v.log 2>&1
   cd $root
   python - "$v" "$spec" <<'P'
 import csv, sys, json

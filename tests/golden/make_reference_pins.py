@@ -31,7 +31,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 PY_KEYWORDS = {"del", "lambda", "in", "is", "not", "and", "or", "from", "pass", "def", "class", "global", "with", "as",
                "yield", "try", "except", "raise", "import", "None", "True", "False", "print", "exec", "assert", "type"}
-TYPE_WORDS = r"(?:const\s+)?(?:unsigned\s+)?(?:tmp\s*<\s*scalarField\s*>|(?:scalarField|double|int|float|scalar|label)\b)"
+TYPE_WORDS = r"(?:const\s+)?(?:unsigned\s+)?(?:tmp\s*<\s*scalarField\s*>|(?:scalarField|vectorField|double|int|float|scalar|label|bool|vector|softParticle)\b)"
 
 
 def strip_comments(text):
@@ -197,6 +197,10 @@ def expr_stmt(text):
     out = []
     for part in split_top(text, ","):        # declarator list, or a C comma sequence of assignments
         part = part.lstrip("*& ").strip()
+        mc = re.match(r"^(\w+)\s*\((.*)\)$", part) if decl else None
+        if mc and not re.search(r"(?<![=!<>+\-*/])=(?!=)", part):
+            out.append("%s = %s" % (ident(mc.group(1)), expr(mc.group(2))))   # `vector FH(vector::zero);`
+            continue
         if decl and not re.search(r"(?<![=!<>+\-*/])=(?!=)", part):
             continue                          # `double a, b;`
         mi = re.match(r"^(\w+)\s*(\+\+|--)$", part)
@@ -207,9 +211,55 @@ def expr_stmt(text):
     return out
 
 
-def translate(path, first, last):
+# sha256 of every line range this script transliterates and executes: the reference is untrusted input, and a range that
+# drifted upstream would silently pin other code.  A mismatch stops the run (--rehash prints the table of the tree as it is).
+RANGE_SHA256 = {
+    "interfaceToLammps/fix_cohesive.cpp:161-262": "003e983519653da296838b2904397a4e269bd878e125abaa75baa1112c34644f",
+    "interfaceToLammps/fix_fluid_drag.cpp:143-163": "83502a041fa38900270b79fc0904ed49adfe15229c6e1a76e880ad342c72ef7b",
+    "interfaceToLammps/fix_wall_granFix.cpp:286-344": "d245fef1bd51f68b65958a0f84181ef38a2976abca9aa15273c9574424018b92",
+    "interfaceToLammps/fix_wall_granFix.cpp:361-436": "3cae0ab1a03d4fe9f22aa64f1baa84a115f3d0079f9850342abfa296505eba6f",
+    "interfaceToLammps/fix_wall_granFix.cpp:446-553": "308811f0d5eb8203f64e20d27398b357a607cf0baf3597938d15cdbedf151c27",
+    "interfaceToLammps/fix_wall_granFix.cpp:563-678": "9c1234ff74feb4f6d4ed7d48304c104c6fc618711e36a018d939d1f1da71a6d9",
+    "interfaceToLammps/pair_gran_hertzFix_history.cpp:109-286": "2d86a6765e5bf2d008296f938bfba0132fa7bfad6e9bd4a3ad699a46093f3f62",
+    "interfaceToLammps/pair_lubricate_poly.cpp:193-407": "f1aaf4d7ad20d6bd0347dfb98af97e235f8b3b1c6d0f233af8f18cef1703547c",
+    "interfaceToLammps/pair_lubricate_poly.cpp:539-559": "9a7d10bfec50de372b8ee8f2249640ae499d124644ecc5dafea34ae40ca78cb1",
+    "lammpsFoam/dragModels/ErgunWenYu/ErgunWenYu.C:104-132": "e5d4f42819875f2598b9c41b7a8ff017ba90da8b62d776d04f8f085067d35445",
+    "lammpsFoam/dragModels/SyamlalOBrien/SyamlalOBrien.C:105-143": "afe1a4b13462921569630cfd38a6a48c2d1f548405dda559d032d7e4b3f1ebb5",
+    "lammpsFoam/enhancedCloud.C:129-311": "5d5af2bcdf07ed7d45efdc1d8a59482ee731e89b382f5777ce3e6c63ba72a8a9",
+    "lammpsFoam/enhancedCloud.C:1374-1383": "04e9b7228a0e9277c73347e6441d2c40a313df84b2a34624adfc5f7078536805",
+    "lammpsFoam/enhancedCloud.C:318-439": "6ef6f1f544d1645f54d08146bde67552cfaa15f2135db1fdebbbc67077def731",
+    "lammpsFoam/enhancedCloud.C:41-51": "7b080873d889934e87dd0eefe18fc348f76420a3ffac20aca3226a2ae68b2c80",
+    "lammpsFoam/enhancedCloud.C:59-75": "b0f6850a59cbf579c30c7fe77038b905a573dfe1117210dd76e1f0c1581d482a",
+    "lammpsFoam/enhancedCloud.C:88-108": "51ebac1e81262371b0cb9374f25cc4f18570bde0ca2bc78c675bb2f10025f3db",
+    "lammpsFoam/enhancedCloud.C:913-979": "0c3d67732147530f150d4cf566da1823a1365093b998ef0c69aab9c4eda6a043",
+    "lammpsFoam/softParticle.C:72-72": "e6aa5f11acf47d49b473f1b0bb265c022edab593223d53710ce773fc839f36db",
+    "lammpsFoam/softParticle.H:272-272": "7c76c48bc2e1e9280d76584046263afd261c00c432ee53082a42d6ea783c197d",
+    "lammpsFoam/softParticleCloud.C:1356-1416": "7251901c4d147f687814a665419c5f136327c426f8d35a82486cf6bac884e8bb",
+}
+SAFE_BUILTINS = {"range": range, "len": len, "abs": abs, "float": float, "int": int, "min": min, "max": max, "bool": bool}
+
+
+def run(code, ns):
+    """execute transliterated reference lines with nothing but arithmetic in reach: no import, no open, no eval"""
+    if re.search(r"__|\bimport\b|\bopen\b|\beval\b|\bexec\b|\bcompile\b|\bgetattr\b|\bglobals\b|\blocals\b", code):
+        raise SystemExit("make_reference_pins: the transliterated code holds a name it must not:\n" + code[:400])
+    ns["__builtins__"] = SAFE_BUILTINS
+    exec(code, ns)
+
+
+def translate(path, first, last, dialect=None):
     lines = open(os.path.join(REF, path)).read().split("\n")[first - 1:last]
+    import hashlib
+    key = "%s:%d-%d" % (path, first, last)
+    digest = hashlib.sha256("\n".join(lines).encode()).hexdigest()
+    if "--rehash" in sys.argv:
+        print('    "%s": "%s",' % (key, digest))
+    elif RANGE_SHA256.get(key) != digest:
+        raise SystemExit("make_reference_pins: %s is not the text this script was written against (sha256 %s, expected %s)"
+                         % (key, digest, RANGE_SHA256.get(key)))
     src = strip_comments("\n".join(lines))
+    if dialect:
+        src = dialect(src)
     P = Parser(src)
     out = []
     while True:
@@ -289,7 +339,7 @@ def case_hertz(code, seed, n, nlocal, poly, shearupdate, frozen):
               firstneigh=firstneigh, numneigh=numneigh, firsttouch=firsttouch, firstshear=firstshear,
               NEIGHMASK=0x3FFFFFFF, kn=inp["kn"], kt=inp["kt"], gamman=inp["gamman"], xmu=inp["xmu"], dt=inp["dt"],
               shearupdate=shearupdate, nlocal=nlocal, evflag=0, ev_tally_xyz=lambda *a: None, f=f, torque=torque)
-    exec(code, ns)
+    run(code, ns)
     out = dict(f=[hexs(a) for a in f], torque=[hexs(a) for a in torque], touch=firsttouch,
                shear=[hexs(a) for a in firstshear])
     return dict(inp=inp, out=out)
@@ -317,7 +367,7 @@ def case_cohesive(code, seed, n, nlocal, opt, newton_pair, smin, group):
     ns = dict(MATH, opt=opt, inum=nlocal, nlocal=nlocal, ilist=list(range(nlocal)), mask=mask, groupbit=4, x=x,
               radius=radius, firstneigh=firstneigh, numneigh=[len(l) for l in firstneigh], smax=smax, smin=smin, lam=lam,
               ah=inp["ah"], PInv=0.25 / math.atan(1.0), newton_pair=newton_pair, f=f, error=Err(), FLERR=0)
-    exec(code, ns)
+    run(code, ns)
     return dict(inp=inp, out=dict(f=[hexs(a) for a in f]))
 
 
@@ -335,7 +385,7 @@ def case_fdrag(code, seed, n, carrier_rho):
                groupbit=2, dt=1.0e-6, carrier_rho=carrier_rho, f=[list(a) for a in f])
     ns = dict(MATH, nlocal=n, mask=mask, groupbit=2, rmass=rmass, r=radius, v=v, vOld=vOld, timeStep=1.0e-6,
               ffluiddrag=ffl, DuDt=DuDt, carrier_rho=carrier_rho, f=f, rho=0.0, accX=0.0, accY=0.0, accZ=0.0)
-    exec(code, ns)
+    run(code, ns)
     return dict(inp=inp, out=dict(f=[hexs(a) for a in f], vOld=[hexs(a) for a in vOld]))
 
 
@@ -344,7 +394,7 @@ def make_function(name, args, path, first, last, ns):
     (kn, kt, gamman, gammat, xmu, dt, shearupdate ...) are looked up there"""
     body = translate(path, first, last)
     src = "def %s(%s):\n" % (name, ", ".join(args)) + "\n".join("    " + l for l in body.split("\n"))
-    exec(src, ns)
+    run(src, ns)
     return src
 
 
@@ -385,7 +435,7 @@ def case_wall(seed, n, pairstyle, wallstyle, shearupdate):
     make_function("hertz_history", args + ["shear"], path, 563, 678, ns)
     ns["update"] = type("Update", (), {"setupflag": 0 if shearupdate else 1})()   # :286-287 derive shearupdate from it
     ns["shearupdate"] = -1
-    exec(translate(path, 286, 344), ns)
+    run(translate(path, 286, 344), ns)
     return dict(inp=inp, out=dict(f=[hexs(a) for a in f], torque=[hexs(a) for a in torque], shear=[hexs(a) for a in shear]))
 
 
@@ -414,7 +464,7 @@ def case_lubricate(seed, n, nlocal, flaglog, flagfld, flagVF):
               MPI_Allreduce=allreduce, MPI_DOUBLE=0, MPI_SUM=0, world=0)
     # :539-559 -- `MPI_Allreduce(&volP,&vol_P,...)` with one rank: vol_P = volP
     code = re.sub(r"MPI_Allreduce\(&volP,&vol_P,[^\n]*", "vol_P = volP", translate(path, 539, 559))
-    exec(code, ns)
+    run(code, ns)
     R0, RT0, RS0 = ns["R0"], ns["RT0"], ns["RS0"]
     f = [[0.0] * 3 for _ in range(n)]
     torque = [[0.0] * 3 for _ in range(n)]
@@ -425,7 +475,7 @@ def case_lubricate(seed, n, nlocal, flaglog, flagfld, flagVF):
               newton_pair=0, Ef=[z3(), z3(), z3()], cutsq=[[0.0, 0.0], [0.0, cut_global * cut_global]],
               cut_inner=[[0.0, 0.0], [0.0, cut_inner]], wi=z3(), wj=z3(), xl=z3(), jl=z3(), vi=z3(), vj=z3(), overlaps=0,
               f=f, torque=torque, ev_tally_xyz=lambda *a: None, v_tally_tensor=lambda *a: None)
-    exec(translate(path, 193, 407), ns)
+    run(translate(path, 193, 407), ns)
     return dict(inp=inp, out=dict(R0=float(R0).hex(), RT0=float(RT0).hex(), RS0=float(RS0).hex(),
                                   f=[hexs(a) for a in f], torque=[hexs(a) for a in torque], overlaps=ns["overlaps"]))
 
@@ -474,9 +524,229 @@ def case_drag(code, result_name, seed, n, nuf, rhof):
     for k in range(n):
         ns = dict(max=fmax, pow=fpow, sqrt=fsqrt, sqr=fsqr, float=float, len=len, range=range, ROOTVSMALL=1.0e-150,
                   alpha_=Field([alpha[k]]), pd_=Field([pd[k]]), Ur=Field([Ur[k]]), nuf_=nuf, rhof_=rhof)
-        exec(code, ns)
+        run(code, ns)
         out.append(ns[result_name][0])
     return dict(inp=dict(n=n, Ur=Ur, alpha=alpha, pd=pd, nuf=nuf, rhof=rhof), out=dict(Jd=hexs(out)))
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The OpenFOAM-side loops of enhancedCloud.C (drag assembly :129-311 with g1n :1374-1383 and pointInRegion
+# softParticleCloud.C:1356-1416; particleToEulerianField :913-979; calcTcFields :318-439): plain loops over `vector`s and
+# particle accessors.  A three-component Vec with OpenFOAM's operator set (+ - * / ^ & mag, evaluated component by component in
+# OpenFOAM's order), list-backed fields and a particle object with the accessors of softParticle.H let the same
+# statement-by-statement transliteration run them.
+
+class Vec:
+    __slots__ = ("a",)
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.a = (float(x), float(y), float(z))
+
+    def x(self): return self.a[0]
+    def y(self): return self.a[1]
+    def z(self): return self.a[2]
+    def component(self, k): return self.a[k]
+    def __add__(self, o): return Vec(self.a[0] + o.a[0], self.a[1] + o.a[1], self.a[2] + o.a[2])
+    def __sub__(self, o): return Vec(self.a[0] - o.a[0], self.a[1] - o.a[1], self.a[2] - o.a[2])
+    def __neg__(self): return Vec(-self.a[0], -self.a[1], -self.a[2])
+    def __mul__(self, s): return Vec(self.a[0] * s, self.a[1] * s, self.a[2] * s)        # vs * s   (VectorSpaceI.H)
+    def __rmul__(self, s): return Vec(s * self.a[0], s * self.a[1], s * self.a[2])       # s * vs
+    def __truediv__(self, s): return Vec(self.a[0] / s, self.a[1] / s, self.a[2] / s)    # vs / s: component / s
+    def __xor__(self, o):                                                                 # cross product (VectorI.H)
+        a, b = self.a, o.a
+        return Vec(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+    def __and__(self, o): return self.a[0] * o.a[0] + self.a[1] * o.a[1] + self.a[2] * o.a[2]   # inner product
+
+
+def fmag(v):
+    if isinstance(v, Vec):   # sqrt(magSqr): x*x, += y*y, += z*z
+        return math.sqrt(v.a[0] * v.a[0] + v.a[1] * v.a[1] + v.a[2] * v.a[2])
+    return abs(v)
+
+
+class Tensor9(list):
+    def component(self, k): return self[k]
+
+
+class GeoField:
+    """a vol*Field seen through what the loops touch: internalField() (here .f), operator[], oldTime()"""
+
+    def __init__(self, values, old=None):
+        self.f = Field(values)
+        self.old = old
+
+    def __getitem__(self, k): return self.f[k]
+    def oldTime(self): return self.old
+    def correctBoundaryConditions(self): pass
+
+
+class Particle:
+    """softParticle.H:196-290: the accessors the loops call; Vol() and the mass are the reference's own lines"""
+
+    def __init__(self, ns, pos, U, UOld, d, rho, cell, n0, sumFb):
+        self.pos, self.U_, self.UOld_, self.d_, self.cell_, self.n0_, self.sumDeltaFb_ = pos, U, UOld, d, cell, n0, sumFb
+        self.vol_ = ns["Vol"](d)
+        self.m_ = ns["mass"](rho, d)
+
+    def position(self): return self.pos
+    def U(self): return self.U_
+    def UOld(self): return self.UOld_
+    def d(self): return self.d_
+    def cell(self): return self.cell_
+    def Vol(self): return self.vol_
+    def m(self): return self.m_
+    def n0(self): return self.n0_
+    def sumDeltaFb(self): return self.sumDeltaFb_
+
+
+def foam_dialect(src):
+    src = re.sub(r"\b(?:Info|Pout)\s*<<[^;]*;", "", src)
+    src = re.sub(r"\breduce\s*\([^;]*;", "", src)
+    src = re.sub(r"for\s*\(\s*softParticleCloud::iterator\s+pIter\s*=\s*softParticleCloud::begin\(\)\s*;\s*pIter\s*!=\s*"
+                 r"softParticleCloud::end\(\)\s*;\s*\+\+pIter\s*,\s*\+\+particleI\s*\)", "forAll(particles_, particleI)", src)
+    src = re.sub(r"forAllIter\s*\(\s*softParticleCloud\s*,\s*\*this\s*,\s*iter\s*\)", "forAll(particles_, particleI)", src)
+    src = re.sub(r"\b(?:pIter|iter)\(\)", "particles_[particleI]", src)
+    src = re.sub(r"\+\+pIter\s*;", "", src)
+    src = src.replace(".internalField()", ".f")
+    src = src.replace("constant::mathematical::pi", "M_PI_")
+    src = src.replace("vector::zero", "Vec(0.0, 0.0, 0.0)")
+    src = re.sub(r"\bvector\s*\(", "Vec(", src)
+    src = re.sub(r"(\w+)\.(n0|sumDeltaFb)\(\)\s*=(?!=)", r"\1.\2_ =", src)
+    return src
+
+
+def make_value_function(name, args, path, first, last, ns, dialect=None):
+    body = translate(path, first, last, dialect)
+    src = ("def %s(%s):\n    _result = None\n" % (name, ", ".join(args)) + "\n".join("    " + l for l in body.split("\n"))
+           + "\n    return _result\n")
+    run(src, ns)
+
+
+FOAM = dict(MATH, Vec=Vec, mag=fmag, sqr=lambda a: a * a, M_PI_=math.pi, ROOTVSMALL=1.0e-150, debug=0, pIter=0)   # [3P] doubleScalar.H
+
+
+def cloud_namespace(addParticleOption=0, ecc=(0.0, 0.0, 0.0)):
+    ns = dict(FOAM)
+    make_value_function("Vol", ["d_"], "lammpsFoam/softParticle.H", 272, 272, ns, foam_dialect)
+    # softParticle.C:72  mass_ = density_*4./3.*pi*d_*d_*d_/8.;
+    run("def mass(density_, d_):\n    " + translate("lammpsFoam/softParticle.C", 72, 72, foam_dialect).strip()
+        + "\n    return mass_\n", ns)
+    make_value_function("g1n", ["n"], "lammpsFoam/enhancedCloud.C", 1374, 1383, ns, foam_dialect)
+    ns["addParticleOption_"] = addParticleOption
+    ns["addParticleBoxEccentricity_"] = Vec(*ecc)
+    make_value_function("pointInRegion", ["point", "box"], "lammpsFoam/softParticleCloud.C", 1356, 1416, ns, foam_dialect)
+    return ns
+
+
+def vecs(rows):
+    return [Vec(*r) for r in rows]
+
+
+def vout(vs):
+    return [hexs(v.a) for v in vs]
+
+
+def case_cloud(seed, n, mesh_n, flags, model, n_steps=1, inlet=None, big_accel=False):
+    """one mesh block of mesh_n cells with n particles inside; per CFD step: particleToEulerianField (no smoothing) ->
+    updateParticleAlpha / Ur -> Jd (the drag model's own lines) -> the force assembly -> calcTcFields (dragSmooth off).
+    n_steps > 1 walks the history force through its window: the particle velocities of every step are inputs."""
+    rng = random.Random(seed)
+    nx, ny, nz = mesh_n
+    dx = 3.0e-3
+    ncells = nx * ny * nz
+    d = [1.0e-3 * rng.uniform(0.5, 1.2) for _ in range(n)]
+    rho = 2650.0
+    pos = [[rng.uniform(0.02, nx - 0.02) * dx, rng.uniform(0.02, ny - 0.02) * dx, rng.uniform(0.02, nz - 0.02) * dx]
+           for _ in range(n)]
+    for k in range(0, n, 7):   # some grains within the lubrication window above the y = 0 wall (0.0001 d .. 0.1 d)
+        pos[k][1] = 0.5 * d[k] + d[k] * 10.0 ** rng.uniform(-3.5, -1.2)
+    cell = [int(p[0] / dx) + nx * (int(p[1] / dx) + ny * int(p[2] / dx)) for p in pos]
+    Useq = [[[rng.uniform(-0.3, 0.3) for _ in range(3)] for _ in range(n)] for _ in range(n_steps + 1)]
+    if big_accel:              # |DDtUf - dupdt| > 10: the added-mass cap
+        for k in range(0, n, 3):
+            Useq[1][k] = [u + 2.0e-3 * rng.uniform(-1, 1) for u in Useq[0][k]]
+    Uf = [[0.05 * rng.uniform(-1, 1), 0.05 + 0.05 * rng.uniform(-1, 1), 0.05 * rng.uniform(-1, 1)] for _ in range(ncells)]
+    UfOld = [[u + 0.01 * rng.uniform(-1, 1) for u in row] for row in Uf]
+    DDtUf = [[rng.gauss(0.0, 3.0) for _ in range(3)] for _ in range(ncells)]
+    gradp = [[rng.gauss(0.0, 50.0), -9810.0 + rng.gauss(0.0, 50.0), rng.gauss(0.0, 50.0)] for _ in range(ncells)]
+    curlU = [[rng.gauss(0.0, 5.0) for _ in range(3)] for _ in range(ncells)]
+    V = [dx * dx * dx] * ncells
+    deltaT = 5.0e-5
+    inp = dict(n=n, mesh_n=list(mesh_n), dx=dx, d=d, rho=rho, pos=pos, cell=cell, U=Useq, Uf=Uf, UfOld=UfOld, DDtUf=DDtUf,
+               gradp=gradp, curlU=curlU, deltaT=deltaT, flags=flags, model=model, rhob=1000.0, nub=1.0e-6,
+               gravity=[0.0, -9.81, 0.0], inlet=inlet, n_steps=n_steps)
+    ns = cloud_namespace(inlet["addParticleOption"] if inlet else 0, inlet["eccentricity"] if inlet else (0.0, 0.0, 0.0))
+    jd_path, jd_first, jd_last, jd_result = {0: ("lammpsFoam/dragModels/ErgunWenYu/ErgunWenYu.C", 104, 132, "tKWenYu"),
+                                             1: ("lammpsFoam/dragModels/SyamlalOBrien/SyamlalOBrien.C", 105, 143, "_result")}[model]
+    jd_code = translate(jd_path, jd_first, jd_last)
+
+    class Drag:
+        def Jd(self, Ur):
+            out = []
+            for k in range(len(Ur)):   # the field algebra of the model, one element at a time (as case_drag)
+                dns = dict(MATH, Ur=Field([Ur[k]]), alpha_=Field([ns["pAlpha_"][k]]), pd_=Field([ns["pDia_"][k]]),
+                           nuf_=inp["nub"], rhof_=inp["rhob"], pow=fpow, max=fmax, sqrt=fsqrt, sqr=fsqr, ROOTVSMALL=1.0e-150,
+                           scalar=float)
+                run(jd_code, dns)
+                out.append(dns[jd_result][0])
+            return Field(out)
+
+    RT = type("RT", (), {})()
+    ns.update(drag_=Drag(), runTime=lambda: RT, mesh_=type("Mesh", (), {"V": lambda self: Field(V)})(),
+              gravity_=Vec(*inp["gravity"]), rhob_=inp["rhob"], nub_=inp["nub"],
+              particleDragFlag_=flags.get("particleDrag", 1), particlePressureGradFlag_=flags.get("particlePressureGrad", 1),
+              particleBuoyancyFlag_=flags.get("particleBuoyancy", 0), particleAddedMassFlag_=flags.get("particleAddedMass", 0),
+              particleLiftForceFlag_=flags.get("particleLift", 0), particleHistoryForceFlag_=flags.get("particleHistoryForce", 0),
+              lubricationFlag_=flags.get("lubricationForce", 0),
+              inletForceRatio_=Vec(*(inlet["inletForce"] if inlet else (0.0, 0.0, 0.0))),
+              inletBox_=Tensor9(inlet["inletBox"] if inlet else [0.0] * 9),
+              alphaSmoothFlag_=0, UpSmoothFlag_=0, dragSmoothFlag_=0, semiImplicit=0)
+    code_scatter = translate("lammpsFoam/enhancedCloud.C", 913, 979, foam_dialect)
+    code_alpha = translate("lammpsFoam/enhancedCloud.C", 59, 75, foam_dialect)
+    code_ur = translate("lammpsFoam/enhancedCloud.C", 88, 108, foam_dialect)
+    code_dia = translate("lammpsFoam/enhancedCloud.C", 41, 51, foam_dialect)
+    code_drag = translate("lammpsFoam/enhancedCloud.C", 129, 311, foam_dialect)
+    code_tc = translate("lammpsFoam/enhancedCloud.C", 318, 439, foam_dialect)
+    if "--show" in sys.argv:
+        print(code_scatter, code_ur, code_drag, code_tc, sep="\n# ----\n")
+    parts = [Particle(ns, Vec(*pos[k]), Vec(*Useq[0][k]), Vec(*Useq[0][k]), d[k], rho, cell[k], 0.0, Vec()) for k in range(n)]
+    ns["particles_"] = parts
+    ns["particleCount_"] = n
+    inp["mass"] = [p.m_ for p in parts]   # (softParticle.C:72, executed: what the inlet override multiplies by)
+    # (calcTcFields calls the three list updates itself, :323-325)
+    ns.update(updateParticleAlpha=lambda: run(code_alpha, ns), updateParticleUr=lambda: run(code_ur, ns),
+              setupParticleDia=lambda: run(code_dia, ns))
+    steps = []
+    for step in range(1, n_steps + 1):
+        for k, p in enumerate(parts):
+            p.UOld_, p.U_ = p.U_, Vec(*Useq[step][k])
+        RT.deltaT = lambda: type("DT", (), {"value": lambda self: deltaT})()
+        RT.timeIndex = lambda step=step: step
+        ns.update(gamma_=GeoField([0.0] * ncells), Ue_=GeoField([Vec() for _ in range(ncells)]),
+                  UfSmoothed_=GeoField(vecs(Uf), old=GeoField(vecs(UfOld))), DDtUf_=GeoField(vecs(DDtUf)),
+                  gradp=Field(vecs(gradp)), curlU=Field(vecs(curlU)), Omega_=GeoField([0.0] * ncells),
+                  Asrc_=GeoField([Vec() for _ in range(ncells)]), Asrc2_=GeoField([Vec() for _ in range(ncells)]),
+                  pDia_=Field([0.0] * n), pAlpha_=Field([0.0] * n), Uri_=Field([Vec()] * n), magUri_=Field([0.0] * n),
+                  pDrag_=Field([Vec()] * n), pDuDt_=Field([Vec()] * n), Jd_=Field([0.0] * n))
+        for name in ("pDia_", "pAlpha_", "Uri_", "magUri_", "pDrag_", "pDuDt_"):
+            ns[name].setSize = lambda m: None
+        run(code_scatter, ns)                       # gamma_, Ue_
+        gamma_now, Ue_now = list(ns["gamma_"].f), list(ns["Ue_"].f)
+        run(code_dia, ns); run(code_alpha, ns); run(code_ur, ns)
+        run(code_drag, ns)                          # Jd_, pDrag_, pDuDt_, history state
+        out = dict(gamma=hexs(gamma_now), Ue=vout(Ue_now), Uri=vout(ns["Uri_"]), magUri=hexs(ns["magUri_"]),
+                   Jd=hexs(ns["Jd_"]), pDrag=vout(ns["pDrag_"]), pDuDt=vout(ns["pDuDt_"]),
+                   sumDeltaFb=vout([p.sumDeltaFb_ for p in parts]), n0=hexs([p.n0_ for p in parts]))
+        # liftDragCoeffs.H:6-14 caps alpha before calcTcFields; the case stays below the cap, the field goes in as it is
+        run(code_tc, ns)
+        out.update(Asrc=vout(ns["Asrc_"].f), Omega=hexs(ns["Omega_"].f), step=step)
+        steps.append(out)
+    if n_steps > 3:   # a long walk: the first two steps, the first one after a history-window reset, the last two
+        reset = next((k for k, o in enumerate(steps) if any(float.fromhex(v) > 0.0 for v in o["n0"])), n_steps - 2)
+        keep = sorted({0, 1, reset, min(reset + 1, n_steps - 1), n_steps - 2, n_steps - 1})
+        steps = [steps[k] for k in keep]
+    return dict(inp=inp, out=steps)
 
 
 def main():
@@ -514,6 +784,19 @@ def main():
         print(code)
     pins["SyamlalOBrien.C:105-143"] = [case_drag(code, "_result", 51, 200, 1.0e-6, 1000.0),
                                        case_drag(code, "_result", 52, 100, 1.5e-5, 1.2)]
+    allf = dict(particleDrag=1, particlePressureGrad=1, particleBuoyancy=1, particleAddedMass=1, particleLift=1,
+                lubricationForce=1)
+    pins["enhancedCloud.C:41-108,129-311,318-439,913-979"] = [
+        case_cloud(81, 160, (3, 4, 3), dict(particleDrag=1, particlePressureGrad=1), 0),
+        case_cloud(82, 200, (4, 3, 3), allf, 0, big_accel=True),
+        case_cloud(83, 120, (3, 3, 3), allf, 1, n_steps=2, big_accel=True),
+        case_cloud(84, 40, (2, 3, 2), dict(allf, particleHistoryForce=1), 0, n_steps=260),
+        case_cloud(85, 150, (3, 4, 3), dict(particleDrag=1, particlePressureGrad=1), 0,
+                   inlet=dict(addParticleOption=1, inletForce=[0.3, 0.0, 0.0], inletBox=[0.0, 4.5e-3, 0.0, 6.0e-3, 0.0, 9.0e-3, 0.0, 0.0, 0.0],
+                              eccentricity=[0.0, 0.0, 0.0])),
+        case_cloud(86, 150, (3, 4, 3), dict(particleDrag=1, particlePressureGrad=1), 0,
+                   inlet=dict(addParticleOption=2, inletForce=[0.0, 0.2, 0.0], inletBox=[4.5e-3, 4.5e-3, 0.0, 12.0e-3, 4.5e-3, 4.5e-3, 1.0e-3, 4.0e-3, 0.0],
+                              eccentricity=[3.0e-4, 0.0, -2.0e-4]))]
     with open(os.path.join(HERE, "reference_pins.json"), "w") as fh:
         json.dump(pins, fh, separators=(",", ":"))
     print("wrote reference_pins.json: " + ", ".join("%s x%d" % (k, len(v)) for k, v in pins.items() if k[0] != "_"))

@@ -161,3 +161,87 @@ def test_lubricate_poly_equals_the_reference_lines(k):
     ref_f = unhex(O["f"])
     assert np.count_nonzero(ref_f) > 60 and O["overlaps"] >= 1
     assert ulps(f, ref_f) <= 1.0 and ulps(tq, unhex(O["torque"])) <= 1.0
+
+
+# ---- the OpenFOAM-side loops of enhancedCloud.C (A6, A8, A9): particleToEulerianField, updateParticleAlpha / Ur, the force
+# assembly of updateDragOnParticles with the history force and the inlet override, calcTcFields -- executed line by line by
+# tests/golden/make_reference_pins.py through a three-component vector with OpenFOAM's operators ----
+CLOUD_KEY = "enhancedCloud.C:41-108,129-311,318-439,913-979"
+
+
+def _vunhex(rows):
+    return np.array([[float.fromhex(v) for v in r] for r in rows])
+
+
+def replay_cloud_with_the_oracle(I, check):
+    """walk the oracle through the CFD steps of one pin case; check(step, name, value) sees every output of a recorded step"""
+    L = ob.lib()
+    n, (nx, ny, nz) = I["n"], I["mesh_n"]
+    ncells = nx * ny * nz
+    fl = ob.CloudFlags()
+    F = I["flags"]
+    fl.particleDrag = int(F.get("particleDrag", 1)); fl.particlePressureGrad = int(F.get("particlePressureGrad", 1))
+    fl.particleBuoyancy = int(F.get("particleBuoyancy", 0)); fl.particleAddedMass = int(F.get("particleAddedMass", 0))
+    fl.particleLift = int(F.get("particleLift", 0)); fl.lubricationForce = int(F.get("lubricationForce", 0))
+    fl.gravity = (C.c_double * 3)(*I["gravity"]); fl.rhob = I["rhob"]; fl.nub = I["nub"]; fl.deltaT = I["deltaT"]
+    hist = bool(F.get("particleHistoryForce", 0))
+    cell = ob.i32(I["cell"]); pos = ob.f64(I["pos"]); d = ob.f64(I["d"])
+    V = np.full(ncells, I["dx"] ** 3)
+    Uf, UfOld = ob.f64(I["Uf"]), ob.f64(I["UfOld"])
+    DDtUf, gradp, curlU = ob.f64(I["DDtUf"]), ob.f64(I["gradp"]), ob.f64(I["curlU"])
+    sumFb, n0 = np.zeros((n, 3)), np.zeros(n)
+    for step in range(1, I["n_steps"] + 1):
+        U, UOld = ob.f64(I["U"][step]), ob.f64(I["U"][step - 1])
+        gamma, Ue = np.zeros(ncells), np.zeros((ncells, 3))
+        L.orc_particle_to_eulerian(n, ob.P(cell), ob.P(d), ob.P(U), ncells, ob.P(V), ob.P(gamma), ob.P(Ue))
+        Uri, mag, Jd = np.zeros((n, 3)), np.zeros(n), np.zeros(n)
+        pDrag, pDuDt = np.zeros((n, 3)), np.zeros((n, 3))
+        L.orc_drag_on_particles_hist(C.byref(fl), I["model"], n, ob.P(cell), ob.P(pos), ob.P(d), ob.P(U), ob.P(UOld),
+                                     ob.P(gamma), ob.P(Uf), ob.P(gradp), ob.P(DDtUf), ob.P(curlU), step if hist else -1,
+                                     ob.P(UfOld), ob.P(sumFb), ob.P(n0), ob.P(Uri), ob.P(mag), ob.P(Jd), ob.P(pDrag),
+                                     ob.P(pDuDt))
+        if I["inlet"]:
+            J = I["inlet"]
+            L.orc_inlet_force_override(J["addParticleOption"], ob.P(ob.f64(J["inletForce"])), ob.P(ob.f64(J["inletBox"])),
+                                       ob.P(ob.f64(J["eccentricity"])), I["deltaT"], n, ob.P(pos), ob.P(ob.f64(I["mass"])),
+                                       ob.P(U), ob.P(pDrag))
+        Asrc, Omega = np.zeros((ncells, 3)), np.ones(ncells)
+        L.orc_calc_tc_fields(n, ob.P(cell), ob.P(d), ob.P(U), ob.P(Jd), ncells, ob.P(V), ob.P(gamma), ob.P(Uf), ob.P(Asrc),
+                             ob.P(Omega))
+        for name, val in (("gamma", gamma), ("Ue", Ue), ("Uri", Uri), ("magUri", mag), ("Jd", Jd), ("pDrag", pDrag),
+                          ("pDuDt", pDuDt), ("sumDeltaFb", sumFb), ("n0", n0), ("Asrc", Asrc), ("Omega", Omega)):
+            check(step, name, val.copy())
+
+
+@pytest.mark.parametrize("k", range(len(PINS[CLOUD_KEY])))
+def test_cloud_loops_equal_the_reference_lines(k):
+    """orc_cloud.c (A6 drag assembly incl. added-mass cap, lift, wall lubrication, the Basset history force through its
+    window reset, both inlet regions; A8 scatter; A9 Asrc) against the reference's own statements, output by output"""
+    c = PINS[CLOUD_KEY][k]
+    want = {o["step"]: o for o in c["out"]}
+    seen = []
+    worst = {}
+
+    def check(step, name, val):
+        if step not in want:
+            return
+        ref = _vunhex(want[step][name]) if isinstance(want[step][name][0], list) else unhex(want[step][name])
+        seen.append((step, name))
+        worst[name] = max(worst.get(name, 0.0), ulps(val, ref))
+    replay_cloud_with_the_oracle(c["inp"], check)
+    assert len(seen) == 11 * len(want)
+    # sums over the particles of a cell and products of four factors: the oracle keeps the reference's order
+    for name, u in worst.items():
+        assert u <= 2.0, (name, u, worst)
+    F = c["inp"]["flags"]
+    if F.get("particleHistoryForce"):
+        last = c["out"][-1]
+        assert any(float.fromhex(v) > 0.0 for v in last["n0"]), "the history window never reset: the else branch is not pinned"
+    if c["inp"]["inlet"]:
+        # the override replaced the assembled force of the particles inside the region, and only theirs
+        I = c["inp"]
+        m, U = np.array(I["mass"]), np.array(I["U"][1])
+        over = m[:, None] * (np.array(I["inlet"]["inletForce"])[None, :] - U) / I["deltaT"]
+        got = _vunhex(c["out"][0]["pDrag"])
+        inside = np.all(np.abs(got - over) <= 1e-12 * np.abs(over).max(), axis=1)
+        assert 0 < inside.sum() < I["n"]

@@ -4,7 +4,7 @@ tag=$1; n=${2:-125000}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 SF_HALO_SELF_COMM=1 SF_HALO_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $root/gpurun_out/kt_$tag -o p -- \
-  python $root/bench.py --slab-driver --particles $n --steps 4 --warmup 1 --no-cpu-baseline --no-coupled --no-kernel-profile > $root/gpurun_out/kt_$tag.log 2>&1
+  python $root/bench.py --slab-driver --particles $n --steps 4 --warmup 1 --no-cpu-baseline --no-coupled --no-configs --no-kernel-profile > $root/gpurun_out/kt_$tag.log 2>&1
 cd $root
 python - "$tag" <<'P'
 import csv, glob, sys

@@ -5,7 +5,7 @@ tag=$1; args=$2
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $root/gpurun_out/kt_$tag -o p -- \
-  python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-coupled --no-kernel-profile $args > $root/gpurun_out/kt_$tag.log 2>&1
+  python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-coupled --no-configs --no-kernel-profile $args > $root/gpurun_out/kt_$tag.log 2>&1
 cd $root
 python - "$tag" <<'P'
 import csv, glob, sys
