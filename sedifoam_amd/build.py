@@ -39,7 +39,7 @@ def kernel_source_hash():
     kernel it is timing"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("sf_dem_kernels.h", "sf_dem_variants.h", "sf_physics.h", "sf_dem.h", "sf_common.h"):
+    for f in ("sf_dem_kernels.h", "sf_dem_variants.h", "sf_dem_gs.h", "sf_physics.h", "sf_dem.h", "sf_common.h"):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(" ".join(FLAGS + FILE_FLAGS.get("sf_dem.hip", [])).encode())   # (and the flags it is compiled with)
     return h.hexdigest()[:16]

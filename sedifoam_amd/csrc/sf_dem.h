@@ -145,6 +145,15 @@ struct DemPtrs {
                                 // neighbour's uncached area is made of
   const int* tx_hdr_off;
   int* xcd_time;                // StepParams::xcd_time: [64 x + 0] first start, [64 x + 32] last end of XCD x (100 MHz clock)
+  // ghost slots (StepParams::gs_on, sf_halo_rccl.hip): the records of the ghosts of other GPUs are NOT in xr / vm / om but
+  // in a fine-grained area the neighbours' sub-step kernels write straight into: [3][gs_cap] double4 (x | v | omega of
+  // ghost g at index g - nlocal), read with system-coherent loads.  tx_blkptr[q] then is where the x record of block q's
+  // first atom goes in the NEIGHBOUR's area, tx_blkcnt[q] that area's stride (its gs_cap), tx_blkshift[3 q ..] the
+  // periodic shift the sender adds.  gs_sync: who to wait for and who to tell (GsSync), gs_count: completion counters.
+  const double4* gs_in;
+  const double* tx_blkshift;
+  const struct GsSync* gs_sync;
+  int* gs_count;                // [9][32]: one line per XCD (workgroups done), then the XCDs done
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -152,6 +161,15 @@ struct DemPtrs {
   const int* stage_start;       // [ntiles+1] range of the tile in stage_idx
   const int* stage_idx;         // atom indices (owned or ghost) to stage, bin by bin
 };
+
+// ghost slots: the flag / vote lines of the ranks (device copy, set up once per communicator)
+struct GsSync {
+  int world, rank;
+  long long max_ticks;     // 100 MHz clock: how long a wave waits for a peer's flag
+  int* my_sync;            // for sender r the line [kGsStride r]: flag, vote[2]
+  int* peer_sync[32];      // every rank's area as mapped here
+};
+constexpr int kGsStride = 32;   // ints: one 128-byte line per sending rank (one writer per line)
 
 struct StepParams {
   int nlocal, cap, mode;   // mode 0: force + final + next initial ; 1: last (force + final, store f) ; 2: setup
@@ -194,6 +212,11 @@ struct StepParams {
                            // to kBrickSlots) record positions up in DemPtrs::bslot and writes its new x, v, omega there,
                            // unshifted (the receiver adds the periodic shift of the block)
   double tx_lo3[3], tx_hi3[3];
+  // ghost slots (tx_fused == 3 on the sending side): gs_on -- ghost records live in DemPtrs::gs_in ([3][gs_cap]); gs_seq --
+  // the number of this launch: its waves wait until every rank's flag says gs_seq ("my records for launch gs_seq are in
+  // your area", gs_wait = 0: nobody to wait for) and read the votes of parity gs_seq & 1; the last workgroup to finish
+  // stores this rank's vote and the flag gs_seq + 1 into every rank's line
+  int gs_on, gs_cap, gs_seq, gs_wait;
   int tx_n[2];             // atoms in the left / right send list (a face's block is [kForwardDoubles][tx_n])
   double tx_xlo, tx_xhi, tx_shift[2];
 };
@@ -465,6 +488,29 @@ class DemEngine {
   void brick_direct_unpack(const BrickBlocks& rcv, const double* recvarea, const DirectSync& D);
   bool brick_direct_probe(const BrickBlocks& none, const DirectSync& D);   // bring-up: one flag round, no records; synchronises;
                                                                             // false = a peer's flag did not arrive in time
+  // ---- ghost slots (SF_HALO_DIRECT=2, sf_halo_rccl.hip): NO kernel between two sub-step kernels.  The ghosts of other
+  // GPUs live in two fine-grained areas [3][cap] double4 (x | v | omega records, by the parity of the launch number)
+  // that the neighbours' sub-step kernels write straight into; a sub-step kernel waits at its gate for every rank's flag
+  // (DemPtrs::gs_sync) and the last workgroup to finish publishes this rank's vote and flag.  Launches are numbered by
+  // gs_seq(): the same number on every rank (all ranks queue the same launches).
+  void gs_configure(const GsSync& sync, long long first_seq);   // once per communicator: device copy of the sync table,
+                                                                // counters; first_seq: the number of the first launch
+  // after every rebuild: this rank's areas and, per send block, where its first x record goes in the neighbour's area of
+  // each parity (blk2[par * kMaxDirs + q]) and that area's stride (blkcap[q])
+  void brick_set_forward_gs(const BrickBlocks& snd, double4* const area[2], int cap, double4* const* blk2,
+                            const size_t* blkcap);
+  void gs_off();                                     // back to the other transports (areas gone)
+  // can the sub-step kernel write the border records itself (what ghost slots rest on)?  Not in a brick thinner than twice
+  // the ghost cutoff (brick_set_forward_tx) and not with SF_HALO_FUSED_PACK=0
+  bool brick_fused_pack_possible() const;
+  bool gs_on() const { return gs_ready_; }
+  long long gs_seq() const { return gs_seq_; }       // number of the NEXT sub-step launch
+  // the records of every border atom as they are now, for launch gs_seq() (the start of a run, the first launch after a
+  // rebuild: no sub-step kernel has written them), and this rank's flag
+  void gs_pack();
+  // end of a piece: wait for the flags of launch gs_seq() and fold the votes into the trigger word, unless a trigger
+  // before sub-step `kstep_end` is known already (then some rank may never publish that flag)
+  void gs_close(int kstep_end);
   const BrickBlocks& brick_send_blocks() const { return bsend_blocks_; }
   long long migrate_count3();      // owned atoms outside the brick in any external dimension
   long long migrate_pack_dim(int dim, int side, double shift, double* buf, long long max_doubles);
@@ -696,9 +742,15 @@ private:
   int tx_nhdr_ = 0, tx_n_[2] = {0, 0};
   bool tx_ready_ = false, tx_written_ = false;
   bool tx_direct_ = false;             // records go straight into the neighbours' receive areas
+  bool gs_ready_ = false;              // ghost slots: the tables below are valid
+  GsSync* d_gs_sync_ = nullptr;
+  int* d_gs_count_ = nullptr;          // [9][32] completion counters (zero between launches)
+  double4* gs_area_[2] = {nullptr, nullptr};
+  int gs_cap_ = 0;
+  long long gs_seq_ = 1;
   int tx_par_ = 0;
   double** d_blkptr_ = nullptr;        // [2][kMaxDirs] device table of block starts (both rows equal unless tx_direct_),
-                                       // then [kMaxDirs] records per block (size_t)
+                                       // then [kMaxDirs] records per block (size_t), then [kMaxDirs][3] shifts (ghost slots)
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
   // brick decomposition: directions, face masks of the owned atoms, concatenated send lists
   int bndir_ = 0;

@@ -702,6 +702,10 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   static_assert(sizeof(size_t) == sizeof(double*), "the count row of the block table");
   P.tx_blkcnt = d_blkptr_ ? reinterpret_cast<const size_t*>(d_blkptr_ + 2 * (size_t)kMaxDirs) : nullptr;
   P.tx_hdr_off = tx_hdr_off_;
+  P.gs_in = nullptr;
+  P.tx_blkshift = nullptr;
+  P.gs_sync = nullptr;
+  P.gs_count = nullptr;
   P.xcd_time = d_xcd_time_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
   P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
@@ -771,23 +775,23 @@ StepParams DemEngine::step_params(int mode, int kstep) const
   return S;
 }
 
-template <int STYLE, int LPA, bool TP, int NTP>
+template <int STYLE, int LPA, bool TP, int NTP, bool GS = false>
 static void launch_substep_lpa(bool cohe, bool lub, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
                                const StepParams& S)
 {
-  if (cohe && lub) k_substep<STYLE, true, true, LPA, TP, NTP><<<grid, block, 0, s>>>(P, S);
-  else if (cohe) k_substep<STYLE, true, false, LPA, TP, NTP><<<grid, block, 0, s>>>(P, S);
-  else if (lub) k_substep<STYLE, false, true, LPA, true, NTP><<<grid, block, 0, s>>>(P, S);   // (lubrication needs v, omega
-  else k_substep<STYLE, false, false, LPA, TP, NTP><<<grid, block, 0, s>>>(P, S);            //  of every neighbour anyway)
+  if (cohe && lub) k_substep<STYLE, true, true, LPA, TP, NTP, GS><<<grid, block, 0, s>>>(P, S);
+  else if (cohe) k_substep<STYLE, true, false, LPA, TP, NTP, GS><<<grid, block, 0, s>>>(P, S);
+  else if (lub) k_substep<STYLE, false, true, LPA, true, NTP, GS><<<grid, block, 0, s>>>(P, S);   // (lubrication needs v, omega
+  else k_substep<STYLE, false, false, LPA, TP, NTP, GS><<<grid, block, 0, s>>>(P, S);            //  of every neighbour anyway)
 }
 
-template <int STYLE, int LPA, int NTP>
+template <int STYLE, int LPA, int NTP, bool GS = false>
 static void launch_substep_tp(bool cohe, bool lub, bool tp, dim3 grid, int block, hipStream_t s, const DemPtrs& P,
                               const StepParams& S)
 {
   if (lub) tp = true;   // one instantiation
-  tp ? launch_substep_lpa<STYLE, LPA, true, NTP>(cohe, lub, grid, block, s, P, S)
-     : launch_substep_lpa<STYLE, LPA, false, NTP>(cohe, lub, grid, block, s, P, S);
+  tp ? launch_substep_lpa<STYLE, LPA, true, NTP, GS>(cohe, lub, grid, block, s, P, S)
+     : launch_substep_lpa<STYLE, LPA, false, NTP, GS>(cohe, lub, grid, block, s, P, S);
 }
 
 // ntp: non-temporal policy of the row streams (sf_dem_kernels.h); systems small enough for several lanes per atom
@@ -796,6 +800,13 @@ template <int STYLE>
 static void launch_substep_style(bool cohe, bool lub, int lpa, bool tp, int ntp, dim3 grid, int block, hipStream_t s,
                                  const DemPtrs& P, const StepParams& S)
 {
+  // ghost slots (sf_halo_rccl.hip): the per-GPU share of a decomposed bed, nothing non-temporal -- one variant per lane count
+  if (S.gs_on) {
+    if (lpa == 4) launch_substep_tp<STYLE, 4, 0, true>(cohe, lub, tp, grid, block, s, P, S);
+    else if (lpa == 2) launch_substep_tp<STYLE, 2, 0, true>(cohe, lub, tp, grid, block, s, P, S);
+    else launch_substep_tp<STYLE, 1, 0, true>(cohe, lub, tp, grid, block, s, P, S);
+    return;
+  }
   if (lpa == 4) launch_substep_tp<STYLE, 4, 0>(cohe, lub, tp, grid, block, s, P, S);
   else if (lpa == 2) launch_substep_tp<STYLE, 2, 0>(cohe, lub, tp, grid, block, s, P, S);
   else if (ntp == 0) launch_substep_tp<STYLE, 1, 0>(cohe, lub, tp, grid, block, s, P, S);
@@ -847,10 +858,34 @@ int DemEngine::lanes_per_atom(int nwork) const
 
 void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
 {
-  if (!nlocal_) return;
+  if (!nlocal_) {
+    // (ghost slots: the other ranks wait for this one's flag whether it owns atoms or not)
+    if (gs_ready_ && brick_ && part == 0 && !lds_active_ && mode != 2) {
+      k_gs_idle<<<1, 64, 0, stream_>>>(d_gs_sync_, d_flags_, (int)gs_seq_, kstep, mode == 0 ? 1 : 0);
+      gs_seq_++;
+      tx_written_ = mode == 0;
+    }
+    return;
+  }
   if (part == 2 && !nb_) return;   // (no event pair opened: the interior part then times itself)
-  const DemPtrs P = ptrs(in_buf);
+  DemPtrs P = ptrs(in_buf);
   StepParams S = step_params(mode, kstep);
+  // ghost slots: every stepping launch of a decomposed engine reads the ghosts of other GPUs from the area of its number's
+  // parity and (mode 0) writes its border records into the neighbours' area of the next parity; the setup evaluation
+  // (mode 2) runs on the ghosts the border exchange has just put into the record arrays
+  const bool gs = gs_ready_ && brick_ && part == 0 && !lds_active_ && mode != 2;
+  if (gs) {
+    S.gs_on = 1;
+    S.gs_cap = gs_cap_;
+    S.gs_seq = (int)gs_seq_;
+    S.gs_wait = 1;
+    P.gs_in = gs_area_[gs_seq_ & 1];
+    P.gs_sync = d_gs_sync_;
+    P.gs_count = d_gs_count_;
+    P.tx_blkptr = d_blkptr_ + (size_t)((gs_seq_ + 1) & 1) * kMaxDirs;
+    P.tx_blkshift = reinterpret_cast<const double*>(d_blkptr_ + 3 * (size_t)kMaxDirs);
+    gs_seq_++;
+  }
   if (part) {
     // overlapped halo: both parts of sub-step k test the vote published by the exchange of sub-step k-1; an
     // interior trigger can only be voted one exchange later, hence "+1" (sub-step k+1 still runs everywhere)
@@ -937,6 +972,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
     // one wave per workgroup: the dispatcher then balances single waves (a 256-thread workgroup holds its CU slots
     // until its slowest wave is done); measured 207.0 -> 203.2 us per sub-step at 1 M atoms, never slower below
     const int block = block_env ? block_env : 64;
+    if (gs && block != 64) fail("ghost slots: the hand-off at the end of the sub-step kernel is written for one-wave workgroups (SF_BLOCK)");
     dim3 grid((unsigned)((lanes + block - 1) / block));
     // The XCDs do not finish together when each gets the same number of workgroups: the two that hold the ends of the
     // sorted range gather across the periodic face from lines no neighbour of theirs has pulled into their L2, and run

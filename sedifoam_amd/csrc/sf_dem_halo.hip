@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "sf_dem.h"
+#include "sf_dem_gs.h"
 
 namespace sf {
 
@@ -778,8 +779,9 @@ void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, co
   tx_sendbuf_ = sendbuf;
   tx_hdr_off_ = hdr_off;
   tx_nhdr_ = nhdr;
+  gs_ready_ = false;
   {
-    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 3 * kMaxDirs));
+    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 6 * kMaxDirs));
     double* h[3 * kMaxDirs];
     for (int par = 0; par < 2; par++)
       for (int q = 0; q < kMaxDirs; q++)
@@ -929,7 +931,8 @@ __global__ __launch_bounds__(256) void k_brick_direct_unpack(DemEngine::BrickBlo
   __syncthreads();
   if ((int)threadIdx.x < W && (int)threadIdx.x != D.rank) {
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < D.seq) {
+    // (32-bit exchange numbers compared by their difference: the count may wrap)
+    while ((int)((unsigned)__hip_atomic_load(&D.my_sync[DemEngine::kSyncStride * threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)D.seq) < 0) {
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > D.max_ticks) {
         ok = 0;
@@ -977,6 +980,120 @@ void DemEngine::brick_direct_unpack(const BrickBlocks& rcv, const double* recvar
                                                               xr_[cur_].as<double4>(), vm_[cur_].as<double4>(),
                                                               om_[cur_].as<double4>());
   launch_ghost_forward(cur_, INT_MIN);   // (index mode only: local images of everything, received ghosts included)
+}
+
+// ------------------------------------------------------------------------------------------------
+// ghost slots: the stand-alone pack (start of a run, first launch after a rebuild), the flag, the end of a piece
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gs_pack(const int* list, DemEngine::BrickBlocks blk, double* const* blkptr,
+                                                 const size_t* blkcap, const double* blkshift, const double4* xr,
+                                                 const double4* vm, const double4* om)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= blk.first[blk.n]) return;
+  const int q = block_of(blk, k);
+  const int i = list[k];
+  const double4 x = xr[i], v = vm[i], w = om[i];
+  double4* g = reinterpret_cast<double4*>(blkptr[q]) + (k - blk.first[q]);
+  const size_t n = blkcap[q];
+  const double* sh = blkshift + 3 * q;
+  gs_store(g, x.x + sh[0], x.y + sh[1], x.z + sh[2], x.w);
+  gs_store(g + n, v.x, v.y, v.z, v.w);
+  gs_store(g + 2 * n, w.x, w.y, w.z, w.w);
+}
+
+__global__ __launch_bounds__(64) void k_gs_publish(const GsSync* Y, int* flags, int seq)
+{
+  int vote = 0;
+  if (threadIdx.x == 0) vote = atomicMin(&flags[F_TRIGGER], INT_MAX);
+  vote = __shfl(vote, 0, 64);
+  gs_publish(Y, vote, seq);
+}
+
+__global__ __launch_bounds__(64) void k_gs_close(const GsSync* Y, int* flags, int seq, int kstep_end)
+{
+  if (__atomic_load_n(&flags[F_TRIGGER], __ATOMIC_RELAXED) < kstep_end) return;   // (known: nobody may publish `seq`)
+  if (__atomic_load_n(&flags[F_HALO_TIMEOUT], __ATOMIC_RELAXED) != 0) return;
+  (void)gs_gate(Y, flags, seq, kstep_end);
+}
+
+void DemEngine::gs_configure(const GsSync& sync, long long first_seq)
+{
+  gs_seq_ = first_seq;
+  if (!d_gs_sync_) SF_HIP(hipMalloc(&d_gs_sync_, sizeof(GsSync)));
+  if (!d_gs_count_) SF_HIP(hipMalloc(&d_gs_count_, sizeof(int) * 9 * 32));
+  SF_HIP(hipMemcpyAsync(d_gs_sync_, &sync, sizeof(GsSync), hipMemcpyHostToDevice, stream_));
+  SF_HIP(hipMemsetAsync(d_gs_count_, 0, sizeof(int) * 9 * 32, stream_));
+  SF_HIP(hipStreamSynchronize(stream_));   // (sync is the caller's)
+}
+
+bool DemEngine::brick_fused_pack_possible() const
+{
+  if (getenv("SF_HALO_FUSED_PACK") && !atoi(getenv("SF_HALO_FUSED_PACK"))) return false;
+  const double cut = cutneighmax();
+  for (int d = 0; d < 3; d++)
+    if (ext_[d] && subhi_[d] - sublo_[d] < 2.0 * cut) return false;
+  return true;
+}
+
+void DemEngine::gs_off()
+{
+  gs_ready_ = false;
+  gs_area_[0] = gs_area_[1] = nullptr;
+}
+
+void DemEngine::brick_set_forward_gs(const BrickBlocks& snd, double4* const area[2], int cap, double4* const* blk2,
+                                     const size_t* blkcap)
+{
+  if (!d_gs_sync_) fail("brick_set_forward_gs: gs_configure first");
+  // (the record-slot table of the border atoms: as for the other transports)
+  brick_set_forward_tx(snd, nullptr, nullptr, 0, nullptr);
+  if (!tx_ready_ && nlocal_)
+    fail("ghost slots need the sub-step kernel to write the border records itself: a brick thinner than twice the ghost "
+         "cutoff (or SF_HALO_FUSED_PACK=0) cannot use SF_HALO_DIRECT=2");
+  if (next_ghost_ > cap) fail("brick_set_forward_gs: %d ghosts, areas of %d records", next_ghost_, cap);
+  struct {
+    double* ptr[2 * kMaxDirs];
+    size_t cap[kMaxDirs];
+    double shift[3 * kMaxDirs];
+  } h;
+  static_assert(sizeof(h) == sizeof(double*) * 6 * kMaxDirs, "the block table of brick_set_forward_tx, three more rows");
+  for (int par = 0; par < 2; par++)
+    for (int q = 0; q < kMaxDirs; q++)
+      h.ptr[par * kMaxDirs + q] = q < snd.n ? reinterpret_cast<double*>(blk2[par * kMaxDirs + q]) : nullptr;
+  for (int q = 0; q < kMaxDirs; q++) {
+    h.cap[q] = q < snd.n ? blkcap[q] : 0;
+    for (int k = 0; k < 3; k++) h.shift[3 * q + k] = q < snd.n ? snd.shift[q][k] : 0.0;
+  }
+  SF_HIP(hipMemcpyAsync(d_blkptr_, &h, sizeof(h), hipMemcpyHostToDevice, stream_));
+  SF_HIP(hipMemsetAsync(d_gs_count_, 0, sizeof(int) * 9 * 32, stream_));
+  SF_HIP(hipStreamSynchronize(stream_));   // (h is on the stack)
+  gs_area_[0] = area[0];
+  gs_area_[1] = area[1];
+  gs_cap_ = cap;
+  tx_direct_ = true;    // (no vote headers in a send buffer)
+  tx_written_ = false;
+  gs_ready_ = true;
+}
+
+void DemEngine::gs_pack()
+{
+  if (!gs_ready_) fail("gs_pack: no ghost-slot layout (rebuild first)");
+  const int par = (int)(gs_seq_ & 1);
+  const int tot = bsend_blocks_.first[bsend_blocks_.n];
+  if (tot)
+    k_gs_pack<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, bsend_blocks_, d_blkptr_ + (size_t)par * kMaxDirs,
+                                                    reinterpret_cast<const size_t*>(d_blkptr_ + 2 * (size_t)kMaxDirs),
+                                                    reinterpret_cast<const double*>(d_blkptr_ + 3 * (size_t)kMaxDirs),
+                                                    xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>());
+  k_gs_publish<<<1, 64, 0, stream_>>>(d_gs_sync_, d_flags_, (int)gs_seq_);
+  tx_written_ = true;
+}
+
+void DemEngine::gs_close(int kstep_end)
+{
+  if (!gs_ready_) fail("gs_close: no ghost-slot layout");
+  k_gs_close<<<1, 64, 0, stream_>>>(d_gs_sync_, d_flags_, (int)gs_seq_, kstep_end);
 }
 
 // returns false when a peer's flag did not arrive in time; the timeout words are cleared again either way (a probe that

@@ -37,6 +37,7 @@
 // row streams, the no-wait persistent kernel, neighbour records by lane shuffle, the two-lane launch tail) were measured,
 // written up (docs/history_r01_r03.md, profiles/r04_README.md, profiles/r05_README.md) and removed from this file.
 #include "sf_dem_variants.h"
+#include "sf_dem_gs.h"
 
 namespace sf {
 
@@ -93,8 +94,9 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // LPA lanes per atom (1, 2 or 4): lane q of an atom's group handles the slots q, q + LPA, ...; the partial force and
 // torque sums are combined with a fixed shuffle tree and lane 0 integrates.  Small systems (< ~3 waves per SIMD at
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
-template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP>
-__device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
+// GS: ghost slots (above).  Returns false when the wave stopped at the gate (nothing was stored).
+template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP, bool GS = false>
+__device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw)
 {
   const size_t cap = (size_t)S.cap;
@@ -166,6 +168,13 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   auto wants_vw = [&](const int jraw) {
     return NEED_VW && (LUB || !TP || (jraw & kTouchBit) != 0);
   };
+  // (ghost slots: the record `which` of a ghost of another GPU comes from the area its owner writes)
+  const __amdgpu_buffer_rsrc_t gs_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(GS ? P.gs_in : nullptr), 0, GS ? S.gs_cap * 96 : 0, 0x00020000);
+  auto ld_rec = [&](const double4* arr, const int which, const int j) -> double4 {
+    if (GS && j >= S.nlocal) return gs_load(gs_rs, (unsigned)(which * S.gs_cap + (j - S.nlocal)) * 32u);
+    return arr[j];
+  };
   // request the records of the neighbour in `slot` (global gather), or its LDS position
   auto fetch = [&](int jraw, int slotrow, Rec& R) {
     if (LDS) {
@@ -174,10 +183,10 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       const int j = neigh_index(jraw, ROOTS);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.vw = wants_vw(jraw);
-      R.x = P.xr_in[j];
+      R.x = ld_rec(P.xr_in, 0, j);
       if (R.vw) {
-        R.v = P.vm_in[j];
-        R.w = P.om_in[j];
+        R.v = ld_rec(P.vm_in, 1, j);
+        R.w = ld_rec(P.om_in, 2, j);
       }
     }
     if (HIST_PF) load_history(jraw, slotrow, R.sh);
@@ -201,6 +210,9 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
   RA.sh = RB.sh = Vec3{0.0, 0.0, 0.0};
   RA.l = RB.l = 0;
   RA.vw = RB.vw = false;
+  // (ghost slots: the flags are asked for behind the wave's own rows -- one round trip for both -- and before anything is
+  // stored or any ghost record is read)
+  if (GS && S.gs_wait && !gs_gate(P.gs_sync, P.flags, S.gs_seq, S.kstep)) return false;
   if (nn > 0) fetch(jraw_n1, q, RA);
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
@@ -258,8 +270,8 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
         if (jraw & kTouchBit) nrow[i] = jraw & ~kTouchBit;
       } else {
         if (!LDS && !cur.vw) {   // a contact that did not exist one sub-step ago
-          vj4 = P.vm_in[cur.l];
-          wj4 = P.om_in[cur.l];
+          vj4 = ld_rec(P.vm_in, 1, cur.l);
+          wj4 = ld_rec(P.om_in, 2, cur.l);
         }
         ContactIn c;
         c.del = del;
@@ -336,7 +348,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       F.x += __shfl_xor(F.x, off, 64); F.y += __shfl_xor(F.y, off, 64); F.z += __shfl_xor(F.z, off, 64);
       T.x += __shfl_xor(T.x, off, 64); T.y += __shfl_xor(T.y, off, 64); T.z += __shfl_xor(T.z, off, 64);
     }
-    if (q != 0) return;
+    if (q != 0) return true;
   }
   if (LUB) {
     if (S.lub.flagfld) {  // isotropic FLD terms, pair_lubricate_poly.cpp:213-220
@@ -488,6 +500,15 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
       const int off = P.bslot[(size_t)k * cap + i];
       if (off < 0) break;
       const int bq = off >> kBlkShift;
+      if (GS) {   // whole records into the neighbour's ghost slots, in the neighbour's frame
+        double4* g = reinterpret_cast<double4*>(P.tx_blkptr[bq]) + (off & kBlkMask);
+        const size_t n = P.tx_blkcnt[bq];   // (the neighbour's [3][n] area)
+        const double* sh = P.tx_blkshift + 3 * bq;
+        gs_store(g, xn.x + sh[0], xn.y + sh[1], xn.z + sh[2], radi);
+        gs_store(g + n, vn.x, vn.y, vn.z, mi);
+        gs_store(g + 2 * n, wn.x, wn.y, wn.z, wi4.w);
+        continue;
+      }
       double* b = P.tx_blkptr[bq] + (off & kBlkMask);
       const size_t n = P.tx_blkcnt[bq];   // (component-major block: [kForwardDoubles][n])
       b[0] = xn.x; b[n] = xn.y; b[2 * n] = xn.z;
@@ -543,6 +564,7 @@ __device__ __forceinline__ void substep_particle(const DemPtrs& P, const StepPar
     P.torque[i] = {T.x, T.y, T.z, 0.0};
   }
   SF_PH(30);
+  return true;
 }
 
 // Registers: the plain contact kernel needs 169 VGPRs when left alone -- one more than three waves per SIMD allow
@@ -566,17 +588,19 @@ __device__ __forceinline__ int xcd_contiguous_block()
 // TP: v and omega of a neighbour are requested with its x only when the pair touched one sub-step ago (a bed that
 // lists many more neighbours than it touches: -11 % in the loose disordered bed), or always (a bed whose listed
 // neighbours nearly all touch: the bookkeeping of the former costs 4 % there)
-template <int STYLE, bool COHE, bool LUB, int LPA, bool TP, int NTP>
+template <int STYLE, bool COHE, bool LUB, int LPA, bool TP, int NTP, bool GS = false>
 __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, StepParams S)
 {
   // a previous sub-step of this batch moved an atom beyond skin/2: the list is stale, do nothing
   // (the host rebuilds and relaunches from that sub-step)
   if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
+  if (GS && __atomic_load_n(&P.flags[F_HALO_TIMEOUT], __ATOMIC_RELAXED) != 0) return;   // (a wait ran out: an error already)
   SF_STAMP_WORKGROUP();   // (variant builds: this workgroup's start / end and phase marks, sf_dem_variants.h)
   // The dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Atoms are sorted by
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
   int bid = blockIdx.x;
+  int gs_expected = 0, gs_nxcd = 0;   // (ghost slots: workgroups of this XCD that run, XCDs that have any)
   // S.sweep_rev: every other sub-step walks each XCD's range from its END.  A sub-step touches ~3 x the 256 MB of the
   // memory-side cache; sweeping always in the same direction it finds nothing of the previous sub-step there (cyclic
   // access, LRU), sweeping back and forth the first third of what it needs is what the previous sub-step touched last.
@@ -584,10 +608,16 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     const int xcd = bid & 7, loc = bid >> 3;
     if (loc >= S.xcd_count[xcd]) return;
     bid = S.xcd_first[xcd] + (S.sweep_rev ? S.xcd_count[xcd] - 1 - loc : loc);
-  } else if (S.xcd_remap) {
+    if (GS) {
+      gs_expected = S.xcd_count[xcd];
+      for (int x = 0; x < 8; x++) gs_nxcd += S.xcd_count[x] > 0 ? 1 : 0;
+    }
+  } else {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     const int cnt = xcd < r ? q + 1 : q, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (S.sweep_rev ? cnt - 1 - loc : loc);
+    if (S.xcd_remap) bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (S.sweep_rev ? cnt - 1 - loc : loc);
+    gs_expected = cnt;
+    gs_nxcd = nb < 8 ? nb : 8;
   }
   const int tid = bid * blockDim.x + threadIdx.x;
   int i = tid / LPA;          // LPA consecutive lanes share an atom
@@ -598,7 +628,7 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   } else if (S.part == 1) {   // everything in between
     i += S.n_lo;
     if (i >= S.n_hi) return;
-  } else if (i >= S.nlocal) {
+  } else if (!GS && i >= S.nlocal) {
     return;
   }
   // a timed launch (one in a few hundred): when did this XCD start, when did it finish?  (the engine evens the shares out)
@@ -606,7 +636,16 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // are resolved one after the other at the memory side, ~11 ns each -- 31 k of them doubled the launch)
   const int xq = (int)(blockIdx.x & 7) * 64;
   if (S.xcd_time && threadIdx.x == 0 && (blockIdx.x >> 3) == 0) atomicMin(&P.xcd_time[xq], (int)(wall_clock64() & 0x3fffffff));
-  substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
+  if (GS) {
+    // (every workgroup that gets here counts itself done, whatever part of it holds atoms: the lanes beyond the last atom
+    // stay for the wave-level hand-off instead of returning)
+    bool ran = true;
+    if (i < S.nlocal) ran = substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP, true>(P, S, i, q, nullptr, nullptr, nullptr);
+    if (__ballot(!ran)) return;   // (stopped at the gate -- the whole wave did: the gate is a wave-level decision)
+    if (S.mode == 0) gs_done(P, S, gs_expected, gs_nxcd);
+  } else {
+    substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
+  }
   if (S.xcd_time && threadIdx.x == 0 && ((blockIdx.x >> 3) & 7) == 0)
     atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
 }

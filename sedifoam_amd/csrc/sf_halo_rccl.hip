@@ -143,21 +143,27 @@ struct BrickState {
 // and border exchange, the reductions, and the IPC handles themselves.
 struct DirectHalo {
   bool on = false;
+  bool must = false;                    // SF_HALO_DIRECT asked for it without "auto": losing it is an error
+  // 1: receive areas + one unpack kernel per exchange; 2: GHOST SLOTS -- the areas ARE the ghost records ([3][rx_cap]
+  // double4 each: x | v | omega), the neighbours' sub-step kernels write whole records into them and this rank's sub-step
+  // kernel gathers from them: no kernel between two sub-step kernels (DemEngine::brick_set_forward_gs, sf_dem_gs.h)
+  int mode = 1;
   int* my_sync = nullptr;               // one 128-byte line per sending rank: {flag, vote[2]}; peers write, this rank polls
   std::vector<int*> peer_sync;          // every rank's area as mapped here
   double* rx[2] = {nullptr, nullptr};   // receive areas (exchange parity); neighbours write, this rank unpacks
-  size_t rx_cap = 0;
+  size_t rx_cap = 0;                    // doubles (mode 1) / records per array (mode 2)
   long long rx_gen = 0;                 // bumped when the areas are re-allocated: the neighbours re-open their mappings
   struct Peer {
     long long gen_seen = -1;
     void* map[2] = {nullptr, nullptr};  // that rank's receive areas as mapped here
-    long long remote_off = 0;           // where this rank's chunk starts in them (doubles)
+    long long remote_off = 0;           // where this rank's chunk starts in them (doubles; mode 2: ghost records)
+    long long remote_cap = 0;           // mode 2: records per array of that rank's areas
   };
   std::vector<Peer> peers;
   long long xseq = 0;                   // exchanges done so far (the same number on every rank)
   long long* d_msg = nullptr;           // [2][world][kMsg] handle / offset messages (device, for the RCCL exchange)
   long long* h_msg = nullptr;
-  static constexpr int kMsg = 18;       // generation, two 64-byte IPC handles, chunk offset
+  static constexpr int kMsg = 19;       // generation, two 64-byte IPC handles, chunk offset, area stride (mode 2)
   ~DirectHalo()
   {
     for (Peer& p : peers)
@@ -746,7 +752,9 @@ static void direct_messages(HaloComm& hc, hipStream_t st, const std::vector<int>
 static void direct_init(SfLammps& S, HaloComm& hc)
 {
   const char* env = getenv("SF_HALO_DIRECT");
-  const int want = !env ? 0 : (!strcmp(env, "auto") ? -1 : atoi(env));
+  // ("2" / "slots": ghost slots, must come up; "auto2": ghost slots, or the RCCL exchange when the bring-up fails)
+  const bool slots = env && (!strcmp(env, "2") || !strcmp(env, "slots") || !strcmp(env, "auto2"));
+  const int want = !env ? 0 : (!strcmp(env, "auto") || !strcmp(env, "auto2") ? -1 : (slots ? 1 : atoi(env)));
   const bool self_only = hc.world == 1 && hc.brick && (hc.brick->ext[0] || hc.brick->ext[1] || hc.brick->ext[2]);
   if (want == 0 || (hc.world < 2 && !self_only)) return;
   if (hc.world > 32) {
@@ -818,79 +826,149 @@ static void direct_init(SfLammps& S, HaloComm& hc)
     return;
   }
   D.on = true;
-  if (getenv("SF_DEBUG_HALO")) fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes on (%d ranks)\n", hc.rank, W);
+  D.must = want == 1;
+  D.mode = slots ? 2 : 1;
+  if (D.mode == 2) {
+    GsSync y;
+    memset(&y, 0, sizeof(y));
+    y.world = W;
+    y.rank = hc.rank;
+    y.max_ticks = direct_sync(hc, 0, 0).max_ticks;
+    y.my_sync = D.my_sync;
+    for (int p = 0; p < W; p++) y.peer_sync[p] = D.peer_sync[p];
+    e.gs_configure(y, D.xseq + 1);   // (the flags stand at xseq after the first round: launch numbers go on from there)
+  }
+  if (getenv("SF_DEBUG_HALO"))
+    fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes on (%d ranks, %s)\n", hc.rank, W,
+            D.mode == 2 ? "ghost slots" : "receive areas");
 }
 
 // after a rebuild fixed the chunk layout: the receive areas (grown if need be), their handles and this rank's chunk
-// offsets to every neighbour, the neighbours' to this rank; returns the [2][kMaxDirs] table of block starts
-static void direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2)
+// offsets to every neighbour, the neighbours' to this rank; fills the [2][kMaxDirs] table of block starts.
+// Collective, and it FAILS collectively: whatever goes wrong on one rank (an allocation, an IPC handle a neighbour's
+// process cannot open) reaches every rank through an all-reduce -- the ranks then leave the direct transport together
+// (returns false: the caller goes on over RCCL) or, when SF_HALO_DIRECT demanded it, fail together with the reason,
+// instead of one rank throwing while the others spin on flags that will never come.
+static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blkcap = nullptr)
 {
   DirectHalo& D = *hc.direct;
   BrickState& B = *hc.brick;
   DemEngine& e = S.eng;
   hipStream_t st = e.stream();
   const int W = hc.world, K = DirectHalo::kMsg;
-  const size_t need = (size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1;
-  if (need > D.rx_cap) {
-    SF_HIP(hipStreamSynchronize(st));
-    for (double*& b : D.rx) {
-      if (b) SF_HIP(hipFree(b));
-      b = nullptr;
+  const bool gs = D.mode == 2;
+  double ok = 1.0;
+  std::string why;
+  // areas a neighbour may still have mapped are freed only after every rank has seen the new generation (below)
+  double* retired[2] = {nullptr, nullptr};
+  hipIpcMemHandle_t h0, h1;
+  memset(&h0, 0, sizeof(h0));
+  memset(&h1, 0, sizeof(h1));
+  try {
+    if (gs && !e.brick_fused_pack_possible())
+      fail("ghost slots need the sub-step kernel to write the border records itself: not in a brick thinner than twice the "
+           "ghost cutoff, not with SF_HALO_FUSED_PACK=0");
+    // mode 1: the chunks of doubles; mode 2: one record per ghost in each of the three arrays
+    const size_t need = gs ? (size_t)B.rcv.first[B.rcv.n] + 1 : (size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1;
+    if (need > D.rx_cap) {
+      SF_HIP(hipStreamSynchronize(st));
+      for (int k = 0; k < 2; k++) {
+        retired[k] = D.rx[k];
+        D.rx[k] = nullptr;
+      }
+      D.rx_cap = need + need / 2 + 4096;
+      D.rx_gen++;
+      for (double*& b : D.rx) b = static_cast<double*>(alloc_fine_grained(sizeof(double) * D.rx_cap * (gs ? 12 : 1)));
     }
-    D.rx_cap = need + need / 2 + 4096;
-    for (double*& b : D.rx) b = static_cast<double*>(alloc_fine_grained(sizeof(double) * D.rx_cap));
-    D.rx_gen++;
+    SF_HIP(hipIpcGetMemHandle(&h0, D.rx[0]));
+    SF_HIP(hipIpcGetMemHandle(&h1, D.rx[1]));
+  } catch (const std::exception& ex) {
+    ok = 0.0;
+    why = ex.what();
   }
+  // (mode 2) where the ghosts of rank p start among this rank's ghosts: its blocks are contiguous, in its send order
+  std::vector<long long> gfirst(W, 0);
+  if (gs)
+    for (int q = (int)B.rdirs.size() - 1; q >= 0; q--) gfirst[B.rdirs[q].peer] = B.rcv.first[q];
   std::vector<int> nbr(W, 0);
   for (const auto& sd : B.sdirs) nbr[sd.peer] = 1;
-  hipIpcMemHandle_t h0, h1;
-  SF_HIP(hipIpcGetMemHandle(&h0, D.rx[0]));
-  SF_HIP(hipIpcGetMemHandle(&h1, D.rx[1]));
   for (int p = 0; p < W; p++) {
     long long* m = D.h_msg + (size_t)p * K;
     m[0] = D.rx_gen;
     memcpy(m + 1, &h0, 64);
     memcpy(m + 9, &h1, 64);
-    m[17] = hc.recv_off[p];   // where rank p's chunk starts in this rank's areas
+    m[17] = gs ? gfirst[p] : hc.recv_off[p];   // where rank p's chunk starts in this rank's areas
+    m[18] = (long long)D.rx_cap;
   }
   {
     std::vector<int> with = nbr;
     with[hc.rank] = 0;
-    direct_messages(hc, st, with);
+    direct_messages(hc, st, with);   // (every rank takes part, whatever happened to it above)
   }
-  for (int p = 0; p < W; p++) {
-    if (!nbr[p]) continue;
-    const long long* m = D.h_msg + (size_t)(W + p) * K;
-    DirectHalo::Peer& P = D.peers[p];
-    if (p == hc.rank) {   // (SF_HALO_SELF_COMM: this rank's own areas, no handle)
-      P.map[0] = D.rx[0];
-      P.map[1] = D.rx[1];
-      P.remote_off = hc.recv_off[p];
-      continue;
-    }
-    if (m[0] != P.gen_seen) {
-      for (void*& mm : P.map) {
-        if (mm) SF_HIP(hipIpcCloseMemHandle(mm));
-        mm = nullptr;
+  ok = slab_allreduce(hc, st, ok, ncclMin);   // (a handle of a failed rank must not be opened)
+  if (ok != 0.0) {
+    try {
+      for (int p = 0; p < W; p++) {
+        if (!nbr[p]) continue;
+        const long long* m = D.h_msg + (size_t)(W + p) * K;
+        DirectHalo::Peer& P = D.peers[p];
+        if (p == hc.rank) {   // (SF_HALO_SELF_COMM: this rank's own areas, no handle)
+          P.map[0] = D.rx[0];
+          P.map[1] = D.rx[1];
+          P.remote_off = gs ? gfirst[p] : hc.recv_off[p];
+          P.remote_cap = (long long)D.rx_cap;
+          continue;
+        }
+        if (m[0] != P.gen_seen) {
+          for (void*& mm : P.map) {
+            if (mm) SF_HIP(hipIpcCloseMemHandle(mm));
+            mm = nullptr;
+          }
+          hipIpcMemHandle_t a, b;
+          memcpy(&a, m + 1, 64);
+          memcpy(&b, m + 9, 64);
+          SF_HIP(hipIpcOpenMemHandle(&P.map[0], a, hipIpcMemLazyEnablePeerAccess));
+          SF_HIP(hipIpcOpenMemHandle(&P.map[1], b, hipIpcMemLazyEnablePeerAccess));
+          P.gen_seen = m[0];
+        }
+        P.remote_off = m[17];
+        P.remote_cap = m[18];
       }
-      hipIpcMemHandle_t a, b;
-      memcpy(&a, m + 1, 64);
-      memcpy(&b, m + 9, 64);
-      SF_HIP(hipIpcOpenMemHandle(&P.map[0], a, hipIpcMemLazyEnablePeerAccess));
-      SF_HIP(hipIpcOpenMemHandle(&P.map[1], b, hipIpcMemLazyEnablePeerAccess));
-      P.gen_seen = m[0];
+    } catch (const std::exception& ex) {
+      ok = 0.0;
+      why = ex.what();
     }
-    P.remote_off = m[17];
+    ok = slab_allreduce(hc, st, ok, ncclMin);
+  }
+  // (every rank has closed its mappings of the old generation, or never will use them again: the old areas can go)
+  for (double* b : retired)
+    if (b) (void)hipFree(b);
+  if (ok == 0.0) {
+    D.on = false;
+    e.gs_off();
+    if (D.must)
+      fail("SF_HALO_DIRECT: the direct transport was lost at a rebuild (%s)", why.empty() ? "on another rank" : why.c_str());
+    if (getenv("SF_DEBUG_HALO"))
+      fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes off from this rebuild on, RCCL exchange (%s)\n", hc.rank,
+              why.empty() ? "another rank failed" : why.c_str());
+    return false;
   }
   // block q of this rank's chunk for peer p sits where it sits in the local send buffer, relative to the chunk's start
-  for (int par = 0; par < 2; par++)
-    for (int q = 0; q < DemEngine::kMaxDirs; q++) {
-      blk2[par * DemEngine::kMaxDirs + q] = nullptr;
-      if (q >= (int)B.sdirs.size()) continue;
-      const int p = B.sdirs[q].peer;
+  // (mode 2: behind the records of the earlier blocks for the same peer, in that peer's x array)
+  std::vector<long long> sent(W, 0);
+  for (int q = 0; q < DemEngine::kMaxDirs; q++) {
+    for (int par = 0; par < 2; par++) blk2[par * DemEngine::kMaxDirs + q] = nullptr;
+    if (blkcap) blkcap[q] = 0;
+    if (q >= (int)B.sdirs.size()) continue;
+    const int p = B.sdirs[q].peer;
+    for (int par = 0; par < 2; par++)
       blk2[par * DemEngine::kMaxDirs + q] =
-          static_cast<double*>(D.peers[p].map[par]) + D.peers[p].remote_off + (B.snd.off[q] - hc.send_off[p]);
-    }
+          gs ? static_cast<double*>(D.peers[p].map[par]) + 4 * (D.peers[p].remote_off + sent[p])
+             : static_cast<double*>(D.peers[p].map[par]) + D.peers[p].remote_off + (B.snd.off[q] - hc.send_off[p]);
+    if (blkcap) blkcap[q] = (size_t)D.peers[p].remote_cap;
+    sent[p] += B.nsend[q];
+  }
+  return true;
 }
 
 static void brick_rebuild(SfLammps& S, HaloComm& hc)
@@ -1031,13 +1109,16 @@ static void brick_rebuild(SfLammps& S, HaloComm& hc)
   L.dev_tx = hc.a2a_tx.need((size_t)(hc.send_off[W - 1] + hc.send_cnt[W - 1]) + 1);
   L.dev_rx = hc.a2a_rx.need((size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1);
   hc.lay_valid = true;
-  if (hc.direct && hc.direct->on) {
-    double* blk2[2 * DemEngine::kMaxDirs];
-    direct_rebuild(S, hc, blk2);
+  double* blk2[2 * DemEngine::kMaxDirs];
+  size_t blkcap[DemEngine::kMaxDirs];
+  if (hc.direct && hc.direct->on && hc.direct->mode == 2 && direct_rebuild(S, hc, blk2, blkcap)) {
+    double4* area[2] = {reinterpret_cast<double4*>(hc.direct->rx[0]), reinterpret_cast<double4*>(hc.direct->rx[1])};
+    e.brick_set_forward_gs(B.snd, area, (int)hc.direct->rx_cap, reinterpret_cast<double4* const*>(blk2), blkcap);
+  } else if (hc.direct && hc.direct->on && hc.direct->mode == 1 && direct_rebuild(S, hc, blk2)) {
     e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1, blk2);
     e.set_tx_parity((int)(hc.direct->xseq & 1));
   } else {
-    e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1);
+    e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1);   // (the RCCL exchange; also after a lost direct transport)
   }
   hc.rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
@@ -1051,6 +1132,22 @@ static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int
   DemEngine& e = S.eng;
   hipStream_t main = e.stream();
   const int nh = hc.world - 1;
+  if (hc.direct && hc.direct->on && hc.direct->mode == 2) {
+    // ghost slots: the sub-step kernels hand the border records and the votes to each other; what is left for the host
+    // is the stand-alone pack in front of a launch no sub-step kernel has written the records for (start of a run, first
+    // launch after a rebuild) and, at the end of a piece that stops early, the wait for the last votes
+    for (int s = first_k; s < end_k; s++) {
+      if (!e.forward_tx_written()) e.gs_pack();
+      e.substep_k(s == n - 1, s);
+    }
+    if (end_k < n) e.gs_close(end_k);
+    const int trigger = e.batch_end(first_k, end_k - first_k);
+    if (e.halo_timeout())
+      fail("ghost slots: rank %d waited for the flag of launch %d, rank %d stood at %d when the wait ran out (a peer died, or "
+           "the ranks disagree about the launches they queue); SF_HALO_DIRECT=0 selects the RCCL exchange",
+           hc.rank, e.halo_timeout(), e.halo_timeout_peer(), e.halo_timeout_seen());
+    return trigger;
+  }
   auto exchange = [&]() {
     // (the sub-step kernel that integrated the border atoms has written their records and the vote headers itself;
     // the pack kernel runs only in front of the first sub-step after a rebuild / at the start of a run)
@@ -1567,7 +1664,7 @@ int sf_slab_direct_halo(void* ptr)
 {
   SF_API_BEGIN
   auto* hc = static_cast<sf::HaloComm*>(H(ptr)->halo);
-  const int on = hc && hc->direct && hc->direct->on ? 1 : 0;
+  const int on = hc && hc->direct && hc->direct->on ? hc->direct->mode : 0;   // (1: receive areas, 2: ghost slots)
   SF_API_END(on)
 }
 

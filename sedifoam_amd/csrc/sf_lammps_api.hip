@@ -465,10 +465,18 @@ int sf_lammps_open_world(int, char**, intptr_t comm, int rank, int world, const 
   if (world < 1 || rank < 0 || rank >= world) sf::fail("sf_lammps_open_world: rank %d of %d", rank, world);
   if (world > 1 && !id128) sf::fail("sf_lammps_open_world: %d ranks need the communicator id of rank 0", world);
   // one process per GPU: choose the device BEFORE the engine creates its stream and buffers
+  // (SF_DEVICE pins it; otherwise the NODE-LOCAL rank the launcher exports -- mpirun / srun / torchrun -- and only then the
+  // global rank modulo the device count, which is right when ranks are placed node by node in blocks of the device count)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 1 && world > 1) {
-    const char* want = getenv("SF_DEVICE");
-    SF_HIP(hipSetDevice(want ? atoi(want) : rank % ndev));
+    int local = rank;
+    for (const char* name : {"SF_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK",
+                             "SLURM_LOCALID", "LOCAL_RANK"})
+      if (const char* v = getenv(name)) {
+        local = atoi(v);
+        break;
+      }
+    SF_HIP(hipSetDevice(((local % ndev) + ndev) % ndev));
   }
   SfLammps* L = new SfLammps();
   L->comm = comm;

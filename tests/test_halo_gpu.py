@@ -272,8 +272,8 @@ _BRICK_CASES = [((2, 1, 2), (8, 5, 8), "hertz", True), ((2, 2, 2), (8, 8, 8), "h
 # (eight processes that all spin on flags time-slice the ONE GPU of the box: correct, but tens of seconds per case)
 @pytest.mark.parametrize("grid,ncells,physics,periodic_x,direct",
                          [c + ("0",) for c in _BRICK_CASES] +
-                         [c + ("1",) for c in _BRICK_CASES if c[0][0] * c[0][1] * c[0][2] <= 6 or c[1] in ((8, 8, 8), (12, 5, 8))
-                          and c[2] == "hertz"])
+                         [c + (d,) for d in ("1", "2") for c in _BRICK_CASES
+                          if c[0][0] * c[0][1] * c[0][2] <= 6 or c[1] in ((8, 8, 8), (12, 5, 8)) and c[2] == "hertz"])
 def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncells, physics, periodic_x, direct):
     """The brick driver (sf_brick_init + sf_slab_setup / _step / _rebuild): a 3-D processor grid -- 2 x 1 x 2 and
     2 x 2 x 2 (BASELINE config C4's 8 GPUs; the y cut crosses the wall dimension, the end bricks have a face without a
@@ -285,7 +285,10 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncell
     direct = "1": the forward halo by DIRECT GHOST WRITES (SF_HALO_DIRECT=1: required to come up) -- every rank's sub-step
     kernel writes its border records through IPC mappings into the receive areas of the neighbours' processes, one kernel
     per exchange publishes / awaits the per-rank flags and votes; "0": one grouped send / receive per sub-step over the
-    wire.  Both must reproduce the single-domain run."""
+    wire; "2": GHOST SLOTS (SF_HALO_DIRECT=2) -- the border records go straight into the neighbours' ghost records (two
+    fine-grained areas the sub-step kernel gathers from), the last workgroup of a sub-step kernel publishes the vote and
+    the flag, the next sub-step kernel waits for the flags at its gate: no kernel between two sub-step kernels.  All three
+    must reproduce the single-domain run."""
     import socket
     import torch.multiprocessing as mp
     monkeypatch.setenv("SF_HALO_DIRECT", direct)

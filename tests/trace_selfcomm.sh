@@ -7,7 +7,7 @@
 tag=$1; n=${2:-125000}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-SF_HALO_SELF_COMM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/kt_$tag -o p -- \
+SF_HALO_SELF_COMM=1 SF_HALO_DIRECT_TIMEOUT=10 timeout -k 20 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/kt_$tag -o p -- \
   python $root/bench.py --slab-driver --particles $n --steps 4 --warmup 1 --no-cpu-baseline --no-coupled --no-configs --no-kernel-profile $BENCH_EXTRA > $root/gpurun_out/kt_$tag.log 2>&1
 cd $root
 tail -1 gpurun_out/kt_$tag.log | cut -c1-300
