@@ -549,7 +549,9 @@ def main():
             par = {"against": "the same %d-particle bed on ONE domain (rank 0's GPU), setup + %d sub-steps from the same "
                               "start; the %d domains gathered by tag" % (len(ref["tag"]), sub, world),
                    "n": int(len(ref["tag"])), "substeps": sub, "tags_identical": same,
-                   "halo": "direct ghost writes" if direct_on else "RCCL exchange"}
+                   "halo": {0: "RCCL exchange", 1: "direct ghost writes (receive areas + one unpack kernel per exchange)",
+                            2: "ghost slots (border records straight into the neighbours' ghost records, no kernel "
+                               "between two sub-step kernels)"}.get(direct_on, "direct ghost writes")}
             if same:
                 dx = np.concatenate([q["x"] for q in parts])[o] - ref["x"]
                 per = np.array(gbed["periodic"], bool)
@@ -565,22 +567,30 @@ def main():
             ok = par["ok"]
         return par, all_ok(ok), direct_on
 
-    # N > 1, before anything is timed: the parity leg, first with the direct ghost writes (SF_HALO_DIRECT=auto: bricks whose
-    # sub-step kernels write their border records straight into the neighbours' receive areas), and -- should that
-    # transport not come up, run out of time or disagree with the single-domain run on this node -- once more over RCCL,
-    # which then also carries the timed runs.  The line says which one it was.
+    # N > 1, before anything is timed: the parity leg, first with the ghost slots (SF_HALO_DIRECT=auto2: the sub-step
+    # kernels write their border records straight into the neighbours' ghost records and hand over with flags, nothing
+    # between two sub-step kernels), then -- should that transport not come up, run out of time or disagree with the
+    # single-domain run on this node -- with the direct ghost writes into receive areas (auto: one unpack kernel per
+    # exchange), then over RCCL; the transport that passed also carries the timed runs.  The line says which one it was.
     parity_first, halo_note = None, None
     parity_ok = True
     if world > 1 and not args.no_parity and args.scaling != "weak":
         asked = os.environ.get("SF_HALO_DIRECT")
-        if asked is None:
-            os.environ["SF_HALO_DIRECT"] = "auto"
-        parity_first, ok_all, was_direct = decomposed_parity()
-        if not ok_all and os.environ.get("SF_HALO_DIRECT") != "0":
-            os.environ["SF_HALO_DIRECT"] = "0"
-            halo_note = ("direct ghost writes were tried first and %s; the RCCL exchange carried the run"
-                         % ("disagreed with the single-domain run" if parity_first is not None else "did not run through"))
+        ladder = ["auto2", "auto", "0"] if asked is None else ([asked] if asked == "0" else [asked, "0"])
+        tried = []
+        for transport in ladder:
+            os.environ["SF_HALO_DIRECT"] = transport
             parity_first, ok_all, was_direct = decomposed_parity()
+            if ok_all and (was_direct or transport == ladder[-1]):
+                break
+            if ok_all:   # ("auto*": the bring-up failed on some rank and the library fell back to RCCL by itself)
+                tried.append("SF_HALO_DIRECT=%s did not come up" % transport)
+                continue
+            tried.append("SF_HALO_DIRECT=%s %s" % (transport, "disagreed with the single-domain run"
+                                                   if parity_first is not None else "did not run through"))
+        if tried:
+            halo_note = "tried first: " + "; ".join(tried) + ("" if not ok_all else "; SF_HALO_DIRECT=%s carried the run"
+                                                               % os.environ["SF_HALO_DIRECT"])
         parity_ok = ok_all
 
     # N > 1: BASELINE config C4 -- ONE --particles bed split into `world` spatial domains -- is the headline (`value`,

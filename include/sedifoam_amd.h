@@ -263,13 +263,16 @@ int sf_slab_step(void *ptr, int n);
  * and the `run` command then ARE sf_slab_step(ptr, n) (interfaceToLammps/library.cpp:372-386 is the same call on
  * one rank and on N) */
 int sf_slab_active(void *ptr);
-/* 1 when the forward halo of this (brick) engine goes by DIRECT GHOST WRITES: the sub-step kernel writes the border atoms'
- * records straight into the neighbour ranks' receive areas (IPC mappings of fine-grained device memory, opened at
- * sf_brick_init / at a rebuild) and one kernel per exchange publishes and awaits a flag word per rank -- no RCCL kernel
- * and no pack / unpack pass between two sub-steps.  SF_HALO_DIRECT unset or 0: the RCCL exchange; "auto": tried at
- * sf_brick_init with a flag round between all ranks, RCCL exchange when it does not come up on every rank; 1: required
- * (sf_brick_init fails otherwise).  A flag that does not arrive within SF_HALO_DIRECT_TIMEOUT seconds (20) is an error
- * of sf_slab_step, never a hang. */
+/* How the forward halo of this (brick) engine travels.  0: the RCCL exchange (one grouped send / receive + an unpack kernel
+ * per sub-step).  1: DIRECT GHOST WRITES -- the sub-step kernel writes the border atoms' records straight into the
+ * neighbour ranks' receive areas (IPC mappings of fine-grained device memory, opened at sf_brick_init / at a rebuild) and
+ * one kernel per exchange publishes and awaits a flag word per rank.  2: GHOST SLOTS -- the records go straight into the
+ * ghost range of the neighbours' record arrays (IPC mappings of the arrays themselves), the sub-step kernel's last wave
+ * publishes vote and flag and the next sub-step kernel waits for the flags at its gate: NO kernel between two sub-step
+ * kernels.  SF_HALO_DIRECT unset or 0: RCCL; 1 / 2: that transport, required (sf_brick_init or the rebuild fails on every
+ * rank otherwise); "auto" / "auto2": tried with a flag round between all ranks, RCCL exchange when it does not come up on
+ * every rank or is lost at a later rebuild.  A flag that does not arrive within SF_HALO_DIRECT_TIMEOUT seconds (20) is an
+ * error of sf_slab_step, never a hang. */
 int sf_slab_direct_halo(void *ptr);
 long long sf_slab_rebuild_count(void *ptr);
 /* values[0..n) summed over the ranks of the engine's communicator, in place on the host (MPI_Allreduce(MPI_SUM) of

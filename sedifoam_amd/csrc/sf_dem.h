@@ -145,15 +145,15 @@ struct DemPtrs {
                                 // neighbour's uncached area is made of
   const int* tx_hdr_off;
   int* xcd_time;                // StepParams::xcd_time: [64 x + 0] first start, [64 x + 32] last end of XCD x (100 MHz clock)
-  // ghost slots (StepParams::gs_on, sf_halo_rccl.hip): the records of the ghosts of other GPUs are NOT in xr / vm / om but
-  // in a fine-grained area the neighbours' sub-step kernels write straight into: [3][gs_cap] double4 (x | v | omega of
-  // ghost g at index g - nlocal), read with system-coherent loads.  tx_blkptr[q] then is where the x record of block q's
-  // first atom goes in the NEIGHBOUR's area, tx_blkcnt[q] that area's stride (its gs_cap), tx_blkshift[3 q ..] the
-  // periodic shift the sender adds.  gs_sync: who to wait for and who to tell (GsSync), gs_count: completion counters.
-  const double4* gs_in;
+  // ghost slots (StepParams::gs_on, sf_halo_rccl.hip, sf_dem_gs.h): the neighbours' sub-step kernels write the records of
+  // this rank's ghosts straight into the ghost range of xr / vm / om.  On the sending side tx_blkptr is then [3][kMaxDirs]:
+  // where block q's first x | v | omega record goes in the NEIGHBOUR's arrays (the buffer its launch of the next number
+  // reads), tx_blkshift[3 q ..] the periodic shift the sender adds.  gs_sync: who to wait for and who to tell (GsSync),
+  // gs_count: completion counters.
   const double* tx_blkshift;
   const struct GsSync* gs_sync;
-  int* gs_count;                // [9][32]: one line per XCD (workgroups done), then the XCDs done
+  int* gs_my_sync;              // GsSync::my_sync (the flag / vote lines the gate polls)
+  int* gs_count;                // [8][32]: one line per XCD, a 64-bit word each: workgroups done + 2^32 x those that triggered
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -212,11 +212,12 @@ struct StepParams {
                            // to kBrickSlots) record positions up in DemPtrs::bslot and writes its new x, v, omega there,
                            // unshifted (the receiver adds the periodic shift of the block)
   double tx_lo3[3], tx_hi3[3];
-  // ghost slots (tx_fused == 3 on the sending side): gs_on -- ghost records live in DemPtrs::gs_in ([3][gs_cap]); gs_seq --
+  // ghost slots: gs_on -- the ghost records of this launch's input buffers were written by the neighbours' kernels; gs_seq --
   // the number of this launch: its waves wait until every rank's flag says gs_seq ("my records for launch gs_seq are in
-  // your area", gs_wait = 0: nobody to wait for) and read the votes of parity gs_seq & 1; the last workgroup to finish
-  // stores this rank's vote and the flag gs_seq + 1 into every rank's line
-  int gs_on, gs_cap, gs_seq, gs_wait;
+  // your arrays", gs_wait = 0: nobody to wait for) and read the votes of parity gs_seq & 1; the wave that stays behind
+  // (sf_dem_gs.h) stores this rank's vote and the flag gs_seq + 1 into every rank's line
+  int gs_on, gs_seq, gs_wait;
+  int gs_world, gs_rank;   // (copies of GsSync::world / rank: the gate reads them from the kernel arguments)
   int tx_n[2];             // atoms in the left / right send list (a face's block is [kForwardDoubles][tx_n])
   double tx_xlo, tx_xhi, tx_shift[2];
 };
@@ -488,17 +489,23 @@ class DemEngine {
   void brick_direct_unpack(const BrickBlocks& rcv, const double* recvarea, const DirectSync& D);
   bool brick_direct_probe(const BrickBlocks& none, const DirectSync& D);   // bring-up: one flag round, no records; synchronises;
                                                                             // false = a peer's flag did not arrive in time
-  // ---- ghost slots (SF_HALO_DIRECT=2, sf_halo_rccl.hip): NO kernel between two sub-step kernels.  The ghosts of other
-  // GPUs live in two fine-grained areas [3][cap] double4 (x | v | omega records, by the parity of the launch number)
-  // that the neighbours' sub-step kernels write straight into; a sub-step kernel waits at its gate for every rank's flag
-  // (DemPtrs::gs_sync) and the last workgroup to finish publishes this rank's vote and flag.  Launches are numbered by
-  // gs_seq(): the same number on every rank (all ranks queue the same launches).
+  // ---- ghost slots (SF_HALO_DIRECT=2, sf_halo_rccl.hip): NO kernel between two sub-step kernels.  The neighbours'
+  // sub-step kernels write the records of this rank's ghosts straight into the ghost range of its record arrays (IPC
+  // mappings of xr / vm / om themselves); a sub-step kernel waits at its gate for every rank's flag (DemPtrs::gs_sync)
+  // and one wave that stays behind publishes this rank's vote and flag.  Launches are numbered by gs_seq(): the same
+  // number on every rank (all ranks queue the same launches).
   void gs_configure(const GsSync& sync, long long first_seq);   // once per communicator: device copy of the sync table,
                                                                 // counters; first_seq: the number of the first launch
-  // after every rebuild: this rank's areas and, per send block, where its first x record goes in the neighbour's area of
-  // each parity (blk2[par * kMaxDirs + q]) and that area's stride (blkcap[q])
-  void brick_set_forward_gs(const BrickBlocks& snd, double4* const area[2], int cap, double4* const* blk2,
-                            const size_t* blkcap);
+  // the record arrays a launch whose number has parity `par` READS (what the neighbours must write the ghosts of that
+  // launch into), as things stand now: valid until the next rebuild (a rebuild may swap allocations, a trigger shifts the
+  // parity of the buffers against the launch numbers)
+  void gs_input_arrays(int par, void** x, void** v, void** w) const;
+  // after every rebuild: per send block q and launch parity, where its first x | v | omega record goes in the neighbour's
+  // arrays: blk6[(par * 3 + a) * kMaxDirs + q]
+  void brick_set_forward_gs(const BrickBlocks& snd, double4* const* blk6);
+  // false when the buffers were flipped since then by something that is not a numbered launch (the setup evaluation):
+  // the neighbours' tables then point at the wrong buffer of this rank and must be made again
+  bool gs_mapping_valid() const { return gs_ready_ && ((cur_ ^ (int)(gs_seq_ & 1)) == gs_map_base_); }
   void gs_off();                                     // back to the other transports (areas gone)
   // can the sub-step kernel write the border records itself (what ghost slots rest on)?  Not in a brick thinner than twice
   // the ghost cutoff (brick_set_forward_tx) and not with SF_HALO_FUSED_PACK=0
@@ -744,13 +751,15 @@ private:
   bool tx_direct_ = false;             // records go straight into the neighbours' receive areas
   bool gs_ready_ = false;              // ghost slots: the tables below are valid
   GsSync* d_gs_sync_ = nullptr;
+  GsSync h_gs_sync_{};
   int* d_gs_count_ = nullptr;          // [9][32] completion counters (zero between launches)
-  double4* gs_area_[2] = {nullptr, nullptr};
-  int gs_cap_ = 0;
   long long gs_seq_ = 1;
+  int gs_map_base_ = 0;                // buffer that launches of EVEN number read, as the neighbours were told
   int tx_par_ = 0;
   double** d_blkptr_ = nullptr;        // [2][kMaxDirs] device table of block starts (both rows equal unless tx_direct_),
-                                       // then [kMaxDirs] records per block (size_t), then [kMaxDirs][3] shifts (ghost slots)
+                                       // then [kMaxDirs] records per block (size_t)
+  double** d_gsblk_ = nullptr;         // ghost slots: [2][3][kMaxDirs] block starts in the neighbours' x | v | omega arrays,
+                                       // then [kMaxDirs][3] shifts
   DevArray isb_;                       // (check only, SF_CHECK_BOUNDARY=1) list-derived boundary flags
   // brick decomposition: directions, face masks of the owned atoms, concatenated send lists
   int bndir_ = 0;

@@ -702,9 +702,9 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   static_assert(sizeof(size_t) == sizeof(double*), "the count row of the block table");
   P.tx_blkcnt = d_blkptr_ ? reinterpret_cast<const size_t*>(d_blkptr_ + 2 * (size_t)kMaxDirs) : nullptr;
   P.tx_hdr_off = tx_hdr_off_;
-  P.gs_in = nullptr;
   P.tx_blkshift = nullptr;
   P.gs_sync = nullptr;
+  P.gs_my_sync = nullptr;
   P.gs_count = nullptr;
   P.xcd_time = d_xcd_time_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
@@ -876,14 +876,16 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   const bool gs = gs_ready_ && brick_ && part == 0 && !lds_active_ && mode != 2;
   if (gs) {
     S.gs_on = 1;
-    S.gs_cap = gs_cap_;
     S.gs_seq = (int)gs_seq_;
-    S.gs_wait = 1;
-    P.gs_in = gs_area_[gs_seq_ & 1];
+    S.gs_wait = h_gs_sync_.world > 1 ? 1 : 0;   // (one rank that exchanges with itself: stream order is the hand-off)
+    S.gs_world = h_gs_sync_.world;
+    S.gs_rank = h_gs_sync_.rank;
+    P.gs_my_sync = h_gs_sync_.my_sync;
     P.gs_sync = d_gs_sync_;
     P.gs_count = d_gs_count_;
-    P.tx_blkptr = d_blkptr_ + (size_t)((gs_seq_ + 1) & 1) * kMaxDirs;
-    P.tx_blkshift = reinterpret_cast<const double*>(d_blkptr_ + 3 * (size_t)kMaxDirs);
+    // (the records of the NEXT launch: the neighbours read them from the buffers of that launch's parity)
+    P.tx_blkptr = d_gsblk_ + (size_t)((gs_seq_ + 1) & 1) * 3 * kMaxDirs;
+    P.tx_blkshift = reinterpret_cast<const double*>(d_gsblk_ + 6 * (size_t)kMaxDirs);
     gs_seq_++;
   }
   if (part) {

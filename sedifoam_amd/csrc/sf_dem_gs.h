@@ -8,31 +8,46 @@
 namespace sf {
 
 // ------------------------------------------------------------------------------------------------
-// ghost slots (decomposed domain, template parameter GS of the sub-step kernel): the records of the ghosts of other GPUs
-// live in a fine-grained area the NEIGHBOURS' sub-step kernels write straight into (IPC mapping), so nothing stands
-// between two sub-step kernels.  Both sides use system-coherent accesses (sc0 sc1: write-through stores, loads that take
-// nothing from L1 / L2), the hand-off is {records, s_waitcnt vmcnt(0), completion count, vote, flag} on the sending side
-// and {flag poll, vote, records} on the receiving side: no fence instruction anywhere (MI355X_MICROARCH.md, visibility).
+// ghost slots (decomposed domain, template parameter GS of the sub-step kernel): the neighbours' sub-step kernels write the
+// records of this rank's ghosts straight into the ghost range of its record arrays xr / vm / om (IPC mappings of the
+// arrays themselves), so nothing stands between two sub-step kernels and the gathers of the sub-step kernel are the same
+// instructions for owned atoms and ghosts.  The writer uses write-through system-scope stores; the hand-off is
+// {records, s_waitcnt vmcnt(0), completion count, vote, flag} on the sending side and {flag poll, vote, gathers} on the
+// receiving side.  The reader needs no fence: a kernel starts with its caches invalidated, and no wave touches a cache
+// line that holds ghost records before its gate has seen every flag (the waves whose OWN records share a line with the
+// first ghosts pass the gate before their first load).
 // ------------------------------------------------------------------------------------------------
-typedef unsigned int sf_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double4 gs_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off)
-{
-  constexpr int kSystem = 17;   // aux bits of the buffer instructions: sc0 | sc1
-  const sf_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, kSystem);
-  const sf_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off + 16, 0, kSystem);
-  return {__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z),
-          __hiloint2double((int)b.y, (int)b.x), __hiloint2double((int)b.w, (int)b.z)};
-}
 __device__ __forceinline__ void gs_store(double4* p, double a, double b, double c, double d)
 {
+#ifdef SF_GS_EXP_PLAIN_STORE   // (pricing arm of tests/ab_gs_arms.sh: not a correct hand-off)
+  *p = double4{a, b, c, d};
+  return;
+#endif
   double* q = reinterpret_cast<double*>(p);
   __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(q + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(q + 3, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// (flag words are 32-bit launch numbers compared by their difference, so the count may wrap)
+// A rank's line in another rank's sync area holds ONE 64-bit word: (flag << 32) | vote -- the number of the launch this
+// rank's records are in place for, and its vote for that launch (the sub-step index of its trigger, INT_MAX: none) --
+// written by ONE store and read by ONE load: nothing to order.  A flag AHEAD of the launch a reader is in means "no vote":
+// the sender has run the reader's launch number itself, which a trigger of its own would have stopped at the first test.
+// (32-bit launch numbers compared by their difference, so the count may wrap)
 __device__ __forceinline__ bool gs_behind(int flag, int seq) { return (int)((unsigned)flag - (unsigned)seq) < 0; }
+__device__ __forceinline__ unsigned long long gs_word(int flag, int vote)
+{
+  return ((unsigned long long)(unsigned)flag << 32) | (unsigned long long)(unsigned)vote;
+}
+__device__ __forceinline__ int gs_flag_of(unsigned long long w) { return (int)(unsigned)(w >> 32); }
+__device__ __forceinline__ int gs_vote_of(unsigned long long w, int seq)
+{
+  return gs_flag_of(w) == seq ? (int)(unsigned)(w & 0xffffffffull) : INT_MAX;
+}
+__device__ __forceinline__ unsigned long long gs_read_line(int* line)
+{
+  return __hip_atomic_load(reinterpret_cast<unsigned long long*>(line), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // The gate of a wave: every rank's flag must have reached the number of this launch (its records and its vote are then in
 // place), bounded by GsSync::max_ticks (F_HALO_TIMEOUT: an error of the step, never a hang).  Returns false when the wave
 // must not run: a rank voted for a rebuild at an earlier sub-step (the vote is folded into this rank's trigger word, so
@@ -48,25 +63,25 @@ __device__ __forceinline__ bool gs_gate(const GsSync* Y, int* flags, const int s
     const int r = base + pos;
     const bool mine = r < W && r != me;
     int* line = Y->my_sync + kGsStride * (mine ? r : me);
-    int f = seq;
-    if (mine) f = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (__ballot(gs_behind(f, seq))) {
+    unsigned long long w = gs_word(seq, INT_MAX);
+    if (mine) w = gs_read_line(line);
+    if (__ballot(gs_behind(gs_flag_of(w), seq))) {
       const long long t0 = wall_clock64();
       for (;;) {
         __builtin_amdgcn_s_sleep(2);
-        if (mine) f = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!__ballot(gs_behind(f, seq))) break;
+        if (mine) w = gs_read_line(line);
+        if (!__ballot(gs_behind(gs_flag_of(w), seq))) break;
         if (wall_clock64() - t0 > Y->max_ticks) {
-          if (mine && gs_behind(f, seq)) {
+          if (mine && gs_behind(gs_flag_of(w), seq)) {
             flags[F_HALO_TIMEOUT_PEER] = r;
-            flags[F_HALO_TIMEOUT_SEEN] = f;
+            flags[F_HALO_TIMEOUT_SEEN] = gs_flag_of(w);
             flags[F_HALO_TIMEOUT] = seq;
           }
           return false;
         }
       }
     }
-    if (mine) vote = min(vote, __hip_atomic_load(line + 1 + (seq & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    if (mine) vote = min(vote, gs_vote_of(w, seq));
   }
   // (no shuffle reduction: the lanes beyond the last atom are inactive and their registers hold anything)
   const bool stale = vote < kstep;
@@ -76,7 +91,8 @@ __device__ __forceinline__ bool gs_gate(const GsSync* Y, int* flags, const int s
   }
   return true;
 }
-// this rank's vote and then its flag `seq` into every other rank's line (one wave; the caller has drained its stores)
+// this rank's flag `seq` and its vote for that launch into every other rank's line (one wave; the caller has drained the
+// record stores the flag stands for)
 __device__ __forceinline__ void gs_publish(const GsSync* Y, const int vote, const int seq)
 {
   const int W = Y->world, me = Y->rank;
@@ -86,44 +102,55 @@ __device__ __forceinline__ void gs_publish(const GsSync* Y, const int vote, cons
   for (int base = 0; base < W; base += nact) {
     const int r = base + pos;
     if (r < W && r != me)
-      __hip_atomic_store(Y->peer_sync[r] + kGsStride * me + 1 + (seq & 1), vote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int base = 0; base < W; base += nact) {
-    const int r = base + pos;
-    if (r < W && r != me)
-      __hip_atomic_store(Y->peer_sync[r] + kGsStride * me, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(Y->peer_sync[r] + kGsStride * me), gs_word(seq, vote),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-// The end of a workgroup (one wave): its border records and its trigger have left (vmcnt), it counts itself done on its
-// XCD's line; the last one of an XCD counts the XCD, the last XCD tells every rank: vote first, then the flag.
-// `expected`: workgroups of this XCD that run the kernel, `nxcd`: XCDs that have any.
-__device__ __forceinline__ void gs_done(const DemPtrs& P, const StepParams& S, int expected, int nxcd)
+// The end of a workgroup (one wave).  A wave that wrote border records waits until those have left (vmcnt), then every
+// wave counts itself done on its XCD's line with ONE fire-and-forget 64-bit atomic: +1, and +2^32 when one of its atoms
+// moved beyond skin / 2 (this launch's vote travels with the count: no second word to order, nothing to wait for).  ONE
+// wave of the launch (`poller`: the first workgroup of the first XCD that has any) stays behind, watches the eight counters
+// until every XCD has counted all of its workgroups, clears them and tells every rank: vote first, then the flag.
+// `expected_lane`: workgroups of XCD x that run the kernel (the poller's lane x < 8 holds it).
+__device__ __forceinline__ void gs_done(const DemPtrs& P, const StepParams& S, const bool wrote, const bool triggered,
+                                        const bool poller, const int expected_lane)
 {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SF_GS_EXP_NODONE
+  return;
+#endif
+#ifndef SF_GS_EXP_NOWAIT
+  if (__ballot(wrote)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   const int lane = threadIdx.x & 63;
-  const unsigned long long act = __ballot(1);
-  const int first = __ffsll((long long)act) - 1;
-  int last = 0;
-  if (lane == first) {
-    int* c = P.gs_count + 32 * (int)(blockIdx.x & 7);
-    if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == expected) {
-      __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int* t = P.gs_count + 32 * 8;
-      if (__hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == nxcd) {
-        __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
+  const unsigned long long trig = __ballot(triggered) ? (1ull << 32) : 0ull;
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(P.gs_count);
+  if (lane == 0)
+    (void)__hip_atomic_fetch_add(cnt + 16 * (int)(blockIdx.x & 7), 1ull + trig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!poller) return;
+  // (a full wave: in the ghost-slot kernel the lanes beyond the last atom do not return before the hand-off)
+  const GsSync* Y = P.gs_sync;
+  const long long t0 = wall_clock64();
+  unsigned long long c = 0;
+  for (;;) {
+    c = (unsigned long long)(unsigned)expected_lane;
+    if (lane < 8) c = __hip_atomic_load(cnt + 16 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!__ballot(lane < 8 && (unsigned)c != (unsigned)expected_lane)) break;
+    if (wall_clock64() - t0 > Y->max_ticks) {
+      if (lane == 0) {
+        P.flags[F_HALO_TIMEOUT_PEER] = Y->rank;   // (this rank's own launch did not complete)
+        P.flags[F_HALO_TIMEOUT_SEEN] = -1;
+        P.flags[F_HALO_TIMEOUT] = S.gs_seq;
       }
+      return;
     }
+    __builtin_amdgcn_s_sleep(2);
   }
-  if (!__ballot(last)) return;
-  // (the trigger word as the memory side holds it: a read-modify-write, not a load some cache could answer)
-  int vote = 0;
-  if (lane == first) vote = atomicMin(&P.flags[F_TRIGGER], INT_MAX);
-  vote = __shfl(vote, first, 64);
-  gs_publish(P.gs_sync, vote, S.gs_seq + 1);
+  if (lane < 8) __hip_atomic_store(cnt + 16 * lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // this rank's vote: a trigger of an EARLIER sub-step would have stopped this launch at its first test, so the vote is
+  // this sub-step's index when any wave counted a trigger, "none" otherwise
+  const int vote = __ballot(lane < 8 && (c >> 32) != 0) ? S.kstep + S.trig_add : INT_MAX;
+  gs_publish(Y, vote, S.gs_seq + 1);
 }
-
 
 // a rank that owns no atom launches no sub-step kernel: its part of the hand-off alone (the gate, then vote and flag)
 __global__ __launch_bounds__(64) static void k_gs_idle(const GsSync* Y, int* flags, int seq, int kstep, int publish)
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(64) static void k_gs_idle(const GsSync* Y, int* fla
   if (__atomic_load_n(&flags[F_TRIGGER], __ATOMIC_RELAXED) < kstep) return;
   if (__atomic_load_n(&flags[F_HALO_TIMEOUT], __ATOMIC_RELAXED) != 0) return;
   if (!gs_gate(Y, flags, seq, kstep)) return;
-  if (publish) gs_publish(Y, INT_MAX, seq + 1);
+  if (publish) gs_publish(Y, INT_MAX, seq + 1);   // (no atom: no trigger of its own)
 }
 
 }  // namespace sf

@@ -781,7 +781,7 @@ void DemEngine::brick_set_forward_tx(const BrickBlocks& snd, double* sendbuf, co
   tx_nhdr_ = nhdr;
   gs_ready_ = false;
   {
-    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 6 * kMaxDirs));
+    if (!d_blkptr_) SF_HIP(hipMalloc(&d_blkptr_, sizeof(double*) * 3 * kMaxDirs));
     double* h[3 * kMaxDirs];
     for (int par = 0; par < 2; par++)
       for (int q = 0; q < kMaxDirs; q++)
@@ -985,21 +985,20 @@ void DemEngine::brick_direct_unpack(const BrickBlocks& rcv, const double* recvar
 // ------------------------------------------------------------------------------------------------
 // ghost slots: the stand-alone pack (start of a run, first launch after a rebuild), the flag, the end of a piece
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gs_pack(const int* list, DemEngine::BrickBlocks blk, double* const* blkptr,
-                                                 const size_t* blkcap, const double* blkshift, const double4* xr,
-                                                 const double4* vm, const double4* om)
+__global__ __launch_bounds__(256) void k_gs_pack(const int* list, DemEngine::BrickBlocks blk, double* const* blk3,
+                                                 const double* blkshift, const double4* xr, const double4* vm,
+                                                 const double4* om)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= blk.first[blk.n]) return;
   const int q = block_of(blk, k);
   const int i = list[k];
   const double4 x = xr[i], v = vm[i], w = om[i];
-  double4* g = reinterpret_cast<double4*>(blkptr[q]) + (k - blk.first[q]);
-  const size_t n = blkcap[q];
+  const size_t r = (size_t)(k - blk.first[q]);
   const double* sh = blkshift + 3 * q;
-  gs_store(g, x.x + sh[0], x.y + sh[1], x.z + sh[2], x.w);
-  gs_store(g + n, v.x, v.y, v.z, v.w);
-  gs_store(g + 2 * n, w.x, w.y, w.z, w.w);
+  gs_store(reinterpret_cast<double4*>(blk3[q]) + r, x.x + sh[0], x.y + sh[1], x.z + sh[2], x.w);
+  gs_store(reinterpret_cast<double4*>(blk3[DemEngine::kMaxDirs + q]) + r, v.x, v.y, v.z, v.w);
+  gs_store(reinterpret_cast<double4*>(blk3[2 * DemEngine::kMaxDirs + q]) + r, w.x, w.y, w.z, w.w);
 }
 
 __global__ __launch_bounds__(64) void k_gs_publish(const GsSync* Y, int* flags, int seq)
@@ -1020,10 +1019,11 @@ __global__ __launch_bounds__(64) void k_gs_close(const GsSync* Y, int* flags, in
 void DemEngine::gs_configure(const GsSync& sync, long long first_seq)
 {
   gs_seq_ = first_seq;
+  h_gs_sync_ = sync;
   if (!d_gs_sync_) SF_HIP(hipMalloc(&d_gs_sync_, sizeof(GsSync)));
-  if (!d_gs_count_) SF_HIP(hipMalloc(&d_gs_count_, sizeof(int) * 9 * 32));
+  if (!d_gs_count_) SF_HIP(hipMalloc(&d_gs_count_, sizeof(int) * 8 * 32));
   SF_HIP(hipMemcpyAsync(d_gs_sync_, &sync, sizeof(GsSync), hipMemcpyHostToDevice, stream_));
-  SF_HIP(hipMemsetAsync(d_gs_count_, 0, sizeof(int) * 9 * 32, stream_));
+  SF_HIP(hipMemsetAsync(d_gs_count_, 0, sizeof(int) * 8 * 32, stream_));
   SF_HIP(hipStreamSynchronize(stream_));   // (sync is the caller's)
 }
 
@@ -1036,14 +1036,18 @@ bool DemEngine::brick_fused_pack_possible() const
   return true;
 }
 
-void DemEngine::gs_off()
+void DemEngine::gs_off() { gs_ready_ = false; }
+
+void DemEngine::gs_input_arrays(int par, void** x, void** v, void** w) const
 {
-  gs_ready_ = false;
-  gs_area_[0] = gs_area_[1] = nullptr;
+  // launch gs_seq_ reads buffer cur_; every launch flips both
+  const int b = cur_ ^ (int)(((long long)(par & 1) - gs_seq_) & 1);
+  *x = xr_[b].ptr;
+  *v = vm_[b].ptr;
+  *w = om_[b].ptr;
 }
 
-void DemEngine::brick_set_forward_gs(const BrickBlocks& snd, double4* const area[2], int cap, double4* const* blk2,
-                                     const size_t* blkcap)
+void DemEngine::brick_set_forward_gs(const BrickBlocks& snd, double4* const* blk6)
 {
   if (!d_gs_sync_) fail("brick_set_forward_gs: gs_configure first");
   // (the record-slot table of the border atoms: as for the other transports)
@@ -1051,40 +1055,39 @@ void DemEngine::brick_set_forward_gs(const BrickBlocks& snd, double4* const area
   if (!tx_ready_ && nlocal_)
     fail("ghost slots need the sub-step kernel to write the border records itself: a brick thinner than twice the ghost "
          "cutoff (or SF_HALO_FUSED_PACK=0) cannot use SF_HALO_DIRECT=2");
-  if (next_ghost_ > cap) fail("brick_set_forward_gs: %d ghosts, areas of %d records", next_ghost_, cap);
   struct {
-    double* ptr[2 * kMaxDirs];
-    size_t cap[kMaxDirs];
+    double* ptr[6 * kMaxDirs];
     double shift[3 * kMaxDirs];
   } h;
-  static_assert(sizeof(h) == sizeof(double*) * 6 * kMaxDirs, "the block table of brick_set_forward_tx, three more rows");
-  for (int par = 0; par < 2; par++)
+  for (int k = 0; k < 6; k++)
     for (int q = 0; q < kMaxDirs; q++)
-      h.ptr[par * kMaxDirs + q] = q < snd.n ? reinterpret_cast<double*>(blk2[par * kMaxDirs + q]) : nullptr;
-  for (int q = 0; q < kMaxDirs; q++) {
-    h.cap[q] = q < snd.n ? blkcap[q] : 0;
+      h.ptr[k * kMaxDirs + q] = q < snd.n ? reinterpret_cast<double*>(blk6[k * kMaxDirs + q]) : nullptr;
+  for (int q = 0; q < kMaxDirs; q++)
     for (int k = 0; k < 3; k++) h.shift[3 * q + k] = q < snd.n ? snd.shift[q][k] : 0.0;
-  }
-  SF_HIP(hipMemcpyAsync(d_blkptr_, &h, sizeof(h), hipMemcpyHostToDevice, stream_));
-  SF_HIP(hipMemsetAsync(d_gs_count_, 0, sizeof(int) * 9 * 32, stream_));
+  if (!d_gsblk_) SF_HIP(hipMalloc(&d_gsblk_, sizeof(h)));
+  SF_HIP(hipMemcpyAsync(d_gsblk_, &h, sizeof(h), hipMemcpyHostToDevice, stream_));
+  SF_HIP(hipMemsetAsync(d_gs_count_, 0, sizeof(int) * 8 * 32, stream_));
   SF_HIP(hipStreamSynchronize(stream_));   // (h is on the stack)
-  gs_area_[0] = area[0];
-  gs_area_[1] = area[1];
-  gs_cap_ = cap;
   tx_direct_ = true;    // (no vote headers in a send buffer)
   tx_written_ = false;
+  gs_map_base_ = cur_ ^ (int)(gs_seq_ & 1);
   gs_ready_ = true;
 }
 
 void DemEngine::gs_pack()
 {
   if (!gs_ready_) fail("gs_pack: no ghost-slot layout (rebuild first)");
+  // A launch number must never be published twice: the last kernel that ran has published gs_seq_ ("my records for launch
+  // gs_seq_ are in place") when no early-exited launch followed it -- a trigger in the last sub-step of a piece, then the
+  // rebuild, then this pack -- and a neighbour that still sees that flag would pass its gate before these records and
+  // this vote have arrived.  Two numbers on: the parity of the buffers against the launch numbers stays what the
+  // neighbours were told (every rank packs at the same points).
+  gs_seq_ += 2;
   const int par = (int)(gs_seq_ & 1);
   const int tot = bsend_blocks_.first[bsend_blocks_.n];
   if (tot)
-    k_gs_pack<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, bsend_blocks_, d_blkptr_ + (size_t)par * kMaxDirs,
-                                                    reinterpret_cast<const size_t*>(d_blkptr_ + 2 * (size_t)kMaxDirs),
-                                                    reinterpret_cast<const double*>(d_blkptr_ + 3 * (size_t)kMaxDirs),
+    k_gs_pack<<<div_up(tot, 256), 256, 0, stream_>>>(bsend_list_, bsend_blocks_, d_gsblk_ + (size_t)par * 3 * kMaxDirs,
+                                                    reinterpret_cast<const double*>(d_gsblk_ + 6 * (size_t)kMaxDirs),
                                                     xr_[cur_].as<double4>(), vm_[cur_].as<double4>(), om_[cur_].as<double4>());
   k_gs_publish<<<1, 64, 0, stream_>>>(d_gs_sync_, d_flags_, (int)gs_seq_);
   tx_written_ = true;

@@ -94,10 +94,12 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // LPA lanes per atom (1, 2 or 4): lane q of an atom's group handles the slots q, q + LPA, ...; the partial force and
 // torque sums are combined with a fixed shuffle tree and lane 0 integrates.  Small systems (< ~3 waves per SIMD at
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
-// GS: ghost slots (above).  Returns false when the wave stopped at the gate (nothing was stored).
+// GS: ghost slots (sf_dem_gs.h).  Returns 0 when the wave stopped at the gate (nothing was stored), else 1 | 2 when the atom
+// may have written border records (what the hand-off must wait for) | 4 when it moved beyond skin / 2 (its vote).
 template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP, bool GS = false>
-__device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
-                                                 const double4* lx, const double4* lv, const double* lw)
+__device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
+                                                 const double4* lx, const double4* lv, const double* lw,
+                                                 const unsigned long long gs_w = 0ull)
 {
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
@@ -109,6 +111,16 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
   __builtin_assume(i >= 0 && i < (1 << kIdxBits));
 
   SF_PH(0);
+  // (ghost slots: the gate normally waits behind the wave's own rows -- one round trip for both.  The wave whose own
+  // records share a 128-byte line with the first ghost records must not pull that line in before the ghosts are there)
+  bool gs_gated = false;
+#ifdef SF_GS_EXP_NOGATE   // (pricing arm of tests/ab_gs_arms.sh: not a correct hand-off)
+  gs_gated = true;
+#endif
+  if (GS && S.gs_wait && !gs_gated && __ballot(i >= (S.nlocal & ~3))) {
+    if (!gs_gate(P.gs_sync, P.flags, S.gs_seq, S.kstep)) return 0;
+    gs_gated = true;
+  }
   const double4 xi4 = P.xr_in[i];   // also a gather target of the neighbours: keep it cached
   const double4 vi4 = P.vm_in[i];
   const double4 wi4 = P.om_in[i];
@@ -168,13 +180,6 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
   auto wants_vw = [&](const int jraw) {
     return NEED_VW && (LUB || !TP || (jraw & kTouchBit) != 0);
   };
-  // (ghost slots: the record `which` of a ghost of another GPU comes from the area its owner writes)
-  const __amdgpu_buffer_rsrc_t gs_rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<double4*>(GS ? P.gs_in : nullptr), 0, GS ? S.gs_cap * 96 : 0, 0x00020000);
-  auto ld_rec = [&](const double4* arr, const int which, const int j) -> double4 {
-    if (GS && j >= S.nlocal) return gs_load(gs_rs, (unsigned)(which * S.gs_cap + (j - S.nlocal)) * 32u);
-    return arr[j];
-  };
   // request the records of the neighbour in `slot` (global gather), or its LDS position
   auto fetch = [&](int jraw, int slotrow, Rec& R) {
     if (LDS) {
@@ -183,10 +188,10 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
       const int j = neigh_index(jraw, ROOTS);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.vw = wants_vw(jraw);
-      R.x = ld_rec(P.xr_in, 0, j);
+      R.x = P.xr_in[j];
       if (R.vw) {
-        R.v = ld_rec(P.vm_in, 1, j);
-        R.w = ld_rec(P.om_in, 2, j);
+        R.v = P.vm_in[j];
+        R.w = P.om_in[j];
       }
     }
     if (HIST_PF) load_history(jraw, slotrow, R.sh);
@@ -212,7 +217,20 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
   RA.vw = RB.vw = false;
   // (ghost slots: the flags are asked for behind the wave's own rows -- one round trip for both -- and before anything is
   // stored or any ghost record is read)
-  if (GS && S.gs_wait && !gs_gate(P.gs_sync, P.flags, S.gs_seq, S.kstep)) return false;
+  if (GS && S.gs_wait && !gs_gated) {
+    // gs_w: the flag | vote word of rank `lane`, requested by the kernel before anything else (a full wave: lane r holds
+    // rank r's).  All there and nobody voted: on; a flag missing: the bounded wait; a vote: fold it and stop.
+    if (__ballot(1) == ~0ull && !__ballot(gs_behind(gs_flag_of(gs_w), S.gs_seq))) {
+      const int gs_v = gs_vote_of(gs_w, S.gs_seq);
+      const bool stale = gs_v < S.kstep;
+      if (__ballot(stale)) {
+        if (stale) atomicMin(&P.flags[F_TRIGGER], gs_v);
+        return 0;
+      }
+    } else if (!gs_gate(P.gs_sync, P.flags, S.gs_seq, S.kstep)) {
+      return 0;
+    }
+  }
   if (nn > 0) fetch(jraw_n1, q, RA);
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
@@ -270,8 +288,8 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
         if (jraw & kTouchBit) nrow[i] = jraw & ~kTouchBit;
       } else {
         if (!LDS && !cur.vw) {   // a contact that did not exist one sub-step ago
-          vj4 = ld_rec(P.vm_in, 1, cur.l);
-          wj4 = ld_rec(P.om_in, 2, cur.l);
+          vj4 = P.vm_in[cur.l];
+          wj4 = P.om_in[cur.l];
         }
         ContactIn c;
         c.del = del;
@@ -348,7 +366,7 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
       F.x += __shfl_xor(F.x, off, 64); F.y += __shfl_xor(F.y, off, 64); F.z += __shfl_xor(F.z, off, 64);
       T.x += __shfl_xor(T.x, off, 64); T.y += __shfl_xor(T.y, off, 64); T.z += __shfl_xor(T.z, off, 64);
     }
-    if (q != 0) return true;
+    if (q != 0) return 1;
   }
   if (LUB) {
     if (S.lub.flagfld) {  // isotropic FLD terms, pair_lubricate_poly.cpp:213-220
@@ -471,6 +489,7 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
     T = Ta;
   }
   Vec3 vn = vi, wn = wi, xn = xi;
+  bool gs_trig = false;
   if (S.mode != 2 && S.have_nve && (mk & S.nve_bit)) {
     const double dtf = 0.5 * S.dt;
     const double dtfm = dtf / mi;
@@ -483,6 +502,7 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
       wn = wn + dtirot * T;
       const double dx = xn.x - xh_in.x, dy = xn.y - xh_in.y, dz = xn.z - xh_in.z;
       if (dx * dx + dy * dy + dz * dz > S.trigger_sq) {
+        gs_trig = true;
         atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
         // (fused forward pack: no kernel will copy the trigger word into the vote headers before the exchange)
         for (int p = 0; p < S.tx_nhdr; p++) atomicMin(header_vote_ptr(P.tx_sendbuf + P.tx_hdr_off[p]), S.kstep + S.trig_add);
@@ -500,13 +520,12 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
       const int off = P.bslot[(size_t)k * cap + i];
       if (off < 0) break;
       const int bq = off >> kBlkShift;
-      if (GS) {   // whole records into the neighbour's ghost slots, in the neighbour's frame
-        double4* g = reinterpret_cast<double4*>(P.tx_blkptr[bq]) + (off & kBlkMask);
-        const size_t n = P.tx_blkcnt[bq];   // (the neighbour's [3][n] area)
+      if (GS) {   // whole records into the neighbour's ghost slots (its x | v | omega arrays), in the neighbour's frame
+        const size_t r = (size_t)(off & kBlkMask);
         const double* sh = P.tx_blkshift + 3 * bq;
-        gs_store(g, xn.x + sh[0], xn.y + sh[1], xn.z + sh[2], radi);
-        gs_store(g + n, vn.x, vn.y, vn.z, mi);
-        gs_store(g + 2 * n, wn.x, wn.y, wn.z, wi4.w);
+        gs_store(reinterpret_cast<double4*>(P.tx_blkptr[bq]) + r, xn.x + sh[0], xn.y + sh[1], xn.z + sh[2], radi);
+        gs_store(reinterpret_cast<double4*>(P.tx_blkptr[DemEngine::kMaxDirs + bq]) + r, vn.x, vn.y, vn.z, mi);
+        gs_store(reinterpret_cast<double4*>(P.tx_blkptr[2 * DemEngine::kMaxDirs + bq]) + r, wn.x, wn.y, wn.z, wi4.w);
         continue;
       }
       double* b = P.tx_blkptr[bq] + (off & kBlkMask);
@@ -564,7 +583,7 @@ __device__ __forceinline__ bool substep_particle(const DemPtrs& P, const StepPar
     P.torque[i] = {T.x, T.y, T.z, 0.0};
   }
   SF_PH(30);
-  return true;
+  return 1 | (txb ? 2 : 0) | (gs_trig ? 4 : 0);
 }
 
 // Registers: the plain contact kernel needs 169 VGPRs when left alone -- one more than three waves per SIMD allow
@@ -600,7 +619,10 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   // bin, so giving every XCD one contiguous range of blocks keeps an atom's neighbours in the L2 of
   // the XCD that gathers them (bijective remap, speed only: any placement gives the same result).
   int bid = blockIdx.x;
-  int gs_expected = 0, gs_nxcd = 0;   // (ghost slots: workgroups of this XCD that run, XCDs that have any)
+  // (ghost slots: lane x < 8 holds the number of workgroups of XCD x that run this launch; the poller of sf_dem_gs.h is the
+  // first workgroup of the first XCD that has any)
+  int gs_expected = 0;
+  bool gs_poller = false;
   // S.sweep_rev: every other sub-step walks each XCD's range from its END.  A sub-step touches ~3 x the 256 MB of the
   // memory-side cache; sweeping always in the same direction it finds nothing of the previous sub-step there (cyclic
   // access, LRU), sweeping back and forth the first third of what it needs is what the previous sub-step touched last.
@@ -609,15 +631,28 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     if (loc >= S.xcd_count[xcd]) return;
     bid = S.xcd_first[xcd] + (S.sweep_rev ? S.xcd_count[xcd] - 1 - loc : loc);
     if (GS) {
-      gs_expected = S.xcd_count[xcd];
-      for (int x = 0; x < 8; x++) gs_nxcd += S.xcd_count[x] > 0 ? 1 : 0;
+      const int lx = (int)(threadIdx.x & 7);
+      gs_expected = S.xcd_count[lx];
+      int firstx = 0;
+      while (firstx < 7 && S.xcd_count[firstx] == 0) firstx++;
+      gs_poller = loc == 0 && xcd == firstx;
     }
   } else {
     const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
     const int cnt = xcd < r ? q + 1 : q, loc = bid >> 3;
     if (S.xcd_remap) bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (S.sweep_rev ? cnt - 1 - loc : loc);
-    gs_expected = cnt;
-    gs_nxcd = nb < 8 ? nb : 8;
+    if (GS) {
+      const int lx = (int)(threadIdx.x & 7);
+      gs_expected = lx < r ? q + 1 : q;
+      gs_poller = blockIdx.x == 0;
+    }
+  }
+  // (ghost slots: rank `lane`'s flag | vote word, asked for before the wave's own rows so that
+  // the round trip to the uncached lines runs under them; consumed at the gate in substep_particle)
+  unsigned long long gs_w = gs_word(S.gs_seq, INT_MAX);
+  if (GS && S.gs_wait) {
+    const int r = (int)(threadIdx.x & 63);
+    if (r < S.gs_world && r != S.gs_rank) gs_w = gs_read_line(P.gs_my_sync + kGsStride * r);
   }
   const int tid = bid * blockDim.x + threadIdx.x;
   int i = tid / LPA;          // LPA consecutive lanes share an atom
@@ -639,10 +674,11 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   if (GS) {
     // (every workgroup that gets here counts itself done, whatever part of it holds atoms: the lanes beyond the last atom
     // stay for the wave-level hand-off instead of returning)
-    bool ran = true;
-    if (i < S.nlocal) ran = substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP, true>(P, S, i, q, nullptr, nullptr, nullptr);
-    if (__ballot(!ran)) return;   // (stopped at the gate -- the whole wave did: the gate is a wave-level decision)
-    if (S.mode == 0) gs_done(P, S, gs_expected, gs_nxcd);
+    int ran = 1;
+    if (i < S.nlocal)
+      ran = substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP, true>(P, S, i, q, nullptr, nullptr, nullptr, gs_w);
+    if (__ballot(ran == 0)) return;   // (stopped at the gate -- the whole wave did: the gate is a wave-level decision)
+    if (S.mode == 0) gs_done(P, S, (ran & 2) != 0, (ran & 4) != 0, gs_poller, gs_expected);
   } else {
     substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
   }

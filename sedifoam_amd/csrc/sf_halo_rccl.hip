@@ -15,6 +15,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
+#include <array>
 
 #include "../../include/sedifoam_amd.h"
 #include "sf_handles.h"
@@ -144,9 +146,9 @@ struct BrickState {
 struct DirectHalo {
   bool on = false;
   bool must = false;                    // SF_HALO_DIRECT asked for it without "auto": losing it is an error
-  // 1: receive areas + one unpack kernel per exchange; 2: GHOST SLOTS -- the areas ARE the ghost records ([3][rx_cap]
-  // double4 each: x | v | omega), the neighbours' sub-step kernels write whole records into them and this rank's sub-step
-  // kernel gathers from them: no kernel between two sub-step kernels (DemEngine::brick_set_forward_gs, sf_dem_gs.h)
+  // 1: receive areas + one unpack kernel per exchange; 2: GHOST SLOTS -- the neighbours' sub-step kernels write whole
+  // records into the ghost range of this rank's record arrays (IPC mappings of the arrays themselves): no kernel between
+  // two sub-step kernels (gs_rebuild, DemEngine::brick_set_forward_gs, sf_dem_gs.h)
   int mode = 1;
   int* my_sync = nullptr;               // one 128-byte line per sending rank: {flag, vote[2]}; peers write, this rank polls
   std::vector<int*> peer_sync;          // every rank's area as mapped here
@@ -156,19 +158,23 @@ struct DirectHalo {
   struct Peer {
     long long gen_seen = -1;
     void* map[2] = {nullptr, nullptr};  // that rank's receive areas as mapped here
-    long long remote_off = 0;           // where this rank's chunk starts in them (doubles; mode 2: ghost records)
-    long long remote_cap = 0;           // mode 2: records per array of that rank's areas
+    long long remote_off = 0;           // where this rank's chunk starts in them (doubles)
+    // ghost slots: that rank's record arrays as mapped here, by IPC handle (an allocation is opened once; the owner may
+    // retire it -- the mapping then only keeps the memory alive until this object goes)
+    std::map<std::array<char, 64>, void*> opened;
   };
   std::vector<Peer> peers;
   long long xseq = 0;                   // exchanges done so far (the same number on every rank)
   long long* d_msg = nullptr;           // [2][world][kMsg] handle / offset messages (device, for the RCCL exchange)
   long long* h_msg = nullptr;
-  static constexpr int kMsg = 19;       // generation, two 64-byte IPC handles, chunk offset, area stride (mode 2)
+  static constexpr int kMsg = 50;       // generation, two 64-byte IPC handles, chunk offset; ghost slots: six handles, first ghost
   ~DirectHalo()
   {
-    for (Peer& p : peers)
+    for (Peer& p : peers) {
       for (void* m : p.map)
         if (m && m != rx[0] && m != rx[1]) (void)hipIpcCloseMemHandle(m);
+      for (auto& kv : p.opened) (void)hipIpcCloseMemHandle(kv.second);
+    }
     for (size_t r = 0; r < peer_sync.size(); r++)
       if (peer_sync[r] && peer_sync[r] != my_sync) (void)hipIpcCloseMemHandle(peer_sync[r]);
     if (my_sync) (void)hipFree(my_sync);
@@ -836,7 +842,12 @@ static void direct_init(SfLammps& S, HaloComm& hc)
     y.max_ticks = direct_sync(hc, 0, 0).max_ticks;
     y.my_sync = D.my_sync;
     for (int p = 0; p < W; p++) y.peer_sync[p] = D.peer_sync[p];
-    e.gs_configure(y, D.xseq + 1);   // (the flags stand at xseq after the first round: launch numbers go on from there)
+    // (ghost slots keep ONE 64-bit word per line, (flag << 32) | vote: wipe what the first round left there -- every rank its
+    // own area, nobody writes between the two collectives -- and number the launches from 2)
+    SF_HIP(hipStreamSynchronize(st));
+    SF_HIP(hipMemset(D.my_sync, 0, sizeof(int) * DemEngine::kSyncStride * 32));
+    (void)slab_allreduce(hc, st, 1.0, ncclMin);
+    e.gs_configure(y, 2);
   }
   if (getenv("SF_DEBUG_HALO"))
     fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes on (%d ranks, %s)\n", hc.rank, W,
@@ -849,14 +860,26 @@ static void direct_init(SfLammps& S, HaloComm& hc)
 // process cannot open) reaches every rank through an all-reduce -- the ranks then leave the direct transport together
 // (returns false: the caller goes on over RCCL) or, when SF_HALO_DIRECT demanded it, fail together with the reason,
 // instead of one rank throwing while the others spin on flags that will never come.
-static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blkcap = nullptr)
+static bool direct_lost(SfLammps& S, HaloComm& hc, const std::string& why)
+{
+  DirectHalo& D = *hc.direct;
+  D.on = false;
+  S.eng.gs_off();
+  if (D.must)
+    fail("SF_HALO_DIRECT: the direct transport was lost at a rebuild (%s)", why.empty() ? "on another rank" : why.c_str());
+  if (getenv("SF_DEBUG_HALO"))
+    fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes off from this rebuild on, RCCL exchange (%s)\n", hc.rank,
+            why.empty() ? "another rank failed" : why.c_str());
+  return false;
+}
+
+static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2)
 {
   DirectHalo& D = *hc.direct;
   BrickState& B = *hc.brick;
   DemEngine& e = S.eng;
   hipStream_t st = e.stream();
   const int W = hc.world, K = DirectHalo::kMsg;
-  const bool gs = D.mode == 2;
   double ok = 1.0;
   std::string why;
   // areas a neighbour may still have mapped are freed only after every rank has seen the new generation (below)
@@ -865,11 +888,7 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
   memset(&h0, 0, sizeof(h0));
   memset(&h1, 0, sizeof(h1));
   try {
-    if (gs && !e.brick_fused_pack_possible())
-      fail("ghost slots need the sub-step kernel to write the border records itself: not in a brick thinner than twice the "
-           "ghost cutoff, not with SF_HALO_FUSED_PACK=0");
-    // mode 1: the chunks of doubles; mode 2: one record per ghost in each of the three arrays
-    const size_t need = gs ? (size_t)B.rcv.first[B.rcv.n] + 1 : (size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1;
+    const size_t need = (size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1;
     if (need > D.rx_cap) {
       SF_HIP(hipStreamSynchronize(st));
       for (int k = 0; k < 2; k++) {
@@ -878,7 +897,7 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
       }
       D.rx_cap = need + need / 2 + 4096;
       D.rx_gen++;
-      for (double*& b : D.rx) b = static_cast<double*>(alloc_fine_grained(sizeof(double) * D.rx_cap * (gs ? 12 : 1)));
+      for (double*& b : D.rx) b = static_cast<double*>(alloc_fine_grained(sizeof(double) * D.rx_cap));
     }
     SF_HIP(hipIpcGetMemHandle(&h0, D.rx[0]));
     SF_HIP(hipIpcGetMemHandle(&h1, D.rx[1]));
@@ -886,10 +905,6 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
     ok = 0.0;
     why = ex.what();
   }
-  // (mode 2) where the ghosts of rank p start among this rank's ghosts: its blocks are contiguous, in its send order
-  std::vector<long long> gfirst(W, 0);
-  if (gs)
-    for (int q = (int)B.rdirs.size() - 1; q >= 0; q--) gfirst[B.rdirs[q].peer] = B.rcv.first[q];
   std::vector<int> nbr(W, 0);
   for (const auto& sd : B.sdirs) nbr[sd.peer] = 1;
   for (int p = 0; p < W; p++) {
@@ -897,8 +912,7 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
     m[0] = D.rx_gen;
     memcpy(m + 1, &h0, 64);
     memcpy(m + 9, &h1, 64);
-    m[17] = gs ? gfirst[p] : hc.recv_off[p];   // where rank p's chunk starts in this rank's areas
-    m[18] = (long long)D.rx_cap;
+    m[17] = hc.recv_off[p];   // where rank p's chunk starts in this rank's areas
   }
   {
     std::vector<int> with = nbr;
@@ -915,8 +929,7 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
         if (p == hc.rank) {   // (SF_HALO_SELF_COMM: this rank's own areas, no handle)
           P.map[0] = D.rx[0];
           P.map[1] = D.rx[1];
-          P.remote_off = gs ? gfirst[p] : hc.recv_off[p];
-          P.remote_cap = (long long)D.rx_cap;
+          P.remote_off = hc.recv_off[p];
           continue;
         }
         if (m[0] != P.gen_seen) {
@@ -932,7 +945,6 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
           P.gen_seen = m[0];
         }
         P.remote_off = m[17];
-        P.remote_cap = m[18];
       }
     } catch (const std::exception& ex) {
       ok = 0.0;
@@ -943,29 +955,105 @@ static bool direct_rebuild(SfLammps& S, HaloComm& hc, double** blk2, size_t* blk
   // (every rank has closed its mappings of the old generation, or never will use them again: the old areas can go)
   for (double* b : retired)
     if (b) (void)hipFree(b);
-  if (ok == 0.0) {
-    D.on = false;
-    e.gs_off();
-    if (D.must)
-      fail("SF_HALO_DIRECT: the direct transport was lost at a rebuild (%s)", why.empty() ? "on another rank" : why.c_str());
-    if (getenv("SF_DEBUG_HALO"))
-      fprintf(stderr, "[sedifoam_amd] rank %d: direct ghost writes off from this rebuild on, RCCL exchange (%s)\n", hc.rank,
-              why.empty() ? "another rank failed" : why.c_str());
-    return false;
-  }
+  if (ok == 0.0) return direct_lost(S, hc, why);
   // block q of this rank's chunk for peer p sits where it sits in the local send buffer, relative to the chunk's start
-  // (mode 2: behind the records of the earlier blocks for the same peer, in that peer's x array)
+  for (int par = 0; par < 2; par++)
+    for (int q = 0; q < DemEngine::kMaxDirs; q++) {
+      blk2[par * DemEngine::kMaxDirs + q] = nullptr;
+      if (q >= (int)B.sdirs.size()) continue;
+      const int p = B.sdirs[q].peer;
+      blk2[par * DemEngine::kMaxDirs + q] =
+          static_cast<double*>(D.peers[p].map[par]) + D.peers[p].remote_off + (B.snd.off[q] - hc.send_off[p]);
+    }
+  return true;
+}
+
+// Ghost slots, after a rebuild (or when the buffer parity moved against the launch numbers): every rank tells its
+// neighbours the IPC handles of the record arrays its launches of even / odd number will read, and where their ghosts start
+// in them; fills blk6[(par * 3 + a) * kMaxDirs + q] -- where block q's first x | v | omega record goes.  The arrays are
+// the engine's own (a re-sort swaps them with its scratch arrays, a capacity growth replaces them): mappings are cached
+// by handle, an allocation is opened once per neighbour.  Collective, fails collectively like direct_rebuild.
+static bool gs_rebuild(SfLammps& S, HaloComm& hc, double4** blk6)
+{
+  DirectHalo& D = *hc.direct;
+  BrickState& B = *hc.brick;
+  DemEngine& e = S.eng;
+  hipStream_t st = e.stream();
+  const int W = hc.world, K = DirectHalo::kMsg;
+  static_assert(DirectHalo::kMsg >= 50, "six handles + the first ghost index");
+  double ok = 1.0;
+  std::string why;
+  void* mine[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipIpcMemHandle_t h[6];
+  memset(h, 0, sizeof(h));
+  try {
+    if (!e.brick_fused_pack_possible())
+      fail("ghost slots need the sub-step kernel to write the border records itself: not in a brick thinner than twice the "
+           "ghost cutoff, not with SF_HALO_FUSED_PACK=0");
+    for (int par = 0; par < 2; par++) e.gs_input_arrays(par, &mine[3 * par], &mine[3 * par + 1], &mine[3 * par + 2]);
+    if (W > 1)
+      for (int k = 0; k < 6; k++) SF_HIP(hipIpcGetMemHandle(&h[k], mine[k]));
+  } catch (const std::exception& ex) {
+    ok = 0.0;
+    why = ex.what();
+  }
+  // where the ghosts of rank p start in this rank's arrays: behind the owned atoms, its blocks contiguous in its send order
+  std::vector<long long> gfirst(W, 0);
+  for (int q = (int)B.rdirs.size() - 1; q >= 0; q--) gfirst[B.rdirs[q].peer] = (long long)e.nlocal() + B.rcv.first[q];
+  std::vector<int> nbr(W, 0);
+  for (const auto& sd : B.sdirs) nbr[sd.peer] = 1;
+  for (int p = 0; p < W; p++) {
+    long long* m = D.h_msg + (size_t)p * K;
+    memcpy(m, h, sizeof(h));   // 48 int64
+    m[48] = gfirst[p];
+  }
+  {
+    std::vector<int> with = nbr;
+    with[hc.rank] = 0;
+    direct_messages(hc, st, with);
+  }
+  ok = slab_allreduce(hc, st, ok, ncclMin);
+  std::vector<std::array<void*, 6>> base(W);
+  std::vector<long long> first(W, 0);
+  if (ok != 0.0) {
+    try {
+      for (int p = 0; p < W; p++) {
+        if (!nbr[p]) continue;
+        if (p == hc.rank) {   // (SF_HALO_SELF_COMM: this rank's own arrays, no handle)
+          for (int k = 0; k < 6; k++) base[p][k] = mine[k];
+          first[p] = gfirst[p];
+          continue;
+        }
+        const long long* m = D.h_msg + (size_t)(W + p) * K;
+        for (int k = 0; k < 6; k++) {
+          std::array<char, 64> key;
+          memcpy(key.data(), m + 8 * k, 64);
+          auto it = D.peers[p].opened.find(key);
+          if (it == D.peers[p].opened.end()) {
+            hipIpcMemHandle_t hh;
+            memcpy(&hh, key.data(), 64);
+            void* mm = nullptr;
+            SF_HIP(hipIpcOpenMemHandle(&mm, hh, hipIpcMemLazyEnablePeerAccess));
+            it = D.peers[p].opened.emplace(key, mm).first;
+          }
+          base[p][k] = it->second;
+        }
+        first[p] = m[48];
+      }
+    } catch (const std::exception& ex) {
+      ok = 0.0;
+      why = ex.what();
+    }
+    ok = slab_allreduce(hc, st, ok, ncclMin);
+  }
+  if (ok == 0.0) return direct_lost(S, hc, why);
   std::vector<long long> sent(W, 0);
   for (int q = 0; q < DemEngine::kMaxDirs; q++) {
-    for (int par = 0; par < 2; par++) blk2[par * DemEngine::kMaxDirs + q] = nullptr;
-    if (blkcap) blkcap[q] = 0;
+    for (int k = 0; k < 6; k++) blk6[k * DemEngine::kMaxDirs + q] = nullptr;
     if (q >= (int)B.sdirs.size()) continue;
     const int p = B.sdirs[q].peer;
-    for (int par = 0; par < 2; par++)
-      blk2[par * DemEngine::kMaxDirs + q] =
-          gs ? static_cast<double*>(D.peers[p].map[par]) + 4 * (D.peers[p].remote_off + sent[p])
-             : static_cast<double*>(D.peers[p].map[par]) + D.peers[p].remote_off + (B.snd.off[q] - hc.send_off[p]);
-    if (blkcap) blkcap[q] = (size_t)D.peers[p].remote_cap;
+    for (int k = 0; k < 6; k++)
+      blk6[k * DemEngine::kMaxDirs + q] = static_cast<double4*>(base[p][k]) + first[p] + sent[p];
     sent[p] += B.nsend[q];
   }
   return true;
@@ -1110,10 +1198,9 @@ static void brick_rebuild(SfLammps& S, HaloComm& hc)
   L.dev_rx = hc.a2a_rx.need((size_t)(hc.recv_off[W - 1] + hc.recv_cnt[W - 1]) + 1);
   hc.lay_valid = true;
   double* blk2[2 * DemEngine::kMaxDirs];
-  size_t blkcap[DemEngine::kMaxDirs];
-  if (hc.direct && hc.direct->on && hc.direct->mode == 2 && direct_rebuild(S, hc, blk2, blkcap)) {
-    double4* area[2] = {reinterpret_cast<double4*>(hc.direct->rx[0]), reinterpret_cast<double4*>(hc.direct->rx[1])};
-    e.brick_set_forward_gs(B.snd, area, (int)hc.direct->rx_cap, reinterpret_cast<double4* const*>(blk2), blkcap);
+  double4* blk6[6 * DemEngine::kMaxDirs];
+  if (hc.direct && hc.direct->on && hc.direct->mode == 2 && gs_rebuild(S, hc, blk6)) {
+    e.brick_set_forward_gs(B.snd, blk6);
   } else if (hc.direct && hc.direct->on && hc.direct->mode == 1 && direct_rebuild(S, hc, blk2)) {
     e.brick_set_forward_tx(B.snd, L.dev_tx, L.dev_shdr, W - 1, blk2);
     e.set_tx_parity((int)(hc.direct->xseq & 1));
@@ -1136,12 +1223,39 @@ static int brick_halo_run(SfLammps& S, HaloComm& hc, int first_k, int end_k, int
     // ghost slots: the sub-step kernels hand the border records and the votes to each other; what is left for the host
     // is the stand-alone pack in front of a launch no sub-step kernel has written the records for (start of a run, first
     // launch after a rebuild) and, at the end of a piece that stops early, the wait for the last votes
+    static FILE* tr = nullptr;   // (SF_DEBUG_HALO_TRACE=<prefix>: one line per piece and rank, flushed: what a stalled rank did last)
+    if (!tr && getenv("SF_DEBUG_HALO_TRACE")) {
+      char name[512];
+      snprintf(name, sizeof(name), "%s.%d", getenv("SF_DEBUG_HALO_TRACE"), hc.rank);
+      tr = fopen(name, "w");
+    }
+    if (tr) {
+      fprintf(tr, "piece [%d, %d) of %d: first launch %lld, records %s\n", first_k, end_k, n, e.gs_seq(),
+              e.forward_tx_written() ? "written by the last kernel" : "to be packed");
+      fflush(tr);
+    }
     for (int s = first_k; s < end_k; s++) {
       if (!e.forward_tx_written()) e.gs_pack();
       e.substep_k(s == n - 1, s);
     }
     if (end_k < n) e.gs_close(end_k);
     const int trigger = e.batch_end(first_k, end_k - first_k);
+    if (tr) {
+      fprintf(tr, "  done: trigger %d, next launch %lld, timeout word %d (peer %d at %d)\n", trigger, e.gs_seq(), e.halo_timeout(),
+              e.halo_timeout_peer(), e.halo_timeout_seen());
+      fflush(tr);
+    }
+    if (e.halo_timeout() && getenv("SF_DEBUG_HALO")) {
+      // what this rank sees of everybody: the (flag << 32) | vote word of every sending rank
+      int lines[32 * DemEngine::kSyncStride];
+      (void)hipMemcpy(lines, hc.direct->my_sync, sizeof(int) * DemEngine::kSyncStride * hc.world, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[sedifoam_amd] rank %d: ghost-slot wait ran out in launch %d (peer %d stood at %d); next launch %lld, "
+              "piece [%d, %d) of %d, trigger word %d; lines:", hc.rank, e.halo_timeout(), e.halo_timeout_peer(),
+              e.halo_timeout_seen(), e.gs_seq(), first_k, end_k, n, trigger);
+      for (int r = 0; r < hc.world; r++)
+        fprintf(stderr, "  r%d {flag %d, vote %d}", r, lines[DemEngine::kSyncStride * r + 1], lines[DemEngine::kSyncStride * r]);
+      fprintf(stderr, "\n");
+    }
     if (e.halo_timeout())
       fail("ghost slots: rank %d waited for the flag of launch %d, rank %d stood at %d when the wait ran out (a peer died, or "
            "the ranks disagree about the launches they queue); SF_HALO_DIRECT=0 selects the RCCL exchange",
@@ -1206,6 +1320,13 @@ static void brick_step(SfLammps& S, HaloComm& hc, int n)
   DemEngine& e = S.eng;
   e.run_begin();
   hc.pre_exchanged = false;
+  if (hc.direct && hc.direct->on && hc.direct->mode == 2 && e.gs_on() && !e.gs_mapping_valid()) {
+    // (the buffer parity moved against the launch numbers without a rebuild -- the setup evaluation flips the buffers: the
+    // neighbours must learn which arrays this rank's next launch reads.  The same event on every rank: collective)
+    double4* blk6[6 * DemEngine::kMaxDirs];
+    if (gs_rebuild(S, hc, blk6)) e.brick_set_forward_gs(hc.brick->snd, blk6);
+    else e.brick_set_forward_tx(hc.brick->snd, hc.lay.dev_tx, hc.lay.dev_shdr, hc.world - 1);
+  }
   int k = 0;
   while (k < n) {
     const int end = k + hc.predict.chunk(e.nsteps(), n - k);

@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -146,6 +147,23 @@ int main(int argc, char** argv)
   }
   MPI_Allreduce(loc, glob, 3, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
   const double y1 = glob[0] / nGlobal;
+  // SHIM_DUMP=<prefix>: every rank writes its atoms -- tag, wrapped position, velocity -- to <prefix>.<rank>, so that the
+  // test can compare the N-rank run with the 1-rank run atom by atom instead of by checksum
+  if (const char* prefix = std::getenv("SHIM_DUMP")) {
+    char name[1024];
+    std::snprintf(name, sizeof(name), "%s.%d", prefix, myrank);
+    if (std::FILE* f = std::fopen(name, "w")) {
+      const double Lx = whole[1] - whole[0], Lz = whole[5] - whole[4];
+      std::fprintf(f, "# %.17g %.17g\n", Lx, Lz);
+      for (int i = 0; i < nLocal; i++) {
+        const double xw = x[3 * i] - whole[0] - Lx * std::floor((x[3 * i] - whole[0]) / Lx);
+        const double zw = x[3 * i + 2] - whole[4] - Lz * std::floor((x[3 * i + 2] - whole[4]) / Lz);
+        std::fprintf(f, "%d %.17g %.17g %.17g %.17g %.17g %.17g\n", tag[i], xw, x[3 * i + 1], zw, v[3 * i], v[3 * i + 1],
+                     v[3 * i + 2]);
+      }
+      std::fclose(f);
+    }
+  }
 
   // particle injection / removal (softParticleCloud.C:1198, :1231): collective calls; a rank creates what falls into
   // its sub-domain (npAdd = 0 elsewhere) and deletes the listed atoms it owns

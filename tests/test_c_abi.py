@@ -172,10 +172,11 @@ def test_lammps_object_shim_runs_in_parallel_from_the_reference_calls_alone(tmp_
     script, n = _bed_script(tmp_path, nx=nx, nz=nz, processors=processors, velocity="8.0 0.0 5.0")
     exe = _build_shim_real_mpich(tmp_path)
     mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
-    one = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=300)
+    one = subprocess.run([exe, str(script)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, SHIM_DUMP=str(tmp_path / "one")))
     assert one.returncode == 0 and one.stdout.strip().splitlines()[-1].startswith("OK"), one.stdout + one.stderr
     ref = one.stdout.strip().splitlines()[-1].split()
-    env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path))
+    env = dict(os.environ, SF_RCCL_LIB=_standin_rccl(tmp_path), SHIM_DUMP=str(tmp_path / "many"))
     r = subprocess.run([mpirun, "-np", str(world), exe, str(script)], capture_output=True, text=True, timeout=600,
                        env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -187,3 +188,16 @@ def test_lammps_object_shim_runs_in_parallel_from_the_reference_calls_alone(tmp_
     assert float(tok[2]) == pytest.approx(float(ref[2]), rel=1e-12)
     for k in (3, 5, 6):        # mean height, tag-weighted checksums of positions and velocities
         assert float(tok[k]) == pytest.approx(float(ref[k]), rel=1e-9), (k, tok, ref)
+    # ... and atom by atom (before the create / delete calls): every rank dumped tag, wrapped position, velocity
+    import numpy as np
+    a = np.loadtxt(str(tmp_path / "one.0"))
+    b = np.concatenate([np.loadtxt(str(tmp_path / ("many.%d" % q)), ndmin=2) for q in range(world)])
+    assert len(a) == len(b) == n and np.array_equal(np.sort(a[:, 0]), np.sort(b[:, 0]))
+    a, b = a[np.argsort(a[:, 0])], b[np.argsort(b[:, 0])]
+    scale_x, scale_v = np.max(np.abs(a[:, 1:4])), np.max(np.abs(a[:, 4:7]))
+    Lx, Lz = (float(t) for t in open(str(tmp_path / "one.0")).readline().split()[1:3])
+    dx = np.abs(a[:, 1:4] - b[:, 1:4])
+    dx[:, 0] = np.minimum(dx[:, 0], np.abs(dx[:, 0] - Lx))   # (an atom on the periodic face may be wrapped either way)
+    dx[:, 2] = np.minimum(dx[:, 2], np.abs(dx[:, 2] - Lz))
+    assert np.max(dx) <= 1e-9 * scale_x, np.max(dx)
+    assert np.max(np.abs(a[:, 4:7] - b[:, 4:7])) <= 1e-9 * scale_v

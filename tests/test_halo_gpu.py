@@ -292,7 +292,7 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncell
     import socket
     import torch.multiprocessing as mp
     monkeypatch.setenv("SF_HALO_DIRECT", direct)
-    monkeypatch.setenv("SF_HALO_DIRECT_TIMEOUT", "120")   # (ranks sharing one GPU wait for each other's time slices)
+    monkeypatch.setenv("SF_HALO_DIRECT_TIMEOUT", os.environ.get("SF_TEST_TIMEOUT", "120"))   # (ranks sharing one GPU wait for each other's time slices)
     world = grid[0] * grid[1] * grid[2]
     if world == 1:
         monkeypatch.setenv("SF_HALO_SELF_COMM", "1")
