@@ -7,8 +7,11 @@
 #include <cstring>
 
 #include "atom.h"
+#include "comm.h"
 #include "error.h"
+#include "fix.h"
 #include "force.h"
+#include "memory.h"
 #include "neigh_list.h"
 #include "neighbor.h"
 #include "update.h"
@@ -75,6 +78,21 @@ void PairGranHertzFixHistoryAmd::compute(int eflag, int vflag)
   computeflag = 1;
   const int shearupdate = update->setupflag ? 0 : 1;   // :65-66
 
+  // rigid body masses for owned & ghost atoms when a fix rigid is present (:68-86): body[i] = the body atom i is in, -1 if
+  // none; the base class found fix_rigid in init_style and forwards mass_rigid to the ghosts (pack / unpack_comm)
+  if (fix_rigid && neighbor->ago == 0) {
+    int tmp;
+    int *body = (int *) fix_rigid->extract("body", tmp);
+    double *mass_body = (double *) fix_rigid->extract("masstotal", tmp);
+    if (atom->nmax > nmax) {
+      memory->destroy(mass_rigid);
+      nmax = atom->nmax;
+      memory->create(mass_rigid, nmax, "pair:mass_rigid");
+    }
+    for (int i = 0; i < atom->nlocal; i++) mass_rigid[i] = body[i] >= 0 ? mass_body[body[i]] : 0.0;
+    comm->forward_comm_pair(this);
+  }
+
   if (neighbor->ago == 0 || nrows_ != list->inum) flatten_list();
 
   const int nlocal = atom->nlocal, nall = nlocal + atom->nghost;
@@ -85,13 +103,16 @@ void PairGranHertzFixHistoryAmd::compute(int eflag, int vflag)
   d_radius_.upload(atom->radius, nall);
   d_rmass_.upload(atom->rmass, nall);
   d_mask_.upload(atom->mask, nall);
+  if (fix_rigid) d_mass_rigid_.upload(mass_rigid, nall);
   double *df = d_f_.zeros<double>(3 * (size_t)nall), *dt_ = d_torque_.zeros<double>(3 * (size_t)nall);
 
-  if (sfk_pair_gran_history_compute(1, &gp_, dt, shearupdate, nlocal, nrows_, d_ilist_.as<int>(), d_first_.as<int>(),
-                                    d_jlist_.as<int>(), d_touch_.as<int>(), d_shear_.as<double>(),
-                                    d_x_.as<double>(), d_v_.as<double>(), d_omega_.as<double>(),
-                                    d_radius_.as<double>(), d_rmass_.as<double>(), d_mask_.as<int>(),
-                                    freeze_group_bit, df, dt_, NULL) != 0)
+  // (:182-185: an atom of a rigid body collides with the mass of its body)
+  if (sfk_pair_gran_history_compute_rigid(1, &gp_, dt, shearupdate, nlocal, nrows_, d_ilist_.as<int>(),
+                                          d_first_.as<int>(), d_jlist_.as<int>(), d_touch_.as<int>(),
+                                          d_shear_.as<double>(), d_x_.as<double>(), d_v_.as<double>(),
+                                          d_omega_.as<double>(), d_radius_.as<double>(), d_rmass_.as<double>(),
+                                          d_mask_.as<int>(), freeze_group_bit, df, dt_,
+                                          fix_rigid ? d_mass_rigid_.as<double>() : NULL, NULL) != 0)
     error->one(FLERR, sf_last_error());
 
   // f / torque += (owned atoms only: newton off, :273), history back into FixShearHistory's pages

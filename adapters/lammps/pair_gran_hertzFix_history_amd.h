@@ -30,7 +30,7 @@ class PairGranHertzFixHistoryAmd : public PairGranHookeHistory {
   std::vector<int> ilist_, first_, jlist_, touch_;
   std::vector<double> shear_, hf_, ht_;
   sedifoam_amd::DevBuf d_ilist_, d_first_, d_jlist_, d_touch_, d_shear_, d_x_, d_v_, d_omega_, d_radius_, d_rmass_,
-      d_mask_, d_f_, d_torque_;
+      d_mask_, d_f_, d_torque_, d_mass_rigid_;
 };
 
 }

@@ -576,17 +576,21 @@ def main():
     parity_ok = True
     if world > 1 and not args.no_parity and args.scaling != "weak":
         asked = os.environ.get("SF_HALO_DIRECT")
-        ladder = ["auto2", "auto", "0"] if asked is None else ([asked] if asked == "0" else [asked, "0"])
+        # (--one-gpu: ranks that SHARE a GPU must not use the ghost slots at bench sizes -- the gates of N - 1 kernels spin in
+        # every wave slot of the chip while the kernel they wait for cannot place its last workgroups; measured: the bounded
+        # wait runs out.  On one GPU per rank a kernel only ever waits for OTHER GPUs.)
+        ladder = (["auto", "0"] if args.one_gpu else ["auto2", "auto", "0"]) if asked is None else \
+            ([asked] if asked == "0" else [asked, "0"])
         tried = []
-        for transport in ladder:
-            os.environ["SF_HALO_DIRECT"] = transport
+        for halo_mode in ladder:
+            os.environ["SF_HALO_DIRECT"] = halo_mode
             parity_first, ok_all, was_direct = decomposed_parity()
-            if ok_all and (was_direct or transport == ladder[-1]):
-                break
+            if ok_all and (was_direct or halo_mode == ladder[-1] or not grid_used[0]):
+                break   # (no brick driver -- slabs, or the gloo wire of --one-gpu --: the direct transports do not apply)
             if ok_all:   # ("auto*": the bring-up failed on some rank and the library fell back to RCCL by itself)
-                tried.append("SF_HALO_DIRECT=%s did not come up" % transport)
+                tried.append("SF_HALO_DIRECT=%s did not come up" % halo_mode)
                 continue
-            tried.append("SF_HALO_DIRECT=%s %s" % (transport, "disagreed with the single-domain run"
+            tried.append("SF_HALO_DIRECT=%s %s" % (halo_mode, "disagreed with the single-domain run"
                                                    if parity_first is not None else "did not run through"))
         if tried:
             halo_note = "tried first: " + "; ".join(tried) + ("" if not ok_all else "; SF_HALO_DIRECT=%s carried the run"
@@ -902,12 +906,16 @@ def main():
         if parity_first is not None:
             out["parity"] = parity_first
         try:
-            direct_on = bool(grid_used[0]) and int(lmp.e.lmp.L.sf_slab_direct_halo(lmp.e.lmp.ptr)) == 1
+            direct_on = int(lmp.e.lmp.L.sf_slab_direct_halo(lmp.e.lmp.ptr)) if grid_used[0] else 0
         except Exception:   # noqa: BLE001
-            direct_on = False
-        out["config"]["halo"] = ("direct ghost writes: the sub-step kernel writes the border records into the neighbours' "
-                                 "IPC-mapped receive areas, one kernel per exchange publishes / awaits the ranks' flags"
-                                 if direct_on else "one grouped ncclSend/ncclRecv per sub-step + unpack kernel")
+            direct_on = 0
+        out["config"]["halo"] = {
+            2: "ghost slots: the sub-step kernel writes the border records straight into the ghost range of the neighbours' "
+               "record arrays, its last wave publishes flag | vote, the next sub-step kernel waits at its gate -- no kernel "
+               "between two sub-step kernels",
+            1: "direct ghost writes: the sub-step kernel writes the border records into the neighbours' IPC-mapped receive "
+               "areas, one kernel per exchange publishes / awaits the ranks' flags",
+        }.get(direct_on, "one grouped ncclSend/ncclRecv per sub-step + unpack kernel")
         if halo_note:
             out["config"]["halo_note"] = halo_note
     if rank == 0 and not args.no_cpu_baseline:   # (on rank 0's host cores; at N > 1 the other ranks are done)

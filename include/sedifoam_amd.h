@@ -343,6 +343,16 @@ int sfk_pair_gran_history_compute(int hertz, const sfk_gran_params *p, double dt
                                   const double *v, const double *omega, const double *radius,
                                   const double *rmass, const int *mask, int freeze_group_bit,
                                   double *f, double *torque, void *stream);
+/* the same with the fix_rigid branch of the reference (pair_gran_hertzFix_history.cpp:72-86, 182-185): mass_rigid[n] is the
+ * per-atom array the pair style fills from FixRigid's "body" / "masstotal" (the mass of the atom's rigid body, 0 for a free
+ * atom; NULL: no fix rigid) -- an atom with mass_rigid > 0 enters the effective mass with it instead of rmass.  [3P] fix
+ * rigid itself (the body integration) is LAMMPS' and outside this library. */
+int sfk_pair_gran_history_compute_rigid(int hertz, const sfk_gran_params *p, double dt, int shearupdate,
+                                        int nlocal, int inum, const int *ilist, const int *first,
+                                        const int *jlist, int *touch, double *shear, const double *x,
+                                        const double *v, const double *omega, const double *radius,
+                                        const double *rmass, const int *mask, int freeze_group_bit,
+                                        double *f, double *torque, const double *mass_rigid, void *stream);
 /* FixCohe::post_force  fix_cohesive.cpp:138-263 (half list, CSR) */
 int sfk_fix_cohesive_post_force(double ah, double lam, double smin, double smax, int opt,
                                 int nlocal, int newton_pair, const int *ilist, const int *first,
@@ -358,6 +368,14 @@ int sfk_pair_lubricate_poly_compute(const sfk_lub_params *p, int inum, const int
                                     const int *first, const int *jlist, const double *x,
                                     const double *v, const double *omega, const double *radius,
                                     double *f, double *torque, void *stream);
+/* FixWallGranFix::post_force  fix_wall_granFix.cpp:247-345 with the laws of :361-678, a wall at rest (AoS [n][3];
+ * pairstyle: the reference's enum 0 hooke / 1 hooke/history / 2 hertz/history; wallstyle 0 / 1 / 2: x / y / z plane pair
+ * [lo, hi], 3: z cylinder of radius cylradius; shear[n][3]: the fix's per-atom history, read and updated; f / torque +=) */
+int sfk_fix_wall_granfix_post_force(int pairstyle, const sfk_gran_params *p, int wallstyle, double lo, double hi,
+                                    double cylradius, double dt, int shearupdate, int nlocal, const double *x,
+                                    const double *v, const double *omega, const double *radius,
+                                    const double *rmass, const int *mask, int groupbit, double *shear, double *f,
+                                    double *torque, void *stream);
 /* FixFluidDrag::post_force  fix_fluid_drag.cpp:114-164 (AoS [n][3]) */
 int sfk_fix_fluid_drag_post_force(int nlocal, double dt, double carrier_rho, const double *v,
                                   const double *rmass, const double *radius, const int *mask,

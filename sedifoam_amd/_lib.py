@@ -179,11 +179,16 @@ _SIGS = {
     "sf_dev_sync": (C.c_int, [vp]),
     "sfk_gran_settings": (C.c_int, [C.POINTER(GranParams), C.c_double, C.c_int, C.c_double, C.c_double,
                                     C.c_int, C.c_double, C.c_double, C.c_int, C.c_double]),
+    "sfk_pair_gran_history_compute_rigid": (C.c_int, [C.c_int, C.POINTER(GranParams), C.c_double, C.c_int, C.c_int,
+                                                      C.c_int] + [vp] * 11 + [C.c_int, vp, vp, vp, vp]),
     "sfk_pair_gran_history_compute": (C.c_int, [C.c_int, C.POINTER(GranParams), C.c_double, C.c_int, C.c_int,
                                                 C.c_int] + [vp] * 11 + [C.c_int, vp, vp, vp]),
     "sfk_fix_cohesive_post_force": (C.c_int, [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int] + [vp] * 6 +
                                     [C.c_int, vp, vp]),
     "sfk_pair_lubricate_poly_compute": (C.c_int, [C.POINTER(LubParams), C.c_int] + [vp] * 10),
+    "sfk_fix_wall_granfix_post_force": (C.c_int, [C.c_int, C.POINTER(GranParams), C.c_int, C.c_double, C.c_double,
+                                                  C.c_double, C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int,
+                                                  vp, vp, vp, vp]),
     "sfk_fix_fluid_drag_post_force": (C.c_int, [C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, C.c_int,
                                                 vp, vp, vp, vp, vp]),
     "sfk_drag_model_jd": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp]),

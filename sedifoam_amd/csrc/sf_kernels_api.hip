@@ -28,13 +28,16 @@ __global__ __launch_bounds__(256) void k_pair_gran_csr(GranParams p, double dt, 
                                                        const int* jlist, int* touch, double* shear,
                                                        const double* x, const double* v, const double* omega,
                                                        const double* radius, const double* rmass,
-                                                       const int* mask, int freeze_bit, double* f, double* torque)
+                                                       const int* mask, int freeze_bit, double* f, double* torque,
+                                                       const double* mass_rigid)
 {
   const int ii = blockIdx.x * blockDim.x + threadIdx.x;
   if (ii >= inum) return;
   const int i = ilist[ii];
   const Vec3 xi = ld3(x, i), vi = ld3(v, i), wi = ld3(omega, i);
-  const double radi = radius[i], mi = rmass[i];
+  const double radi = radius[i];
+  // (an atom of a fix rigid body collides with the mass of its body: pair_gran_hertzFix_history.cpp:72-86, 182-185)
+  const double mi = (mass_rigid && mass_rigid[i] > 0.0) ? mass_rigid[i] : rmass[i];
   const int maski = mask[i];
   Vec3 F = {0, 0, 0}, T = {0, 0, 0};
   for (int jj = first[ii]; jj < first[ii + 1]; jj++) {
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void k_pair_gran_csr(GranParams p, double dt, 
     c.vr = vi - ld3(v, j);
     const Vec3 wj = ld3(omega, j);
     c.wsum = {radi * wi.x + radj * wj.x, radi * wi.y + radj * wj.y, radi * wi.z + radj * wj.z};
-    const double mj = rmass[j];
+    const double mj = (mass_rigid && mass_rigid[j] > 0.0) ? mass_rigid[j] : rmass[j];
     c.meff = mi * mj / (mi + mj);
     if (maski & freeze_bit) c.meff = mj;
     if (mask[j] & freeze_bit) c.meff = mi;
@@ -155,6 +158,65 @@ __global__ __launch_bounds__(256) void k_fdrag_aos(int nlocal, double dt, double
   }
 }
 
+// FixWallGranFix::post_force (fix_wall_granFix.cpp:286-344) on LAMMPS-shaped AoS arrays: plane pair (wallstyle 0 / 1 / 2) or
+// z cylinder (3), the three laws of :361-678 through the contact-law functions the engine's sub-step kernel uses
+// (sf_physics.h); geometry as in substep_particle (sf_dem_kernels.h).  shear[n][3] is the fix's per-atom history.
+__global__ __launch_bounds__(256) void k_wall_granfix_aos(GranParams p, int history, int wallstyle, double lo, double hi,
+                                                          double cylradius, double dt, int shearupdate, int nlocal,
+                                                          const double* x, const double* v, const double* omega,
+                                                          const double* radius, const double* rmass, const int* mask,
+                                                          int groupbit, double* shear, double* f, double* torque)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal || !(mask[i] & groupbit)) return;   // :290
+  const Vec3 xi = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+  const double radi = radius[i];
+  Vec3 dw = {0.0, 0.0, 0.0};
+  bool contact = true;
+  if (wallstyle < 3) {   // :294-308
+    const double xc = wallstyle == 0 ? xi.x : (wallstyle == 1 ? xi.y : xi.z);
+    const double del1 = xc - lo, del2 = hi - xc;
+    const double d = del1 < del2 ? del1 : -del2;
+    dw = {wallstyle == 0 ? d : 0.0, wallstyle == 1 ? d : 0.0, wallstyle == 2 ? d : 0.0};
+  } else {               // :309-322
+    const double delxy = sqrt(xi.x * xi.x + xi.y * xi.y);
+    const double delr = cylradius - delxy;
+    if (delr > radi) contact = false;
+    else dw = {-delr / delxy * xi.x, -delr / delxy * xi.y, 0.0};
+  }
+  const double rsq = dot(dw, dw);
+  if (!contact || rsq > radi * radi) {   // :324-329
+    if (history) shear[3 * i] = shear[3 * i + 1] = shear[3 * i + 2] = 0.0;
+    return;
+  }
+  ContactIn c;
+  c.del = dw;
+  c.rsq = rsq;
+  c.r = sqrt(rsq);
+  c.rinv = 1.0 / c.r;
+  c.vr = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};   // (a wall at rest: vwall = 0)
+  c.wsum = {radi * omega[3 * i], radi * omega[3 * i + 1], radi * omega[3 * i + 2]};
+  c.meff = rmass[i];
+  c.overlap = radi - c.r;
+  c.reff = (radi - c.r) * radi;
+  Vec3 sh = {0.0, 0.0, 0.0};
+  if (history) sh = {shear[3 * i], shear[3 * i + 1], shear[3 * i + 2]};
+  ContactOut o;
+  if (p.style == 2) hertz_history_law(p, dt, shearupdate != 0, c, sh, o);
+  else hooke_history_law(p, dt, shearupdate != 0, c, sh, o);
+  if (history) {
+    shear[3 * i] = sh.x;
+    shear[3 * i + 1] = sh.y;
+    shear[3 * i + 2] = sh.z;
+  }
+  f[3 * i] += o.F.x;
+  f[3 * i + 1] += o.F.y;
+  f[3 * i + 2] += o.F.z;
+  torque[3 * i] -= radi * o.tor.x;
+  torque[3 * i + 1] -= radi * o.tor.y;
+  torque[3 * i + 2] -= radi * o.tor.z;
+}
+
 static double beta_of(double gamman)
 {
   const double lg = std::log(gamman) / std::log(std::exp(1.0));
@@ -232,11 +294,12 @@ int sfk_gran_settings(sfk_gran_params* p, double kn, int kt_null, double kt, dou
   return 0;
 }
 
-int sfk_pair_gran_history_compute(int hertz, const sfk_gran_params* p, double dt, int shearupdate, int nlocal,
+int sfk_pair_gran_history_compute_rigid(int hertz, const sfk_gran_params* p, double dt, int shearupdate, int nlocal,
                                   int inum, const int* ilist, const int* first, const int* jlist, int* touch,
                                   double* shear, const double* x, const double* v, const double* omega,
                                   const double* radius, const double* rmass, const int* mask,
-                                  int freeze_group_bit, double* f, double* torque, void* stream)
+                                  int freeze_group_bit, double* f, double* torque, const double* mass_rigid,
+                                        void* stream)
 {
   SF_API_BEGIN
   sf::GranParams g;
@@ -255,14 +318,24 @@ int sfk_pair_gran_history_compute(int hertz, const sfk_gran_params* p, double dt
     if (hertz)
       sf::k_pair_gran_csr<2><<<grid, 256, 0, s>>>(g, dt, shearupdate, nlocal, inum, ilist, first, jlist, touch,
                                                   shear, x, v, omega, radius, rmass, mask, freeze_group_bit, f,
-                                                  torque);
+                                                  torque, mass_rigid);
     else
       sf::k_pair_gran_csr<1><<<grid, 256, 0, s>>>(g, dt, shearupdate, nlocal, inum, ilist, first, jlist, touch,
                                                   shear, x, v, omega, radius, rmass, mask, freeze_group_bit, f,
-                                                  torque);
+                                                  torque, mass_rigid);
     SF_HIP(hipGetLastError());
   }
   SF_API_END(0)
+}
+
+int sfk_pair_gran_history_compute(int hertz, const sfk_gran_params* p, double dt, int shearupdate, int nlocal,
+                                  int inum, const int* ilist, const int* first, const int* jlist, int* touch,
+                                  double* shear, const double* x, const double* v, const double* omega,
+                                  const double* radius, const double* rmass, const int* mask,
+                                  int freeze_group_bit, double* f, double* torque, void* stream)
+{
+  return sfk_pair_gran_history_compute_rigid(hertz, p, dt, shearupdate, nlocal, inum, ilist, first, jlist, touch, shear, x, v,
+                                             omega, radius, rmass, mask, freeze_group_bit, f, torque, nullptr, stream);
 }
 
 int sfk_fix_cohesive_post_force(double ah, double lam, double smin, double smax, int opt, int nlocal,
@@ -303,6 +376,33 @@ int sfk_pair_lubricate_poly_compute(const sfk_lub_params* p, int inum, const int
   if (inum > 0) {
     sf::k_lubricate_csr<<<sf::div_up(inum, 256), 256, 0, (hipStream_t)stream>>>(l, inum, ilist, first, jlist, x, v,
                                                                                 omega, radius, f, torque);
+    SF_HIP(hipGetLastError());
+  }
+  SF_API_END(0)
+}
+
+int sfk_fix_wall_granfix_post_force(int pairstyle, const sfk_gran_params* p, int wallstyle, double lo, double hi,
+                                    double cylradius, double dt, int shearupdate, int nlocal, const double* x,
+                                    const double* v, const double* omega, const double* radius, const double* rmass,
+                                    const int* mask, int groupbit, double* shear, double* f, double* torque, void* stream)
+{
+  SF_API_BEGIN
+  if (pairstyle < 0 || pairstyle > 2 || wallstyle < 0 || wallstyle > 3) sf::fail("Illegal fix wall/gran command");
+  sf::GranParams g;
+  g.kn = p->kn;
+  g.kt = p->kt;
+  g.gamman = p->gamman;
+  g.gammat = p->gammat;
+  g.xmu = p->xmu;
+  g.dampflag = p->dampflag;
+  // the reference's enum {HOOKE, HOOKE_HISTORY, HERTZ_HISTORY} (fix_wall_granFix.cpp:38) -> the engine's law selector
+  g.style = pairstyle == 2 ? 2 : (pairstyle == 1 ? 1 : 3);
+  g.beta = (pairstyle == 2 && p->gamman > 0.0) ? sf::beta_of(p->gamman) : 0.0;
+  sf::fold_hertz_constants(g);
+  if (nlocal > 0) {
+    sf::k_wall_granfix_aos<<<sf::div_up(nlocal, 256), 256, 0, (hipStream_t)stream>>>(
+        g, pairstyle != 0 ? 1 : 0, wallstyle, lo, hi, cylradius, dt, shearupdate, nlocal, x, v, omega, radius, rmass, mask,
+        groupbit, shear, f, torque);
     SF_HIP(hipGetLastError());
   }
   SF_API_END(0)

@@ -13,6 +13,7 @@ class Fix : protected Pointers {
   virtual void setup(int) {}
   virtual void post_force(int) {}
   virtual double memory_usage() { return 0.0; }
+  virtual void *extract(const char *, int &) { return NULL; }
   virtual void grow_arrays(int) {}
   virtual void copy_arrays(int, int, int) {}
   virtual int pack_exchange(int, double *) { return 0; }

@@ -12,6 +12,9 @@ class PairGranHookeHistory : public Pair {
  protected:
   double kn, kt, gamman, gammat, xmu; int dampflag; double dt; int freeze_group_bit;
   class NeighList *listgranhistory;
+  class Fix *fix_rigid;      // storage of rigid body masses for use in granular interactions ([3P] pair_gran_hooke_history.h)
+  double *mass_rigid;
+  int nmax;
 };
 }
 #endif

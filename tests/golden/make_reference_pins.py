@@ -316,7 +316,7 @@ def half_list(x, r, extra, nlocal):
     return first
 
 
-def case_hertz(code, seed, n, nlocal, poly, shearupdate, frozen):
+def case_hertz(code, seed, n, nlocal, poly, shearupdate, frozen, rigid=False):
     rng = random.Random(seed)
     d0 = 1.0e-3
     x, radius = cluster(rng, n, d0, poly)
@@ -332,10 +332,16 @@ def case_hertz(code, seed, n, nlocal, poly, shearupdate, frozen):
     inp = dict(n=n, nlocal=nlocal, x=x, v=v, omega=omega, radius=radius, rmass=rmass, mask=mask, firstneigh=firstneigh,
                touch=[list(t) for t in firsttouch], shear=[list(s) for s in firstshear], kn=1.0e7, kt=2.0e7 / 7.0,
                gamman=0.5, xmu=0.4, dt=1.0e-6, shearupdate=shearupdate, freeze_group_bit=2 if frozen else 0)
+    # the fix_rigid branch (:182-185): a third of the atoms belong to rigid bodies and collide with their body's mass
+    mass_rigid = None
+    if rigid:
+        mass_rigid = [(rng.uniform(5.0, 40.0) * rmass[k] if rng.random() < 0.35 else 0.0) for k in range(n)]
+        inp["mass_rigid"] = mass_rigid
     f = [[0.0] * 3 for _ in range(n)]
     torque = [[0.0] * 3 for _ in range(n)]
     ns = dict(MATH, inum=nlocal, ilist=list(range(nlocal)), x=x, v=v, omega=omega, radius=radius, rmass=rmass, mass=None,
-              type_=[1] * n, mask=mask, freeze_group_bit=inp["freeze_group_bit"], fix_rigid=0, mass_rigid=None,
+              type_=[1] * n, mask=mask, freeze_group_bit=inp["freeze_group_bit"], fix_rigid=1 if rigid else 0,
+              mass_rigid=mass_rigid,
               firstneigh=firstneigh, numneigh=numneigh, firsttouch=firsttouch, firstshear=firstshear,
               NEIGHMASK=0x3FFFFFFF, kn=inp["kn"], kt=inp["kt"], gamman=inp["gamman"], xmu=inp["xmu"], dt=inp["dt"],
               shearupdate=shearupdate, nlocal=nlocal, evflag=0, ev_tally_xyz=lambda *a: None, f=f, torque=torque)
@@ -757,7 +763,8 @@ def main():
         print(code)
     pins["pair_gran_hertzFix_history.cpp:109-286"] = [
         case_hertz(code, 11, 27, 27, False, 1, False), case_hertz(code, 12, 48, 30, True, 1, False),
-        case_hertz(code, 13, 48, 36, True, 0, True), case_hertz(code, 14, 64, 64, True, 1, True)]
+        case_hertz(code, 13, 48, 36, True, 0, True), case_hertz(code, 14, 64, 64, True, 1, True),
+        case_hertz(code, 15, 48, 36, True, 1, True, rigid=True)]
     code = translate("interfaceToLammps/fix_cohesive.cpp", 161, 262)
     if "--show" in sys.argv:
         print(code)

@@ -52,9 +52,16 @@ def test_hertzfix_history_compute_equals_the_reference_lines(k):
     ilist = np.arange(nlocal, dtype=np.int32)
     nl = ob.NeighList(nlocal, ob.P(ilist), ob.P(first), ob.P(jl), ob.P(touch), ob.P(shear))
     f, tq = np.zeros((n, 3)), np.zeros((n, 3))
+    # the fix_rigid branch (:182-185) replaces mi / mj of an atom of a rigid body by the body's mass and nothing else: the
+    # oracle's mass argument IS the mass the pair law sees
+    mass = ob.f64(I["rmass"])
+    if "mass_rigid" in I:
+        mr = ob.f64(I["mass_rigid"])
+        assert 5 < np.count_nonzero(mr) < n
+        mass = np.where(mr > 0.0, mr, mass)
     L.orc_pair_gran_hertzfix_history(C.byref(p), I["dt"], I["shearupdate"], nlocal, ob.P(ob.f64(I["x"])),
                                      ob.P(ob.f64(I["v"])), ob.P(ob.f64(I["omega"])), ob.P(ob.f64(I["radius"])),
-                                     ob.P(ob.f64(I["rmass"])), ob.P(ob.i32(I["mask"])), I["freeze_group_bit"],
+                                     ob.P(mass), ob.P(ob.i32(I["mask"])), I["freeze_group_bit"],
                                      C.byref(nl), ob.P(f), ob.P(tq))
     ref_touch = [t for i in range(nlocal) for t in O["touch"][i]]
     ref_shear = np.array([float.fromhex(s) for i in range(nlocal) for s in O["shear"][i]])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests import dem_cases as dc
-from tests.test_reference_pins import LUB_KEY, PINS, csr, unhex
+from tests.test_reference_pins import LUB_KEY, PINS, WALL_KEY, csr, unhex
 
 pytestmark = pytest.mark.gpu
 
@@ -38,12 +38,22 @@ def test_hip_hertzfix_history_equals_the_reference_lines(k):
     dfirst, djl, dtouch, dshear = _t(first), _t(jl), _t(touch), _t(shear)
     df = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
     dtq = torch.zeros_like(df)
-    assert S.sfk_pair_gran_history_compute(1, C.byref(pg), I["dt"], I["shearupdate"], nlocal, nlocal,
-                                           d["ilist"].data_ptr(), dfirst.data_ptr(), djl.data_ptr(), dtouch.data_ptr(),
-                                           dshear.data_ptr(), d["x"].data_ptr(), d["v"].data_ptr(), d["w"].data_ptr(),
-                                           d["r"].data_ptr(), d["m"].data_ptr(), d["mask"].data_ptr(),
-                                           I["freeze_group_bit"], df.data_ptr(), dtq.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream) == 0
+    if "mass_rigid" in I:   # the fix_rigid branch (:72-86, 182-185): the per-atom body masses go in as they are
+        dmr = _t(I["mass_rigid"], np.float64)
+        assert S.sfk_pair_gran_history_compute_rigid(1, C.byref(pg), I["dt"], I["shearupdate"], nlocal, nlocal,
+                                                     d["ilist"].data_ptr(), dfirst.data_ptr(), djl.data_ptr(),
+                                                     dtouch.data_ptr(), dshear.data_ptr(), d["x"].data_ptr(),
+                                                     d["v"].data_ptr(), d["w"].data_ptr(), d["r"].data_ptr(),
+                                                     d["m"].data_ptr(), d["mask"].data_ptr(), I["freeze_group_bit"],
+                                                     df.data_ptr(), dtq.data_ptr(), dmr.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream) == 0
+    else:
+        assert S.sfk_pair_gran_history_compute(1, C.byref(pg), I["dt"], I["shearupdate"], nlocal, nlocal,
+                                               d["ilist"].data_ptr(), dfirst.data_ptr(), djl.data_ptr(), dtouch.data_ptr(),
+                                               dshear.data_ptr(), d["x"].data_ptr(), d["v"].data_ptr(), d["w"].data_ptr(),
+                                               d["r"].data_ptr(), d["m"].data_ptr(), d["mask"].data_ptr(),
+                                               I["freeze_group_bit"], df.data_ptr(), dtq.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     ref_touch = np.array([t for i in range(nlocal) for t in O["touch"][i]], dtype=np.int32)
     ref_shear = np.array([float.fromhex(s) for i in range(nlocal) for s in O["shear"][i]]).reshape(-1, 3)
@@ -118,6 +128,38 @@ def test_hip_fix_fluid_drag_equals_the_reference_lines(k):
     torch.cuda.synchronize()
     assert dc.rel_err(df.cpu().numpy(), unhex(O["f"])) <= 1e-13
     assert np.array_equal(dvo.cpu().numpy(), unhex(O["vOld"]))
+
+
+@pytest.mark.parametrize("k", range(len(PINS[WALL_KEY])))
+def test_hip_fix_wall_granfix_equals_the_reference_lines(k):
+    """the HIP wall law (the contact-law functions of the sub-step kernel behind sfk_fix_wall_granfix_post_force) on the
+    inputs fix_wall_granFix.cpp:286-344 + the three laws of :361-678 were executed on: x / y / z plane pairs, hooke,
+    hooke/history, hertz/history, shearupdate 0 and 1, atoms outside the fix's group, history of atoms that left the wall"""
+    import torch
+    import sedifoam_amd
+    S = sedifoam_amd.lib()
+    from sedifoam_amd._lib import GranParams
+    c = PINS[WALL_KEY][k]
+    I, O = c["inp"], c["out"]
+    n = I["n"]
+    p = GranParams()
+    assert S.sfk_gran_settings(C.byref(p), I["kn"], 0, I["kt"], I["gamman"], 0, I["gammat"], I["xmu"], 1, 1.0) == 0
+    dx, dv, dw = _t(I["x"], np.float64), _t(I["v"], np.float64), _t(I["omega"], np.float64)
+    dr, dm, dmask = _t(I["radius"], np.float64), _t(I["rmass"], np.float64), _t(I["mask"], np.int32)
+    dsh = _t(I["shear"], np.float64)
+    df, dtq = torch.zeros((n, 3), dtype=torch.float64, device="cuda"), torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    assert S.sfk_fix_wall_granfix_post_force(I["pairstyle"], C.byref(p), I["wallstyle"], I["lo"], I["hi"], 0.0, I["dt"],
+                                             I["shearupdate"], n, dx.data_ptr(), dv.data_ptr(), dw.data_ptr(),
+                                             dr.data_ptr(), dm.data_ptr(), dmask.data_ptr(), I["groupbit"],
+                                             dsh.data_ptr(), df.data_ptr(), dtq.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream) == 0, S.sf_last_error()
+    torch.cuda.synchronize()
+    ref_f = unhex(O["f"])
+    assert np.count_nonzero(ref_f[:, I["wallstyle"]]) >= 20
+    assert dc.rel_err(df.cpu().numpy(), ref_f) <= 1e-12
+    assert dc.rel_err(dtq.cpu().numpy(), unhex(O["torque"])) <= 1e-12
+    if I["pairstyle"] != 0:
+        assert dc.rel_err(dsh.cpu().numpy(), unhex(O["shear"])) <= 1e-12
 
 
 @pytest.mark.parametrize("key,model", [("ErgunWenYu.C:104-132", 0), ("SyamlalOBrien.C:105-143", 1)])
