@@ -2,7 +2,8 @@
 driver over the stand-in wire against the single-domain run); development helper, GPU box.
 Both transports: the wire (SF_HALO_DIRECT=0) and direct ghost writes (=1, grids of up to 6 ranks: more spinning processes
 than that time-slice the one GPU for minutes).
-usage: python tests/fuzz_bricks.py [seed] [cases]   (42 cases on the final code of round 3, 40 on that of round 4: none failing)"""
+usage: [FUZZ_DIRECT=2] python tests/fuzz_bricks.py [seed] [cases]   (42 cases on the final code of round 3, 40 on that of
+round 4, 40 with FUZZ_DIRECT=2 -- ghost slots -- on that of round 5: none failing)"""
 import os, sys, tempfile, pathlib, traceback
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +31,8 @@ def main():
             physics = "hertz"
         px = bool(rng.random() < 0.8) or physics != "hertz"
         direct = "1" if (g[0] * g[1] * g[2] <= 6 and rng.random() < 0.5) else "0"
+        if os.environ.get("FUZZ_DIRECT") and g[0] * g[1] * g[2] <= 6:   # (FUZZ_DIRECT=2: every case of up to 6 ranks on ghost slots)
+            direct = os.environ["FUZZ_DIRECT"]
         c = (g, nc, physics, px, direct)
         with tempfile.TemporaryDirectory() as d:
             try:

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests import dem_cases as dc
-from tests.test_reference_pins import LUB_KEY, PINS, WALL_KEY, csr, unhex
+from tests.test_reference_pins import CLOUD_KEY, LUB_KEY, PINS, WALL_KEY, _vunhex, csr, unhex
 
 pytestmark = pytest.mark.gpu
 
@@ -179,3 +179,52 @@ def test_hip_drag_model_jd_equals_the_reference_lines(key, model):
         # per element: the values span 30 decades (Re clamps to ROOTVSMALL for a particle at rest)
         ok = np.abs(got - ref) <= 1e-9 * np.abs(ref) if model == 1 else np.abs(got - ref) <= 1e-12 * np.abs(ref)
         assert ok.all(), (key, np.max(np.abs(got - ref) / np.abs(ref)))
+
+
+# the cloud cases the HIP cloud can be walked through without a DEM step in between: one CFD step, no force that needs the
+# previous step's particle velocity (added mass, history force)
+_CLOUD_HIP = [k for k, c in enumerate(PINS[CLOUD_KEY])
+              if c["inp"]["n_steps"] == 1 and not any(c["inp"]["flags"].get(f) for f in
+                                                      ("particleAddedMass", "particleHistoryForce", "particleLift",
+                                                       "lubricationForce", "particleBuoyancy"))]
+
+
+@pytest.mark.parametrize("k", _CLOUD_HIP)
+def test_hip_cloud_kernels_equal_the_reference_lines(k):
+    """the HIP cloud (sf_cloud_*: cell owner, particleToEulerianField, the drag closure + force assembly of
+    updateDragOnParticles with the inlet override, calcTcFields) on the inputs enhancedCloud.C:41-108, 129-311, 318-439,
+    913-979 were executed on line by line: gamma, Ue, Jd, the force handed to the DEM, Asrc, Omega"""
+    from sedifoam_amd import enhancedCloud
+    c = PINS[CLOUD_KEY][k]
+    I, O = c["inp"], c["out"][0]
+    assert len(_CLOUD_HIP) >= 3
+    n = I["n"]
+    mesh_n = np.array(I["mesh_n"], np.int32)
+    dx = np.full(3, I["dx"])
+    pos = np.array(I["pos"])
+    bed = dict(x=pos, v=np.array(I["U"][1]), diameter=np.array(I["d"]), density=np.full(n, I["rho"]),
+               boxlo=np.zeros(3), boxhi=mesh_n * dx, periodic=(0, 0, 0), n=n)
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=9.81, dt=1.0e-6, skin=0.25e-3, walls=[])
+    lmp = dc.make_hip(bed, cfg)
+    cloudDict = dict(dragModel={0: "ErgunWenYu", 1: "SyamlalOBrien"}[I["model"]], subCycles=1, g=tuple(I["gravity"]),
+                     **{f: bool(v) for f, v in I["flags"].items()})
+    if I["inlet"]:
+        cloudDict.update(I["inlet"])
+    cloud = enhancedCloud(lmp, np.zeros(3), dx, mesh_n, cloudDict, dict(rhob=I["rhob"], nub=I["nub"]), I["deltaT"])
+    cloud.setFluid(Uf=np.array(I["Uf"]), DDtUf=np.array(I["DDtUf"]), gradp=np.array(I["gradp"]), curlU=np.array(I["curlU"]))
+    cloud._phase(0)        # the next time step
+    cloud._phase(1)        # updateParticleAlpha / Ur, Jd, updateDragOnParticles
+    cloud.calcTcFields()
+    P = cloud.particles()
+    o = np.argsort(P["tag"])
+    assert np.array_equal(P["tag"][o], np.arange(1, n + 1))
+    assert np.array_equal(P["cell"][o], np.array(I["cell"]))       # (the owner the reference's tracking would give)
+    g, ue, asrc, om = cloud._fields()
+    assert dc.rel_err(g, unhex(O["gamma"])) <= 1e-12
+    assert dc.rel_err(ue, _vunhex(O["Ue"])) <= 1e-12
+    assert dc.rel_err(P["Jd"][o], unhex(O["Jd"])) <= 1e-12
+    assert dc.rel_err(P["pDrag"][o], _vunhex(O["pDrag"])) <= 1e-12
+    assert dc.rel_err(asrc, _vunhex(O["Asrc"])) <= 1e-12
+    assert dc.rel_err(om, unhex(O["Omega"])) <= 1e-12
+    if I["inlet"]:
+        assert np.count_nonzero(np.any(_vunhex(O["pDrag"]) != 0.0, axis=1)) > 10
