@@ -1314,6 +1314,51 @@ void DemEngine::rebuild_sort()
   }
 }
 
+static thread_local bool ghost_sync_once_ = false;   // (bin_and_build: a deferred count overflowed -- make the ghosts again, synchronously)
+// The ghost count stays on the device between the ghost creation and the list build (no host round trip for it: the
+// host learns it with the flags it reads behind the list build anyway).  These are k_ghost_cells / k_key_place /
+// k_key_rank of sf_dem_kernels.h for a count the kernel reads itself; launched for the most ghosts the capacity could
+// hold.  A count that overflowed the capacity (F_GHOST_OVER) makes them do nothing: the host grows and repeats.
+__device__ __forceinline__ int ghosts_on_device(const int* flags, int nlocal, size_t cap)
+{
+  const int n = flags[F_GHOST_COUNT];
+  return (flags[F_GHOST_OVER] || (size_t)nlocal + (size_t)n > cap) ? 0 : n;
+}
+__global__ __launch_bounds__(256) static void k_ghost_cells_dev(const double4* xr, int nlocal, size_t cap, BinGrid g,
+                                                                unsigned* keys, int* count, int* flags)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ghosts_on_device(flags, nlocal, cap)) return;
+  int lost = 0;
+  const unsigned b = (unsigned)bin_of(xr[nlocal + k], g, lost);
+  keys[k] = b;
+  atomicAdd(&count[b], 1);
+  if (lost) flags[F_LOST] = 1;
+}
+__global__ __launch_bounds__(256) static void k_key_place_dev(const unsigned* keys, const int* flags, int nlocal, size_t cap,
+                                                              int* count, const int* first, int* arrival)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ghosts_on_device(flags, nlocal, cap)) return;
+  const unsigned b = keys[i];
+  arrival[first[b] + atomicSub(&count[b], 1) - 1] = i;
+}
+__global__ __launch_bounds__(256) static void k_key_rank_dev(const unsigned* keys, const int* flags, int nlocal, size_t cap,
+                                                             const int* first, const int* arrival, const int* tag, int* perm)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ghosts_on_device(flags, nlocal, cap)) return;
+  const unsigned b = keys[i];
+  const int s = first[b], e = first[b + 1];
+  const int ti = tag[nlocal + i];
+  int r = 0;
+  for (int k = s; k < e; k++) {
+    const int a = arrival[k], ta = tag[nlocal + a];
+    r += (ta < ti || (ta == ti && a < i)) ? 1 : 0;
+  }
+  perm[s + r] = nlocal + i;
+}
+
 void DemEngine::make_periodic_ghosts()
 {
   // external ghosts (other GPUs) were appended by border_unpack: slots [nlocal, nlocal+next_ghost_)
@@ -1337,6 +1382,13 @@ void DemEngine::make_periodic_ghosts()
       k_ghost_create<<<std::max(1, div_up((long long)(cap_ - nlocal_), 256)), 256, 0, stream_>>>(
           G, perm_.as<int>(), nlocal_, dim, boxhi_[dim] - boxlo_[dim], cap_, d_flags_, F_GHOST_BEFORE + dim,
           q + 1 < nd ? F_GHOST_BEFORE + dims[q + 1] : -1);
+    }
+    // (the count can stay on the device until the flags are read behind the list build: bin_and_build; nghost_ < 0 =
+    // "on the device".  SF_GHOST_DEFER=0: read it here, as before round 5)
+    static const bool defer = !(getenv("SF_GHOST_DEFER") && !atoi(getenv("SF_GHOST_DEFER")));
+    if (defer && attempt == 0 && row_tables_ && !ghost_sync_once_) {
+      nghost_ = -1;
+      return;
     }
     read_flags();
     if (!h_flags_[F_GHOST_OVER] && (size_t)nlocal_ + h_flags_[F_GHOST_COUNT] <= cap_) {
@@ -1426,7 +1478,24 @@ void DemEngine::bin_and_build()
   int* cellLE = cell_start_ + 1;
   int* cellGS = cell_start_ + 2;
   int* cellGE = cell_start_ + 3;
-  if (nghost_ && row_tables_) {
+  // (nghost_ < 0: the ghost count is still on the device -- make_periodic_ghosts did not wait for it; the kernels below read
+  // it themselves and are launched for the most ghosts the capacity could hold)
+  const bool ghosts_pending = nghost_ < 0;
+  if (ghosts_pending && !row_tables_) fail("bin_and_build: deferred ghost count without row tables");
+  if (ghosts_pending) {
+    const int ne = grid_.nbins + 1;
+    const int ng = std::max(1, div_up((long long)(cap_ - (size_t)nlocal_), 256));
+    int* count = cell_start_ + 2 * cell_alloc_;
+    int* first = cell_start_ + 3 * cell_alloc_;
+    hist_clean_ = false;
+    k_ghost_cells_dev<<<ng, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, cap_, grid_, keys_.as<unsigned>(), count,
+                                               d_flags_);
+    exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, first, ne, stream_);
+    k_key_place_dev<<<ng, 256, 0, stream_>>>(keys_.as<unsigned>(), d_flags_, nlocal_, cap_, count, first, perm_.as<int>());
+    k_key_rank_dev<<<ng, 256, 0, stream_>>>(keys_.as<unsigned>(), d_flags_, nlocal_, cap_, first, perm_.as<int>(),
+                                            tag_.as<int>(), perm_alt_.as<int>());
+    hist_clean_ = true;
+  } else if (nghost_ && row_tables_) {
     // ghosts in (cell, tag) order by the same counting sort as the owned atoms; its scan IS the table of first
     // ghost-order positions per cell that the list build reads
     const int ne = grid_.nbins + 1, ng = div_up(nghost_, 256);
@@ -1470,7 +1539,7 @@ void DemEngine::bin_and_build()
     B.two_copies = hist_single_ ? 0 : 1;
     B.touch_first = touch_first_ ? 1 : 0;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
-    B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;
+    B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;   // (nghost_ < 0: on the device)
     B.roots = roots_ ? 1 : 0;
     B.gsrc = gsrc_.as<int>();
     B.gshift = gshift_.as<double>();
@@ -1488,6 +1557,19 @@ void DemEngine::bin_and_build()
     k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_old_.as<int>(), nlocal_, cap_,
                                                             roots_ ? 1 : 0);
     SF_HIP(hipEventSynchronize(ev_flags_));
+    if (ghosts_pending && nghost_ < 0) {
+      // the ghost count arrives with these flags.  More ghosts than the capacity held: nothing above saw a ghost -- grow,
+      // make the ghosts again (this time waiting for the count) and start over
+      if (h_flags_[F_GHOST_OVER] || (size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] > cap_) {
+        ensure_capacity((size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] * 2 + 1024);
+        ghost_sync_once_ = true;
+        make_periodic_ghosts();
+        ghost_sync_once_ = false;
+        bin_and_build();
+        return;
+      }
+      nghost_ = h_flags_[F_GHOST_COUNT];
+    }
     if (h_flags_[F_NEIGH_OVER] > M_) {
       // more neighbours than slots: widen the slot-major arrays and build again.  The old-history
       // arrays keep their first rows, so the re-injection still finds every partner.
