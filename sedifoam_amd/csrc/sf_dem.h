@@ -607,6 +607,10 @@ private:
   bool external_stream_ = false;
   size_t cap_ = 0;
   int nlocal_ = 0, nghost_ = 0, next_ghost_ = 0;   // next_ghost_: external ghosts appended by border_unpack
+                                                   // nghost_ < 0 (inside a rebuild only): the count is still on the device --
+                                                   // make_periodic_ghosts did not wait for it, bin_and_build reads it with its flags
+  bool ghost_sync_ = false;                        // bin_and_build: a deferred count overflowed the capacity -- make the ghosts
+                                                   // again and wait for the count
   int cur_ = 0;
   int M_ = 32;
   int max_neigh_used_ = 0;

@@ -1314,51 +1314,6 @@ void DemEngine::rebuild_sort()
   }
 }
 
-static thread_local bool ghost_sync_once_ = false;   // (bin_and_build: a deferred count overflowed -- make the ghosts again, synchronously)
-// The ghost count stays on the device between the ghost creation and the list build (no host round trip for it: the
-// host learns it with the flags it reads behind the list build anyway).  These are k_ghost_cells / k_key_place /
-// k_key_rank of sf_dem_kernels.h for a count the kernel reads itself; launched for the most ghosts the capacity could
-// hold.  A count that overflowed the capacity (F_GHOST_OVER) makes them do nothing: the host grows and repeats.
-__device__ __forceinline__ int ghosts_on_device(const int* flags, int nlocal, size_t cap)
-{
-  const int n = flags[F_GHOST_COUNT];
-  return (flags[F_GHOST_OVER] || (size_t)nlocal + (size_t)n > cap) ? 0 : n;
-}
-__global__ __launch_bounds__(256) static void k_ghost_cells_dev(const double4* xr, int nlocal, size_t cap, BinGrid g,
-                                                                unsigned* keys, int* count, int* flags)
-{
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ghosts_on_device(flags, nlocal, cap)) return;
-  int lost = 0;
-  const unsigned b = (unsigned)bin_of(xr[nlocal + k], g, lost);
-  keys[k] = b;
-  atomicAdd(&count[b], 1);
-  if (lost) flags[F_LOST] = 1;
-}
-__global__ __launch_bounds__(256) static void k_key_place_dev(const unsigned* keys, const int* flags, int nlocal, size_t cap,
-                                                              int* count, const int* first, int* arrival)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ghosts_on_device(flags, nlocal, cap)) return;
-  const unsigned b = keys[i];
-  arrival[first[b] + atomicSub(&count[b], 1) - 1] = i;
-}
-__global__ __launch_bounds__(256) static void k_key_rank_dev(const unsigned* keys, const int* flags, int nlocal, size_t cap,
-                                                             const int* first, const int* arrival, const int* tag, int* perm)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ghosts_on_device(flags, nlocal, cap)) return;
-  const unsigned b = keys[i];
-  const int s = first[b], e = first[b + 1];
-  const int ti = tag[nlocal + i];
-  int r = 0;
-  for (int k = s; k < e; k++) {
-    const int a = arrival[k], ta = tag[nlocal + a];
-    r += (ta < ti || (ta == ti && a < i)) ? 1 : 0;
-  }
-  perm[s + r] = nlocal + i;
-}
-
 void DemEngine::make_periodic_ghosts()
 {
   // external ghosts (other GPUs) were appended by border_unpack: slots [nlocal, nlocal+next_ghost_)
@@ -1386,7 +1341,7 @@ void DemEngine::make_periodic_ghosts()
     // (the count can stay on the device until the flags are read behind the list build: bin_and_build; nghost_ < 0 =
     // "on the device".  SF_GHOST_DEFER=0: read it here, as before round 5)
     static const bool defer = !(getenv("SF_GHOST_DEFER") && !atoi(getenv("SF_GHOST_DEFER")));
-    if (defer && attempt == 0 && row_tables_ && !ghost_sync_once_) {
+    if (defer && attempt == 0 && row_tables_ && !ghost_sync_) {
       nghost_ = -1;
       return;
     }
@@ -1562,9 +1517,9 @@ void DemEngine::bin_and_build()
       // make the ghosts again (this time waiting for the count) and start over
       if (h_flags_[F_GHOST_OVER] || (size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] > cap_) {
         ensure_capacity((size_t)nlocal_ + (size_t)h_flags_[F_GHOST_COUNT] * 2 + 1024);
-        ghost_sync_once_ = true;
+        ghost_sync_ = true;
         make_periodic_ghosts();
-        ghost_sync_once_ = false;
+        ghost_sync_ = false;
         bin_and_build();
         return;
       }

@@ -1286,6 +1286,50 @@ __global__ __launch_bounds__(256) void k_ghost_cells(const double4* xr, int nloc
   if (lost) flags[F_LOST] = 1;
 }
 
+// The ghost count stays on the device between the ghost creation and the list build (no host round trip for it: the
+// host learns it with the flags it reads behind the list build anyway).  These are k_ghost_cells / k_key_place /
+// k_key_rank of sf_dem_kernels.h for a count the kernel reads itself; launched for the most ghosts the capacity could
+// hold.  A count that overflowed the capacity (F_GHOST_OVER) makes them do nothing: the host grows and repeats.
+__device__ __forceinline__ int ghosts_on_device(const int* flags, int nlocal, size_t cap)
+{
+  const int n = flags[F_GHOST_COUNT];
+  return (flags[F_GHOST_OVER] || (size_t)nlocal + (size_t)n > cap) ? 0 : n;
+}
+__global__ __launch_bounds__(256) void k_ghost_cells_dev(const double4* xr, int nlocal, size_t cap, BinGrid g,
+                                                                unsigned* keys, int* count, int* flags)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ghosts_on_device(flags, nlocal, cap)) return;
+  int lost = 0;
+  const unsigned b = (unsigned)bin_of(xr[nlocal + k], g, lost);
+  keys[k] = b;
+  atomicAdd(&count[b], 1);
+  if (lost) flags[F_LOST] = 1;
+}
+__global__ __launch_bounds__(256) void k_key_place_dev(const unsigned* keys, const int* flags, int nlocal, size_t cap,
+                                                              int* count, const int* first, int* arrival)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ghosts_on_device(flags, nlocal, cap)) return;
+  const unsigned b = keys[i];
+  arrival[first[b] + atomicSub(&count[b], 1) - 1] = i;
+}
+__global__ __launch_bounds__(256) void k_key_rank_dev(const unsigned* keys, const int* flags, int nlocal, size_t cap,
+                                                             const int* first, const int* arrival, const int* tag, int* perm)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ghosts_on_device(flags, nlocal, cap)) return;
+  const unsigned b = keys[i];
+  const int s = first[b], e = first[b + 1];
+  const int ti = tag[nlocal + i];
+  int r = 0;
+  for (int k = s; k < e; k++) {
+    const int a = arrival[k], ta = tag[nlocal + a];
+    r += (ta < ti || (ta == ti && a < i)) ? 1 : 0;
+  }
+  perm[s + r] = nlocal + i;
+}
+
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
 // history re-injected by partner tag (FixShearHistory)
 __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double4* xr, const int* tag,
