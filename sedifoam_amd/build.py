@@ -34,13 +34,18 @@ def _stale(target, deps):
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) of the sources the sub-step kernel is compiled from: stored next to a PMC summary
+    """sha256 (first 16 hex digits) of the sources the sub-step kernel is compiled from -- their CODE: comments and white
+    space are taken out first, so that a corrected comment does not disown a measurement -- stored next to a PMC summary
     (tests/pmc_summarize.py) so that bench.py can tell whether the committed HBM-traffic counters still describe the
     kernel it is timing"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in ("sf_dem_kernels.h", "sf_dem_variants.h", "sf_dem_gs.h", "sf_physics.h", "sf_dem.h", "sf_common.h"):
-        h.update(open(os.path.join(CSRC, f), "rb").read())
+        src = open(os.path.join(CSRC, f), "r").read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)     # (none of these files holds "//" or "/*" inside a string)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(" ".join(src.split()).encode())
     h.update(" ".join(FLAGS + FILE_FLAGS.get("sf_dem.hip", [])).encode())   # (and the flags it is compiled with)
     return h.hexdigest()[:16]
 

@@ -12,7 +12,7 @@ namespace sf {
 // records of this rank's ghosts straight into the ghost range of its record arrays xr / vm / om (IPC mappings of the
 // arrays themselves), so nothing stands between two sub-step kernels and the gathers of the sub-step kernel are the same
 // instructions for owned atoms and ghosts.  The writer uses write-through system-scope stores; the hand-off is
-// {records, s_waitcnt vmcnt(0), completion count, vote, flag} on the sending side and {flag poll, vote, gathers} on the
+// {records, s_waitcnt vmcnt(0), completion count, the flag | vote word} on the sending side and {the word, gathers} on the
 // receiving side.  The reader needs no fence: a kernel starts with its caches invalidated, and no wave touches a cache
 // line that holds ghost records before its gate has seen every flag (the waves whose OWN records share a line with the
 // first ghosts pass the gate before their first load).
@@ -115,7 +115,7 @@ __device__ __forceinline__ void gs_publish(const GsSync* Y, const int vote, cons
 // wave counts itself done on its XCD's line with ONE fire-and-forget 64-bit atomic: +1, and +2^32 when one of its atoms
 // moved beyond skin / 2 (this launch's vote travels with the count: no second word to order, nothing to wait for).  ONE
 // wave of the launch (`poller`: the first workgroup of the first XCD that has any) stays behind, watches the eight counters
-// until every XCD has counted all of its workgroups, clears them and tells every rank: vote first, then the flag.
+// until every XCD has counted all of its workgroups, clears them and tells every rank (one flag | vote word each).
 // `expected_lane`: workgroups of XCD x that run the kernel (the poller's lane x < 8 holds it).
 __device__ __forceinline__ void gs_done(const DemPtrs& P, const StepParams& S, const bool wrote, const bool triggered,
                                         const bool poller, const int expected_lane)
@@ -157,7 +157,7 @@ __device__ __forceinline__ void gs_done(const DemPtrs& P, const StepParams& S, c
   gs_publish(Y, vote, S.gs_seq + 1);
 }
 
-// a rank that owns no atom launches no sub-step kernel: its part of the hand-off alone (the gate, then vote and flag)
+// a rank that owns no atom launches no sub-step kernel: its part of the hand-off alone (the gate, then its word)
 __global__ __launch_bounds__(64) static void k_gs_idle(const GsSync* Y, int* flags, int seq, int kstep, int publish)
 {
   if (__atomic_load_n(&flags[F_TRIGGER], __ATOMIC_RELAXED) < kstep) return;
