@@ -3,7 +3,7 @@ driver over the stand-in wire against the single-domain run); development helper
 Both transports: the wire (SF_HALO_DIRECT=0) and direct ghost writes (=1, grids of up to 6 ranks: more spinning processes
 than that time-slice the one GPU for minutes).
 usage: [FUZZ_DIRECT=2] python tests/fuzz_bricks.py [seed] [cases]   (42 cases on the final code of round 3, 40 on that of
-round 4, 40 with FUZZ_DIRECT=2 -- ghost slots -- on that of round 5: none failing)"""
+round 4, 80 (seeds 7 and 11) with FUZZ_DIRECT=2 -- ghost slots -- on that of round 5: none failing)"""
 import os, sys, tempfile, pathlib, traceback
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
