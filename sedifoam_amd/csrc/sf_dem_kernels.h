@@ -32,6 +32,9 @@
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
+#ifndef SF_COOP_GATHER
+#define SF_COOP_GATHER 1      // a neighbour's 32-byte record is read by the two lanes l, l + 32 together (see coop_merge)
+#endif
 // Instrumentation of variant builds (tests/build_variant.sh): SF_EXP_STAMP / SF_EXP_PHASE, the workgroup timeline of one
 // launch -- sf_dem_variants.h.  The pricing arms of rounds 1-4 (history traffic off, agent-coherent access forms, LDS-DMA
 // row streams, the no-wait persistent kernel, neighbour records by lane shuffle, the two-lane launch tail) were measured,
@@ -96,11 +99,81 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // one lane per atom) are bound by the latency of one lane's 12 dependent neighbour iterations, not by bandwidth.
 // GS: ghost slots (sf_dem_gs.h).  Returns 0 when the wave stopped at the gate (nothing was stored), else 1 | 2 when the atom
 // may have written border records (what the hand-off must wait for) | 4 when it moved beyond skin / 2 (its vote).
+// ------------------------------------------------------------------------------------------------
+// Half-wave gather.  The texture addresser prices a vector load by the 128-byte lines it touches (tests/micro/gather_bench:
+// 2.2 cycles per line + ~5), and a record gather as "16 bytes per lane, twice" touches every neighbour's line twice: 37.8
+// cycles per instruction on consecutive records, 141 on scattered ones.  Here instruction A reads the records of the
+// neighbours of lanes 0..31 -- lane l their first 16 bytes, lane l + 32 their second 16 bytes -- and instruction B those of
+// lanes 32..63: every line is touched once (22.7 cycles on consecutive records, half the lines on scattered ones).  One
+// v_permlane32_swap per dword puts the halves where the arithmetic expects them: A' = first halves, B' = second halves of
+// every lane's OWN neighbour.  Same bytes, same arithmetic, same results.
+// ------------------------------------------------------------------------------------------------
+// Which kernels gather that way -- measured (profiles/r05_README.md section 6): it pays where the launch is bound by the
+// throughput of the memory pipe -- beds that do not fit the memory-side cache (non-temporal policies 1, 2: beyond ~650 k
+// grains; the 1 M headline bed -2 to -3 %, 2 M -2 %), and most in the kernel with both the cohesive and the lubrication
+// arm on a polydisperse bed, whose gathers scatter (500 k: -5 to -8 %).  Beds of a few rounds of resident waves are bound
+// by the length of ONE wave, which the exchanges lengthen (60 k - 250 k grains: 0 to +2 %, loose 126 k: +5 %); the kernels
+// that request v, omega only of touching pairs (loose beds) gain nothing at any size, the lean kernels with one arm lose
+// 1 - 1.5 %: all of those keep the plain gather.
+__host__ __device__ constexpr bool sf_coop_variant(bool cohe, bool lub, int lpa, bool tp, int ntp)
+{
+  return SF_COOP_GATHER && lpa == 1 && (ntp == 1 || ntp == 2) && ((cohe && lub) || (!cohe && !lub && !tp));
+}
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b)
+{
+  typedef unsigned sf_u2 __attribute__((ext_vector_type(2)));
+  const sf_u2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);   // a[32..63] <-> b[0..31]
+  a = r.x;
+  b = r.y;
+}
+__device__ __forceinline__ void swap32(double& a, double& b)
+{
+  unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  swap32(alo, blo);
+  swap32(ahi, bhi);
+  a = __hiloint2double((int)ahi, (int)alo);
+  b = __hiloint2double((int)bhi, (int)blo);
+}
+// what the two cooperative loads of a record returned (.x .y: instruction A, .z .w: instruction B) -> the lane's record
+__device__ __forceinline__ double4 coop_merge(double4 r)
+{
+  swap32(r.x, r.z);
+  swap32(r.y, r.w);
+  return r;
+}
+// lane l < 32: (j(l), j(l + 32)); lane l + 32: the same pair -- and whether v, omega of the two are wanted (bit 31 travels
+// with the index)
+__device__ __forceinline__ void coop_indices(const int j, const bool vw, int& ja, int& jb, bool& vwa, bool& vwb)
+{
+  unsigned a = (unsigned)j | (vw ? 0x80000000u : 0u), b = a;
+  swap32(a, b);
+  ja = (int)(a & (unsigned)kIdxMask);   // (tells the compiler what it knew about j: record offsets fit 32 bits)
+  jb = (int)(b & (unsigned)kIdxMask);
+  vwa = (int)a < 0;
+  vwb = (int)b < 0;
+}
+// (half: byte offset of the lane's half of a record -- 0 in lanes 0..31, 16 in lanes 32..63)
+__device__ __forceinline__ double4 coop_load(const double4* arr, const int ja, const int jb, const int half,
+                                             const bool wa = true, const bool wb = true)
+{
+  const char* p = reinterpret_cast<const char*>(arr);
+  double2 a = {0.0, 0.0}, b = {0.0, 0.0};
+  if (wa) a = *reinterpret_cast<const double2*>(p + (((unsigned)ja << 5) | (unsigned)half));
+  if (wb) b = *reinterpret_cast<const double2*>(p + (((unsigned)jb << 5) | (unsigned)half));
+  return double4{a.x, a.y, b.x, b.y};
+}
+
 template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP, bool GS = false>
 __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw,
-                                                 const unsigned long long gs_w = 0ull)
+                                                 const unsigned long long gs_w = 0ull, const bool live = true)
 {
+  // COOP: the records of a neighbour are read by lane pairs (l, l + 32) -- every lane of the wave walks the neighbour loop
+  // to the wave's largest count, `live` = this lane holds an atom (the caller clamps i of the others to a valid one: they
+  // load, take part in the exchanges, and store nothing)
+  constexpr bool COOP = !LDS && sf_coop_variant(COHE, LUB, LPA, TP, NTP);
+  const int coop_half = (int)(threadIdx.x & 32) >> 1;   // (byte offset of this lane's half of a record: 0 | 16)
   const size_t cap = (size_t)S.cap;
   const bool shearupdate = (S.mode != 2);
   // the gathering kernel always runs on (root, image code) words, the LDS-staged one on plain indices: a compile-time
@@ -130,7 +203,8 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
   const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
   const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
-  const int nn = LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
+  const int nn = COOP ? (live ? nn_all : 0)
+                      : LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
   // Latency structure of one slot: index -> gather of the neighbour's three records -> contact law.
@@ -188,13 +262,39 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
       const int j = neigh_index(jraw, ROOTS);
       R.l = j;   // (gather mode: the root index, used by the register reuse below)
       R.vw = wants_vw(jraw);
-      R.x = P.xr_in[j];
-      if (R.vw) {
-        R.v = P.vm_in[j];
-        R.w = P.om_in[j];
+      if (COOP) {   // (every lane of the wave is here; merged by the consumer, coop_merge)
+        int ja, jb;
+        bool vwa, vwb;
+        coop_indices(j, R.vw, ja, jb, vwa, vwb);
+        R.x = coop_load(P.xr_in, ja, jb, coop_half);
+        if (NEED_VW) {
+          if (TP) {   // (v, omega only of the neighbours whose pair touched one sub-step ago: both lanes of a pair know)
+            R.v = coop_load(P.vm_in, ja, jb, coop_half, vwa, vwb);
+            R.w = coop_load(P.om_in, ja, jb, coop_half, vwa, vwb);
+          } else {
+            R.v = coop_load(P.vm_in, ja, jb, coop_half);
+            R.w = coop_load(P.om_in, ja, jb, coop_half);
+          }
+        }
+      } else {
+        R.x = P.xr_in[j];
+        if (R.vw) {
+          R.v = P.vm_in[j];
+          R.w = P.om_in[j];
+        }
       }
     }
     if (HIST_PF) load_history(jraw, slotrow, R.sh);
+  };
+  // COOP: the halves of a prefetched record are exchanged at the END of the slot that requested it (the contact evaluation
+  // in between hides the gather), so the register set that crosses into the next slot holds plain records
+  auto coop_finish = [&](Rec& R) {
+    if (!COOP) return;
+    R.x = coop_merge(R.x);
+    if (NEED_VW) {
+      R.v = coop_merge(R.v);
+      R.w = coop_merge(R.w);
+    }
   };
   // rows of the slot-major arrays are addressed as (row pointer)[i]: with one lane per atom the slot -- hence the row
   // pointer -- is wave-uniform (scalar registers), the element offset 32 bits
@@ -231,7 +331,16 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
       return 0;
     }
   }
-  if (nn > 0) fetch(jraw_n1, q, RA);
+  // COOP: every lane walks the neighbour loop to the largest count of the wave (all 64 lanes are here)
+  int nn_wave = nn;
+  if (COOP) {
+    for (int off = 32; off > 0; off >>= 1) nn_wave = max(nn_wave, __shfl_xor(nn_wave, off, 64));
+    nn_wave = __builtin_amdgcn_readfirstlane(nn_wave);
+  }
+  if (COOP ? nn_wave > 0 : nn > 0) {
+    fetch(jraw_n1, q, RA);
+    coop_finish(RA);
+  }
 
   // one slot: `cur` holds the neighbour's records, `nxt` receives the prefetch of slot s+1
   auto slot_body = [&](const int s, const Rec& cur, Rec& nxt, const bool more, const bool uniform_s) {
@@ -250,6 +359,7 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
     if (STYLE != 0 && LPA == 1 && !own && (jraw & kTouchBit)) sh = {-sh.x, -sh.y, -sh.z};
     jraw_n1 = jraw_n2;
     if (s + 2 < nn) jraw_n2 = ld_stream<NT_LD>(&(nrow + (size_t)(2 * LPA) * cap)[i]);
+    else if (COOP) jraw_n2 = 0;   // (a lane beyond its count keeps loading for its partner: word 0 = atom 0, no bits)
     if (more) {
       bool reuse = false;
       if (!reuse) fetch(jraw_n1, sl + LPA, nxt);
@@ -274,7 +384,8 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
       }
     }
     const Vec3 del = xi - v3(xj4);
-    const double rsq = dot(del, del);
+    // (COOP: a lane beyond its own count is here for its partner's loads: no pair, nothing touches, nothing is stored)
+    const double rsq = (COOP && s >= nn) ? 1.0e300 : dot(del, del);
     const double radj = xj4.w;
     const double radsum = radi + radj;
 
@@ -343,11 +454,24 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
         lubricate_poly_pair(S.lub, del, r_pair, rinv_pair, radi, radj, vi, v3(vj4), wi, v3(wj4), F, T);
       }
     }
+    if (more) coop_finish(nxt);
   };
   // unrolled by two so that the prefetch ping-pongs between RA and RB without register copies
   SF_PH(1);
   int s = 0;
-  if constexpr (SF_UNROLL2 && !LEAN) {
+  if constexpr (COOP && SF_UNROLL2 && !LEAN) {
+    // (a counted loop in scalar registers: the largest count of the wave)
+    for (; s + 1 < nn_wave; s += 2) {
+      slot_body(s, RA, RB, true, true);
+      slot_body(s + 1, RB, RA, s + 2 < nn_wave, true);
+    }
+    if (s < nn_wave) slot_body(s, RA, RB, false, true);
+  } else if constexpr (COOP) {
+    for (; s < nn_wave; s++) {
+      slot_body(s, RA, RB, s + 1 < nn_wave, true);
+      RA = RB;
+    }
+  } else if constexpr (SF_UNROLL2 && !LEAN) {
     for (; s + 1 < nn; s += 2) {
       slot_body(s, RA, RB, true, true);
       slot_body(s + 1, RB, RA, s + 2 < nn, true);
@@ -360,6 +484,7 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
     }
   }
   SF_PH(27);
+  if (COOP && !live) return 1;
   if (LPA > 1) {
     // fixed tree: (q0 + q1) [+ (q2 + q3)] -- the same bits on every run
     for (int off = 1; off < LPA; off <<= 1) {
@@ -657,15 +782,21 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
   const int tid = bid * blockDim.x + threadIdx.x;
   int i = tid / LPA;          // LPA consecutive lanes share an atom
   const int q = tid % LPA;
+  // (half-wave gather, COOP in substep_particle: the lanes of a wave that hold no atom stay -- on atom 0, storing nothing --
+  // because their partner lanes l +- 32 read a neighbour's record together with them)
+  constexpr bool COOPK = sf_coop_variant(COHE, LUB, LPA, TP, NTP);
+  bool live = true;
   if (S.part == 2) {          // atoms next to the slab's x faces: a prefix and a suffix of the x-slowest order
-    if (i >= S.nb) return;
-    if (i >= S.n_lo) i += S.n_hi - S.n_lo;
+    live = i < S.nb;
+    if (live && i >= S.n_lo) i += S.n_hi - S.n_lo;
   } else if (S.part == 1) {   // everything in between
     i += S.n_lo;
-    if (i >= S.n_hi) return;
-  } else if (!GS && i >= S.nlocal) {
-    return;
+    live = i < S.n_hi;
+  } else {
+    live = i < S.nlocal;
   }
+  if (!live) i = 0;
+  if (!GS && !(COOPK ? __ballot(live) != 0 : live)) return;
   // a timed launch (one in a few hundred): when did this XCD start, when did it finish?  (the engine evens the shares out)
   // (each XCD's two words on a cache line of their own, the end stamped by one workgroup in eight: atomics on one line
   // are resolved one after the other at the memory side, ~11 ns each -- 31 k of them doubled the launch)
@@ -675,12 +806,12 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     // (every workgroup that gets here counts itself done, whatever part of it holds atoms: the lanes beyond the last atom
     // stay for the wave-level hand-off instead of returning)
     int ran = 1;
-    if (i < S.nlocal)
-      ran = substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP, true>(P, S, i, q, nullptr, nullptr, nullptr, gs_w);
+    if (COOPK ? __ballot(live) != 0 : live)
+      ran = substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP, true>(P, S, i, q, nullptr, nullptr, nullptr, gs_w, live);
     if (__ballot(ran == 0)) return;   // (stopped at the gate -- the whole wave did: the gate is a wave-level decision)
     if (S.mode == 0) gs_done(P, S, (ran & 2) != 0, (ran & 4) != 0, gs_poller, gs_expected);
   } else {
-    substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr);
+    substep_particle<STYLE, COHE, LUB, false, LPA, TP, NTP>(P, S, i, q, nullptr, nullptr, nullptr, 0ull, live);
   }
   if (S.xcd_time && threadIdx.x == 0 && ((blockIdx.x >> 3) & 7) == 0)
     atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));

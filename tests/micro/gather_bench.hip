@@ -84,6 +84,19 @@ int main()
     for (int l = 0; l < 64; l++) off[l] = (l >> 1) * 32 + (l & 1) * 16;
     CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
     run<16, 1024>("16 B/lane, lane pairs share a record, consecutive records (8 lines)", base, d_off, 1, blocks);
+    // the half-wave split: lanes 0..31 read the first 16 bytes of 32 consecutive records, lanes 32..63 the second 16 bytes
+    // of the SAME records (1 KB contiguous, 8 lines; v_permlane32_swap afterwards puts the halves together)
+    for (int l = 0; l < 64; l++) off[l] = (l & 31) * 32 + (l >> 5) * 16;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16, 1024>("16 B/lane, HALF-WAVES share consecutive records (8 lines)", base, d_off, 1, blocks);
+    // the same by quarters: lanes 16 q .. 16 q + 15 read bytes 16 (q & 1) of records 16 (q >> 1) + (l & 15) ...
+    for (int l = 0; l < 64; l++) off[l] = ((l >> 5) * 16 + (l & 15)) * 32 + ((l >> 4) & 1) * 16;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16, 1024>("16 B/lane, 16-lane groups share consecutive records (8 lines)", base, d_off, 1, blocks);
+    // half-wave split over records two apart (the neighbours of every second atom): 16 lines
+    for (int l = 0; l < 64; l++) off[l] = (l & 31) * 64 + (l >> 5) * 16;
+    CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    run<16, 32>("16 B/lane, half-waves share records 64 B apart (16 lines)", base, d_off, 1, blocks);
     for (int l = 0; l < 64; l++) off[l] = (l >> 2) * 128 + (l & 3) * 32;
     CK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
     run<16>("16 B/lane, four lanes per line, own records (16 lines)", base, d_off, 1, blocks);
