@@ -346,3 +346,44 @@ def test_queueing_up_to_the_predicted_rebuild_changes_nothing(monkeypatch):
     assert outs[0][1] == outs[1][1] and outs[0][1] >= 6
     for k in ("x", "v", "omega", "f", "torque"):
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+
+
+@pytest.mark.parametrize("arms", [False, True])
+def test_half_wave_gather_against_the_plain_gather(arms, monkeypatch):
+    """The half-wave gather (sf_dem_kernels.h, sf_coop_variant: lanes l and l + 32 read a neighbour's record together,
+    v_permlane32_swap puts the halves back) is chosen for beds beyond the memory-side cache (non-temporal policy 1 / 2);
+    it moves the same bytes into the same operations in the same order.  A small bed forced through it -- closed box
+    (neighbour counts from 3 to 12 inside one wave, so lanes wait at the wave's largest count), an atom count that
+    leaves the last wave partly empty, rebuilds, and the kernel with both the cohesive and the lubrication arm -- must
+    give the bits of the plain gather (policy 0) after the first sub-step, and after 105 sub-steps and two or three rebuilds
+    differ from it by roundings only: the two are different instantiations of the kernel template, and the compiler
+    contracts a rarely taken branch of the contact law differently in them (measured: one pair in two thousand gets one
+    last bit per sub-step, tests/micro/debug_coop_bits2.py) -- 1e-12 here against the 1e-9 of the parity tests."""
+    monkeypatch.setenv("SF_LPA", "1")
+    monkeypatch.setenv("SF_TOUCH_PREFETCH", "0")
+    if arms:
+        bed = _bed((5, 5, 5), periodic=True, seed=11, poly=(0.85e-3, 1.0e-3), spacing=0.95, vmax=0.3)
+        cfg = dict(BASE, skin=0.08e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
+                   lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1), walls=_walls(bed))
+    else:
+        bed = _bed((7, 5, 6), periodic=False, seed=21, vmax=0.6)
+        cfg = dict(BASE, skin=0.05e-3, walls=_walls(bed))
+    assert len(bed["x"]) % 64 != 0
+    first, last = [], []
+    for policy in ("0", "2"):
+        monkeypatch.setenv("SF_NT_POLICY", policy)
+        lmp = dc.make_hip(bed, cfg)
+        lmp.setup()
+        lmp.step(1)
+        first.append(lmp.get_state())
+        for n in (39, 25, 40):
+            lmp.step(n)
+        last.append((lmp.get_state(), lmp.info().nbuilds, lmp.history()))
+    for k in ("x", "v", "omega", "f", "torque"):
+        assert np.array_equal(first[0][k], first[1][k]), k
+    assert last[0][1] == last[1][1] and last[0][1] >= (2 if arms else 3)
+    assert (last[0][0]["tag"] == last[1][0]["tag"]).all()
+    assert np.max(np.abs(last[0][0]["x"] - last[1][0]["x"])) <= 1e-12 * 1e-3
+    for k in ("v", "omega", "f", "torque"):
+        assert dc.rel_err(last[1][0][k], last[0][0][k]) <= 1e-12, k
+    assert last[0][2].keys() == last[1][2].keys()
