@@ -106,8 +106,8 @@ __device__ __forceinline__ void st_stream4(double4* p, double4 v)
 // neighbours of lanes 0..31 -- lane l their first 16 bytes, lane l + 32 their second 16 bytes -- and instruction B those of
 // lanes 32..63: every line is touched once (22.7 cycles on consecutive records, half the lines on scattered ones).  One
 // v_permlane32_swap per dword puts the halves where the arithmetic expects them: A' = first halves, B' = second halves of
-// every lane's OWN neighbour.  Same bytes into the same operations in the same order (against the plain instantiation the
-// compiler may still contract a rarely taken branch differently: last bits, tests/test_dem_gpu.py).
+// every lane's OWN neighbour.  Same bytes into the same operations in the same order (against the plain instantiation:
+// the same bits after one sub-step, last bits in one pair in two thousand later -- tests/test_dem_gpu.py).
 // ------------------------------------------------------------------------------------------------
 // Which kernels gather that way -- measured (profiles/r05_README.md section 6): it pays where the launch is bound by the
 // throughput of the memory pipe -- beds that do not fit the memory-side cache (non-temporal policies 1, 2: beyond ~650 k

@@ -356,9 +356,9 @@ def test_half_wave_gather_against_the_plain_gather(arms, monkeypatch):
     (neighbour counts from 3 to 12 inside one wave, so lanes wait at the wave's largest count), an atom count that
     leaves the last wave partly empty, rebuilds, and the kernel with both the cohesive and the lubrication arm -- must
     give the bits of the plain gather (policy 0) after the first sub-step, and after 105 sub-steps and two or three rebuilds
-    differ from it by roundings only: the two are different instantiations of the kernel template, and the compiler
-    contracts a rarely taken branch of the contact law differently in them (measured: one pair in two thousand gets one
-    last bit per sub-step, tests/micro/debug_coop_bits2.py) -- 1e-12 here against the 1e-9 of the parity tests."""
+    differ from it by last bits only: the two are different instantiations of the kernel template (measured: one pair
+    in two thousand gets a different last bit of its history per sub-step, tests/micro/debug_coop_bits2.py) -- 1e-12
+    here against the 1e-9 of the parity tests."""
     monkeypatch.setenv("SF_LPA", "1")
     monkeypatch.setenv("SF_TOUCH_PREFETCH", "0")
     if arms:
