@@ -678,15 +678,15 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
   if (LPA == 1 && S.part == 0 && __ballot(1) == ~0ull && (i & 63) == (int)(threadIdx.x & 63)) {
     const int lane = threadIdx.x & 63;
     const int base = i - lane;
+    // (the half-wave exchange of the gathers, backwards: the first store writes records 0..31 -- lane l their first 16
+    // bytes, lane l + 32 their second 16 bytes --, the second one records 32..63; four v_permlane32_swap per record where
+    // rounds 1-4 sent eight values through the LDS crossbar)
     auto store_shuffled = [&](double4* arr, double a0, double a1, double a2, double a3) {
-      double2* dst = reinterpret_cast<double2*>(arr + base);
-      for (int half = 0; half < 2; half++) {
-        const int src = 32 * half + (lane >> 1);
-        const double b0 = __shfl(a0, src, 64), b1 = __shfl(a1, src, 64);
-        const double b2 = __shfl(a2, src, 64), b3 = __shfl(a3, src, 64);
-        const double2 val = (lane & 1) ? double2{b2, b3} : double2{b0, b1};
-        dst[64 * half + lane] = val;
-      }
+      swap32(a0, a2);   // a0 a1: lanes < 32 keep their first half, lanes >= 32 receive the second half of lane - 32
+      swap32(a1, a3);   // a2 a3: lanes < 32 receive the first half of lane + 32, lanes >= 32 keep their second half
+      char* dst = reinterpret_cast<char*>(arr + base) + ((lane & 31) << 5) + ((lane & 32) >> 1);
+      *reinterpret_cast<double2*>(dst) = double2{a0, a1};
+      *reinterpret_cast<double2*>(dst + 1024) = double2{a2, a3};
     };
     store_shuffled(P.xr_out, xn.x, xn.y, xn.z, radi);
     store_shuffled(P.vm_out, vn.x, vn.y, vn.z, mi);
