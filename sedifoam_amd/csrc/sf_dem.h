@@ -633,6 +633,10 @@ private:
   // environment overrides, all measured: SF_SUB sort cells per cutoff length, SF_TILE tile-major
   // sort, SF_XCD_REMAP contiguous block range per XCD, SF_LDS the LDS-staged kernel
   int opt_tile_ = 0, opt_xcd_remap_ = 1, opt_lds_ = 0, opt_sub_ = 2;
+  // sort cells per cutoff length chosen from the list statistics (0: opt_sub_): cells of the full cutoff for a loose bed,
+  // whose lanes do not gather consecutive records anyway and whose rebuilds are many (choose_kernel)
+  int sort_sub_ = 0;
+  bool opt_sub_env_ = false;
   double xcd_weight_[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // share of the sorted range each XCD works on (launch_substep)
   bool xcd_weighted_ = false;
   // XCD balance: a launch a few sub-steps after every list build is timed per XCD (two atomics per wave), and the shares
