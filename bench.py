@@ -149,6 +149,68 @@ def error_line(args_gpus, steps, warmup, msg):
 FLUIDISED = dict(jitter=0.3, spacing=1.1)   # --bed fluidised
 
 
+def self_launch(n, steps, warmup):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks here -- the same command line, RANK / LOCAL_RANK /
+    WORLD_SIZE in the environment, rendezvous through a FileStore in a directory of this run (no port to collide on) -- pass
+    rank 0's standard output through, and return the job's exit code: 0 only when every rank returned 0.  A rank that dies takes
+    the others with it after a short grace (they would wait in a collective for ever); if rank 0 has not printed its JSON
+    line by then, the `error` line is printed here, so the caller always gets exactly one parseable line."""
+    import shutil
+    import subprocess
+    import tempfile
+    import threading
+    d = tempfile.mkdtemp(prefix="sf_bench_rdzv_")
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), SF_BENCH_RDZV="file://" + os.path.join(d, "store"),
+               MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    got_line = [False]
+
+    def forward():
+        for line in procs[0].stdout:
+            if line.lstrip().startswith("{") and '"metric"' in line:
+                got_line[0] = True
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=forward, daemon=True)
+    th.start()
+    rc, first_bad, t_bad = 0, None, None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad and first_bad is None:
+                first_bad, t_bad = bad[0], time.time()
+            if first_bad is not None and time.time() - t_bad > 20.0:   # (rank 0's own handler gets its chance to print first)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()      # (exactly the processes started above)
+            time.sleep(0.2)
+        th.join(10)
+        codes = [p.returncode for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+        if first_bad is None and bad:
+            first_bad = bad[0]
+        rc = 0 if not bad else (first_bad[1] if first_bad[1] and first_bad[1] > 0 else 1)
+        if not got_line[0]:
+            STAGE[0] = "self-launch of %d ranks" % n
+            print(error_line(n, steps, warmup, "no result line from rank 0; exit codes by rank: %s" % codes))
+            sys.stdout.flush()
+            rc = rc or 1
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
+    return rc
+
+
 def cpu_worker(argv):
     """`bench.py --cpu-worker NPART SUBSTEPS SEED`: one reference-style rank (its own slab of the bed) on one core."""
     npart, sub, seed = int(argv[0]), int(argv[1]), int(argv[2])
@@ -324,10 +386,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python3 bench.py --gpus N`: launch the N ranks from here (one process per GPU, FileStore rendezvous)
+        raise SystemExit(self_launch(args.gpus, args.steps, args.warmup))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=%d: one rank per GPU, the two must agree"
+                         % (args.gpus, world))
 
     wd = args.watchdog if args.watchdog is not None else (1500.0 if world > 1 else 0.0)
     if wd > 0:
@@ -370,10 +434,12 @@ def main():
         dist = dist_mod
         STAGE[0] = "torch.distributed.init_process_group (%s, %s:%s)" % ("gloo" if args.one_gpu else "nccl = RCCL",
                                                                           os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))
+        rdzv = os.environ.get("SF_BENCH_RDZV")      # (set by self_launch: a FileStore, no port; else the launcher's env://)
+        rdzv_kw = dict(init_method=rdzv, rank=rank, world_size=world) if rdzv else {}
         if args.one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **rdzv_kw)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **rdzv_kw)
             # (the first collective brings the RCCL communicator up: fail here, with this stage name, rather than inside a driver)
             STAGE[0] = "first RCCL all-reduce over %d ranks" % world
             t_ = torch.ones(1, device="cuda")

@@ -221,3 +221,21 @@ def test_bench_prints_an_error_line_when_a_multi_gpu_run_cannot_come_up():
     assert r.returncode != 0
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 3 and line["error"] and line["stage"]
+
+
+def test_bench_launches_its_own_ranks_and_still_prints_one_line():
+    """plain `python3 bench.py --gpus 2` (the shape of the driver's command, no torch.distributed.run): bench.py starts the two
+    ranks itself; here, without a GPU, both refuse -- the caller still gets exactly ONE parseable line (n_gpus 2, error +
+    stage) and a non-zero exit code, never a bare launcher exit"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 3 and line["error"] and line["stage"]

@@ -3,7 +3,6 @@
 over torch.distributed/gloo, with the CPU oracle standing in for the HIP engine behind the same adaptor
 interface and the same record layouts.  The decomposed run must reproduce the single-domain oracle."""
 import os
-import socket
 import sys
 import tempfile
 
@@ -14,11 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """(kept name) a FileStore rendezvous, not a port: see tests/rdzv.py"""
+    sys.path.insert(0, ROOT)
+    from tests.rdzv import new_rendezvous
+    return new_rendezvous()
 
 
 def _case(periodic_x=True, vmax=0.5, skin=0.05e-3, seed=31, physics="hertz"):
@@ -52,7 +50,7 @@ def _worker(rank, world, port, outdir, periodic_x, steps, mode, physics="hertz")
     from oracle import binding as ob
     from sedifoam_amd.halo import SlabDriver
     from tests import dem_cases as dc
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     bed, cfg = _case(periodic_x, physics=physics)
     lo, hi = float(bed["boxlo"][0]), float(bed["boxhi"][0])
     dem = dc.make_oracle(dc.subset(bed, dc.slab_mask(bed, rank, world)), cfg)

@@ -8,6 +8,7 @@ import pytest
 
 from sedifoam_amd import synthetic
 from tests import dem_cases as dc
+from tests.rdzv import new_rendezvous
 import tests.test_dem_gpu as T
 
 pytestmark = pytest.mark.gpu
@@ -113,7 +114,7 @@ def _two_rank_worker(rank, world, port, outdir, steps, overlap=False, physics="h
     from tests import dem_cases as dc
     import tests.test_dem_gpu as T
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     if physics == "c5":
         bed, cfg = _c5_case(ncells) if grid is not None else _c5_case()
     elif physics == "loose":
@@ -155,7 +156,7 @@ def test_two_ranks_sharing_one_gpu_match_single_domain(overlap):
     """Two HIP engines (two processes on the same GPU) exchanging their halo through the driver -- the
     decomposed N > 1 path with the real kernels; only the wire is gloo-through-host instead of RCCL.
     overlap=True: boundary kernel / exchange on a second stream / interior kernel (sf_dem_set_overlap)."""
-    import os, socket, tempfile
+    import os, tempfile
     import torch.multiprocessing as mp
     steps = (50, 50)
     bed = T._bed((8, 5, 5), periodic=True, seed=41, vmax=0.5)
@@ -167,7 +168,7 @@ def test_two_ranks_sharing_one_gpu_match_single_domain(overlap):
         ref.step(n)
     a = ref.get_state(); ha = ref.history()
     assert ref.info().nbuilds >= 3
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = new_rendezvous()
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_two_rank_worker, args=(2, port, out, steps, overlap), nprocs=2, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
@@ -214,7 +215,6 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
     then have a face without a neighbour) -- against the single-domain run.  The ranks share the
     one GPU of the box; only the wire is a stand-in (tests/c_abi/standin_rccl.cpp, NCCL's grouped point-to-point
     semantics through host shared memory), every line of the driver and every kernel is the product's."""
-    import socket
     import torch.multiprocessing as mp
     lib = _standin_rccl(tmp_path)
     steps = (50, 50) if physics == "hertz" else (40, 40)
@@ -232,7 +232,7 @@ def test_cxx_slab_driver_on_several_ranks(tmp_path, world, ncells, physics, over
         ref.step(n)
     a = ref.get_state(); ha = ref.history()
     assert ref.info().nbuilds >= 3
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = new_rendezvous()
     out = str(tmp_path)
     mp.spawn(_two_rank_worker, args=(world, port, out, steps, overlap, physics, "rccl", lib, ncells, periodic_x),
              nprocs=world, join=True)
@@ -289,7 +289,6 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncell
     fine-grained areas the sub-step kernel gathers from), the last workgroup of a sub-step kernel publishes the vote and
     the flag, the next sub-step kernel waits for the flags at its gate: no kernel between two sub-step kernels.  All three
     must reproduce the single-domain run."""
-    import socket
     import torch.multiprocessing as mp
     monkeypatch.setenv("SF_HALO_DIRECT", direct)
     monkeypatch.setenv("SF_HALO_DIRECT_TIMEOUT", os.environ.get("SF_TEST_TIMEOUT", "120"))   # (ranks sharing one GPU wait for each other's time slices)
@@ -316,7 +315,7 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncell
         ref.step(n)
     a = ref.get_state(); ha = ref.history()
     assert ref.info().nbuilds >= 3
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = new_rendezvous()
     out = str(tmp_path)
     mp.spawn(_two_rank_worker, args=(world, port, out, steps, False, physics, "rccl", lib, ncells, periodic_x, grid),
              nprocs=world, join=True)
@@ -407,7 +406,7 @@ def test_two_ranks_cohesive_lubricate_match_single_domain_and_oracle():
     with the real kernels: two HIP engines on one GPU against the single-domain HIP run and the single-domain oracle.
     Checks the global volume fraction (pair_lubricate_poly.cpp:540-543), the ghost cutoff max(2 r_max, lubrication
     cutoff) + skin across the slab face and the migration of polydisperse atoms with their history."""
-    import os, socket, tempfile
+    import os, tempfile
     import torch.multiprocessing as mp
     steps = (40, 40)
     bed, cfg = _c5_case()
@@ -418,7 +417,7 @@ def test_two_ranks_cohesive_lubricate_match_single_domain_and_oracle():
         ref.step(n); orc.run(n)
     a = ref.get_state(); ha = ref.history(); c = orc.get()
     assert ref.info().nbuilds >= 3
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = new_rendezvous()
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_two_rank_worker, args=(2, port, out, steps, False, "c5"), nprocs=2, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
@@ -455,7 +454,7 @@ def _rccl_self_worker(port, outdir, overlap=False, transport="direct"):
     from tests import dem_cases as dc
     import tests.test_dem_gpu as T
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+    dist.init_process_group("nccl", init_method=port, rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     bed = T._bed((6, 6, 6), periodic=True, seed=77, vmax=0.5)
     cfg = dict(T.BASE, skin=0.05e-3)
@@ -479,7 +478,7 @@ def test_rccl_transport_self_images(tmp_path, overlap, transport):
     from Python; transport="rccl": the whole sub-step loop in C++ (sf_dem_halo_run, grouped ncclSend/ncclRecv on
     the engine's own communicator)."""
     import torch.multiprocessing as mp
-    port = 29600 + (hash(str(tmp_path)) % 300)
+    port = new_rendezvous(tmp_path)
     ctx = mp.get_context("spawn")
     p = ctx.Process(target=_rccl_self_worker, args=(port, str(tmp_path), overlap, transport))
     p.start()
@@ -545,7 +544,7 @@ def _coupled_worker(rank, world, port, outdir, ncfd, transport="host", rccl_lib=
     from tests import dem_cases as dc
     import tests.test_dem_gpu as T
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     bed = _coupled_bed()
     cfg = dict(T.BASE, skin=_COUPLED_SKIN)
     cfg["walls"] = T._walls(bed)
@@ -579,7 +578,7 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
     every rank) against the single-GPU cloud: drag closure, 2 sub-cycles of DEM sub-steps through the halo driver,
     void fraction / Ue scatter, diffusion smoothing, Asrc.  transport="rccl": the DEM side through the C++ driver
     (sf_slab_*; the cloud's per-particle rows migrate inside its record), over the stand-in for librccl."""
-    import os, socket, tempfile
+    import os, tempfile
     import torch.multiprocessing as mp
     from sedifoam_amd import enhancedCloud
     grid = (2, 1, 2) if transport == "bricks" else None      # the same coupled step over a 2 x 1 x 2 processor grid
@@ -601,7 +600,7 @@ def test_coupled_cloud_on_two_ranks_matches_single_domain(tmp_path, transport):
         cloud.evolve()
         cloud.calcTcFields()
     a = ref.get_state()
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = new_rendezvous()
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_coupled_worker, args=(world, port, out, ncfd, transport, lib, grid), nprocs=world, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
@@ -642,7 +641,7 @@ def _partition_worker(rank, world, port, outdir, ncfd, smooth, per, mesh, rccl_l
     from tests import dem_cases as dc
     import tests.test_dem_gpu as T
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     bed = _coupled_bed()
     cfg = dict(T.BASE, skin=_COUPLED_SKIN)
     cfg["walls"] = T._walls(bed)
@@ -692,7 +691,7 @@ def test_cloud_mesh_partitioned_by_the_slab_planes(tmp_path, smooth, per, mesh, 
     whole (cyclic) mesh; grains cross the slab face and the cyclic box face during the run.  cxx: the face-halo adds
     and the x-line all-to-all run in C++ over the engine's RCCL communicator (sf_cloud_slab_halo_add /
     sf_cloud_slab_phase, the stand-in wire on this one-GPU box), otherwise in Python over torch.distributed."""
-    import os, socket, tempfile
+    import os, tempfile
     import torch.multiprocessing as mp
     from sedifoam_amd import enhancedCloud
     lib = _standin_rccl(tmp_path) if cxx else None
@@ -710,7 +709,7 @@ def test_cloud_mesh_partitioned_by_the_slab_planes(tmp_path, smooth, per, mesh, 
         cloud.evolve()
         cloud.calcTcFields()
     a = ref.get_state()
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = new_rendezvous()
     with tempfile.TemporaryDirectory() as out:
         mp.spawn(_partition_worker, args=(2, port, out, ncfd, smooth, per, mesh, lib), nprocs=2, join=True)
         parts = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
