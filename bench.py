@@ -261,6 +261,8 @@ def cpu_baseline_all_cores(npart, sub):
 # ---- BASELINE.json configs[1], [2], [4] (C2, C3, C5) next to the headline (configs[3] = C4): the `configs` object ----
 C5_LUB = (1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)        # pair lubricate/poly mu flaglog flagfld cut_inner cut_global flagHI flagVF
 C5_COHESIVE = (1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1)     # fix cohesive ah lam smin smax opt
+C5W_LUB = (1.0e-3, 1, 0, 1.001 * 1.5e-3, 1.1 * 1.5e-3, 1, 1)   # flagfld 0, cutoffs in units of the largest pair
+C5W_COHESIVE = (1.0e-20, 1.0e-7, 1.0e-9, 1.0e-4, 1)           # ah 1e-20, smin 1e-9, smax 0.1 d
 
 
 def config_cases(synthetic):
@@ -296,6 +298,16 @@ def config_cases(synthetic):
                cohesive=C5_COHESIVE, lub=C5_LUB)
     out["C5"] = (bed, cfg, None, "%d polydisperse grains (d = 0.85-1.0 mm), pair hybrid/overlay gran/hertzFix/history + "
                                  "lubricate/poly, fix cohesive, periodic box, 50 DEM sub-steps per step" % bed["n"])
+    # C5 on the size distribution SURVEY.md 8(d) fixes: d ~ U(0.5, 1.5) mm (ratio 3), fix cohesive 1e-20 1e-7 1e-9 0.1 d 1,
+    # lubricate/poly 1e-3 1 0 with the inner / outer cutoff 1.001 / 1.1 of the largest pair; a dense disordered periodic bed
+    # grown by the engine itself (synthetic.grown_poly_bed: deterministic)
+    bed = synthetic.grown_poly_bed(500000, seed=15, vmax=0.05)
+    cfg = dict(kn=KW["kn"], gamman=KW["gamman"], xmu=KW["xmu"], g=0.0, dt=KW["dt"], skin=0.06e-3, walls=[],
+               cohesive=C5W_COHESIVE, lub=C5W_LUB)
+    out["C5_wide"] = (bed, cfg, None, "%d polydisperse grains d ~ U(0.5, 1.5) mm (SURVEY.md 8d), dense disordered periodic bed "
+                                      "(solid fraction 0.58, grown), pair hybrid/overlay gran/hertzFix/history + lubricate/poly "
+                                      "1e-3 1 0 1.5015e-3 1.65e-3, fix cohesive 1e-20 1e-7 1e-9 1e-4 1, 50 DEM sub-steps per "
+                                      "step" % bed["n"])
     return out
 
 
@@ -965,12 +977,13 @@ def main():
         for name, (cbed, ccfg, cmesh, label) in cfg_cases.items():
             try:
                 clmp = build_engine(cbed, config_script(cbed, ccfg))
-                args.steps, args.warmup = {"C2": (keep[0], 2), "C3": (max(2, keep[0] // 2), 1), "C5": (max(2, keep[0] // 3), 1)}[name]
+                args.steps, args.warmup = {"C2": (keep[0], 2), "C3": (max(2, keep[0] // 2), 1), "C5": (max(2, keep[0] // 3), 1),
+                                            "C5_wide": (max(2, keep[0] // 3), 1)}[name]
                 el_c, n_c, l_c, k_c, i_c, i_c1 = timed_run(clmp)
                 kh_c = i_c1.npairs_full / 2.0 / max(i_c1.nlocal, 1)
                 o = {"workload": label, "value": n_c * args.substeps * args.steps / el_c, "unit": "particle-substeps/s",
                      "ms_per_step": 1e3 * el_c / args.steps, "steps": args.steps, "warmup": args.warmup,
-                     "particles": int(n_c), "k_half": round(kh_c, 3),
+                     "particles": int(n_c), "k_half": round(kh_c, 3), "longest_row": int(i_c1.max_neigh_used),
                      "neighbor_rebuilds_in_run": int(i_c1.nbuilds - i_c.nbuilds),
                      "algorithmic_bytes_per_particle_substep": 284.0 + 52.0 * kh_c}
                 if l_c:

@@ -95,7 +95,7 @@ __device__ __forceinline__ double sf_sqrt(double x)
 #endif
 }
 
-// natural logarithm of a positive, finite, normal x: frexp, (m - 1) / (m + 1) and the odd atanh series to s^21 -- ~30
+// natural logarithm of a finite, normal x (positive: the fast path; zero / negative: -inf / NaN like the library): frexp, (m - 1) / (m + 1) and the odd atanh series to s^21 -- ~30
 // instructions against the ~100 of the library's log with its special cases; within 1-2 ulp of it (the lubrication
 // series takes one per listed pair: pair_lubricate_poly.cpp:311-333)
 __device__ __forceinline__ double sf_log(double x)
@@ -106,7 +106,11 @@ __device__ __forceinline__ double sf_log(double x)
   const bool low = m < 0.70710678118654752440;
   m = low ? m + m : m;                                     // [sqrt(1/2), sqrt(2))
   e = low ? e - 1 : e;
-  const double s = (m - 1.0) * sf_rcp(m + 1.0);            // |s| <= 0.1716
+  // (x <= 0 takes the library's answers -- log(0) = -inf, log(negative) = NaN -- through the same arithmetic: the reference
+  // leaves h_sep negative for an overlapping pair beyond the inner cutoff, pair_lubricate_poly.cpp:286-300, and its run
+  // shows NaN forces; a finite value made up from the bits of a negative number would hide that)
+  const double s = x > 0.0 ? (m - 1.0) * sf_rcp(m + 1.0)   // |s| <= 0.1716
+                           : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
   const double z = s * s;
   double p = 2.0 / 21.0;
   p = fma(p, z, 2.0 / 19.0);

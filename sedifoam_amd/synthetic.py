@@ -72,3 +72,63 @@ def hertz_script(bed, kn=1.0e7, gamman=0.5, xmu=0.4, dt=1.0e-6, skin_d=0.25, g=9
     ]
     lines.extend(extra)
     return lines
+
+
+def grown_poly_bed(n_target, dlo=0.5e-3, dhi=1.5e-3, phi=0.58, seed=15, vmax=0.05, rho=2650.0, growth=1.02,
+                   relax_steps=150, final_steps=600, verbose=False):
+    """A DENSE disordered polydisperse bed in a fully periodic box: d ~ U(dlo, dhi) (seeded; SURVEY.md 8d: C5 is
+    d ~ U(0.5, 1.5) mm, size ratio 3), solid fraction `phi`.
+
+    A lattice cannot hold such a bed (a site spacing that fits the largest grains leaves the small ones floating, one that
+    fits the mean makes every fourth pair overlap by a quarter of a diameter), so the bed is GROWN: grains start on
+    jittered FCC sites at a common scale factor at which nothing overlaps and are inflated by `growth` per stage to their
+    full size; every stage is relaxed by the HIP engine itself (Hertz contacts, near-critical normal damping, no gravity,
+    velocities zeroed between stages) -- a Lubachevsky-Stillinger-style compression.  The engine is bit-reproducible, so
+    the bed is a deterministic function of its arguments.  Runs on the GPU (no CPU fallback exists): for `bench.py` and the
+    `-m gpu` tests, which hand the SAME finished bed to the engine and to the CPU oracle.
+
+    Returns the dictionary of `fcc_bed` (+ `stages`: how many growth stages ran)."""
+    from .lammps import Lammps
+    ncx, ncy, ncz = fcc_cells_for(n_target)
+    rng = np.random.default_rng(seed)
+    n = 4 * ncx * ncy * ncz
+    diam = rng.uniform(dlo, dhi, size=n)
+    vol = float(np.sum(np.pi / 6.0 * diam ** 3))
+    boxvol = vol / phi
+    edge = (boxvol / (ncx * ncy * ncz)) ** (1.0 / 3.0)   # conventional cubic cell
+    a = edge / np.sqrt(2.0)                              # nearest-neighbour distance of the sites
+    basis = np.array([[0, 0, 0], [0.5, 0.5, 0], [0.5, 0, 0.5], [0, 0.5, 0.5]])
+    ii, jj, kk = np.meshgrid(np.arange(ncx), np.arange(ncy), np.arange(ncz), indexing="ij")
+    cells = np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1).astype(np.float64)
+    x = ((cells[:, None, :] + basis[None, :, :]).reshape(-1, 3) + 0.25) * edge
+    x += rng.uniform(-0.04 * a, 0.04 * a, size=(n, 3))
+    v = rng.uniform(-vmax, vmax, size=(n, 3))
+    boxlo = np.zeros(3)
+    boxhi = np.array([ncx, ncy, ncz], dtype=np.float64) * edge
+    dens = np.full(n, rho)
+    tag = np.arange(1, n + 1, dtype=np.int32)
+    s = 0.9 * a / dhi          # (largest pair: 0.9 a apart at most 0.08 a closer than a: nothing overlaps)
+    stage = 0
+    while True:
+        s = min(1.0, s * growth)
+        last = s >= 1.0
+        lmp = Lammps()
+        lmp.set_box(boxlo, boxhi)
+        lmp.create_atoms(x, diam * s, dens, v=np.zeros((n, 3)), tag=tag)
+        for line in ["atom_style sphere", "boundary p p p", "newton off", "communicate single vel yes",
+                     "neighbor %.17g bin" % (0.1 * dhi), "neigh_modify delay 0",
+                     "pair_style gran/hertzFix/history 1e7 NULL 2e4 NULL 0.0 1", "pair_coeff * *", "timestep 1e-6",
+                     "fix 1 all nve/sphere"]:
+            lmp.command(line)
+        lmp.setup()
+        lmp.step(final_steps if last else relax_steps)
+        st = lmp.get_state()
+        x = np.mod(st["x"] - boxlo, boxhi - boxlo) + boxlo
+        if verbose:
+            print("grown_poly_bed: stage %d scale %.4f max|v| %.3g" % (stage, s, float(np.abs(st["v"]).max())))
+        lmp.close()
+        stage += 1
+        if last:
+            break
+    return dict(x=x, v=v, diameter=diam, density=dens, boxlo=boxlo, boxhi=boxhi, periodic=(1, 1, 1), n=n, edge=edge,
+                stages=stage)

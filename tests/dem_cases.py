@@ -124,3 +124,13 @@ def rel_err(a, b):
     """max |a-b| / max |b| (a global scale, so near-zero components do not blow up)"""
     scale = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (scale if scale > 0 else 1.0))
+
+
+def rel_err_nan(a, b):
+    """rel_err for outputs the reference itself leaves NaN in places (lubricate/poly: the log of a negative gap): the NaN
+    pattern must be the reference's exactly, the finite entries are compared as usual"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if not np.array_equal(np.isnan(a), np.isnan(b)):
+        return float("inf")
+    ok = ~np.isnan(b)
+    return rel_err(a[ok], b[ok])

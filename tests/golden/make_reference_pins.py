@@ -445,7 +445,7 @@ def case_wall(seed, n, pairstyle, wallstyle, shearupdate):
     return dict(inp=inp, out=dict(f=[hexs(a) for a in f], torque=[hexs(a) for a in torque], shear=[hexs(a) for a in shear]))
 
 
-def case_lubricate(seed, n, nlocal, flaglog, flagfld, flagVF):
+def case_lubricate(seed, n, nlocal, flaglog, flagfld, flagVF, cut_inner_d=1.45):
     """PairLubricatePoly: the volume-fraction constants of init_style (pair_lubricate_poly.cpp:539-559, the MPI_Allreduce
     of one rank being the identity) and the ii / jj loop of compute (:193-407) on a full list"""
     rng = random.Random(seed)
@@ -456,7 +456,9 @@ def case_lubricate(seed, n, nlocal, flaglog, flagfld, flagVF):
         x[i] = [c * 1.18 for c in x[i]]
     v = [[rng.uniform(-0.3, 0.3) for _ in range(3)] for _ in range(n)]
     omega = [[rng.uniform(-200.0, 200.0) for _ in range(3)] for _ in range(n)]
-    mu, cut_inner, cut_global = 1.0e-3, 1.45 * d0, 1.9 * d0   # (inner cutoff above the largest ri + rj: no log of a negative gap)
+    # (1.45 d: an inner cutoff above the largest ri + rj, no log of a negative gap; the last case puts it BELOW the contact
+    # distance of most pairs: an overlapping pair beyond it keeps h_sep < 0, :286-300, and C's log returns NaN)
+    mu, cut_inner, cut_global = 1.0e-3, cut_inner_d * d0, 1.9 * d0
     vol_T = (1.18 * d0 * 4.0) ** 3
     full = [[j for j in range(n) if j != i and sum((x[i][k] - x[j][k]) ** 2 for k in range(3)) < (1.1 * cut_global) ** 2]
             for i in range(nlocal)]
@@ -475,7 +477,9 @@ def case_lubricate(seed, n, nlocal, flaglog, flagfld, flagVF):
     f = [[0.0] * 3 for _ in range(n)]
     torque = [[0.0] * 3 for _ in range(n)]
     z3 = lambda: [0.0, 0.0, 0.0]
-    ns = dict(MATH, inum=nlocal, ilist=list(range(nlocal)), x=x, v=v, omega=omega, radius=radius, atom=atom,
+    def c_log(a):   # libm: log(negative) = NaN, log(0) = -inf (math.log raises instead)
+        return math.log(a) if a > 0.0 else (-math.inf if a == 0.0 else math.nan)
+    ns = dict(MATH, log=c_log, inum=nlocal, ilist=list(range(nlocal)), x=x, v=v, omega=omega, radius=radius, atom=atom,
               type_=[1] * n, firstneigh=full, numneigh=[len(l) for l in full], flagfld=flagfld, flagHI=1, flaglog=flaglog,
               vxmu2f=1.0, R0=R0, RT0=RT0, RS0=RS0, mu=mu, shearing=0, vflag_either=0, evflag=0, nlocal=nlocal,
               newton_pair=0, Ef=[z3(), z3(), z3()], cutsq=[[0.0, 0.0], [0.0, cut_global * cut_global]],
@@ -780,7 +784,7 @@ def main():
         case_wall(61, 60, 2, 1, 1), case_wall(62, 60, 2, 0, 0), case_wall(63, 60, 1, 2, 1), case_wall(64, 60, 0, 1, 1)]
     pins["pair_lubricate_poly.cpp:193-407,539-559"] = [
         case_lubricate(71, 64, 64, 1, 0, 1), case_lubricate(72, 64, 40, 1, 1, 1), case_lubricate(73, 48, 48, 0, 1, 0),
-        case_lubricate(74, 48, 30, 0, 0, 1)]
+        case_lubricate(74, 48, 30, 0, 0, 1), case_lubricate(75, 64, 64, 1, 0, 1, cut_inner_d=0.8)]
     code = translate("lammpsFoam/dragModels/ErgunWenYu/ErgunWenYu.C", 104, 132)
     if "--show" in sys.argv:
         print(code)

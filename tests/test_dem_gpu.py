@@ -288,6 +288,31 @@ def test_mid_size_polydisperse_cohesive_lubricate_32k():
     assert lmp.info().nbuilds >= 2 and orc.nbuilds == lmp.info().nbuilds
 
 
+# SURVEY.md 8(d), config C5 as written: d ~ U(0.5, 1.5) mm (size ratio 3), fix cohesive ah = 1e-20 lam = 1e-7 smin = 1e-9
+# smax = 0.1 d opt = 1, lubricate/poly mu = 1e-3 flaglog = 1 flagfld = 0, inner / outer cutoff 1.001 / 1.1 -- LAMMPS takes the
+# two cutoffs as lengths: 1.001 / 1.1 of the LARGEST pair (d_max), so that every overlapping pair is inside the inner cutoff
+# (beyond it the reference takes log(h_sep) of a negative gap, pair_lubricate_poly.cpp:286-300).  flagHI, flagVF: defaults 1 1
+C5_WIDE = dict(cohesive=(1.0e-20, 1.0e-7, 1.0e-9, 1.0e-4, 1), lub=(1.0e-3, 1, 0, 1.001 * 1.5e-3, 1.1 * 1.5e-3, 1, 1))
+C5_WIDE_STRONG = dict(C5_WIDE, cohesive=(1.0e-13, 1.0e-7, 1.0e-9, 1.0e-4, 1))   # (a Hamaker constant the forces can see)
+
+
+@pytest.mark.parametrize("params", [C5_WIDE, C5_WIDE_STRONG], ids=["survey_8d", "strong_cohesion"])
+def test_c5_wide_polydisperse_32k_through_a_rebuild(params):
+    """Config C5 on the size distribution SURVEY.md 8(d) fixes: 32 k grains d ~ U(0.5, 1.5) mm in a dense disordered
+    periodic bed (grown, synthetic.grown_poly_bed), Hertz history + fix cohesive + lubricate/poly with beta0 = rj / ri
+    anywhere in [1/3, 3] (pair_lubricate_poly.cpp:299-324, fix_cohesive.cpp:236-245), cells of 2 r_max + skin holding up to
+    27 x more small grains than large ones, rows of very different length in one wave: setup + 1 + 70 sub-steps through a
+    rebuild, HIP vs oracle."""
+    bed = synthetic.grown_poly_bed(32000, seed=17, vmax=0.5)
+    ratio = bed["diameter"].max() / bed["diameter"].min()
+    assert ratio > 2.9
+    cfg = dict(BASE, skin=0.06e-3, g=0.0, **params)
+    lmp, orc = _run_case(bed, cfg, steps=(1, 70), tol_f=5e-12, walls=[])
+    info = lmp.info()
+    assert info.nbuilds >= 2 and orc.nbuilds == info.nbuilds
+    assert info.npairs_full / info.nlocal > 14      # (a full list twice as long as the narrow C5 bed's)
+
+
 def test_cohesive_opt0():
     bed = _bed((4, 4, 4), periodic=True, seed=12)
     cfg = dict(BASE, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 0))

@@ -341,3 +341,20 @@ def test_c5_500k_full_physics_matches_the_oracle_after_10_substeps(c5bed):
     lmp.setup(); orc.setup()
     lmp.step(10); orc.run(10)
     _compare_with_oracle(lmp, orc, 1.0e-3)
+
+
+def test_c5_wide_500k_matches_the_oracle_after_10_substeps():
+    """Config C5 at its named size ON THE SIZE DISTRIBUTION SURVEY.md 8(d) fixes -- 500 k grains d ~ U(0.5, 1.5) mm, dense
+    disordered periodic bed (synthetic.grown_poly_bed), fix cohesive ah = 1e-20 lam = 1e-7 smin = 1e-9 smax = 0.1 d opt = 1,
+    lubricate/poly mu = 1e-3 flaglog = 1 flagfld = 0 -- HIP vs oracle after setup + 10 sub-steps."""
+    from tests import dem_cases as dc
+    from tests.test_dem_gpu import C5_WIDE
+    bed = synthetic.grown_poly_bed(N_C5, seed=15, vmax=0.05)
+    assert bed["n"] >= N_C5
+    cfg = dict(pair="hertz", kn=1.0e7, gamman=0.5, xmu=0.4, g=0.0, dt=1.0e-6, skin=0.06e-3, walls=[], **C5_WIDE)
+    lmp = dc.make_hip(bed, cfg)
+    orc = dc.make_oracle(bed, cfg)
+    lmp.setup(); orc.setup()
+    lmp.step(10); orc.run(10)
+    a, b = _compare_with_oracle(lmp, orc, 1.0e-3)
+    assert dc.rel_err(a["f"], b["f"]) <= 1e-10
