@@ -82,7 +82,8 @@ def grown_poly_bed(n_target, dlo=0.5e-3, dhi=1.5e-3, phi=0.58, seed=15, vmax=0.0
     A lattice cannot hold such a bed (a site spacing that fits the largest grains leaves the small ones floating, one that
     fits the mean makes every fourth pair overlap by a quarter of a diameter), so the bed is GROWN: grains start on
     jittered FCC sites at a common scale factor at which nothing overlaps and are inflated by `growth` per stage to their
-    full size; every stage is relaxed by the HIP engine itself (Hertz contacts, near-critical normal damping, no gravity,
+    full size; every stage is relaxed by the HIP engine itself (frictionless Hertz contacts at restitution 0.05 -- gran/hertzFix's
+    `gamman` IS the restitution coefficient --, no gravity,
     velocities zeroed between stages) -- a Lubachevsky-Stillinger-style compression.  The engine is bit-reproducible, so
     the bed is a deterministic function of its arguments.  Runs on the GPU (no CPU fallback exists): for `bench.py` and the
     `-m gpu` tests, which hand the SAME finished bed to the engine and to the CPU oracle.
@@ -117,7 +118,7 @@ def grown_poly_bed(n_target, dlo=0.5e-3, dhi=1.5e-3, phi=0.58, seed=15, vmax=0.0
         lmp.create_atoms(x, diam * s, dens, v=np.zeros((n, 3)), tag=tag)
         for line in ["atom_style sphere", "boundary p p p", "newton off", "communicate single vel yes",
                      "neighbor %.17g bin" % (0.1 * dhi), "neigh_modify delay 0",
-                     "pair_style gran/hertzFix/history 1e7 NULL 2e4 NULL 0.0 1", "pair_coeff * *", "timestep 1e-6",
+                     "pair_style gran/hertzFix/history 1e7 NULL 0.05 NULL 0.0 1", "pair_coeff * *", "timestep 1e-6",
                      "fix 1 all nve/sphere"]:
             lmp.command(line)
         lmp.setup()
