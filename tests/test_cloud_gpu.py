@@ -915,3 +915,26 @@ def test_smooth_field_three_solvers_agree_and_default_is_bitwise_reproducible(mo
     assert dc.rel_err(a1, b) <= 1e-12 and dc.rel_err(c, b) <= 1e-12
     assert not np.array_equal(a1, c)             # (really different code paths)
     assert np.sum(a1, axis=0) == pytest.approx(np.sum(f, axis=0), rel=1e-12)
+
+
+def test_hip_smooth_field_point_source_is_the_documents_gaussian():
+    """the HIP smoother (direct solve in the cosine basis) against the Gaussian kernel the reference's documentation derives
+    for smoothField (documentation/diffusionEqn/diffusionEqn.tex section 2; tests/test_oracle_known_answers.py holds the
+    oracle to the same numbers)"""
+    from sedifoam_amd import Lammps, enhancedCloud
+    from tests.test_oracle_known_answers import check_against_the_gaussian
+
+    def smooth(n, dx, f, band, steps):
+        lmp = Lammps()
+        hi = n * dx
+        lmp.set_box([0, 0, 0], hi)
+        lmp.create_atoms([0.5 * hi], [1e-4], [2500.0])
+        lmp.commands("atom_style sphere\nboundary ff ff ff\nnewton off\npair_style gran/hooke/history 1e4 NULL 10 NULL 0.5 1\n"
+                     "pair_coeff * *\nneighbor 1e-4 bin\ntimestep 1e-6\nfix 1 all nve/sphere\nfix 2 all fdrag")
+        cloud = enhancedCloud(lmp, np.zeros(3), dx, n,
+                              dict(dragModel="ErgunWenYu", subCycles=1, g=(0, 0, 0), diffusionBandWidth=band,
+                                   diffusionSteps=steps), dict(rhob=1000.0, nub=1e-6), 1e-5)
+        out = cloud.smoothField(f)
+        cloud.close()
+        return np.asarray(out)
+    check_against_the_gaussian(smooth)
