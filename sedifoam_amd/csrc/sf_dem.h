@@ -145,6 +145,8 @@ struct DemPtrs {
                                 // neighbour's uncached area is made of
   const int* tx_hdr_off;
   int* xcd_time;                // StepParams::xcd_time: [64 x + 0] first start, [64 x + 32] last end of XCD x (100 MHz clock)
+  int* pq_head;                 // persistent tiles (k_substep_persist): [2][8][32] -- per launch parity and XCD one head word
+                                // on a line of its own: the next tile of that XCD's range nobody has taken yet
   // ghost slots (StepParams::gs_on, sf_halo_rccl.hip, sf_dem_gs.h): the neighbours' sub-step kernels write the records of
   // this rank's ghosts straight into the ghost range of xr / vm / om.  On the sending side tx_blkptr is then [3][kMaxDirs]:
   // where block q's first x | v | omega record goes in the NEIGHBOUR's arrays (the buffer its launch of the next number
@@ -195,6 +197,7 @@ struct StepParams {
   int xcd_first[8], xcd_count[8];
   int sweep_rev;   // walk each XCD's range backwards (every other sub-step)
   int xcd_time;    // this launch records when each XCD starts and ends (DemPtrs::xcd_time): the engine balances the shares
+  int pq_par;      // persistent tiles: which of the two sets of head words this launch pulls from (it zeroes the other one)
   WallParams wall[kMaxWalls];
   int have_gravity;
   double gacc[3];
@@ -703,6 +706,11 @@ private:
   bool touch_first_ = false;
   int touch_first_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
+  int opt_persist_ = -1;                     // SF_PERSIST: persistent tiles (k_substep_persist) off (0), on wherever the kernel
+                                             // exists (1), default (-1): where it measured faster (launch_substep)
+  int opt_persist_waves_ = 0;                // SF_PERSIST_WAVES: waves per XCD of the persistent launch (0: the resident ones)
+  int* d_pq_head_ = nullptr;                 // [2][8][32] head words of the persistent launch (DemPtrs::pq_head)
+  int pq_par_ = 0;
   bool in_run_ = false;                      // rebuild() called from the stepping loop of run()
   RebuildPredictor predict_;                 // single-domain run(): how far to queue (SF_QUEUE_PREDICT=0: everything)
   int nt_policy_ = 2, nt_policy_env_ = -1;   // non-temporal policy of the row streams (sf_dem_kernels.h, NTP)

@@ -124,6 +124,10 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_TOUCH_FIRST")) touch_first_env_ = atoi(e);
   if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
   if (const char* e = getenv("SF_LPA")) opt_lpa_ = atoi(e);
+  if (const char* e = getenv("SF_PERSIST")) opt_persist_ = atoi(e);
+  if (const char* e = getenv("SF_PERSIST_WAVES")) opt_persist_waves_ = atoi(e);
+  SF_HIP(hipMalloc(&d_pq_head_, sizeof(int) * 2 * 8 * 32));
+  SF_HIP(hipMemsetAsync(d_pq_head_, 0, sizeof(int) * 2 * 8 * 32, stream_));
   if (const char* e = getenv("SF_QUEUE_PREDICT")) predict_.on = atoi(e) != 0;
   memset(&gran_, 0, sizeof(gran_));
   memset(&cohe_, 0, sizeof(cohe_));
@@ -142,6 +146,7 @@ DemEngine::~DemEngine()
   for (DevArray* a : per_atom_) a->release();
   if (d_blkptr_) (void)hipFree(d_blkptr_);
   if (d_xcd_time_) (void)hipFree(d_xcd_time_);
+  if (d_pq_head_) (void)hipFree(d_pq_head_);
   if (h_xcd_time_) (void)hipHostFree(h_xcd_time_);
   bslot_.release();   // (not in per_atom_: allocated by the first brick rebuild, re-allocated when the capacity moves)
   if (cell_start_) (void)hipFree(cell_start_);
@@ -710,6 +715,7 @@ DemPtrs DemEngine::ptrs(int in_buf) const
   P.gs_my_sync = nullptr;
   P.gs_count = nullptr;
   P.xcd_time = d_xcd_time_;
+  P.pq_head = d_pq_head_;
   P.tile_last = tile_tab_ ? tile_tab_ + tile_alloc_ : nullptr;
   P.stage_start = tile_tab_ ? tile_tab_ + 3 * tile_alloc_ : nullptr;
   P.stage_idx = stage_idx_;
@@ -816,6 +822,22 @@ static void launch_substep_style(bool cohe, bool lub, int lpa, bool tp, int ntp,
   else if (ntp == 1) launch_substep_tp<STYLE, 1, 1>(cohe, lub, tp, grid, block, s, P, S);
   else if (ntp == 3) launch_substep_tp<STYLE, 1, 3>(cohe, lub, tp, grid, block, s, P, S);
   else launch_substep_tp<STYLE, 1, 2>(cohe, lub, tp, grid, block, s, P, S);
+}
+
+// persistent tiles (k_substep_persist): the plain Hertz contact kernel, one lane per atom
+static void launch_substep_persist(bool tp, int ntp, dim3 grid, hipStream_t s, const DemPtrs& P, const StepParams& S)
+{
+  if (tp) {
+    if (ntp == 0) k_substep_persist<2, false, false, true, 0><<<grid, 64, 0, s>>>(P, S);
+    else if (ntp == 1) k_substep_persist<2, false, false, true, 1><<<grid, 64, 0, s>>>(P, S);
+    else if (ntp == 3) k_substep_persist<2, false, false, true, 3><<<grid, 64, 0, s>>>(P, S);
+    else k_substep_persist<2, false, false, true, 2><<<grid, 64, 0, s>>>(P, S);
+  } else {
+    if (ntp == 0) k_substep_persist<2, false, false, false, 0><<<grid, 64, 0, s>>>(P, S);
+    else if (ntp == 1) k_substep_persist<2, false, false, false, 1><<<grid, 64, 0, s>>>(P, S);
+    else if (ntp == 3) k_substep_persist<2, false, false, false, 3><<<grid, 64, 0, s>>>(P, S);
+    else k_substep_persist<2, false, false, false, 2><<<grid, 64, 0, s>>>(P, S);
+  }
 }
 
 template <int STYLE, bool COHE, bool LUB>
@@ -1005,6 +1027,30 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
       grid = dim3((unsigned)(8 * most));
     }
     stamp_last_grid_ = grid.x;
+    // Persistent tiles: the resident waves walk the tiles of their XCD's range and request the next tile's records under
+    // the current tile's epilogue (k_substep_persist).  The plain Hertz kernel with one lane per atom and one-wave tiles,
+    // when the launch is at least three rounds of resident waves.
+    static const int resident_per_xcd = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return std::max(1, cus * 4 * 3 / 8);
+    }();
+    const int pw = opt_persist_waves_ > 0 ? opt_persist_waves_ : resident_per_xcd;
+    const int tiles = (int)((lanes + 63) / 64);
+    const bool persist = opt_persist_ != 0 && !gs && part == 0 && lpa == 1 && block == 64 && gran_.style == 2 && !cohe &&
+                         !lub && S.xcd_remap != 0 && mode != 2 && (opt_persist_ == 1 || tiles >= 3 * 8 * pw);
+    if (persist) {
+      if (S.xcd_remap == 1) {   // equal shares: the ranges xcd_contiguous_block() gives
+        const int q = tiles >> 3, r = tiles & 7;
+        for (int x = 0; x < 8; x++) {
+          S.xcd_count[x] = x < r ? q + 1 : q;
+          S.xcd_first[x] = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        }
+      }
+      S.pq_par = pq_par_;
+      pq_par_ ^= 1;
+      launch_substep_persist(touch_prefetch_, nt_policy_, dim3((unsigned)(8 * pw)), stream_, P, S);
+    } else
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
       case 3:

@@ -165,10 +165,33 @@ __device__ __forceinline__ double4 coop_load(const double4* arr, const int ja, c
   return double4{a.x, a.y, b.x, b.y};
 }
 
-template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP, bool GS = false>
+// Persistent tiles (k_substep_persist, PERS): what a wave reads about its atom before it can start the neighbour loop -- the
+// atom's three records, its row count and its first two list words.  The persistent kernel requests these for the wave's NEXT
+// tile when the neighbour loop of the current tile is over (the loop's register sets are dead by then), so that they arrive
+// while the current tile's fixes, integration and stores run.
+struct TilePre {
+  double4 x, v, w;
+  int nn_all, w_first, w_second;
+  int q;        // lane 0: what the XCD's head word returned (the wave's tile after the next one is 2 x resident + q)
+  int* head;
+};
+template <bool NT_LD>
+__device__ __forceinline__ void tile_prefetch(const DemPtrs& P, const StepParams& S, const int i, TilePre& t)
+{
+  const size_t cap = (size_t)S.cap;
+  t.x = P.xr_in[i];
+  t.v = P.vm_in[i];
+  t.w = P.om_in[i];
+  t.nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
+  t.w_first = ld_stream<NT_LD>(&P.neigh[i]);
+  t.w_second = ld_stream<NT_LD>(&(P.neigh + (S.nslots > 1 ? cap : 0))[i]);
+}
+
+template <int STYLE, bool COHE, bool LUB, bool LDS, int LPA, bool TP, int NTP, bool GS = false, bool PERS = false>
 __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepParams& S, const int i, const int q,
                                                  const double4* lx, const double4* lv, const double* lw,
-                                                 const unsigned long long gs_w = 0ull, const bool live = true)
+                                                 const unsigned long long gs_w = 0ull, const bool live = true,
+                                                 TilePre* pre = nullptr, const int i_next = -1)
 {
   // COOP: the records of a neighbour are read by lane pairs (l, l + 32) -- every lane of the wave walks the neighbour loop
   // to the wave's largest count, `live` = this lane holds an atom (the caller clamps i of the others to a valid one: they
@@ -195,16 +218,17 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
     if (!gs_gate(P.gs_sync, P.flags, S.gs_seq, S.kstep)) return 0;
     gs_gated = true;
   }
-  const double4 xi4 = P.xr_in[i];   // also a gather target of the neighbours: keep it cached
-  const double4 vi4 = P.vm_in[i];
-  const double4 wi4 = P.om_in[i];
+  // (PERS: requested one tile ago, see TilePre)
+  const double4 xi4 = PERS ? pre->x : P.xr_in[i];   // also a gather target of the neighbours: keep it cached
+  const double4 vi4 = PERS ? pre->v : P.vm_in[i];
+  const double4 wi4 = PERS ? pre->w : P.om_in[i];
   const Vec3 xi = v3(xi4), vi = v3(vi4), wi = v3(wi4);
   const double radi = xi4.w, mi = vi4.w;
 
   Vec3 F = {0.0, 0.0, 0.0}, T = {0.0, 0.0, 0.0};
   const int mk = S.use_groups ? P.mask[i] : 1;   // group bits of this atom (bit 0 = all)
-  const int nn_all = ld_stream<NT_LD>(&P.numneigh[i]);
-  const int nn = COOP ? (live ? nn_all : 0)
+  const int nn_all = PERS ? pre->nn_all : ld_stream<NT_LD>(&P.numneigh[i]);
+  const int nn = (COOP || PERS) ? (live ? nn_all : 0)   // (PERS: the lanes past the last atom stay for the wave's other tiles)
                       : LPA == 1 ? nn_all : (nn_all > q ? (nn_all - q + LPA - 1) / LPA : 0);   // slots of this lane
   const double lub_cutsq = S.lub.cut_global * S.lub.cut_global;
 
@@ -304,8 +328,8 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
   const int row1 = q + LPA < S.nslots ? q + LPA : S.nslots - 1;
   // (one lane per atom only: with several lanes per atom the two extra live registers spill)
   const bool ld0 = LPA == 1 || nn > 0, ld1 = LPA == 1 || nn > 1;
-  const int w_first = ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
-  const int w_second = ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0;
+  const int w_first = PERS ? pre->w_first : ld0 ? ld_stream<NT_LD>(&(P.neigh + (size_t)q * cap)[i]) : 0;
+  const int w_second = PERS ? pre->w_second : ld1 ? ld_stream<NT_LD>(&(P.neigh + (size_t)row1 * cap)[i]) : 0;
   int jraw_n1 = nn > 0 ? w_first : 0;
   int jraw_n2 = nn > 1 ? w_second : 0;
   // One history copy per contact: a partner-side slot (kOwnBit clear) reads the owner's previous value from the
@@ -485,7 +509,7 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
     }
   }
   SF_PH(27);
-  if (COOP && !live) return 1;
+  if (COOP && !PERS && !live) return 1;   // (PERS: behind the prefetch of the next tile, below)
   if (LPA > 1) {
     // fixed tree: (q0 + q1) [+ (q2 + q3)] -- the same bits on every run
     for (int off = 1; off < LPA; off <<= 1) {
@@ -514,6 +538,15 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
   if (S.mode == 0 && S.have_nve)
     xh_in = {ld_stream<NT_LD>(&P.xhold[i]), ld_stream<NT_LD>(&P.xhold[cap + i]), ld_stream<NT_LD>(&P.xhold[2 * cap + i])};
   if (S.nwalls) wt_in = P.wtouch[i];
+  // (PERS: the next tile's records and first words, requested BEHIND this tile's fix rows -- memory returns in order, the
+  // epilogue waits for its rows only -- and ahead of everything the epilogue computes and stores)
+  // (i_next: 64 x the next tile -- wave-uniform, so that nothing per lane crosses the neighbour loop for it; -1: no next tile)
+  if (PERS && i_next >= 0) {
+    if ((threadIdx.x & 63) == 0) pre->q = atomicAdd(pre->head, 1);
+    const int in = i_next + (int)(threadIdx.x & 63);
+    tile_prefetch<NT_LD>(P, S, in < S.nlocal ? in : 0, *pre);
+  }
+  if (PERS && !live) return 1;
   // (fused forward pack: the send slots of a border atom, requested here so that they have arrived by the end)
   int txk0 = -1, txk1 = -1;
   if (S.tx_fused == 1 && (xi.x < S.tx_xlo || xi.x >= S.tx_xhi)) {
@@ -818,6 +851,72 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
     atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent tiles (round 6).  k_substep starts one wave per 64 atoms: every wave pays its own start -- kernel arguments,
+// the round trip for its atom's records, row count and first list words (3.7 us of a 33 us life) -- with nothing else of its
+// own to hide it behind.  Here the grid is the RESIDENT waves (three per SIMD), each walking tiles of 64 atoms of its XCD's
+// range: the first two by position, the others pulled from the XCD's head word (one returning atomic per tile, requested
+// two tiles ahead so that nothing ever waits for it).  When the neighbour loop of tile t is over -- its two prefetch
+// register sets are dead -- the wave requests tile t + 1's records, row count and first words (TilePre) and only then runs
+// tile t's fixes, integration and stores: the next tile's start-up round trip runs under the current tile's epilogue.
+// Same atoms, same operations in the same order as k_substep (tiles are the one-wave workgroups of the plain launch): the
+// results are bit-identical; which wave works on which tile never enters them.
+// One lane per atom, no ghost slots, no boundary / interior split.  Head words: two sets, the launch pulls from set
+// S.pq_par and clears the other one for the next launch (every launch does, before the trigger test: a launch that
+// returns at once still leaves the invariant in place).
+// ------------------------------------------------------------------------------------------------
+template <int STYLE, bool COHE, bool LUB, bool TP, int NTP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((COHE && LUB) ? 1 : 3)))
+void k_substep_persist(DemPtrs P, StepParams S)
+{
+  const int lane = (int)threadIdx.x;
+  if (blockIdx.x < 8 && lane == 0) P.pq_head[((S.pq_par ^ 1) * 8 + (int)blockIdx.x) * 32] = 0;
+  if (__atomic_load_n(&P.flags[S.trig_test], __ATOMIC_RELAXED) < S.kstep) return;
+  const int xcd = (int)(blockIdx.x & 7), loc = (int)(blockIdx.x >> 3), nres = (int)(gridDim.x >> 3);
+  const int cnt = S.xcd_count[xcd], first = S.xcd_first[xcd];
+  if (loc >= cnt) return;
+  int* const head = P.pq_head + (S.pq_par * 8 + xcd) * 32;
+  const int xq = xcd * 64;
+  if (S.xcd_time && lane == 0 && loc == 0) atomicMin(&P.xcd_time[xq], (int)(wall_clock64() & 0x3fffffff));
+  constexpr bool NT_LD = NTP != 0;
+  // tile t of this XCD's range -> its first atom (wave-uniform); a lane past the last atom works on atom 0 and stores nothing
+  auto base_of = [&](const int t) { return (first + (S.sweep_rev ? cnt - 1 - t : t)) * 64; };
+  // tiles of this wave: loc, loc + nres (by position), then 2 nres + what the head word returns.  The pull for the tile
+  // after the next one is issued with the next tile's prefetch (substep_particle, behind the neighbour loop) and read here,
+  // one epilogue later: nothing waits for it
+  int t_next = loc + nres;                   // (wave-uniform: scalar registers)
+  int base = base_of(loc);
+  TilePre pre;
+  pre.head = head;
+  pre.q = 0;
+  {
+    const int i0 = base + lane;
+    tile_prefetch<NT_LD>(P, S, i0 < S.nlocal ? i0 : 0, pre);
+  }
+  // The kernel arguments are read through a pointer the compiler cannot see through, once per tile: left alone it hoists
+  // every scalar load of the ~150 words of StepParams out of the tile loop, keeps them all live across it and spills
+  // (169 scalar + 37 vector registers); re-read per tile they are what they are in k_substep -- scalar loads next to
+  // their use, from the constant cache.
+  typedef const char __attribute__((address_space(4))) * KernArg;
+  const KernArg ka0 = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr size_t kSOff = (sizeof(DemPtrs) + alignof(StepParams) - 1) / alignof(StepParams) * alignof(StepParams);
+  for (;;) {
+    KernArg ka = ka0;
+    asm volatile("" : "+s"(ka));
+    const DemPtrs& Pt = *(const DemPtrs*)(ka);
+    const StepParams& St = *(const StepParams*)(ka + kSOff);
+    const int base_next = t_next < cnt ? base_of(t_next) : -1;
+    const int i = base + lane;
+    const bool live = i < St.nlocal;
+    substep_particle<STYLE, COHE, LUB, false, 1, TP, NTP, false, true>(Pt, St, live ? i : 0, 0, nullptr, nullptr, nullptr, 0ull,
+                                                                        live, &pre, base_next);
+    if (base_next < 0) break;
+    base = base_next;
+    t_next = 2 * nres + __builtin_amdgcn_readfirstlane(pre.q);
+  }
+  if (S.xcd_time && lane == 0 && (loc & 7) == 0) atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
+}
 
 // (the LDS-staged cell-bin kernel, k_substep_lds -- the same substep_particle on a tile's staged copy -- is in
 // sf_dem_lds_kernel.h)

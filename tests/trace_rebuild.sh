@@ -18,7 +18,9 @@ for f in glob.glob("gpurun_out/kt_%s/*memory_copy_trace.csv" % tag):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "MEMCPY " + r.get("Direction", "") + " " + r.get("Bytes", "")))
 rows.sort()
-big = [k for k, r in enumerate(rows) if "k_substep" in r[2] and r[1] - r[0] > 50000]
+import os
+thr = int(os.environ.get("SF_TRACE_MIN_NS", "50000"))   # (an executed sub-step kernel: longer than an early exit)
+big = [k for k, r in enumerate(rows) if "k_substep" in r[2] and r[1] - r[0] > thr]
 # rebuilds: pairs of consecutive executed sub-steps with a k_build_neigh in between; take the last one
 spans = [(a, b) for a, b in zip(big[:-1], big[1:]) if any("k_build_neigh" in rows[k][2] for k in range(a, b))]
 a, b = spans[-1]
