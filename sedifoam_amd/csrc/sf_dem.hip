@@ -824,6 +824,7 @@ static void launch_substep_style(bool cohe, bool lub, int lpa, bool tp, int ntp,
   else launch_substep_tp<STYLE, 1, 2>(cohe, lub, tp, grid, block, s, P, S);
 }
 
+#ifdef SF_EXP_PERSIST
 // persistent tiles (k_substep_persist): the plain Hertz contact kernel, one lane per atom
 static void launch_substep_persist(bool tp, int ntp, dim3 grid, hipStream_t s, const DemPtrs& P, const StepParams& S)
 {
@@ -839,6 +840,8 @@ static void launch_substep_persist(bool tp, int ntp, dim3 grid, hipStream_t s, c
     else k_substep_persist<2, false, false, false, 2><<<grid, 64, 0, s>>>(P, S);
   }
 }
+
+#endif
 
 template <int STYLE, bool COHE, bool LUB>
 static void launch_lds_one(dim3 grid, size_t lds, hipStream_t s, const DemPtrs& P, const StepParams& S)
@@ -1027,6 +1030,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
       grid = dim3((unsigned)(8 * most));
     }
     stamp_last_grid_ = grid.x;
+#ifdef SF_EXP_PERSIST
     // Persistent tiles: the resident waves walk the tiles of their XCD's range and request the next tile's records under
     // the current tile's epilogue (k_substep_persist).  The plain Hertz kernel with one lane per atom and one-wave tiles,
     // when the launch is at least three rounds of resident waves.
@@ -1051,6 +1055,7 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
       pq_par_ ^= 1;
       launch_substep_persist(touch_prefetch_, nt_policy_, dim3((unsigned)(8 * pw)), stream_, P, S);
     } else
+#endif
     switch (gran_.style) {
       case 2: launch_substep_style<2>(cohe, lub, lpa, touch_prefetch_, nt_policy_, grid, block, stream_, P, S); break;
       case 3:

@@ -32,6 +32,12 @@
 #ifndef SF_HIST_PREFETCH
 #define SF_HIST_PREFETCH 1    // the history of slot s+1 is requested with the records of slot s+1, one contact evaluation ahead
 #endif
+#ifndef SF_PERS_PREFETCH
+#define SF_PERS_PREFETCH 1    // k_substep_persist: the next tile's records are requested under the current tile's epilogue
+#endif
+#ifndef SF_PERS_DYNAMIC
+#define SF_PERS_DYNAMIC 1     // k_substep_persist: tiles beyond a wave's first two come from the XCD's head word (0: by position)
+#endif
 #ifndef SF_COOP_GATHER
 #define SF_COOP_GATHER 1      // a neighbour's 32-byte record is read by the two lanes l, l + 32 together (see coop_merge)
 #endif
@@ -174,6 +180,8 @@ struct TilePre {
   int nn_all, w_first, w_second;
   int q;        // lane 0: what the XCD's head word returned (the wave's tile after the next one is 2 x resident + q)
   int* head;
+  const DemPtrs* Pe;       // the kernel arguments as the epilogue reads them (see substep_particle)
+  const StepParams* Se;
 };
 template <bool NT_LD>
 __device__ __forceinline__ void tile_prefetch(const DemPtrs& P, const StepParams& S, const int i, TilePre& t)
@@ -527,68 +535,73 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
     }
   }
 
+  // (PERS: what follows reads the kernel arguments through a pointer the compiler cannot see through -- pre->ka, renewed per
+  // tile -- so that the ~100 scalar words only the fixes and the integration need are loaded where they are used, as in
+  // k_substep, instead of being kept live across the tile loop; the neighbour loop above keeps its scalars in registers)
+  const DemPtrs& PE = PERS ? *pre->Pe : P;
+  const StepParams& SE = PERS ? *pre->Se : S;
   // the rows the fixes and the integration read, requested TOGETHER here (one memory round trip instead of one per fix)
-  const bool use_fd = S.have_fdrag && (mk & S.fdrag_bit);   // fix_fluid_drag.cpp:145
+  const bool use_fd = SE.have_fdrag && (mk & SE.fdrag_bit);   // fix_fluid_drag.cpp:145
   Vec3 fd_in = {0.0, 0.0, 0.0}, xh_in = {0.0, 0.0, 0.0};
   unsigned wt_in = 0;
-  if (S.have_fdrag) {
+  if (SE.have_fdrag) {
     const size_t k = use_fd ? (size_t)i : 0;   // (a lane outside the group reads a valid element and drops it)
-    fd_in = {P.fdrag[k], P.fdrag[cap + k], P.fdrag[2 * cap + k]};
+    fd_in = {PE.fdrag[k], PE.fdrag[cap + k], PE.fdrag[2 * cap + k]};
   }
-  if (S.mode == 0 && S.have_nve)
-    xh_in = {ld_stream<NT_LD>(&P.xhold[i]), ld_stream<NT_LD>(&P.xhold[cap + i]), ld_stream<NT_LD>(&P.xhold[2 * cap + i])};
-  if (S.nwalls) wt_in = P.wtouch[i];
+  if (SE.mode == 0 && SE.have_nve)
+    xh_in = {ld_stream<NT_LD>(&PE.xhold[i]), ld_stream<NT_LD>(&PE.xhold[cap + i]), ld_stream<NT_LD>(&PE.xhold[2 * cap + i])};
+  if (SE.nwalls) wt_in = PE.wtouch[i];
   // (PERS: the next tile's records and first words, requested BEHIND this tile's fix rows -- memory returns in order, the
   // epilogue waits for its rows only -- and ahead of everything the epilogue computes and stores)
   // (i_next: 64 x the next tile -- wave-uniform, so that nothing per lane crosses the neighbour loop for it; -1: no next tile)
-  if (PERS && i_next >= 0) {
-    if ((threadIdx.x & 63) == 0) pre->q = atomicAdd(pre->head, 1);
+  if (PERS && SF_PERS_PREFETCH && i_next >= 0) {
+    if (SF_PERS_DYNAMIC && (threadIdx.x & 63) == 0) pre->q = atomicAdd(pre->head, 1);
     const int in = i_next + (int)(threadIdx.x & 63);
     tile_prefetch<NT_LD>(P, S, in < S.nlocal ? in : 0, *pre);
   }
   if (PERS && !live) return 1;
   // (fused forward pack: the send slots of a border atom, requested here so that they have arrived by the end)
   int txk0 = -1, txk1 = -1;
-  if (S.tx_fused == 1 && (xi.x < S.tx_xlo || xi.x >= S.tx_xhi)) {
-    txk0 = P.sendslot[0][i];
-    txk1 = P.sendslot[1][i];
+  if (SE.tx_fused == 1 && (xi.x < SE.tx_xlo || xi.x >= SE.tx_xhi)) {
+    txk0 = PE.sendslot[0][i];
+    txk1 = PE.sendslot[1][i];
   }
   // (brick driver: near an external face in any dimension)
-  const bool txb = S.tx_fused == 2 && (xi.x < S.tx_lo3[0] || xi.x >= S.tx_hi3[0] || xi.y < S.tx_lo3[1] ||
-                                       xi.y >= S.tx_hi3[1] || xi.z < S.tx_lo3[2] || xi.z >= S.tx_hi3[2]);
+  const bool txb = SE.tx_fused == 2 && (xi.x < SE.tx_lo3[0] || xi.x >= SE.tx_hi3[0] || xi.y < SE.tx_lo3[1] ||
+                                       xi.y >= SE.tx_hi3[1] || xi.z < SE.tx_lo3[2] || xi.z >= SE.tx_hi3[2]);
 
   // ---- post_force fixes: gravity -> fdrag -> walls; fix freeze zeroes what the fixes BEFORE it in the script (and
   // the pair styles) gave a frozen atom, the fixes after it still act ([3P] Modify::post_force runs them in script
   // order; the reference's bed cases have `fix 4 bottom freeze` followed by `fix ywall all wall/gran`).  Fa, Ta: what
   // the fixes after fix freeze add, in their order; a free atom sums everything in F, T as before ----
   Vec3 Fa = {0.0, 0.0, 0.0}, Ta = {0.0, 0.0, 0.0};
-  const bool any_post = S.freeze_bit != 0;   // (wave-uniform: no fix freeze, nothing to keep apart)
-  if (S.have_gravity && (mk & S.grav_bit)) {
-    const Vec3 g = {mi * S.gacc[0], mi * S.gacc[1], mi * S.gacc[2]};
+  const bool any_post = SE.freeze_bit != 0;   // (wave-uniform: no fix freeze, nothing to keep apart)
+  if (SE.have_gravity && (mk & SE.grav_bit)) {
+    const Vec3 g = {mi * SE.gacc[0], mi * SE.gacc[1], mi * SE.gacc[2]};
     F = F + g;
-    if (any_post && (S.post_freeze & 1)) Fa = Fa + g;
+    if (any_post && (SE.post_freeze & 1)) Fa = Fa + g;
   }
   if (use_fd) {
     Vec3 fd = fd_in;
-    if (S.carrier_rho != 0.0) {
+    if (SE.carrier_rho != 0.0) {
       const double rho = 3.0 * mi / (4.0 * kPiTypo * radi * radi * radi);
-      const Vec3 vo = {P.vOld[i], P.vOld[cap + i], P.vOld[2 * cap + i]};
-      const Vec3 du = {P.DuDt[i], P.DuDt[cap + i], P.DuDt[2 * cap + i]};
-      const double k = S.carrier_rho / rho * 0.5 * mi;
-      fd.x += k * (du.x - (vi.x - vo.x) / S.dt);
-      fd.y += k * (du.y - (vi.y - vo.y) / S.dt);
-      fd.z += k * (du.z - (vi.z - vo.z) / S.dt);
-      P.vOld[i] = vi.x;
-      P.vOld[cap + i] = vi.y;
-      P.vOld[2 * cap + i] = vi.z;
+      const Vec3 vo = {PE.vOld[i], PE.vOld[cap + i], PE.vOld[2 * cap + i]};
+      const Vec3 du = {PE.DuDt[i], PE.DuDt[cap + i], PE.DuDt[2 * cap + i]};
+      const double k = SE.carrier_rho / rho * 0.5 * mi;
+      fd.x += k * (du.x - (vi.x - vo.x) / SE.dt);
+      fd.y += k * (du.y - (vi.y - vo.y) / SE.dt);
+      fd.z += k * (du.z - (vi.z - vo.z) / SE.dt);
+      PE.vOld[i] = vi.x;
+      PE.vOld[cap + i] = vi.y;
+      PE.vOld[2 * cap + i] = vi.z;
     }
     F = F + fd;
-    if (any_post && (S.post_freeze & 2)) Fa = Fa + fd;
+    if (any_post && (SE.post_freeze & 2)) Fa = Fa + fd;
   }
-  if (S.nwalls) {
+  if (SE.nwalls) {
     unsigned wt = wt_in, wt_new = 0;
-    for (int w = 0; w < S.nwalls; w++) {
-      const WallParams& W = S.wall[w];
+    for (int w = 0; w < SE.nwalls; w++) {
+      const WallParams& W = SE.wall[w];
       if (!(mk & W.bit)) continue;   // fix_wall_granFix.cpp:290
       Vec3 dw = {0.0, 0.0, 0.0};
       Vec3 vw = {W.vwall[0], W.vwall[1], W.vwall[2]};   // 0 unless the wall wiggles or shears (:255-264)
@@ -619,16 +632,16 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
       const size_t wb = ((size_t)(3 * w)) * cap + i;
       Vec3 sh = {0.0, 0.0, 0.0};
       if (wt & (1u << w)) {
-        sh.x = P.wshear[wb];
-        sh.y = P.wshear[wb + cap];
-        sh.z = P.wshear[wb + 2 * cap];
+        sh.x = PE.wshear[wb];
+        sh.y = PE.wshear[wb + cap];
+        sh.z = PE.wshear[wb + 2 * cap];
       }
       ContactOut o;
-      if (W.gp.style == 2) hertz_history_law(W.gp, S.dt, shearupdate, c, sh, o);
-      else hooke_history_law(W.gp, S.dt, shearupdate, c, sh, o);
-      P.wshear[wb] = sh.x;
-      P.wshear[wb + cap] = sh.y;
-      P.wshear[wb + 2 * cap] = sh.z;
+      if (W.gp.style == 2) hertz_history_law(W.gp, SE.dt, shearupdate, c, sh, o);
+      else hooke_history_law(W.gp, SE.dt, shearupdate, c, sh, o);
+      PE.wshear[wb] = sh.x;
+      PE.wshear[wb + cap] = sh.y;
+      PE.wshear[wb + 2 * cap] = sh.z;
       wt_new |= (1u << w);
       F = F + o.F;
       T = T - radi * o.tor;
@@ -637,38 +650,38 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
         Ta = Ta - radi * o.tor;
       }
     }
-    if (wt_new != wt) P.wtouch[i] = (unsigned char)wt_new;
+    if (wt_new != wt) PE.wtouch[i] = (unsigned char)wt_new;
   }
 
   SF_PH(28);
   // ---- integrate: final(k) [+ initial(k+1)]  ([3P] FixNVESphere, dtf = dt/2, INERTIA = 0.4) ----
   // [3P] fix freeze: force and torque of the group's atoms are zeroed where the fix stands in the script
-  if (mk & S.freeze_bit) {
+  if (mk & SE.freeze_bit) {
     F = Fa;
     T = Ta;
   }
   Vec3 vn = vi, wn = wi, xn = xi;
   bool gs_trig = false;
-  if (S.mode != 2 && S.have_nve && (mk & S.nve_bit)) {
-    const double dtf = 0.5 * S.dt;
+  if (SE.mode != 2 && SE.have_nve && (mk & SE.nve_bit)) {
+    const double dtf = 0.5 * SE.dt;
     const double dtfm = dtf / mi;
     const double dtirot = (dtf / 0.4) / (radi * radi * mi);
     vn = vn + dtfm * F;
     wn = wn + dtirot * T;
-    if (S.mode == 0) {
+    if (SE.mode == 0) {
       vn = vn + dtfm * F;
-      xn = xn + S.dt * vn;
+      xn = xn + SE.dt * vn;
       wn = wn + dtirot * T;
       const double dx = xn.x - xh_in.x, dy = xn.y - xh_in.y, dz = xn.z - xh_in.z;
-      if (dx * dx + dy * dy + dz * dz > S.trigger_sq) {
+      if (dx * dx + dy * dy + dz * dz > SE.trigger_sq) {
         gs_trig = true;
-        atomicMin(&P.flags[S.trig_set], S.kstep + S.trig_add);
+        atomicMin(&PE.flags[SE.trig_set], SE.kstep + SE.trig_add);
         // (fused forward pack: no kernel will copy the trigger word into the vote headers before the exchange)
-        for (int p = 0; p < S.tx_nhdr; p++) atomicMin(header_vote_ptr(P.tx_sendbuf + P.tx_hdr_off[p]), S.kstep + S.trig_add);
+        for (int p = 0; p < SE.tx_nhdr; p++) atomicMin(header_vote_ptr(PE.tx_sendbuf + PE.tx_hdr_off[p]), SE.kstep + SE.trig_add);
       }
-      if (S.margin_sq > 0.0) {
+      if (SE.margin_sq > 0.0) {
         const double sx = xn.x - xi.x, sy = xn.y - xi.y, sz = xn.z - xi.z;
-        if (sx * sx + sy * sy + sz * sz > S.margin_sq) P.flags[F_MARGIN_FAIL] = 1;
+        if (sx * sx + sy * sy + sz * sz > SE.margin_sq) PE.flags[F_MARGIN_FAIL] = 1;
       }
     }
   }
@@ -676,39 +689,39 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
   // k_forward_pack_fused would gather after this kernel
   if (txb) {
     for (int k = 0; k < kBrickSlots; k++) {
-      const int off = P.bslot[(size_t)k * cap + i];
+      const int off = PE.bslot[(size_t)k * cap + i];
       if (off < 0) break;
       const int bq = off >> kBlkShift;
       if (GS) {   // whole records into the neighbour's ghost slots (its x | v | omega arrays), in the neighbour's frame
         const size_t r = (size_t)(off & kBlkMask);
-        const double* sh = P.tx_blkshift + 3 * bq;
-        gs_store(reinterpret_cast<double4*>(P.tx_blkptr[bq]) + r, xn.x + sh[0], xn.y + sh[1], xn.z + sh[2], radi);
-        gs_store(reinterpret_cast<double4*>(P.tx_blkptr[DemEngine::kMaxDirs + bq]) + r, vn.x, vn.y, vn.z, mi);
-        gs_store(reinterpret_cast<double4*>(P.tx_blkptr[2 * DemEngine::kMaxDirs + bq]) + r, wn.x, wn.y, wn.z, wi4.w);
+        const double* sh = PE.tx_blkshift + 3 * bq;
+        gs_store(reinterpret_cast<double4*>(PE.tx_blkptr[bq]) + r, xn.x + sh[0], xn.y + sh[1], xn.z + sh[2], radi);
+        gs_store(reinterpret_cast<double4*>(PE.tx_blkptr[DemEngine::kMaxDirs + bq]) + r, vn.x, vn.y, vn.z, mi);
+        gs_store(reinterpret_cast<double4*>(PE.tx_blkptr[2 * DemEngine::kMaxDirs + bq]) + r, wn.x, wn.y, wn.z, wi4.w);
         continue;
       }
-      double* b = P.tx_blkptr[bq] + (off & kBlkMask);
-      const size_t n = P.tx_blkcnt[bq];   // (component-major block: [kForwardDoubles][n])
+      double* b = PE.tx_blkptr[bq] + (off & kBlkMask);
+      const size_t n = PE.tx_blkcnt[bq];   // (component-major block: [kForwardDoubles][n])
       b[0] = xn.x; b[n] = xn.y; b[2 * n] = xn.z;
       b[3 * n] = vn.x; b[4 * n] = vn.y; b[5 * n] = vn.z;
       b[6 * n] = wn.x; b[7 * n] = wn.y; b[8 * n] = wn.z;
     }
   }
-  if (S.tx_fused == 1) {
+  if (SE.tx_fused == 1) {
     auto put = [&](double* b, size_t n, double shift) {
       b[0] = xn.x + shift; b[n] = xn.y; b[2 * n] = xn.z;
       b[3 * n] = vn.x; b[4 * n] = vn.y; b[5 * n] = vn.z;
       b[6 * n] = wn.x; b[7 * n] = wn.y; b[8 * n] = wn.z;
     };
-    if (txk0 >= 0) put(P.tx[0] + txk0, (size_t)S.tx_n[0], S.tx_shift[0]);
-    if (txk1 >= 0) put(P.tx[1] + txk1, (size_t)S.tx_n[1], S.tx_shift[1]);
+    if (txk0 >= 0) put(PE.tx[0] + txk0, (size_t)SE.tx_n[0], SE.tx_shift[0]);
+    if (txk1 >= 0) put(PE.tx[1] + txk1, (size_t)SE.tx_n[1], SE.tx_shift[1]);
   }
   SF_PH(29);
 #if SF_ST_SHUFFLE
   // A 32-byte record per lane is two 16-byte stores at a 32-byte stride: each store instruction covers only half
   // of every cache line it touches.  When the whole wave holds consecutive atoms the halves are exchanged between
   // lanes so that each instruction writes 1 KiB of contiguous memory (lane l stores chunk l, then chunk 64 + l).
-  if (LPA == 1 && S.part == 0 && __ballot(1) == ~0ull && (i & 63) == (int)(threadIdx.x & 63)) {
+  if (LPA == 1 && SE.part == 0 && __ballot(1) == ~0ull && (i & 63) == (int)(threadIdx.x & 63)) {
     const int lane = threadIdx.x & 63;
     const int base = i - lane;
     // (the half-wave exchange of the gathers, backwards: the first store writes records 0..31 -- lane l their first 16
@@ -721,25 +734,25 @@ __device__ __forceinline__ int substep_particle(const DemPtrs& P, const StepPara
       *reinterpret_cast<double2*>(dst) = double2{a0, a1};
       *reinterpret_cast<double2*>(dst + 1024) = double2{a2, a3};
     };
-    store_shuffled(P.xr_out, xn.x, xn.y, xn.z, radi);
-    store_shuffled(P.vm_out, vn.x, vn.y, vn.z, mi);
-    store_shuffled(P.om_out, wn.x, wn.y, wn.z, wi4.w);
+    store_shuffled(PE.xr_out, xn.x, xn.y, xn.z, radi);
+    store_shuffled(PE.vm_out, vn.x, vn.y, vn.z, mi);
+    store_shuffled(PE.om_out, wn.x, wn.y, wn.z, wi4.w);
   } else
 #endif
   {
 #if SF_NT_OUT
-    st_stream4<NT_ST>(&P.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
-    st_stream4<NT_ST>(&P.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
-    st_stream4<NT_ST>(&P.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
+    st_stream4<NT_ST>(&PE.xr_out[i], double4{xn.x, xn.y, xn.z, radi});
+    st_stream4<NT_ST>(&PE.vm_out[i], double4{vn.x, vn.y, vn.z, mi});
+    st_stream4<NT_ST>(&PE.om_out[i], double4{wn.x, wn.y, wn.z, wi4.w});
 #else
-    P.xr_out[i] = {xn.x, xn.y, xn.z, radi};
-    P.vm_out[i] = {vn.x, vn.y, vn.z, mi};
-    P.om_out[i] = {wn.x, wn.y, wn.z, wi4.w};   // .w: frozen mark travels with the record
+    PE.xr_out[i] = {xn.x, xn.y, xn.z, radi};
+    PE.vm_out[i] = {vn.x, vn.y, vn.z, mi};
+    PE.om_out[i] = {wn.x, wn.y, wn.z, wi4.w};   // .w: frozen mark travels with the record
 #endif
   }
-  if (S.mode != 0) {
-    P.force[i] = {F.x, F.y, F.z, 0.0};
-    P.torque[i] = {T.x, T.y, T.z, 0.0};
+  if (SE.mode != 0) {
+    PE.force[i] = {F.x, F.y, F.z, 0.0};
+    PE.torque[i] = {T.x, T.y, T.z, 0.0};
   }
   SF_PH(30);
   return 1 | (txb ? 2 : 0) | (gs_trig ? 4 : 0);
@@ -852,6 +865,8 @@ __global__ __launch_bounds__(256) SF_SUBSTEP_ATTR void k_substep(DemPtrs P, Step
 }
 
 
+#ifdef SF_EXP_PERSIST   // (pricing arm of round 6, tests/build_variant.sh pers -DSF_EXP_PERSIST=1: measured slower, not shipped --
+                        //  profiles/r06_README.md section 2)
 // ------------------------------------------------------------------------------------------------
 // Persistent tiles (round 6).  k_substep starts one wave per 64 atoms: every wave pays its own start -- kernel arguments,
 // the round trip for its atom's records, row count and first list words (3.7 us of a 33 us life) -- with nothing else of its
@@ -894,29 +909,36 @@ void k_substep_persist(DemPtrs P, StepParams S)
     const int i0 = base + lane;
     tile_prefetch<NT_LD>(P, S, i0 < S.nlocal ? i0 : 0, pre);
   }
-  // The kernel arguments are read through a pointer the compiler cannot see through, once per tile: left alone it hoists
-  // every scalar load of the ~150 words of StepParams out of the tile loop, keeps them all live across it and spills
-  // (169 scalar + 37 vector registers); re-read per tile they are what they are in k_substep -- scalar loads next to
-  // their use, from the constant cache.
+  // The epilogue of a tile reads the kernel arguments through a pointer the compiler cannot see through, renewed per tile:
+  // left alone it hoists every scalar load of the ~150 words of StepParams out of the tile loop, keeps them all live across
+  // it and spills (169 scalar + 37 vector registers).  The neighbour loop reads P and S directly: its scalars stay in
+  // registers across the tiles, as they do across the loop in k_substep (re-reading them inside the loop: +12 %).
   typedef const char __attribute__((address_space(4))) * KernArg;
   const KernArg ka0 = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr size_t kSOff = (sizeof(DemPtrs) + alignof(StepParams) - 1) / alignof(StepParams) * alignof(StepParams);
   for (;;) {
     KernArg ka = ka0;
     asm volatile("" : "+s"(ka));
-    const DemPtrs& Pt = *(const DemPtrs*)(ka);
-    const StepParams& St = *(const StepParams*)(ka + kSOff);
+    pre.Pe = (const DemPtrs*)(ka);
+    pre.Se = (const StepParams*)(ka + kSOff);
     const int base_next = t_next < cnt ? base_of(t_next) : -1;
     const int i = base + lane;
-    const bool live = i < St.nlocal;
-    substep_particle<STYLE, COHE, LUB, false, 1, TP, NTP, false, true>(Pt, St, live ? i : 0, 0, nullptr, nullptr, nullptr, 0ull,
+    const bool live = i < S.nlocal;
+    substep_particle<STYLE, COHE, LUB, false, 1, TP, NTP, false, true>(P, S, live ? i : 0, 0, nullptr, nullptr, nullptr, 0ull,
                                                                         live, &pre, base_next);
     if (base_next < 0) break;
+    if (!SF_PERS_PREFETCH) {   // (pricing arm: the next tile's records requested when the current tile is done -- no overlap)
+      if (SF_PERS_DYNAMIC && lane == 0) pre.q = atomicAdd(head, 1);
+      const int in = base_next + lane;
+      tile_prefetch<NT_LD>(P, S, in < S.nlocal ? in : 0, pre);
+    }
     base = base_next;
-    t_next = 2 * nres + __builtin_amdgcn_readfirstlane(pre.q);
+    t_next = SF_PERS_DYNAMIC ? 2 * nres + __builtin_amdgcn_readfirstlane(pre.q) : t_next + nres;
   }
   if (S.xcd_time && lane == 0 && (loc & 7) == 0) atomicMax(&P.xcd_time[xq + 32], (int)(wall_clock64() & 0x3fffffff));
 }
+
+#endif
 
 // (the LDS-staged cell-bin kernel, k_substep_lds -- the same substep_particle on a tile's staged copy -- is in
 // sf_dem_lds_kernel.h)

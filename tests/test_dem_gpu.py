@@ -293,7 +293,9 @@ def test_mid_size_polydisperse_cohesive_lubricate_32k():
 # two cutoffs as lengths: 1.001 / 1.1 of the LARGEST pair (d_max), so that every overlapping pair is inside the inner cutoff
 # (beyond it the reference takes log(h_sep) of a negative gap, pair_lubricate_poly.cpp:286-300).  flagHI, flagVF: defaults 1 1
 C5_WIDE = dict(cohesive=(1.0e-20, 1.0e-7, 1.0e-9, 1.0e-4, 1), lub=(1.0e-3, 1, 0, 1.001 * 1.5e-3, 1.1 * 1.5e-3, 1, 1))
-C5_WIDE_STRONG = dict(C5_WIDE, cohesive=(1.0e-13, 1.0e-7, 1.0e-9, 1.0e-4, 1))   # (a Hamaker constant the forces can see)
+# (a Hamaker constant the forces can see, with the floor of the narrow C5 case: at smin = 1e-9 the force of a touching pair is
+# ~ 1 / del^2 of a gap del = r - (ri + rj) that cancels to 1e-6 of r -- conditioned 1e-10, not a 1e-11 comparison)
+C5_WIDE_STRONG = dict(C5_WIDE, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1))
 
 
 @pytest.mark.parametrize("params", [C5_WIDE, C5_WIDE_STRONG], ids=["survey_8d", "strong_cohesion"])
