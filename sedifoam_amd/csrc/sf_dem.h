@@ -155,7 +155,7 @@ struct DemPtrs {
   const double* tx_blkshift;
   const struct GsSync* gs_sync;
   int* gs_my_sync;              // GsSync::my_sync (the flag / vote lines the gate polls)
-  int* gs_count;                // [8][32]: one line per XCD, a 64-bit word each: workgroups done + 2^32 x those that triggered
+  int* gs_count;                // [8][32] (eight 128-byte lines): one line per XCD, a 64-bit word each: workgroups done + 2^32 x those that triggered
   // LDS-staged tiles (k_substep_lds)
   const unsigned short* nloc;   // [M][cap] position of the neighbour in its tile's staged copy
   const int* tile_first;        // [ntiles] owned-atom range of a tile
@@ -168,7 +168,7 @@ struct DemPtrs {
 struct GsSync {
   int world, rank;
   long long max_ticks;     // 100 MHz clock: how long a wave waits for a peer's flag
-  int* my_sync;            // for sender r the line [kGsStride r]: flag, vote[2]
+  int* my_sync;            // for sender r the line [kGsStride r]: ONE 64-bit word, (flag << 32) | vote
   int* peer_sync[32];      // every rank's area as mapped here
 };
 constexpr int kGsStride = 32;   // ints: one 128-byte line per sending rank (one writer per line)
@@ -217,7 +217,7 @@ struct StepParams {
   double tx_lo3[3], tx_hi3[3];
   // ghost slots: gs_on -- the ghost records of this launch's input buffers were written by the neighbours' kernels; gs_seq --
   // the number of this launch: its waves wait until every rank's flag says gs_seq ("my records for launch gs_seq are in
-  // your arrays", gs_wait = 0: nobody to wait for) and read the votes of parity gs_seq & 1; the wave that stays behind
+  // your arrays", gs_wait = 0: nobody to wait for) and read the vote that travels in the same word; the wave that stays behind
   // (sf_dem_gs.h) stores this rank's vote and the flag gs_seq + 1 into every rank's line
   int gs_on, gs_seq, gs_wait;
   int gs_world, gs_rank;   // (copies of GsSync::world / rank: the gate reads them from the kernel arguments)
@@ -234,6 +234,9 @@ struct BinGrid {
   int nt[3];       // close in space are close in memory in all three directions; tile <= 1: plain x-fastest
   int xslow;       // 1: z fastest, x slowest (decomposed domain: the atoms next to the two x faces of the slab are
                    // then a prefix and a suffix of the sorted array = the boundary part of the overlapped halo)
+  int wrap[3];     // 1: the cells of this dimension tile the periodic box exactly and the list build walks its stencil
+                   // AROUND the box (candidate = atom of the wrapped cell + the box length): no ghost atoms are made for
+                   // the periodic images of a single-domain run (DemEngine::ghost_free_)
 };
 
 // bin coordinates -> sort key / cell index
@@ -406,7 +409,7 @@ class DemEngine {
 
   // ---- data exchange ----
   int nlocal() const { return nlocal_; }
-  int nghost() const { return nghost_; }
+  int nghost();   // (ghost-free list build: the periodic images are counted on demand, see ghost_free_)
   int rank() const { return rank_; }
   int nranks() const { return nranks_; }
   void sublo_hi(double out[6]) const;
@@ -706,6 +709,14 @@ private:
   bool touch_first_ = false;
   int touch_first_env_ = -1;
   int opt_lpa_ = 0;                          // SF_LPA: lanes per atom pinned (1, 2 or 4; 0 = by size)
+  // Single domain, plain keys, (root, image code) words: the periodic images of a rebuild are not materialised as ghost
+  // atoms -- the list build wraps its cell stencil around the box (BinGrid::wrap) and tests atom j + box length where
+  // LAMMPS tests the ghost copy (the same sum, the same bits).  Twelve launches less per rebuild (ghost selection and
+  // creation per dimension, the counting sort of the ghosts).  nghost() -- a diagnostic -- counts the images LAMMPS would
+  // have made when somebody asks.  SF_GHOST_FREE=0: the ghost path.
+  int opt_ghost_free_ = -1;
+  bool ghost_free_ = false;
+  int nimages_ = -1;                         // ghost_free_: images counted for nghost() (-1: not counted since the last rebuild)
   int opt_persist_ = -1;                     // SF_PERSIST: persistent tiles (k_substep_persist) off (0), on wherever the kernel
                                              // exists (1), default (-1): where it measured faster (launch_substep)
   int opt_persist_waves_ = 0;                // SF_PERSIST_WAVES: waves per XCD of the persistent launch (0: the resident ones)
@@ -768,7 +779,7 @@ private:
   bool gs_ready_ = false;              // ghost slots: the tables below are valid
   GsSync* d_gs_sync_ = nullptr;
   GsSync h_gs_sync_{};
-  int* d_gs_count_ = nullptr;          // [9][32] completion counters (zero between launches)
+  int* d_gs_count_ = nullptr;          // [8][32] completion counters, one 128-byte line per XCD (zero between launches)
   long long gs_seq_ = 1;
   int gs_map_base_ = 0;                // buffer that launches of EVEN number read, as the neighbours were told
   int tx_par_ = 0;

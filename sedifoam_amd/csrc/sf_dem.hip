@@ -124,6 +124,7 @@ DemEngine::DemEngine()
   if (const char* e = getenv("SF_TOUCH_FIRST")) touch_first_env_ = atoi(e);
   if (const char* e = getenv("SF_NT_POLICY")) nt_policy_env_ = atoi(e);
   if (const char* e = getenv("SF_LPA")) opt_lpa_ = atoi(e);
+  if (const char* e = getenv("SF_GHOST_FREE")) opt_ghost_free_ = atoi(e);
   if (const char* e = getenv("SF_PERSIST")) opt_persist_ = atoi(e);
   if (const char* e = getenv("SF_PERSIST_WAVES")) opt_persist_waves_ = atoi(e);
   SF_HIP(hipMalloc(&d_pq_head_, sizeof(int) * 2 * 8 * 32));
@@ -596,6 +597,47 @@ void DemEngine::set_velocity_all(double vx, double vy, double vz)
 
 double DemEngine::max_radius() { return rmax_; }
 
+// images LAMMPS' ghost creation would have made of the owned atoms (dimension by dimension, the later ones also of the
+// ghosts of the earlier ones: k_ghost_select's criteria): an atom within the ghost cutoff of a periodic face counts once
+// per face and dimension, the combinations multiply
+// (xhold: the positions of the last list build, [3][cap] -- what LAMMPS made its ghosts from)
+__global__ __launch_bounds__(1024) static void k_count_images(const double* xhold, size_t cap, int nlocal, double3 lo, double3 hi,
+                                                              int3 per, double cut, int* out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = 0;
+  if (i < nlocal) {
+    const double xs[3] = {xhold[i], xhold[cap + i], xhold[2 * cap + i]};
+    const double los[3] = {lo.x, lo.y, lo.z}, his[3] = {hi.x, hi.y, hi.z};
+    const int ps[3] = {per.x, per.y, per.z};
+    int prod = 1;
+    for (int k = 0; k < 3; k++)
+      if (ps[k]) prod *= 1 + (xs[k] >= los[k] && xs[k] <= los[k] + cut ? 1 : 0) + (xs[k] >= his[k] - cut && xs[k] <= his[k] ? 1 : 0);
+    c = prod - 1;
+  }
+  c = block_sum_int_1024(c);
+  if (threadIdx.x == 0 && c) atomicAdd(out, c);
+}
+
+int DemEngine::nghost()
+{
+  if (!ghost_free_ || !have_list_ || !nlocal_) return nghost_;
+  if (nimages_ < 0) {
+    int* d = nullptr;
+    int h = 0;
+    SF_HIP(hipMalloc(&d, sizeof(int)));
+    SF_HIP(hipMemsetAsync(d, 0, sizeof(int), stream_));
+    k_count_images<<<div_up(nlocal_, 1024), 1024, 0, stream_>>>(
+        xhold_.as<double>(), cap_, nlocal_, double3{boxlo_[0], boxlo_[1], boxlo_[2]}, double3{boxhi_[0], boxhi_[1], boxhi_[2]},
+        int3{periodic_[0] ? 1 : 0, periodic_[1] ? 1 : 0, periodic_[2] ? 1 : 0}, cutneighmax(), d);
+    SF_HIP(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    SF_HIP(hipStreamSynchronize(stream_));
+    SF_HIP(hipFree(d));
+    nimages_ = h;
+  }
+  return nghost_ + nimages_;
+}
+
 double DemEngine::cutneighmax() const
 {
   double c = 0.0;
@@ -903,6 +945,10 @@ void DemEngine::launch_substep(int in_buf, int mode, int kstep, int part)
   // (mode 2) runs on the ghosts the border exchange has just put into the record arrays
   const bool gs = gs_ready_ && brick_ && part == 0 && !lds_active_ && mode != 2;
   if (gs) {
+    // (before the launch takes its number: a refused launch must not leave a gap in the sequence the neighbours count)
+    static const int gs_block_env = getenv("SF_BLOCK") ? atoi(getenv("SF_BLOCK")) : 0;
+    if (gs_block_env && gs_block_env != 64)
+      fail("ghost slots: the hand-off at the end of the sub-step kernel is written for one-wave workgroups (SF_BLOCK)");
     S.gs_on = 1;
     S.gs_seq = (int)gs_seq_;
     S.gs_wait = h_gs_sync_.world > 1 ? 1 : 0;   // (one rank that exchanges with itself: stream order is the hand-off)
@@ -1175,8 +1221,15 @@ void DemEngine::compute_grid()
   // (single domain, plain keys: the cell size follows the bed -- see sort_sub_)
   const int sub = (!opt_sub_env_ && !have_subdomain_ && opt_tile_ <= 1 && !opt_lds_ && sort_sub_ > 0) ? sort_sub_ : opt_sub_;
   grid_.nbins = 1;
+  // ghost-free list build (ghost_free_): every periodic dimension holds at least three cells of the cutoff, so that the
+  // wrapped stencil never meets the same atom twice
+  ghost_free_ = opt_ghost_free_ != 0 && !have_subdomain_ && opt_tile_ <= 1 && !opt_lds_ && roots_ &&
+                (periodic_[0] || periodic_[1] || periodic_[2]);
+  for (int k = 0; k < 3 && ghost_free_; k++)
+    if (periodic_[k] && (ext_[k] || (int)((hi[k] - lo[k]) / cut) < 3)) ghost_free_ = false;
   for (int k = 0; k < 3; k++) {
-    const bool ext = periodic_[k] || ext_[k];
+    const bool wrapk = ghost_free_ && periodic_[k];
+    const bool ext = !wrapk && (periodic_[k] || ext_[k]);
     const double l = ext ? lo[k] - cut : lo[k];
     const double h = ext ? hi[k] + cut : hi[k];
     int n = (int)((h - l) / cut);
@@ -1184,6 +1237,7 @@ void DemEngine::compute_grid()
     grid_.lo[k] = l;
     grid_.n[k] = n;
     grid_.inv[k] = n / (h - l);
+    grid_.wrap[k] = wrapk ? 1 : 0;
   }
   grid_.stencil = sub;
   grid_.tile = opt_tile_ > 1 ? opt_tile_ * sub : 1;   // tiles keep their physical size
@@ -1374,6 +1428,8 @@ void DemEngine::make_periodic_ghosts()
 {
   // external ghosts (other GPUs) were appended by border_unpack: slots [nlocal, nlocal+next_ghost_)
   nghost_ = next_ghost_;
+  nimages_ = -1;
+  if (ghost_free_) return;   // (the list build walks around the box itself: compute_grid)
   const double cut = cutneighmax();
   int dims[3], nd = 0;
   for (int dim = 0; dim < 3; dim++)   // images across an external face come from the neighbour GPUs (or the driver's self loop)
@@ -1554,7 +1610,10 @@ void DemEngine::bin_and_build()
     B.roots = roots_ ? 1 : 0;
     B.gsrc = gsrc_.as<int>();
     B.gshift = gshift_.as<double>();
-    for (int k = 0; k < 3; k++) B.inv_prd[k] = 1.0 / (boxhi_[k] - boxlo_[k]);
+    for (int k = 0; k < 3; k++) {
+      B.inv_prd[k] = 1.0 / (boxhi_[k] - boxlo_[k]);
+      B.prd[k] = boxhi_[k] - boxlo_[k];
+    }
     if (roots_ && cap_ > (size_t)kIdxMask) fail("more than %d atom slots per GPU: not addressable by the neighbour word", kIdxMask);
     k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
         B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),

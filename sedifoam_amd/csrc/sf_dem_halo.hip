@@ -1030,6 +1030,9 @@ void DemEngine::gs_configure(const GsSync& sync, long long first_seq)
 bool DemEngine::brick_fused_pack_possible() const
 {
   if (getenv("SF_HALO_FUSED_PACK") && !atoi(getenv("SF_HALO_FUSED_PACK"))) return false;
+  // (the LDS-staged tile kernel neither writes border records nor runs the hand-off: the ranks decide this BEFORE they
+  // agree on a transport -- gs_rebuild / direct_rebuild all-reduce it --, whatever build_stage_tables later finds per rank)
+  if (opt_lds_) return false;
   const double cut = cutneighmax();
   for (int d = 0; d < 3; d++)
     if (ext_[d] && subhi_[d] - sublo_[d] < 2.0 * cut) return false;

@@ -1040,7 +1040,19 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
   const int i = xcd_contiguous_block() * blockDim.x + threadIdx.x;   // (gathers from the neighbours' rows)
   if (i >= nlocal) return;
   const int nn = numneigh[i];
-  for (int s = 0; s < M; s++) {
+  // (rows beyond an atom's count are never read -- the list build and the migration pack stop at numneigh -- and the walk
+  // ends at the longest row of the WAVE, not of the bed: a loose bed's longest row is twice its mean)
+  int nmax = nn;
+  {
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(nmax, off, 64);
+      if ((act >> (lane ^ off)) & 1ull) nmax = max(nmax, o);
+    }
+    nmax = min(nmax, M);
+  }
+  for (int s = 0; s < nmax; s++) {
     int t = -1;
     if (s < nn) {
       const int jraw = neigh[(size_t)s * cap + i];
@@ -1059,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
         hist_out[dst + 2 * cap] = sign * shear[src + 2 * cap];
       }
     }
-    ptag[(size_t)s * cap + i] = t;
+    if (s < nn) ptag[(size_t)s * cap + i] = t;
   }
 }
 
@@ -1474,6 +1486,7 @@ struct BuildParams {
   const int* gsrc;    // root of a periodic image (-1: ghost owned by another GPU)
   const double* gshift;
   double inv_prd[3];
+  double prd[3];      // box lengths (BinGrid::wrap: the shift of a candidate found around the box)
   // first sorted position of EVERY cell (entry nbins = one past the last atom), or nullptr (tile-major keys, LDS
   // staging): see the row walk in k_build_neigh
   const int* lb_own;
@@ -1627,8 +1640,11 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   // distance test of one candidate
   // (no granular criterion: ri + rj + -inf never exceeds the absolute cutoff -- one max instead of a select per candidate)
   const double skinv = B.skin_gran >= 0.0 ? B.skin_gran : -INFINITY;
+  // (sx, sy, sz: the box lengths a candidate found AROUND the box is shifted by -- BinGrid::wrap; xj + shift is the position
+  // LAMMPS gives the ghost copy)
+  double sx = 0.0, sy = 0.0, sz = 0.0;
   auto in_range = [&](const int j, const double4 xj) {
-    const double dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+    const double dx = xi.x - (xj.x + sx), dy = xi.y - (xj.y + sy), dz = xi.z - (xj.z + sz);
     const double rsq = dx * dx + dy * dy + dz * dz;
     const double cut = fmax(xi.w + xj.w + skinv, B.cut_lub);
     return j != i && rsq <= cut * cut;
@@ -1651,6 +1667,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   // row path: slot of the next touching / next non-touching neighbour (touching ones first, see the second sweep)
   int slot_touch = -1, slot_free = -1;
   int found_known = -2;   // >= -1: the old slot of the pair was looked up before (touch-first placement)
+  int code_known = kNoShift;   // wrapped stencil: which periodic image of j the candidate is (kNoShift: j itself)
   auto accept = [&](const int j, const int tj, const int pos) {
     if (n < B.M) {
       int entry = j;
@@ -1658,7 +1675,8 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       // ghost of another GPU keep a copy on each side (the reference's newton-off treatment of owned-ghost pairs)
       bool own = j > i || B.two_copies;
       if (B.roots) {
-        int code = kNoShift;
+        int code = code_known;
+        if (code != kNoShift) own = true;   // (an image found around the box: a copy on each side, like every owned-ghost pair)
         if (j >= B.nlocal) {
           const int r = B.gsrc[j];
           if (r >= 0) {   // periodic image made on this GPU: refer to its root + which image it is
@@ -1702,10 +1720,13 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   constexpr int kFoundUnknown = 127;
   const bool tf = B.touch_first && nold > 0;
   int* cand_next = cand + i;   // (a running pointer: the row stride is added per accepted candidate, not multiplied)
+  int row_code = kNoShift;      // wrapped stencil: image code of the row being walked (lanes near a periodic face)
+  bool park_codes = false;      // ... which park it next to every accepted candidate (B.nloc: unused without LDS staging)
   auto note = [&](const int j) {
     if (n_total < B.M) {
       *cand_next = j;
       cand_next += B.cap;
+      if (park_codes) B.nloc[(size_t)n_total * B.cap + i] = (unsigned short)row_code;
     }
     n_total++;
   };
@@ -1716,52 +1737,94 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     // are loaded at once, then tested and entered in order.
     const int W = 2 * R + 1;
     const int bi0 = ci - R < 0 ? 0 : ci - R, bi1 = ci + R >= ni ? ni - 1 : ci + R;
-    // keys of successive rows differ by a constant: key(ro, ry) = bi0 + ni (cy - R + ry) + ni n1 (co - R + ro)
-    const int n1 = B.g.n[1], nin1 = ni * n1, width = bi1 - bi0 + 1;
-    const int key00 = bi0 + ni * (cy - R) + nin1 * (co - R);
+    const int n1 = B.g.n[1], nin1 = ni * n1;
+    // Wrapped stencil (BinGrid::wrap, ghost-free build; x fastest: inner = x, outer = z).  A row whose y or z cell lies
+    // beyond a periodic face is the row of the cell on the other side of the box, its atoms shifted by the box length;
+    // the x range of a row that crosses a periodic x face is TWO ranges -- the cells inside the box (segment 0) and the
+    // cells around the box (segment 1, of the lanes within R cells of that face only).
+    const bool wrap_i = B.g.wrap[0] != 0, wrap_y = B.g.wrap[1] != 0, wrap_o = B.g.wrap[2] != 0;
+    int seg1_lo = 0, seg1_hi = -1;      // cells of segment 1 (empty unless this lane's x range crosses a periodic face)
+    double seg1_shift = 0.0;
+    if (wrap_i && ci - R < 0) {
+      seg1_lo = ci - R + ni;
+      seg1_hi = ni - 1;
+      seg1_shift = -B.prd[0];
+    } else if (wrap_i && ci + R >= ni) {
+      seg1_lo = 0;
+      seg1_hi = ci + R - ni;
+      seg1_shift = B.prd[0];
+    }
+    // (lanes whose stencil reaches around the box park the image code of every accepted candidate next to its index)
+    const bool near_face = (wrap_i && (ci < R || ci + R >= ni)) || (wrap_y && (cy < R || cy + R >= n1)) ||
+                           (wrap_o && (co < R || co + R >= no));
+    const int nseg = (wrap_i && __ballot(seg1_hi >= seg1_lo)) ? 2 : 1;   // (wave-uniform)
+    park_codes = near_face;
     for (int pass = 0; pass < 2; pass++) {
       const int* lb = pass ? B.lb_ghost : B.lb_own;   // owned atoms first, then ghosts in their (cell, tag) order
       if (!lb) break;
-      auto row_range = [&](const int ro, const int ry, const int key, int& lo, int& hi) {
-        const int bo = co - R + ro, by = cy - R + ry;
+      // row r = (segment, ro, ry): its range of the sorted array and the shift of its atoms
+      auto row_range = [&](const int seg, const int ro, const int ry, int& lo, int& hi, double& rsx, double& rsy,
+                           double& rsz) {
         lo = hi = 0;
-        if (ro >= W || (unsigned)bo >= (unsigned)no || (unsigned)by >= (unsigned)n1) return;
+        rsx = rsy = rsz = 0.0;
+        if (seg >= nseg || ro >= W) return;
+        int bo = co - R + ro, by = cy - R + ry;
+        if (wrap_o) {
+          if (bo < 0) { bo += no; rsz = -B.prd[2]; }
+          else if (bo >= no) { bo -= no; rsz = B.prd[2]; }
+        } else if ((unsigned)bo >= (unsigned)no) return;
+        if (wrap_y) {
+          if (by < 0) { by += n1; rsy = -B.prd[1]; }
+          else if (by >= n1) { by -= n1; rsy = B.prd[1]; }
+        } else if ((unsigned)by >= (unsigned)n1) return;
+        const int c0 = seg ? seg1_lo : bi0, c1 = seg ? seg1_hi : bi1;
+        if (c1 < c0) return;
+        if (seg) rsx = seg1_shift;
+        const int key = c0 + ni * by + nin1 * bo;
         lo = lb[key];
-        hi = lb[key + width];
+        hi = lb[key + (c1 - c0 + 1)];
       };
-      int nlo, nhi, nkey = key00;
-      row_range(0, 0, nkey, nlo, nhi);
-      for (int ro = 0; ro < W; ro++) {
-        for (int ry = 0; ry < W; ry++) {
-          const int lo = nlo, hi = nhi;
-          if (ry + 1 < W) {
-            nkey += ni;
-            row_range(ro, ry + 1, nkey, nlo, nhi);
-          } else {
-            nkey += nin1 - ni * (W - 1);
-            row_range(ro + 1, 0, nkey, nlo, nhi);
-          }
-          if (pass) {
-            for (int k = lo; k < hi; k++) {
-              const int j = ghost_order[k];
-              if (in_range(j, xr[j])) note(j);
+      int nlo, nhi;
+      double nsx, nsy, nsz;
+      row_range(0, 0, 0, nlo, nhi, nsx, nsy, nsz);
+      for (int seg = 0; seg < nseg; seg++) {
+        for (int ro = 0; ro < W; ro++) {
+          for (int ry = 0; ry < W; ry++) {
+            const int lo = nlo, hi = nhi;
+            sx = nsx;
+            sy = nsy;
+            sz = nsz;
+            // (the range of the next row, requested one row ahead)
+            if (ry + 1 < W) row_range(seg, ro, ry + 1, nlo, nhi, nsx, nsy, nsz);
+            else if (ro + 1 < W) row_range(seg, ro + 1, 0, nlo, nhi, nsx, nsy, nsz);
+            else row_range(seg + 1, 0, 0, nlo, nhi, nsx, nsy, nsz);
+            // image code of this row's atoms ((ix + 1) + 3 (iy + 1) + 9 (iz + 1), ix = shift / box length)
+            if (near_face)
+              row_code = ((sx < 0.0 ? 0 : sx > 0.0 ? 2 : 1)) + 3 * (sy < 0.0 ? 0 : sy > 0.0 ? 2 : 1) +
+                         9 * (sz < 0.0 ? 0 : sz > 0.0 ? 2 : 1);
+            if (pass) {
+              for (int k = lo; k < hi; k++) {
+                const int j = ghost_order[k];
+                if (in_range(j, xr[j])) note(j);
+              }
+              continue;
             }
-            continue;
-          }
-          // four records per step, loaded unconditionally (a lane whose row is shorter reads its last record again:
-          // plain 16-byte loads instead of a branch around every 8 bytes), tested and entered in order
-          for (int k = lo; k < hi; k += 4) {
-            const int last = hi - 1;
-            const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
-            const double4 x0 = xr[k], x1 = xr[k1], x2 = xr[k2], x3 = xr[k3];
-            if (in_range(k, x0)) note(k);
-            if (k + 1 < hi && in_range(k + 1, x1)) note(k + 1);
-            if (k + 2 < hi && in_range(k + 2, x2)) note(k + 2);
-            if (k + 3 < hi && in_range(k + 3, x3)) note(k + 3);
+            // four records per step, loaded unconditionally (a lane whose row is shorter reads its last record again:
+            // plain 16-byte loads instead of a branch around every 8 bytes), tested and entered in order
+            for (int k = lo; k < hi; k += 4) {
+              const int last = hi - 1;
+              const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
+              const double4 x0 = xr[k], x1 = xr[k1], x2 = xr[k2], x3 = xr[k3];
+              if (in_range(k, x0)) note(k);
+              if (k + 1 < hi && in_range(k + 1, x1)) note(k + 1);
+              if (k + 2 < hi && in_range(k + 2, x2)) note(k + 2);
+              if (k + 3 < hi && in_range(k + 3, x3)) note(k + 3);
+            }
           }
         }
       }
     }
+    sx = sy = sz = 0.0;
     // second sweep, slot by slot: every lane of the wave is at the same row of the slot-major arrays, so the history
     // re-injection reads and the neigh/shear stores are coalesced even when the lanes found their neighbours at
     // different moments of the candidate walk (disordered beds)
@@ -1807,6 +1870,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       if (s + 2 < nacc) wn2 = cand[(size_t)(s + 2) * B.cap + i];
       const int j = w & kIdxMask, fcode = (w >> kIdxBits) & 127;
       found_known = !tf || fcode == kFoundUnknown ? -2 : fcode - 1;
+      code_known = park_codes ? (int)B.nloc[(size_t)s * B.cap + i] : kNoShift;
       accept(j, tf && found_known == -2 ? tag[j] : tj, 0);
     }
     n = n_total;

@@ -761,6 +761,7 @@ static void direct_init(SfLammps& S, HaloComm& hc)
   // ("2" / "slots": ghost slots, must come up; "auto2": ghost slots, or the RCCL exchange when the bring-up fails)
   const bool slots = env && (!strcmp(env, "2") || !strcmp(env, "slots") || !strcmp(env, "auto2"));
   const int want = !env ? 0 : (!strcmp(env, "auto") || !strcmp(env, "auto2") ? -1 : (slots ? 1 : atoi(env)));
+  bool slots_effective = slots;
   const bool self_only = hc.world == 1 && hc.brick && (hc.brick->ext[0] || hc.brick->ext[1] || hc.brick->ext[2]);
   if (want == 0 || (hc.world < 2 && !self_only)) return;
   if (hc.world > 32) {
@@ -784,7 +785,19 @@ static void direct_init(SfLammps& S, HaloComm& hc)
     D.my_sync = static_cast<int*>(alloc_fine_grained(sizeof(int) * DemEngine::kSyncStride * 32));
     hipIpcMemHandle_t h;
     SF_HIP(hipIpcGetMemHandle(&h, D.my_sync));
-    for (int p = 0; p < W; p++) memcpy(D.h_msg + (size_t)p * K + 1, &h, 64);
+    // which device this rank runs on (PCI bus id, hashed): ranks that SHARE a device cannot use the ghost slots -- the gates
+    // of one rank's kernel spin in the wave slots the other rank's kernel needs to finish -- and every rank must know
+    int dev = 0;
+    char bus[64] = {0};
+    long long devid = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, dev) == hipSuccess)
+      for (const char* c = bus; *c; c++) devid = devid * 131 + (unsigned char)*c;
+    devid = (devid & 0x7fffffffffffLL) + 1;   // (> 0: a word a rank did not fill reads as "unknown")
+    for (int p = 0; p < W; p++) {
+      memcpy(D.h_msg + (size_t)p * K + 1, &h, 64);
+      D.h_msg[(size_t)p * K + 10] = devid;
+    }
+    D.h_msg[(size_t)(W + hc.rank) * K + 10] = devid;
   } catch (const std::exception& ex) {
     ok = 0.0;
     why = ex.what();
@@ -812,6 +825,23 @@ static void direct_init(SfLammps& S, HaloComm& hc)
     }
   }
   ok = slab_allreduce(hc, st, ok, ncclMin);
+  // two ranks on one device (every rank holds every rank's word: the same answer everywhere)
+  bool shared_device = false;
+  for (int p = 0; p < W && ok != 0.0; p++)
+    for (int q = p + 1; q < W; q++) {
+      const long long a = D.h_msg[(size_t)(W + p) * K + 10], b = D.h_msg[(size_t)(W + q) * K + 10];
+      if (a > 0 && a == b) shared_device = true;
+    }
+  if (slots && shared_device && !self_only && !(getenv("SF_HALO_SHARED_DEVICE_OK") && atoi(getenv("SF_HALO_SHARED_DEVICE_OK")))) {
+    if (strcmp(env, "auto2") != 0) {
+      delete hc.direct;
+      hc.direct = nullptr;
+      fail("SF_HALO_DIRECT=%s: two ranks share one GPU -- the ghost slots' in-kernel hand-off cannot make progress there "
+           "(use auto2, auto or 1; SF_HALO_SHARED_DEVICE_OK=1 overrides for small test beds)", env);
+    }
+    slots_effective = false;   // auto2: the receive areas (SF_HALO_DIRECT=auto), which ranks sharing a device can run
+    if (getenv("SF_DEBUG_HALO")) fprintf(stderr, "[sedifoam_amd] rank %d: ranks share a GPU, ghost slots -> receive areas\n", hc.rank);
+  }
   if (ok != 0.0) {
     // the first round: vote + flag to every rank, every rank's flag awaited (no records yet)
     DemEngine::BrickBlocks none{};
@@ -833,7 +863,7 @@ static void direct_init(SfLammps& S, HaloComm& hc)
   }
   D.on = true;
   D.must = want == 1;
-  D.mode = slots ? 2 : 1;
+  D.mode = slots_effective ? 2 : 1;
   if (D.mode == 2) {
     GsSync y;
     memset(&y, 0, sizeof(y));
@@ -1047,6 +1077,24 @@ static bool gs_rebuild(SfLammps& S, HaloComm& hc, double4** blk6)
     ok = slab_allreduce(hc, st, ok, ncclMin);
   }
   if (ok == 0.0) return direct_lost(S, hc, why);
+  // a neighbour's arrays grow and are swapped with its scratch arrays: a mapping none of its six current handles refers
+  // to is closed here (every rank is past the second all-reduce: nobody uses it any more) -- an open mapping keeps the
+  // owner's hipFree from releasing the memory, and a long run with particle injection would collect them
+  for (int p = 0; p < W; p++) {
+    if (!nbr[p] || p == hc.rank) continue;
+    const long long* m = D.h_msg + (size_t)(W + p) * K;
+    auto& opened = D.peers[p].opened;
+    for (auto it = opened.begin(); it != opened.end();) {
+      bool used = false;
+      for (int k = 0; k < 6 && !used; k++) used = memcmp(it->first.data(), m + 8 * k, 64) == 0;
+      if (used) {
+        ++it;
+      } else {
+        (void)hipIpcCloseMemHandle(it->second);
+        it = opened.erase(it);
+      }
+    }
+  }
   std::vector<long long> sent(W, 0);
   for (int q = 0; q < DemEngine::kMaxDirs; q++) {
     for (int k = 0; k < 6; k++) blk6[k * DemEngine::kMaxDirs + q] = nullptr;

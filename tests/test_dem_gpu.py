@@ -142,6 +142,29 @@ def test_periodic_hertz_bed():
     assert info.npairs_full == 2 * (orc.npairs - 0) - 0 or info.npairs_full > orc.npairs
 
 
+@pytest.mark.parametrize("ghost_free", ["0", "1"])
+@pytest.mark.parametrize("box", ["xz", "xyz"])
+def test_periodic_images_as_ghost_atoms_and_around_the_box(ghost_free, box, monkeypatch):
+    """The two ways a single-domain rebuild treats periodic images -- ghost atoms per dimension as LAMMPS makes them
+    (SF_GHOST_FREE=0) and the list build that walks its cell stencil around the box (the default since round 6) -- on a
+    bed periodic in x and z (walls in y) and on a fully periodic one, hot enough to rebuild several times: the same
+    pairs, forces, histories as the oracle, the same number of rebuilds, the same count of images."""
+    monkeypatch.setenv("SF_GHOST_FREE", ghost_free)
+    bed = _bed((7, 6, 8), periodic=True, seed=19, vmax=0.5)
+    cfg = dict(BASE, skin=0.05e-3)
+    walls = None
+    if box == "xyz":
+        bed["boxhi"][1] = 6 * bed["edge"]
+        bed["x"][:, 1] %= bed["boxhi"][1]
+        bed["periodic"] = (1, 1, 1)
+        cfg["g"] = 0.0
+        walls = []
+    lmp, orc = _run_case(bed, cfg, steps=(1, 60), walls=walls)
+    info = lmp.info()
+    assert info.nbuilds >= 3 and info.nbuilds == orc.nbuilds
+    assert info.nghost > 0 and info.nghost == orc.nghost
+
+
 def test_periodic_hooke_bed():
     cfg = dict(BASE, pair="hooke", kn=2.0e3, gamman=50.0, dampflag=1)
     bed = _bed((6, 5, 6), periodic=True, seed=4)

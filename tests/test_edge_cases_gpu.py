@@ -78,11 +78,16 @@ def test_neighbor_slots_grow_on_overflow():
     assert lmp.info().nbuilds >= 2
 
 
-def test_ghosts_outgrow_the_capacity_of_a_narrow_periodic_column():
+@pytest.mark.parametrize("ghost_free", [False, True])
+def test_ghosts_outgrow_the_capacity_of_a_narrow_periodic_column(ghost_free, monkeypatch):
     """A tall column 3 lattice cells (4.2 d) wide, periodic in x and z: every grain has 1.5 periodic images on average
     (those of the x faces, then the z images of grains AND of x images), which is more than the slack the per-atom
     arrays are created with.  The ghost kernels keep their counts on the device and create nothing once the capacity
-    would be exceeded; the host grows the arrays and repeats (DemEngine::make_periodic_ghosts)."""
+    would be exceeded; the host grows the arrays and repeats (DemEngine::make_periodic_ghosts).
+    ghost_free: the same column through the list build that walks its stencil around the box instead of making ghost
+    atoms (round 6, the default of a single-domain run): 3.37 cutoffs per periodic length, the narrowest box it takes --
+    every atom's stencil reaches around the box in x AND z; the images LAMMPS would have made are still counted."""
+    monkeypatch.setenv("SF_GHOST_FREE", "1" if ghost_free else "0")
     bed = T._bed((3, 600, 3), periodic=True, seed=3, vmax=0.1)
     assert bed["n"] == 21600
     cfg = dict(T.BASE, walls=T._walls(bed))
@@ -91,7 +96,8 @@ def test_ghosts_outgrow_the_capacity_of_a_narrow_periodic_column():
     orc = dc.make_oracle(bed, cfg)
     lmp.setup(); orc.setup()
     info = lmp.info()
-    assert info.nghost == orc.nghost and info.nlocal + info.nghost > cap0 and info.capacity > cap0
+    assert info.nghost == orc.nghost and info.nlocal + info.nghost > cap0
+    assert (info.capacity == cap0) if ghost_free else (info.capacity > cap0)
     T._compare(lmp, orc, tol_f=5e-12)
     lmp.step(5); orc.run(5)
     T._compare(lmp, orc, tol_f=5e-12)

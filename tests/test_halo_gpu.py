@@ -285,12 +285,15 @@ def test_cxx_brick_driver_on_a_processor_grid(tmp_path, monkeypatch, grid, ncell
     direct = "1": the forward halo by DIRECT GHOST WRITES (SF_HALO_DIRECT=1: required to come up) -- every rank's sub-step
     kernel writes its border records through IPC mappings into the receive areas of the neighbours' processes, one kernel
     per exchange publishes / awaits the per-rank flags and votes; "0": one grouped send / receive per sub-step over the
-    wire; "2": GHOST SLOTS (SF_HALO_DIRECT=2) -- the border records go straight into the neighbours' ghost records (two
-    fine-grained areas the sub-step kernel gathers from), the last workgroup of a sub-step kernel publishes the vote and
+    wire; "2": GHOST SLOTS (SF_HALO_DIRECT=2) -- the border records go straight into the ghost range of the neighbours'
+    own record arrays (IPC mappings of xr / vm / om, written with write-through stores), the last workgroup of a sub-step kernel publishes the vote and
     the flag, the next sub-step kernel waits for the flags at its gate: no kernel between two sub-step kernels.  All three
     must reproduce the single-domain run."""
     import torch.multiprocessing as mp
     monkeypatch.setenv("SF_HALO_DIRECT", direct)
+    # (the ranks of this test share the box's one GPU: at these sizes every rank's kernel fits next to the others and the
+    # in-kernel hand-off makes progress; the library refuses ghost slots on a shared device unless told so)
+    monkeypatch.setenv("SF_HALO_SHARED_DEVICE_OK", "1")
     monkeypatch.setenv("SF_HALO_DIRECT_TIMEOUT", os.environ.get("SF_TEST_TIMEOUT", "120"))   # (ranks sharing one GPU wait for each other's time slices)
     world = grid[0] * grid[1] * grid[2]
     if world == 1:
