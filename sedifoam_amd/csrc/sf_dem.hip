@@ -146,6 +146,17 @@ DemEngine::~DemEngine()
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (DevArray* a : per_atom_) a->release();
   if (d_blkptr_) (void)hipFree(d_blkptr_);
+#ifdef SF_EXP_BUILD_PHASE
+  {
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_build_phase), sizeof(h)) == hipSuccess && (h[0] | h[1] | h[3])) {
+      const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+      fprintf(stderr, "[sedifoam_amd] k_build_neigh wave cycles by phase (%d builds): prologue %.3f  walk %.3f  touch-first pass "
+              "%.3f  second sweep %.3f  counts %.3f  (sum %.3e cycles)\n", (int)nbuilds_, h[0] / tot, h[1] / tot, h[2] / tot,
+              h[3] / tot, h[4] / tot, tot);
+    }
+  }
+#endif
   if (d_xcd_time_) (void)hipFree(d_xcd_time_);
   if (d_pq_head_) (void)hipFree(d_pq_head_);
   if (h_xcd_time_) (void)hipHostFree(h_xcd_time_);

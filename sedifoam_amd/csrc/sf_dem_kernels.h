@@ -1052,26 +1052,41 @@ __global__ __launch_bounds__(256) void k_partner_tags(const int* neigh, const in
     }
     nmax = min(nmax, M);
   }
-  for (int s = 0; s < nmax; s++) {
-    int t = -1;
-    if (s < nn) {
-      const int jraw = neigh[(size_t)s * cap + i];
-      if (jraw & kTouchBit) {
-        const int j = neigh_index(jraw, roots);
-        t = tag[j];
-        size_t src = (size_t)(3 * s) * cap + i;
-        double sign = 1.0;
-        if (!(jraw & kOwnBit)) {
-          src = (size_t)(3 * ((jraw >> kIdxBits) & 31)) * cap + j;   // (partner sides exist in root mode only)
-          sign = -1.0;
-        }
-        const size_t dst = (size_t)(3 * s) * cap + i;
-        hist_out[dst] = sign * shear[src];
-        hist_out[dst + cap] = sign * shear[src + cap];
-        hist_out[dst + 2 * cap] = sign * shear[src + 2 * cap];
+  // four slots at a time, their loads issued together: the words, then the partner tags and the histories of those that
+  // touch, then the stores (one slot after the other the walk is a chain of ~14 dependent round trips: 20 us at 100 k grains)
+  constexpr int kU = 4;
+  for (int s0 = 0; s0 < nmax; s0 += kU) {
+    int jraw[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) jraw[u] = s0 + u < nn ? neigh[(size_t)(s0 + u) * cap + i] : 0;
+    int t[kU];
+    double hx[kU], hy[kU], hz[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      t[u] = -1;
+      hx[u] = hy[u] = hz[u] = 0.0;
+      if (jraw[u] & kTouchBit) {   // (a word beyond the row is 0: no bit)
+        const int j = neigh_index(jraw[u], roots);
+        t[u] = tag[j];
+        size_t src = (size_t)(3 * (s0 + u)) * cap + i;
+        if (!(jraw[u] & kOwnBit)) src = (size_t)(3 * ((jraw[u] >> kIdxBits) & 31)) * cap + j;   // (partner sides: root mode only)
+        hx[u] = shear[src];
+        hy[u] = shear[src + cap];
+        hz[u] = shear[src + 2 * cap];
       }
     }
-    if (s < nn) ptag[(size_t)s * cap + i] = t;
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (s0 + u >= nn) continue;
+      if (jraw[u] & kTouchBit) {
+        const double sign = (jraw[u] & kOwnBit) ? 1.0 : -1.0;
+        const size_t dst = (size_t)(3 * (s0 + u)) * cap + i;
+        hist_out[dst] = sign * hx[u];
+        hist_out[dst + cap] = sign * hy[u];
+        hist_out[dst + 2 * cap] = sign * hz[u];
+      }
+      ptag[(size_t)(s0 + u) * cap + i] = t[u];
+    }
   }
 }
 
@@ -1598,6 +1613,19 @@ __global__ __launch_bounds__(256) void k_key_rank_dev(const unsigned* keys, cons
 
 // [3P] Neighbor::build (granular criterion rsq <= (ri+rj+skin)^2) as a FULL list, with the shear
 // history re-injected by partner tag (FixShearHistory)
+// variant builds (tests/build_variant.sh bph -DSF_EXP_BUILD_PHASE=1): cycles the waves of k_build_neigh spend in each phase,
+// summed over all launches, printed when the engine goes (SF_EXP_BUILD_PHASE in sf_dem.hip)
+#ifdef SF_EXP_BUILD_PHASE
+__device__ unsigned long long g_build_phase[8];
+#define SF_BP(k)                                                                          \
+  do {                                                                                    \
+    const unsigned long long t_ = __builtin_readcyclecounter();                           \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_build_phase[(k)], t_ - bp_t_);              \
+    bp_t_ = __builtin_readcyclecounter();                                                 \
+  } while (0)
+#else
+#define SF_BP(k)
+#endif
 __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double4* xr, const int* tag,
                                                      const int* cellLS, const int* cellLE,
                                                      const int* cellGS, const int* cellGE,
@@ -1609,6 +1637,9 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   // (every candidate record is read by the ~35 atoms around it: neighbouring blocks on the same XCD share them in L2)
   const int i = xcd_contiguous_block() * blockDim.x + threadIdx.x;
   if (i >= B.nlocal) return;
+#ifdef SF_EXP_BUILD_PHASE
+  unsigned long long bp_t_ = __builtin_readcyclecounter();
+#endif
   const double4 xi = xr[i];
   // [3P] Neighbor::build: the positions the skin/2 displacement check (Neighbor::check_distance) refers to
   xhold[i] = xi.x;
@@ -1713,6 +1744,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
   auto candidate = [&](const int j, const int pos) {
     if (in_range(j, xr[j])) accept(j, tag[j], pos);
   };
+  SF_BP(0);   // prologue: own record, cell, the old partner tags
   int n_total = 0;   // row path: accepted candidates of the first sweep (may exceed the slots: overflow report)
   // Row path, first sweep: an accepted candidate is parked in the scratch rows `cand`, in candidate order; the old-list
   // look-up (tag gather + comparison with the partner tags held in registers) waits for the second sweep, where every
@@ -1825,6 +1857,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       }
     }
     sx = sy = sz = 0.0;
+    SF_BP(1);   // candidate walk
     // second sweep, slot by slot: every lane of the wave is at the same row of the slot-major arrays, so the history
     // re-injection reads and the neigh/shear stores are coalesced even when the lanes found their neighbours at
     // different moments of the candidate walk (disordered beds)
@@ -1858,6 +1891,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       slot_touch = 0;
       slot_free = nt;
     }
+    SF_BP(2);   // touch-first look-up pass
     n = 0;
     // the candidate word two slots ahead, its tag one slot ahead: neither load waits for the other inside an iteration
     int wn = nacc > 0 ? cand[i] : 0;
@@ -1874,6 +1908,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
       accept(j, tf && found_known == -2 ? tag[j] : tj, 0);
     }
     n = n_total;
+    SF_BP(3);   // second sweep: history re-injection, list and history stores
   } else {
     const int4* cells = reinterpret_cast<const int4*>(cellLS);   // {owned start, end, ghost start, end} per cell
     for (int bo = co - R; bo <= co + R; bo++) {
@@ -1907,6 +1942,7 @@ __global__ __launch_bounds__(128) void k_build_neigh(BuildParams B, const double
     if ((act >> (lane ^ off)) & 1ull) m = max(m, o);
   }
   if (lane == __ffsll((long long)act) - 1) atomicMax(&flags[F_MAXNEIGH], m);
+  SF_BP(4);   // counts
 }
 
 // ---- LDS staging tables: which atoms a tile's workgroup copies into LDS, bin by bin ----

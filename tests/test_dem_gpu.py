@@ -159,7 +159,7 @@ def test_periodic_images_as_ghost_atoms_and_around_the_box(ghost_free, box, monk
         bed["periodic"] = (1, 1, 1)
         cfg["g"] = 0.0
         walls = []
-    lmp, orc = _run_case(bed, cfg, steps=(1, 60), walls=walls)
+    lmp, orc = _run_case(bed, cfg, steps=(1, 150), walls=walls, tol_f=5e-12)   # (g = 0: the forces are a few mN, measured 2e-12)
     info = lmp.info()
     assert info.nbuilds >= 3 and info.nbuilds == orc.nbuilds
     assert info.nghost > 0 and info.nghost == orc.nghost
