@@ -158,6 +158,7 @@ def test_periodic_images_as_ghost_atoms_and_around_the_box(ghost_free, box, monk
         bed["x"][:, 1] %= bed["boxhi"][1]
         bed["periodic"] = (1, 1, 1)
         cfg["g"] = 0.0
+        cfg["skin"] = 0.02e-3   # (no walls to run into: the grains only move skin / 2 often enough against a thinner skin)
         walls = []
     lmp, orc = _run_case(bed, cfg, steps=(1, 150), walls=walls, tol_f=5e-12)   # (g = 0: the forces are a few mN, measured 2e-12)
     info = lmp.info()
