@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_SUMMARIES = ("r05_pmc_summary.json", "r04_pmc_summary.json")   # committed PMC passes, newest first (tests/profile_round.sh)
+PMC_SUMMARIES = ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json")   # committed PMC passes, newest first (tests/profile_round.sh)
 
 
 def build_engine(bed, script):
@@ -262,6 +262,7 @@ def cpu_baseline_all_cores(npart, sub):
 C5_LUB = (1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)        # pair lubricate/poly mu flaglog flagfld cut_inner cut_global flagHI flagVF
 C5_COHESIVE = (1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1)     # fix cohesive ah lam smin smax opt
 C5W_LUB = (1.0e-3, 1, 0, 1.001 * 1.5e-3, 1.1 * 1.5e-3, 1, 1)   # flagfld 0, cutoffs in units of the largest pair
+C5W_SUBSTEPS = 10   # sub-steps per step of configs.C5_wide (1 warm-up + K timed steps: 40 sub-steps in all by default)
 C5W_COHESIVE = (1.0e-20, 1.0e-7, 1.0e-9, 1.0e-4, 1)           # ah 1e-20, smin 1e-9, smax 0.1 d
 
 
@@ -306,8 +307,11 @@ def config_cases(synthetic):
                cohesive=C5W_COHESIVE, lub=C5W_LUB)
     out["C5_wide"] = (bed, cfg, None, "%d polydisperse grains d ~ U(0.5, 1.5) mm (SURVEY.md 8d), dense disordered periodic bed "
                                       "(solid fraction 0.58, grown), pair hybrid/overlay gran/hertzFix/history + lubricate/poly "
-                                      "1e-3 1 0 1.5015e-3 1.65e-3, fix cohesive 1e-20 1e-7 1e-9 1e-4 1, 50 DEM sub-steps per "
-                                      "step" % bed["n"])
+                                      "1e-3 1 0 1.5015e-3 1.65e-3, fix cohesive 1e-20 1e-7 1e-9 1e-4 1, %d DEM sub-steps per "
+                                      "step (the reference's log series with its h_sep = 100 (ri + rj) edit is anti-damped at "
+                                      "this size ratio: oracle and HIP alike multiply the velocities by ~100 per 50 sub-steps, "
+                                      "profiles/r06_README.md section 4 -- the timed region ends before the bed flies apart)"
+                                      % (bed["n"], C5W_SUBSTEPS))
     return out
 
 
@@ -979,10 +983,17 @@ def main():
                 clmp = build_engine(cbed, config_script(cbed, ccfg))
                 args.steps, args.warmup = {"C2": (keep[0], 2), "C3": (max(2, keep[0] // 2), 1), "C5": (max(2, keep[0] // 3), 1),
                                             "C5_wide": (max(2, keep[0] // 3), 1)}[name]
-                el_c, n_c, l_c, k_c, i_c, i_c1 = timed_run(clmp)
+                sub_keep = args.substeps
+                if name == "C5_wide":
+                    args.substeps = C5W_SUBSTEPS
+                try:
+                    el_c, n_c, l_c, k_c, i_c, i_c1 = timed_run(clmp)
+                    sub_c = args.substeps
+                finally:
+                    args.substeps = sub_keep
                 kh_c = i_c1.npairs_full / 2.0 / max(i_c1.nlocal, 1)
-                o = {"workload": label, "value": n_c * args.substeps * args.steps / el_c, "unit": "particle-substeps/s",
-                     "ms_per_step": 1e3 * el_c / args.steps, "steps": args.steps, "warmup": args.warmup,
+                o = {"workload": label, "value": n_c * sub_c * args.steps / el_c, "unit": "particle-substeps/s",
+                     "ms_per_step": 1e3 * el_c / args.steps, "steps": args.steps, "warmup": args.warmup, "substeps": sub_c,
                      "particles": int(n_c), "k_half": round(kh_c, 3), "longest_row": int(i_c1.max_neigh_used),
                      "neighbor_rebuilds_in_run": int(i_c1.nbuilds - i_c.nbuilds),
                      "algorithmic_bytes_per_particle_substep": 284.0 + 52.0 * kh_c}

@@ -76,6 +76,7 @@ enum Flag {
   F_HALO_TIMEOUT,   // direct ghost writes: a peer's "exchange done" flag did not arrive in time (an error, never a hang)
   F_HALO_TIMEOUT_PEER,   // ... which rank's ...
   F_HALO_TIMEOUT_SEEN,   // ... and the value its flag had (adjacent words: brick_direct_probe clears the three together)
+  F_PARK_OVER,      // list build: most accepted candidates of an atom when they did not fit the parking rows in LDS (BuildParams::P)
   F_NFLAGS = 32
 };
 
@@ -693,6 +694,11 @@ private:
   DevArray gsrc_, gshift_;
   DevArray neigh_, numneigh_, shear_[2];
   DevArray neigh_old_, numneigh_old_, ptag_;   // B-side buffers swapped in by permute/build
+  bool build_flags_clean_ = false;   // the list build's counters were zeroed by k_pbc_keys of this rebuild
+  bool trigger_rearmed_ = false;     // F_TRIGGER was set back to INT_MAX by k_back_slots of this rebuild
+  int park_rows_ = 0;                // LDS parking rows of the next list build (0: as many as list slots)
+  bool hist_in_place_ = false;   // this rebuild's list build reads the old list in place (compute_partner_tags)
+  bool build_parks_in_lds() const;
   // During a rebuild shear_[hist_buf_] holds the OLD list's history expanded to a copy per side (what partner tags
   // address: migration, re-injection); the new list's history is built into the other buffer, which then becomes
   // shear_[cur_]

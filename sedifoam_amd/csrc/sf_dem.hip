@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "sf_dem_kernels.h"
+#include "sf_dem_rebuild.h"
+#include "sf_dem_io.h"
 #include "sf_dem_lds_kernel.h"
 #include "sf_roctx.h"
 
@@ -150,10 +152,10 @@ DemEngine::~DemEngine()
   {
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_build_phase), sizeof(h)) == hipSuccess && (h[0] | h[1] | h[3])) {
-      const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
-      fprintf(stderr, "[sedifoam_amd] k_build_neigh wave cycles by phase (%d builds): prologue %.3f  walk %.3f  touch-first pass "
-              "%.3f  second sweep %.3f  counts %.3f  (sum %.3e cycles)\n", (int)nbuilds_, h[0] / tot, h[1] / tot, h[2] / tot,
-              h[3] / tot, h[4] / tot, tot);
+      const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]);
+      fprintf(stderr, "[sedifoam_amd] k_build_neigh wave cycles by phase (%d builds): prologue %.3f  walk %.3f  old tags %.3f  "
+              "touch-first pass %.3f  second sweep %.3f  counts %.3f  (sum %.3e cycles)\n", (int)nbuilds_, h[0] / tot, h[1] / tot,
+              h[5] / tot, h[2] / tot, h[3] / tot, h[4] / tot, tot);
     }
   }
 #endif
@@ -1266,11 +1268,32 @@ void DemEngine::compute_grid()
   }
 }
 
+// k_build_neigh<true>: [M][128] parked words + [M][128] image-code bytes of dynamic LDS per block (160 KB per CU)
+static constexpr size_t kBuildLdsPerSlot = 128 * 5;
+static constexpr size_t kBuildLdsMax = 160 * 1024;
+
+bool DemEngine::build_parks_in_lds() const
+{
+  static const bool env = !(getenv("SF_BUILD_LDS") && !atoi(getenv("SF_BUILD_LDS")));
+  return env && (size_t)M_ * kBuildLdsPerSlot <= kBuildLdsMax / 2;
+}
+
 void DemEngine::compute_partner_tags()
 {
   // the old list's history by partner tag, a copy per SIDE of every contact, in the ping-pong buffer the sub-steps
   // are not using: what migration packs and what the list build re-injects
   hist_buf_ = cur_ ^ 1;
+  // Single domain, row path, parked candidates in LDS: the list build reads the old list IN PLACE (its words, the tags in
+  // the order they index, the current history buffer) and writes the new words into the other word array -- no staging
+  // pass (98 of a 1 M-grain loose bed's 774 us per rebuild, 15 of a 100 k bed's 210).  The staged rows remain what
+  // migration packs (decomposed domains) and what the tiled / LDS-staged builds read.
+  static const bool in_place_env = !(getenv("SF_HIST_IN_PLACE") && !atoi(getenv("SF_HIST_IN_PLACE")));
+  hist_in_place_ = in_place_env && build_parks_in_lds() && !have_subdomain_ && roots_ && grid_.tile <= 1 && !opt_lds_ &&
+                   have_list_ && nlocal_ > 0 && max_neigh_used_ > 0;
+  if (hist_in_place_) {
+    hist_buf_ = cur_;   // (k_build_neigh reads shear_[hist_buf_] and writes shear_[hist_buf_ ^ 1])
+    return;
+  }
   if (have_list_ && nlocal_ && max_neigh_used_ > 0)
     k_partner_tags<<<div_up(nlocal_, 256), 256, 0, stream_>>>(
         neigh_.as<int>(), numneigh_.as<int>(), tag_.as<int>(), ptag_.as<int>(), shear_[cur_].as<double>(),
@@ -1395,6 +1418,7 @@ void DemEngine::rebuild_sort()
   hist_clean_ = false;   // (until the kernels below have run: an error in between leaves it dirty)
   k_pbc_keys<<<nb, 256, 0, stream_>>>(xr_[cur_].as<double4>(), nlocal_, pb, grid_, keys_.as<unsigned>(),
                                       perm_.as<int>(), d_flags_, count);
+  build_flags_clean_ = true;   // (F_NEIGH_OVER, F_MAXNEIGH zeroed by that kernel: the first list build needs no reset launch)
   if (row_tables_) {
     const int ne = grid_.nbins + 1;
     int* first = cell_start_ + cell_alloc_;
@@ -1598,8 +1622,10 @@ void DemEngine::bin_and_build()
         keys64_alt_.as<unsigned long long>(), nghost_, 32, cellGS, cellGE, 4);
   }
   build_stage_tables();
-  for (int attempt = 0; attempt < 3; attempt++) {
-    set_flags3(F_NEIGH_OVER, 0, F_MAXNEIGH, 0, F_MAXNEIGH, 0);   // (two flags: the third pair repeats the second)
+  for (int attempt = 0; attempt < 4; attempt++) {
+    if (build_flags_clean_) h_flags_[F_NEIGH_OVER] = h_flags_[F_MAXNEIGH] = 0;
+    else set_flags3(F_NEIGH_OVER, 0, F_MAXNEIGH, 0, F_PARK_OVER, 0);
+    build_flags_clean_ = false;
     BuildParams B;
     B.nlocal = nlocal_;
     B.M = M_;
@@ -1618,6 +1644,26 @@ void DemEngine::bin_and_build()
     B.touch_first = touch_first_ ? 1 : 0;
     B.lb_own = row_tables_ ? cell_start_ + cell_alloc_ : nullptr;
     B.lb_ghost = (row_tables_ && nghost_) ? cell_start_ + 3 * cell_alloc_ : nullptr;   // (nghost_ < 0: on the device)
+    // parked candidates in LDS (row path): as long as the rows fit; a list read in place needs them there (the scratch
+    // rows of the other form ARE the word array the new list goes into)
+    const bool lc = row_tables_ && (hist_in_place_ || build_parks_in_lds());
+    // (parking rows: the longest row of the previous list + 8 -- a fifth of the LDS of a compute unit per block otherwise,
+    // at four waves per SIMD; an atom with more candidates than that reports F_PARK_OVER and the list is built again)
+    if (park_rows_ <= 0 || park_rows_ > M_ || attempt > 0) park_rows_ = M_;
+    B.P = park_rows_;
+    const size_t lds_bytes = lc ? (size_t)park_rows_ * kBuildLdsPerSlot : 0;
+    if (lds_bytes > kBuildLdsMax)
+      fail("neighbor list rows of more than %d slots do not fit the list build's LDS rows (SF_HIST_IN_PLACE=0 SF_BUILD_LDS=0 "
+           "builds such lists through memory)", (int)(kBuildLdsMax / kBuildLdsPerSlot));
+    static bool lds_attr_set = false;
+    if (lc && !lds_attr_set) {
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
+      lds_attr_set = true;
+    }
+    B.old_words = hist_in_place_ ? neigh_.as<int>() : nullptr;
+    B.old_tag = hist_in_place_ ? tmpi_.as<int>() : nullptr;   // (permute_locals swapped the old tag array out into tmpi_)
+    int* const new_words = hist_in_place_ ? neigh_old_.as<int>() : neigh_.as<int>();
     B.roots = roots_ ? 1 : 0;
     B.gsrc = gsrc_.as<int>();
     B.gshift = gshift_.as<double>();
@@ -1626,17 +1672,29 @@ void DemEngine::bin_and_build()
       B.prd[k] = boxhi_[k] - boxlo_[k];
     }
     if (roots_ && cap_ > (size_t)kIdxMask) fail("more than %d atom slots per GPU: not addressable by the neighbour word", kIdxMask);
-    k_build_neigh<<<div_up(nlocal_, 128), 128, 0, stream_>>>(
-        B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
-        have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), neigh_.as<int>(),
-        numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
+    if (lc)
+      k_build_neigh<true><<<div_up(nlocal_, 128), 128, lds_bytes, stream_>>>(
+          B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
+          have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), new_words,
+          numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, nullptr, xhold_.as<double>());
+    else if (!row_tables_)
+      k_build_neigh<false, false><<<div_up(nlocal_, 128), 128, 0, stream_>>>(
+          B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
+          have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), new_words,
+          numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
+    else
+      k_build_neigh<false><<<div_up(nlocal_, 128), 128, 0, stream_>>>(
+          B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
+          have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), new_words,
+          numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
     // the host looks at the counts (overflow, widest row) while the partner-slot pass below is already running: it
     // needs nothing but the list, and a list that overflowed -- rare -- is built again and the pass repeated
     SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
     SF_HIP(hipEventRecord(ev_flags_, stream_));
     // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
-    k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(neigh_.as<int>(), numneigh_old_.as<int>(), nlocal_, cap_,
-                                                            roots_ ? 1 : 0);
+    k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(new_words, numneigh_old_.as<int>(), nlocal_, cap_,
+                                                            roots_ ? 1 : 0, d_flags_);
+    trigger_rearmed_ = true;
     SF_HIP(hipEventSynchronize(ev_flags_));
     if (ghosts_pending && nghost_ < 0) {
       // the ghost count arrives with these flags.  More ghosts than the capacity held: nothing above saw a ghost -- grow,
@@ -1657,6 +1715,7 @@ void DemEngine::bin_and_build()
       grow_neigh(h_flags_[F_NEIGH_OVER] + 4);
       continue;
     }
+    if (lc && h_flags_[F_PARK_OVER] > park_rows_) continue;   // (again, with as many parking rows as list slots)
     break;
   }
   if (h_flags_[F_NEIGH_OVER] > M_) fail("neighbor list overflow (%d > %d slots)", h_flags_[F_NEIGH_OVER], M_);
@@ -1665,6 +1724,8 @@ void DemEngine::bin_and_build()
     fail("Lost atoms: an atom left the (non-periodic) simulation box");  // thermo_modify lost error
   }
   std::swap(numneigh_, numneigh_old_);
+  if (hist_in_place_) std::swap(neigh_.ptr, neigh_old_.ptr);   // (the new words went into the other array)
+  hist_in_place_ = false;
   // the new list's history was built into shear_[hist_buf_ ^ 1]: that buffer is the one the next sub-step reads
   if ((hist_buf_ ^ 1) != cur_) std::swap(shear_[0].ptr, shear_[1].ptr);
   hist_indirect_ = false;   // the old rows are gone with the old list
@@ -1675,6 +1736,7 @@ void DemEngine::bin_and_build()
   // every fourth one, which only refreshes numbers no decision is near; the counters keep their values in between)
   if (nbuilds_ < 4 || (nbuilds_ & 3) == 0 || list_stats_near_a_threshold()) measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
+  park_rows_ = std::min(M_, max_neigh_used_ + 8);
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
   nbuilds_++;
   if (xcd_auto_ && xcd_countdown_ == 0) xcd_countdown_ = 3;   // the third full launch on the new list is timed per XCD
@@ -1779,9 +1841,11 @@ void DemEngine::choose_kernel()
 void DemEngine::rebuild_finish()
 {
   make_periodic_ghosts();
+  trigger_rearmed_ = false;
   bin_and_build();
   if (overlap_) mark_boundary();
-  reset_flag(F_TRIGGER, INT_MAX);
+  if (trigger_rearmed_) h_flags_[F_TRIGGER] = INT_MAX;   // (by k_back_slots, the last kernel of the list build)
+  else reset_flag(F_TRIGGER, INT_MAX);
 }
 
 void DemEngine::rebuild()

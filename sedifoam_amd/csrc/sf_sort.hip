@@ -135,6 +135,66 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const int* in, int 
     }
   }
 }
+
+// a small table (the cell histogram of a bed of ~100 k grains): ONE workgroup, one launch -- the rebuild chain of a small bed
+// is bound by the launches it takes (rocPRIM's scan is two).  Tiles of 16 k entries, four coalesced int4 loads per thread in
+// flight at once (a tile is one round trip + one block scan: ~1 us).
+constexpr int kOneBlockMax = 1 << 14;   // (one tile: ~4 us; four tiles measured 16.6 us against the 9.3 us of rocPRIM's two launches)
+__global__ __launch_bounds__(1024) void k_scan_one_block(const int* in, int n, int* out)
+{
+  __shared__ int wsum[2][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int kQ = 4, kTile = 1024 * 4 * kQ;
+  int carry = 0;
+  for (int base = 0, it = 0; base < n; base += kTile, it++) {
+    int4 v[kQ];
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < kQ; q++) {
+      // (thread t holds entries [16 t, 16 t + 16) of the tile: four int4, consecutive)
+      const int k = base + 4 * (kQ * (int)threadIdx.x + q);
+      v[q] = make_int4(0, 0, 0, 0);
+      if (k + 3 < n) v[q] = *reinterpret_cast<const int4*>(in + k);   // (the tables are 16-byte aligned: exclusive_scan_i32)
+      else {
+        if (k < n) v[q].x = in[k];
+        if (k + 1 < n) v[q].y = in[k + 1];
+        if (k + 2 < n) v[q].z = in[k + 2];
+      }
+      t += v[q].x + v[q].y + v[q].z + v[q].w;
+    }
+    int incl = t;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int a = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += a;
+    }
+    int* ws = wsum[it & 1];   // (two sets: a fast wave may be a tile ahead of a slow one's reads)
+    if (lane == 63) ws[w] = incl;
+    __syncthreads();
+    int run = carry + incl - t, total = 0;
+    for (int k = 0; k < 16; k++) {
+      const int q = ws[k];
+      if (k < w) run += q;
+      total += q;
+    }
+    carry += total;
+#pragma unroll
+    for (int q = 0; q < kQ; q++) {
+      const int k = base + 4 * (kQ * (int)threadIdx.x + q);
+      int4 o;
+      o.x = run;
+      o.y = o.x + v[q].x;
+      o.z = o.y + v[q].y;
+      o.w = o.z + v[q].z;
+      run = o.w + v[q].w;
+      if (k + 3 < n) *reinterpret_cast<int4*>(out + k) = o;
+      else {
+        if (k < n) out[k] = o.x;
+        if (k + 1 < n) out[k + 1] = o.y;
+        if (k + 2 < n) out[k + 2] = o.z;
+      }
+    }
+  }
+}
 }  // namespace
 
 void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, int n, hipStream_t s)
@@ -143,6 +203,12 @@ void exclusive_scan_i32(void*& tmp, size_t& tmp_bytes, const int* in, int* out, 
   // (read per call -- a rebuild-time function: the tests switch them inside one process)
   const bool own_scan = !(getenv("SF_ROCPRIM_SCAN") && atoi(getenv("SF_ROCPRIM_SCAN")));
   const int own_min = getenv("SF_SCAN_MIN") ? atoi(getenv("SF_SCAN_MIN")) : (1 << 16);   // (tests: 1)
+  if (own_scan && n <= kOneBlockMax && in != out && !getenv("SF_SCAN_MIN") && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {   // (SF_SCAN_MIN: the tests force the tiled scan)
+    k_scan_one_block<<<1, 1024, 0, s>>>(in, n, out);
+    SF_HIP(hipGetLastError());
+    return;
+  }
   if (own_scan && n >= own_min && in != out && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     const int nb = (n + kScanTile - 1) / kScanTile;
