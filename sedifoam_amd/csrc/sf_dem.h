@@ -77,6 +77,7 @@ enum Flag {
   F_HALO_TIMEOUT_PEER,   // ... which rank's ...
   F_HALO_TIMEOUT_SEEN,   // ... and the value its flag had (adjacent words: brick_direct_probe clears the three together)
   F_PARK_OVER,      // list build: most accepted candidates of an atom when they did not fit the parking rows in LDS (BuildParams::P)
+  F_ARRIVAL = 31,   // host side only: "the copy of this block has landed" (DemEngine::flags_copy_wait); never written on the device
   F_NFLAGS = 32
 };
 
@@ -604,6 +605,8 @@ private:
   void read_flags();
   void reset_flag(int idx, int value);
   void reset_flags(int idx, int count, int value);   // `count` adjacent flags, one launch
+  void flags_copy_begin();   // flag words -> pinned host block, asynchronously ...
+  void flags_copy_wait();    // ... and the host waits for that copy (not for the stream)
   void set_flags3(int i0, int v0, int i1, int v1, int i2, int v2);   // three (flag, value) pairs, one launch
   void compute_grid();
   double max_radius();

@@ -5,6 +5,7 @@
 #include "sf_dem.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -690,10 +691,41 @@ void DemEngine::set_flags3(int i0, int v0, int i1, int v1, int i2, int v2)
   k_set_flags3<<<1, 32, 0, stream_>>>(d_flags_, i0, v0, i1, v1, i2, v2);
 }
 
+// The flag words travel to pinned host memory by an asynchronous copy; the host does not wait for the STREAM (a
+// hipStreamSynchronize returns ~10 us after the copy has landed: a fifth of a 100 k-grain rebuild, paid two or three times
+// per rebuild) but for the copy itself: the last word of the pinned block holds a sentinel no device word ever equals until
+// the copy overwrites it (the copy is one 128-byte write; the words before the last arrive with it or before it).  Bounded:
+// after 20 ms without the word the stream is synchronised the ordinary way.  SF_FLAG_SPIN=0: always the ordinary way.
+static constexpr int kArrivalSentinel = 0x5EED1234;
+
+void DemEngine::flags_copy_begin()
+{
+  static_assert(F_ARRIVAL == F_NFLAGS - 1, "the arrival word is the last of the block");
+  volatile int* hf = h_flags_;
+  hf[F_ARRIVAL] = kArrivalSentinel;
+  SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
+}
+
+void DemEngine::flags_copy_wait()
+{
+  static const bool spin = !(getenv("SF_FLAG_SPIN") && !atoi(getenv("SF_FLAG_SPIN")));
+  volatile int* hf = h_flags_;
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0; hf[F_ARRIVAL] == kArrivalSentinel; it++) {
+      if ((it & 1023u) == 1023u &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+        break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (hf[F_ARRIVAL] == kArrivalSentinel) sync();
+}
+
 void DemEngine::read_flags()
 {
-  SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
-  sync();
+  flags_copy_begin();
+  flags_copy_wait();
   if (xcd_sample_pending_) apply_xcd_sample();
 }
 
@@ -1689,13 +1721,12 @@ void DemEngine::bin_and_build()
           numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_, neigh_old_.as<int>(), xhold_.as<double>());
     // the host looks at the counts (overflow, widest row) while the partner-slot pass below is already running: it
     // needs nothing but the list, and a list that overflowed -- rare -- is built again and the pass repeated
-    SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
-    SF_HIP(hipEventRecord(ev_flags_, stream_));
+    flags_copy_begin();
     // partner slots: where does the owner keep this pair?  (a partner whose owner does not list it back owns the pair)
     k_back_slots<<<div_up(nlocal_, 128), 128, 0, stream_>>>(new_words, numneigh_old_.as<int>(), nlocal_, cap_,
                                                             roots_ ? 1 : 0, d_flags_);
     trigger_rearmed_ = true;
-    SF_HIP(hipEventSynchronize(ev_flags_));
+    flags_copy_wait();
     if (ghosts_pending && nghost_ < 0) {
       // the ghost count arrives with these flags.  More ghosts than the capacity held: nothing above saw a ghost -- grow,
       // make the ghosts again (this time waiting for the count) and start over
