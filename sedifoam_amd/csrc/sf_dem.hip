@@ -1691,6 +1691,10 @@ void DemEngine::bin_and_build()
     if (lc && !lds_attr_set) {
       SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh_quad<4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh_quad<8>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
       lds_attr_set = true;
     }
     B.old_words = hist_in_place_ ? neigh_.as<int>() : nullptr;
@@ -1704,7 +1708,23 @@ void DemEngine::bin_and_build()
       B.prd[k] = boxhi_[k] - boxlo_[k];
     }
     if (roots_ && cap_ > (size_t)kIdxMask) fail("more than %d atom slots per GPU: not addressable by the neighbour word", kIdxMask);
-    if (lc)
+    // four lanes per atom on four consecutive records (k_build_neigh_quad): single domain without a ghost pass
+    const char* quad_env = getenv("SF_BUILD_QUAD");   // (read per build: the tests switch it inside a process)
+    // (rows of full-cutoff cells -- loose beds, ~8 records -- keep four lanes busy; the 25 rows of 2-3 records of a packed bed's
+    // half-cutoff cells do not: 398 -> 454 us there, 405 -> 324 us on the loose 1 M bed, 60 -> 42 us at 100 k grains)
+    const int lq = quad_env ? atoi(quad_env) : (grid_.stencil == 1 ? 4 : 0);
+    const bool quad = lc && !B.lb_ghost && !grid_.xslow && (lq == 4 || lq == 8);
+    if (quad && lq == 8)
+      k_build_neigh_quad<8><<<div_up(nlocal_, 16), 128, lds_bytes / 8, stream_>>>(
+          B, xr_[cur_].as<double4>(), tag_.as<int>(), have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(),
+          shear_[hist_buf_].as<double>(), new_words, numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_,
+          xhold_.as<double>());
+    else if (quad)
+      k_build_neigh_quad<4><<<div_up(nlocal_, 32), 128, lds_bytes / 4, stream_>>>(
+          B, xr_[cur_].as<double4>(), tag_.as<int>(), have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(),
+          shear_[hist_buf_].as<double>(), new_words, numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_,
+          xhold_.as<double>());
+    else if (lc)
       k_build_neigh<true><<<div_up(nlocal_, 128), 128, lds_bytes, stream_>>>(
           B, xr_[cur_].as<double4>(), tag_.as<int>(), cellLS, cellLE, cellGS, cellGE, perm_alt_.as<int>(),
           have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(), shear_[hist_buf_].as<double>(), new_words,

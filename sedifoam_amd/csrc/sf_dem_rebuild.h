@@ -1013,6 +1013,243 @@ __global__ __launch_bounds__(128) SF_BUILD_ATTR void k_build_neigh(BuildParams B
   SF_BP(4);   // counts
 }
 
+// k_build_neigh with FOUR lanes per atom, the four of them testing four CONSECUTIVE records of a row per step (single domain,
+// row path, no ghost pass, candidates parked in LDS, the old list in place or staged).  What the walk pays for is the lines
+// its load instructions touch (profiles/r06_README.md section 3): with one lane per atom the 64 lanes of an instruction stand
+// in ~24 cells and read ~18 lines; here 16 atoms stand in ~6 cells, the four lanes of an atom read one line, and 64 tests take
+// two instructions that touch ~7 lines each.  The accepted candidates of a step enter the atom's LDS column in record order
+// (their count below the lane inside the quad), the slots of the second sweep are handed out the same way: the list is the
+// one k_build_neigh<true> builds, word for word.
+// LQ: lanes per atom (4 or 8: a loose bed's rows of full-cutoff cells hold ~8 records).
+template <int LQ>
+__global__ __launch_bounds__(128) void k_build_neigh_quad(BuildParams B, const double4* xr, const int* tag,
+                                                          const int* numneigh_old, const int* ptag_old,
+                                                          const double* shear_old, int* neigh, int* numneigh,
+                                                          double* shear, int* flags, double* xhold)
+{
+  constexpr int AB = 128 / LQ;   // atoms per block
+  const int a = threadIdx.x / LQ, u = threadIdx.x % LQ;
+  const int i = xcd_contiguous_block() * AB + a;
+  if (i >= B.nlocal) return;   // (whole quads leave)
+  const int wl = threadIdx.x & 63;
+  const double4 xi = xr[i];
+  if (u == 0) {
+    xhold[i] = xi.x;
+    xhold[B.cap + i] = xi.y;
+    xhold[2 * B.cap + i] = xi.z;
+  }
+  int lost = 0;
+  const int cx = bin_coord(xi.x, B.g.lo[0], B.g.inv[0], B.g.n[0], lost);
+  const int cy = bin_coord(xi.y, B.g.lo[1], B.g.inv[1], B.g.n[1], lost);
+  const int cz = bin_coord(xi.z, B.g.lo[2], B.g.inv[2], B.g.n[2], lost);
+  const int io = B.old_index ? B.old_index[i] : i;
+  const int nold = numneigh_old ? numneigh_old[io] : 0;
+  extern __shared__ int sf_build_lds[];
+  int* const lc_w = sf_build_lds + a;                                                          // parked word s: lc_w[s * AB]
+  unsigned char* const lc_c = reinterpret_cast<unsigned char*>(sf_build_lds + B.P * AB) + a;   // its image code
+  const int park_rows = B.P;
+  const int R = B.g.stencil, W = 2 * R + 1;
+  const int co = cz, no = B.g.n[2], ci = cx, ni = B.g.n[0], n1 = B.g.n[1], nin1 = ni * n1;   // (x fastest: never the x-slowest order)
+  const double skinv = B.skin_gran >= 0.0 ? B.skin_gran : -INFINITY;
+  // the accept bits of this lane's quad in a wave-wide ballot
+  auto quad_bits = [&](const bool b) { return (unsigned)(__ballot(b) >> (wl & ~(LQ - 1))) & ((1u << LQ) - 1u); };
+  const unsigned below = (1u << u) - 1u;
+  // ---- the walk: rows in key order, four records per step, one per lane ----
+  const int bi0 = ci - R < 0 ? 0 : ci - R, bi1 = ci + R >= ni ? ni - 1 : ci + R;
+  const bool wrap_i = B.g.wrap[0] != 0, wrap_y = B.g.wrap[1] != 0, wrap_o = B.g.wrap[2] != 0;
+  int seg1_lo = 0, seg1_hi = -1;
+  double seg1_shift = 0.0;
+  if (wrap_i && ci - R < 0) {
+    seg1_lo = ci - R + ni;
+    seg1_hi = ni - 1;
+    seg1_shift = -B.prd[0];
+  } else if (wrap_i && ci + R >= ni) {
+    seg1_lo = 0;
+    seg1_hi = ci + R - ni;
+    seg1_shift = B.prd[0];
+  }
+  const bool park_codes = (wrap_i && (ci < R || ci + R >= ni)) || (wrap_y && (cy < R || cy + R >= n1)) ||
+                          (wrap_o && (co < R || co + R >= no));
+  const int nseg = (wrap_i && __ballot(seg1_hi >= seg1_lo)) ? 2 : 1;   // (wave-uniform)
+  const int* const lb = B.lb_own;
+  auto row_range = [&](const int seg, const int ro, const int ry, int& lo, int& hi, double& rsx, double& rsy, double& rsz) {
+    lo = hi = 0;
+    rsx = rsy = rsz = 0.0;
+    if (seg >= nseg || ro >= W) return;
+    int bo = co - R + ro, by = cy - R + ry;
+    if (wrap_o) {
+      if (bo < 0) { bo += no; rsz = -B.prd[2]; }
+      else if (bo >= no) { bo -= no; rsz = B.prd[2]; }
+    } else if ((unsigned)bo >= (unsigned)no) return;
+    if (wrap_y) {
+      if (by < 0) { by += n1; rsy = -B.prd[1]; }
+      else if (by >= n1) { by -= n1; rsy = B.prd[1]; }
+    } else if ((unsigned)by >= (unsigned)n1) return;
+    const int c0 = seg ? seg1_lo : bi0, c1 = seg ? seg1_hi : bi1;
+    if (c1 < c0) return;
+    if (seg) rsx = seg1_shift;
+    const int key = c0 + ni * by + nin1 * bo;
+    lo = lb[key];
+    hi = lb[key + (c1 - c0 + 1)];
+  };
+  int n_total = 0;   // accepted candidates of the atom (the same number in its four lanes)
+  {
+    const int nrow = nseg * W * W;
+    int seg_n = 0, ro_n = 0, ry_n = 0;
+    int nlo = 0, nhi = 0;
+    double nsx = 0.0, nsy = 0.0, nsz = 0.0;
+    row_range(seg_n, ro_n, ry_n, nlo, nhi, nsx, nsy, nsz);
+    for (int r = 0; r < nrow; r++) {
+      const int lo = nlo, hi = nhi;
+      const double sx = nsx, sy = nsy, sz = nsz;
+      if (++ry_n == W) {
+        ry_n = 0;
+        if (++ro_n == W) {
+          ro_n = 0;
+          seg_n++;
+        }
+      }
+      if (r + 1 < nrow) row_range(seg_n, ro_n, ry_n, nlo, nhi, nsx, nsy, nsz);
+      const int row_code = ((sx < 0.0 ? 0 : sx > 0.0 ? 2 : 1)) + 3 * (sy < 0.0 ? 0 : sy > 0.0 ? 2 : 1) +
+                           9 * (sz < 0.0 ? 0 : sz > 0.0 ? 2 : 1);
+      for (int k = lo; k < hi; k += LQ) {
+        const int j = k + u < hi ? k + u : hi - 1;   // (a lane past the row's end reads its last record again: no new line)
+        const double4 xj = xr[j];
+        const double dx = xi.x - (xj.x + sx), dy = xi.y - (xj.y + sy), dz = xi.z - (xj.z + sz);
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        const double cut = fmax(xi.w + xj.w + skinv, B.cut_lub);
+        const bool acc = k + u < hi && j != i && rsq <= cut * cut;
+        const unsigned q4 = quad_bits(acc);
+        if (acc) {
+          const int pos = n_total + __popc(q4 & below);
+          if (pos < park_rows) {
+            lc_w[pos * AB] = j;
+            if (park_codes) lc_c[pos * AB] = (unsigned char)row_code;
+          }
+        }
+        n_total += __popc(q4);
+      }
+    }
+  }
+  const int nacc = n_total < park_rows ? n_total : park_rows;
+  if (u == 0 && n_total > park_rows) atomicMax(&flags[F_PARK_OVER], n_total);
+  // ---- the old partner tags (every lane of the quad holds all of them) ----
+  constexpr int kPT = 16;
+  int pt[kPT];
+  auto old_tag_at = [&](const int s) {
+    if (B.old_words) {
+      const int w = B.old_words[(size_t)s * B.cap + io];
+      return (w & kTouchBit) ? B.old_tag[neigh_index(w, B.roots)] : -1;
+    }
+    return ptag_old[(size_t)s * B.cap + io];
+  };
+  if (B.old_words) {
+    int ow[kPT];
+#pragma unroll
+    for (int s = 0; s < kPT; s++) ow[s] = s < nold ? B.old_words[(size_t)s * B.cap + io] : 0;
+#pragma unroll
+    for (int s = 0; s < kPT; s++) pt[s] = (ow[s] & kTouchBit) ? B.old_tag[neigh_index(ow[s], B.roots)] : -1;
+  } else {
+#pragma unroll
+    for (int s = 0; s < kPT; s++) pt[s] = s < nold ? ptag_old[(size_t)s * B.cap + io] : -1;
+  }
+  auto find_old = [&](const int tj) {
+    int found = -1;
+#pragma unroll
+    for (int s = 0; s < kPT; s++)
+      if (pt[s] == tj) found = s;
+    if (found < 0)
+      for (int s = kPT; s < nold; s++)
+        if (old_tag_at(s) == tj) {
+          found = s;
+          break;
+        }
+    return found;
+  };
+  // ---- second sweep: lane u takes the parked candidates u, u + 4, ...; their slots are their positions (candidate order) or,
+  // touching neighbours first, the count of touching / other candidates before them ----
+  const bool tf = B.touch_first && nold > 0;
+  const int nstep = (nacc + LQ - 1) / LQ;
+  int nt = 0;   // touching among the accepted (touch-first)
+  constexpr int kFoundUnknown = 127;
+  if (tf) {
+    // (the look-up is kept in the parked word, j | (old slot + 1) << 25, for the sweep below)
+    for (int t = 0; t < nstep; t++) {
+      const int s = LQ * t + u;
+      bool touch = false;
+      if (s < nacc) {
+        const int j = lc_w[s * AB];
+        const int f = find_old(tag[j]);
+        touch = f >= 0;
+        lc_w[s * AB] = j | ((f + 1 >= kFoundUnknown ? kFoundUnknown : f + 1) << kIdxBits);
+      }
+      nt += __popc(quad_bits(touch));
+    }
+  }
+  int tbase = 0, fbase = nt;
+  for (int t = 0; t < nstep; t++) {
+    const int s = LQ * t + u;
+    const bool valid = s < nacc;
+    int j = 0, found = -1;
+    if (valid) {
+      const int w = lc_w[s * AB];
+      j = w & kIdxMask;
+      const int fcode = (w >> kIdxBits) & 127;
+      found = (!tf || fcode == kFoundUnknown) ? find_old(tag[j]) : fcode - 1;
+    }
+    int dst = s;
+    if (tf) {
+      const unsigned qt = quad_bits(valid && found >= 0), qv = quad_bits(valid);
+      const unsigned qf = qv & ~qt;
+      dst = found >= 0 ? tbase + __popc(qt & below) : fbase + __popc(qf & below);
+      tbase += __popc(qt);
+      fbase += __popc(qf);
+    }
+    if (valid && dst < B.M) {
+      int entry = j;
+      bool own = j > i || B.two_copies;
+      if (B.roots) {
+        const int code = park_codes ? (int)lc_c[s * AB] : kNoShift;
+        if (code != kNoShift) own = true;   // (an image found around the box: a copy on each side, like every owned-ghost pair)
+        entry |= code << kIdxBits;
+      }
+      if (own) entry |= kOwnBit;
+      if (found >= 0) {
+        entry |= kTouchBit;
+        size_t ob = (size_t)(3 * found) * B.cap + io;
+        double sgn = 1.0;
+        if (B.old_words) {
+          const int wf = B.old_words[(size_t)found * B.cap + io];
+          if (!(wf & kOwnBit)) {
+            ob = (size_t)(3 * ((wf >> kIdxBits) & 31)) * B.cap + neigh_index(wf, B.roots);
+            sgn = -1.0;
+          }
+        }
+        const double hx = shear_old[ob], hy = shear_old[ob + B.cap], hz = shear_old[ob + 2 * B.cap];
+        const size_t nb = (size_t)(3 * dst) * B.cap + i;
+        shear[nb] = sgn * hx;
+        shear[nb + B.cap] = sgn * hy;
+        shear[nb + 2 * B.cap] = sgn * hz;
+      }
+      neigh[(size_t)dst * B.cap + i] = entry;
+    }
+  }
+  int n = n_total;
+  if (n > B.M) {
+    if (u == 0) atomicMax(&flags[F_NEIGH_OVER], n);
+    n = B.M;
+  }
+  if (u == 0) numneigh[i] = n;
+  int m = n;
+  const unsigned long long act = __ballot(1);
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(m, off, 64);
+    if ((act >> (wl ^ off)) & 1ull) m = max(m, o);
+  }
+  if (wl == __ffsll((long long)act) - 1 && m > __atomic_load_n(&flags[F_MAXNEIGH], __ATOMIC_RELAXED))
+    atomicMax(&flags[F_MAXNEIGH], m);
+}
+
 // ---- LDS staging tables: which atoms a tile's workgroup copies into LDS, bin by bin ----
 __global__ __launch_bounds__(128) void k_tile_stage_count(BinGrid g, const int* cellLS, const int* cellLE,
                                                           const int* cellGS, const int* cellGE, int ntiles,

@@ -365,7 +365,8 @@ def test_deterministic_rerun():
                                  {"SF_LPA": "1", "SF_NT_POLICY": "2", "SF_HIST_COPIES": "2"},
                                  {"SF_LPA": "1", "SF_NT_POLICY": "3"}, {"SF_LPA": "2"}, {"SF_LPA": "4"},
                                  {"SF_SCAN_MIN": "1"}, {"SF_ROCPRIM_SCAN": "1"},
-                                 {"SF_HIST_IN_PLACE": "0"}, {"SF_HIST_IN_PLACE": "0", "SF_BUILD_LDS": "0"}])
+                                 {"SF_HIST_IN_PLACE": "0"}, {"SF_HIST_IN_PLACE": "0", "SF_BUILD_LDS": "0"},
+                                 {"SF_BUILD_QUAD": "0"}])
 def test_kernel_variants_agree_with_oracle(env, monkeypatch):
     """The LDS-staged tile kernel (k_substep_lds), the plain / tiled orderings of the gathering kernel, its cache
     policies (non-temporal rows or not, chosen by system size in production), the lanes per atom and the scan of the
@@ -381,6 +382,35 @@ def test_kernel_variants_agree_with_oracle(env, monkeypatch):
     bed = _bed((5, 5, 5), periodic=True, seed=11, poly=(0.85e-3, 1.0e-3), spacing=0.95)
     _run_case(bed, dict(BASE, skin=0.2e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1),
                         lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)), steps=(1, 30))
+
+
+def test_list_build_with_four_lanes_per_atom_gives_the_same_bits(monkeypatch):
+    """k_build_neigh_quad (four or eight lanes per atom on as many consecutive records of a row, single domain without a ghost pass)
+    builds the list k_build_neigh builds, word for word: a hot loose periodic bed (ghost-free build, touching neighbours
+    first), a closed packed one and a polydisperse periodic one with both extra arms end in the same bits after several
+    rebuilds."""
+    cases = ((_bed((7, 6, 8), periodic=True, seed=23, vmax=0.5, jitter=0.3, spacing=1.1), dict(BASE, skin=0.03e-3), 150),
+             (_bed((5, 5, 5), periodic=False, seed=5, vmax=0.5), dict(BASE, skin=0.03e-3), 120),
+             (_bed((5, 5, 5), periodic=True, seed=11, poly=(0.85e-3, 1.0e-3), spacing=0.95, vmax=0.3),
+              dict(BASE, skin=0.03e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1), lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)), 90))
+    for bed, cfg, steps in cases:
+        outs = []
+        for q in ("0", "4", "8"):
+            monkeypatch.setenv("SF_BUILD_QUAD", q)
+            lmp = dc.make_hip(bed, dict(cfg, walls=_walls(bed)))
+            lmp.setup()
+            lmp.step(steps)
+            st = lmp.get_state()
+            st["hist"] = lmp.history()
+            st["nbuilds"] = lmp.info().nbuilds
+            outs.append(st)
+        assert outs[0]["nbuilds"] >= 2
+        for o in outs[1:]:
+            assert o["nbuilds"] == outs[0]["nbuilds"]
+            for k in ("x", "v", "omega", "f", "torque"):
+                assert np.array_equal(outs[0][k], o[k]), k
+            assert set(o["hist"]) == set(outs[0]["hist"])
+            assert all(np.array_equal(o["hist"][k], outs[0]["hist"][k]) for k in o["hist"])
 
 
 def test_queueing_up_to_the_predicted_rebuild_changes_nothing(monkeypatch):
