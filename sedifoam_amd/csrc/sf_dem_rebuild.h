@@ -1143,7 +1143,23 @@ __global__ __launch_bounds__(128) void k_build_neigh_quad(BuildParams B, const d
     }
     return ptag_old[(size_t)s * B.cap + io];
   };
-  if (B.old_words) {
+  if (LQ == 4) {
+    // each lane of the quad fetches four of the sixteen (slots 4 u .. 4 u + 3) and the quad exchanges them lane to lane
+    // (quad_perm broadcasts: register moves) -- a quarter of the loads and tag gathers
+    int mine[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int sl = 4 * u + k;
+      mine[k] = sl < nold ? old_tag_at(sl) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      pt[k] = __builtin_amdgcn_update_dpp(0, mine[k], 0x00, 0xF, 0xF, false);        // quad_perm:[0,0,0,0]
+      pt[4 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0x55, 0xF, 0xF, false);    // quad_perm:[1,1,1,1]
+      pt[8 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0xAA, 0xF, 0xF, false);    // quad_perm:[2,2,2,2]
+      pt[12 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0xFF, 0xF, 0xF, false);   // quad_perm:[3,3,3,3]
+    }
+  } else if (B.old_words) {
     int ow[kPT];
 #pragma unroll
     for (int s = 0; s < kPT; s++) ow[s] = s < nold ? B.old_words[(size_t)s * B.cap + io] : 0;
