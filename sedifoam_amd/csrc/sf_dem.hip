@@ -1693,6 +1693,8 @@ void DemEngine::bin_and_build()
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
       SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh_quad<4>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh_quad<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
       SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_neigh_quad<8>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsMax));
       lds_attr_set = true;
@@ -1710,11 +1712,17 @@ void DemEngine::bin_and_build()
     if (roots_ && cap_ > (size_t)kIdxMask) fail("more than %d atom slots per GPU: not addressable by the neighbour word", kIdxMask);
     // four lanes per atom on four consecutive records (k_build_neigh_quad): single domain without a ghost pass
     const char* quad_env = getenv("SF_BUILD_QUAD");   // (read per build: the tests switch it inside a process)
-    // (rows of full-cutoff cells -- loose beds, ~8 records -- keep four lanes busy; the 25 rows of 2-3 records of a packed bed's
-    // half-cutoff cells do not: 398 -> 454 us there, 405 -> 324 us on the loose 1 M bed, 60 -> 42 us at 100 k grains)
-    const int lq = quad_env ? atoi(quad_env) : (grid_.stencil == 1 ? 4 : 0);
-    const bool quad = lc && !B.lb_ghost && !grid_.xslow && (lq == 4 || lq == 8);
-    if (quad && lq == 8)
+    // (rows of full-cutoff cells -- loose beds, ~8 records -- keep four lanes busy: 405 -> 297 us on the loose 1 M bed, 60 -> 39 us
+    // at 100 k grains)
+    // (the 25 rows of 2-3 records of a packed bed's half-cutoff cells: two lanes, 399 -> 347-355 us at 1 M; four lanes 446)
+    const int lq = quad_env ? atoi(quad_env) : (grid_.stencil == 1 ? 4 : 2);
+    const bool quad = lc && !B.lb_ghost && !grid_.xslow && (lq == 2 || lq == 4 || lq == 8);
+    if (quad && lq == 2)
+      k_build_neigh_quad<2><<<div_up(nlocal_, 64), 128, lds_bytes / 2, stream_>>>(
+          B, xr_[cur_].as<double4>(), tag_.as<int>(), have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(),
+          shear_[hist_buf_].as<double>(), new_words, numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_,
+          xhold_.as<double>());
+    else if (quad && lq == 8)
       k_build_neigh_quad<8><<<div_up(nlocal_, 16), 128, lds_bytes / 8, stream_>>>(
           B, xr_[cur_].as<double4>(), tag_.as<int>(), have_list_ ? numneigh_.as<int>() : nullptr, ptag_.as<int>(),
           shear_[hist_buf_].as<double>(), new_words, numneigh_old_.as<int>(), shear_[hist_buf_ ^ 1].as<double>(), d_flags_,

@@ -1020,7 +1020,8 @@ __global__ __launch_bounds__(128) SF_BUILD_ATTR void k_build_neigh(BuildParams B
 // two instructions that touch ~7 lines each.  The accepted candidates of a step enter the atom's LDS column in record order
 // (their count below the lane inside the quad), the slots of the second sweep are handed out the same way: the list is the
 // one k_build_neigh<true> builds, word for word.
-// LQ: lanes per atom (4 or 8: a loose bed's rows of full-cutoff cells hold ~8 records).
+// LQ: lanes per atom (2, 4 or 8: a loose bed's rows of full-cutoff cells hold ~8 records, a packed bed's rows of half-cutoff
+// cells 2-3).
 template <int LQ>
 __global__ __launch_bounds__(128) void k_build_neigh_quad(BuildParams B, const double4* xr, const int* tag,
                                                           const int* numneigh_old, const int* ptag_old,
@@ -1158,6 +1159,19 @@ __global__ __launch_bounds__(128) void k_build_neigh_quad(BuildParams B, const d
       pt[4 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0x55, 0xF, 0xF, false);    // quad_perm:[1,1,1,1]
       pt[8 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0xAA, 0xF, 0xF, false);    // quad_perm:[2,2,2,2]
       pt[12 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0xFF, 0xF, 0xF, false);   // quad_perm:[3,3,3,3]
+    }
+  } else if (LQ == 2) {
+    // (two lanes per atom: eight each, exchanged between the lanes of the pair)
+    int mine[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int sl = 8 * u + k;
+      mine[k] = sl < nold ? old_tag_at(sl) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      pt[k] = __builtin_amdgcn_update_dpp(0, mine[k], 0xA0, 0xF, 0xF, false);       // quad_perm:[0,0,2,2]
+      pt[8 + k] = __builtin_amdgcn_update_dpp(0, mine[k], 0xF5, 0xF, 0xF, false);   // quad_perm:[1,1,3,3]
     }
   } else if (B.old_words) {
     int ow[kPT];

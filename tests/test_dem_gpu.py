@@ -395,7 +395,7 @@ def test_list_build_with_four_lanes_per_atom_gives_the_same_bits(monkeypatch):
               dict(BASE, skin=0.03e-3, cohesive=(1.0e-13, 1.0e-7, 1.0e-7, 1.0e-4, 1), lub=(1.0e-3, 1, 1, 1.001e-3, 1.1e-3, 1, 1)), 90))
     for bed, cfg, steps in cases:
         outs = []
-        for q in ("0", "4", "8"):
+        for q in ("0", "2", "4", "8"):
             monkeypatch.setenv("SF_BUILD_QUAD", q)
             lmp = dc.make_hip(bed, dict(cfg, walls=_walls(bed)))
             lmp.setup()
