@@ -256,6 +256,27 @@ __global__ __launch_bounds__(1024) void k_count_layers(const double4* xr, int nl
   }
 }
 
+// Runs of equal keys among the lanes of a wave (the atoms arrive nearly sorted: ~2.7 neighbours in memory share a cell): the
+// first lane of a run speaks for it -- one atomic per run instead of one per atom (the atomics of the cell histograms are
+// served at the memory side, ~30 us per million).  `head`: the lane that starts this lane's run, `len`: the run's length
+// (valid in its head), `rank`: this lane's place in it.
+__device__ __forceinline__ void key_runs(const unsigned key, int& head, int& len, int& rank)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned long long act = __ballot(1);
+  const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+  const bool starts = lane == 0 || !((act >> (lane - 1)) & 1ull) || prev != key;
+  const unsigned long long heads = __ballot(starts);
+  const unsigned long long upto = heads & (~0ull >> (63 - lane));          // heads at or below this lane
+  head = 63 - __clzll((long long)upto);
+  rank = lane - head;
+  const unsigned long long above = (heads & act) >> head >> 1;            // heads above this run's head ...
+  const unsigned long long act_above = act >> head >> 1;                  // ... and how far the active lanes reach
+  const int to_next = above ? __ffsll((long long)above) : 65;
+  const int to_end = (~act_above) ? __ffsll((long long)~act_above) : 65;   // first inactive lane above the head
+  len = (to_next < to_end ? to_next : to_end);
+}
+
 // [3P] Domain::pbc for owned atoms + bin key
 // (count: the counting sort's histogram, filled in the same pass; nullptr on the radix-sort path)
 __global__ __launch_bounds__(256) void k_pbc_keys(double4* xr, int nlocal, PbcParams pb, BinGrid g,
@@ -289,7 +310,11 @@ __global__ __launch_bounds__(256) void k_pbc_keys(double4* xr, int nlocal, PbcPa
   const unsigned key = (unsigned)bin_of(x, g, lost);
   keys[i] = key;
   perm[i] = i;
-  if (count) atomicAdd(&count[key], 1);
+  if (count) {
+    int head, len, rank;
+    key_runs(key, head, len, rank);
+    if (rank == 0) atomicAdd(&count[key], len);
+  }
   if (lost) flags[F_LOST] = 1;
   // (the counters of the list build that follows start from zero: no launch of their own -- DemEngine::build_flags_clean_)
   if (i == 0) {
@@ -527,7 +552,13 @@ __global__ __launch_bounds__(256) void k_key_place(const unsigned* keys, int n, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned b = keys[i];
-  arrival[first[b] + atomicSub(&count[b], 1) - 1] = i;
+  // (one atomic per run of equal keys among the lanes: key_runs; the run's lanes take consecutive places)
+  int head, len, rank;
+  key_runs(b, head, len, rank);
+  int base = 0;
+  if (rank == 0) base = atomicSub(&count[b], len);
+  base = __shfl(base, head, 64);
+  arrival[first[b] + base - 1 - rank] = i;
 }
 // ... and then put into ascending TAG inside every cell (tags are unique): perm[new] = old.  The order of the owned
 // atoms -- like that of the ghosts, (cell, tag) -- then depends on nothing but the particles themselves: the same
