@@ -697,6 +697,7 @@ private:
   DevArray gsrc_, gshift_;
   DevArray neigh_, numneigh_, shear_[2];
   DevArray neigh_old_, numneigh_old_, ptag_;   // B-side buffers swapped in by permute/build
+  int flags_seq_ = 0;                // sequence number of the last flag publication (flags_copy_begin / _wait)
   bool build_flags_clean_ = false;   // the list build's counters were zeroed by k_pbc_keys of this rebuild
   bool trigger_rearmed_ = false;     // F_TRIGGER was set back to INT_MAX by k_back_slots of this rebuild
   int park_rows_ = 0;                // LDS parking rows of the next list build (0: as many as list slots)

@@ -97,6 +97,7 @@ DemEngine::DemEngine()
   d_flags_ = own_flags_;
   SF_HIP(hipMalloc(&count64_, sizeof(unsigned long long)));
   SF_HIP(hipHostMalloc(&h_flags_, sizeof(int) * F_NFLAGS));
+  memset(h_flags_, 0, sizeof(int) * F_NFLAGS);   // (the arrival word starts below every sequence number)
   SF_HIP(hipMemsetAsync(d_flags_, 0, sizeof(int) * F_NFLAGS, stream_));
   SF_HIP(hipEventCreate(&ev0_));
   SF_HIP(hipEventCreate(&ev1_));
@@ -691,35 +692,48 @@ void DemEngine::set_flags3(int i0, int v0, int i1, int v1, int i2, int v2)
   k_set_flags3<<<1, 32, 0, stream_>>>(d_flags_, i0, v0, i1, v1, i2, v2);
 }
 
-// The flag words travel to pinned host memory by an asynchronous copy; the host does not wait for the STREAM (a
-// hipStreamSynchronize returns ~10 us after the copy has landed: a fifth of a 100 k-grain rebuild, paid two or three times
-// per rebuild) but for the copy itself: the last word of the pinned block holds a sentinel no device word ever equals until
-// the copy overwrites it (the copy is one 128-byte write; the words before the last arrive with it or before it).  Bounded:
-// after 20 ms without the word the stream is synchronised the ordinary way.  SF_FLAG_SPIN=0: always the ordinary way.
-static constexpr int kArrivalSentinel = 0x5EED1234;
+// The flag words travel to a pinned host block, and the host does not wait for the STREAM (a hipStreamSynchronize returns
+// ~10 us after the words have landed: a fifth of a 100 k-grain rebuild, paid two or three times per rebuild) but for the
+// words themselves.  A one-wave kernel writes them into the block (the pinned allocation is mapped into the device's address
+// space), fences at system scope, and only then stores the call's sequence number into the block's last word with release
+// semantics: a host that sees the number sees every word written before it.  (A plain asynchronous copy of the 128 bytes
+// carries no such order between its two 64-byte halves: a first form that waited for a sentinel in the last word to be
+// overwritten could, once in ~1e5 reads, look at a first half that had not landed yet.)  Bounded: after 20 ms without the
+// number the stream is synchronised the ordinary way.  SF_FLAG_SPIN=0: always the ordinary way.
+__global__ static void k_publish_flags(const int* flags, int* host_block, int seq)
+{
+  const int t = threadIdx.x;
+  if (t < F_ARRIVAL) __hip_atomic_store(&host_block[t], flags[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __atomic_thread_fence(__ATOMIC_RELEASE);   // (system scope: every lane's store above is out before ...)
+  __builtin_amdgcn_s_barrier();
+  if (t == 0) __hip_atomic_store(&host_block[F_ARRIVAL], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the number
+}
 
 void DemEngine::flags_copy_begin()
 {
   static_assert(F_ARRIVAL == F_NFLAGS - 1, "the arrival word is the last of the block");
-  volatile int* hf = h_flags_;
-  hf[F_ARRIVAL] = kArrivalSentinel;
-  SF_HIP(hipMemcpyAsync(h_flags_, d_flags_, sizeof(int) * F_NFLAGS, hipMemcpyDeviceToHost, stream_));
+  flags_seq_ = flags_seq_ == INT_MAX ? 1 : flags_seq_ + 1;
+  k_publish_flags<<<1, 64, 0, stream_>>>(d_flags_, h_flags_, flags_seq_);
 }
 
 void DemEngine::flags_copy_wait()
 {
   static const bool spin = !(getenv("SF_FLAG_SPIN") && !atoi(getenv("SF_FLAG_SPIN")));
-  volatile int* hf = h_flags_;
+  const int* hf = h_flags_;
+  bool seen = false;
   if (spin) {
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned it = 0; hf[F_ARRIVAL] == kArrivalSentinel; it++) {
+    for (unsigned it = 0;; it++) {
+      if (__atomic_load_n(&hf[F_ARRIVAL], __ATOMIC_ACQUIRE) == flags_seq_) {
+        seen = true;
+        break;
+      }
       if ((it & 1023u) == 1023u &&
           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
         break;
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
   }
-  if (hf[F_ARRIVAL] == kArrivalSentinel) sync();
+  if (!seen) sync();   // (the kernel is complete: its stores are)
 }
 
 void DemEngine::read_flags()

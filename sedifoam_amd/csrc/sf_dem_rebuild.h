@@ -263,6 +263,12 @@ __global__ __launch_bounds__(1024) void k_count_layers(const double4* xr, int nl
 __device__ __forceinline__ void key_runs(const unsigned key, int& head, int& len, int& rank)
 {
   const int lane = threadIdx.x & 63;
+#ifdef SF_EXP_NO_KEY_RUNS
+  head = lane;   // pricing / bisecting arm: every lane a run of its own
+  len = 1;
+  rank = 0;
+  return;
+#endif
   const unsigned long long act = __ballot(1);
   const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
   const bool starts = lane == 0 || !((act >> (lane - 1)) & 1ull) || prev != key;
