@@ -593,7 +593,12 @@ private:
   void rebuild();          // rebuild_begin + rebuild_sort + rebuild_finish
   // rows = false: the slot-major history rows (numneigh, partner tags, shear) stay where they are and the list build
   // that follows reads them through hist_perm_ (a copy of perm) -- they are 3/4 of the bytes a re-sort would move
-  void permute_locals(const int* perm, int n_new, bool rows = true);
+  struct RankJob {   // k_rank_permute: the sort keys, the first sorted position of every cell, the arrival order inside the cells
+    const unsigned* keys;
+    const int* first;
+    const int* arrival;
+  };
+  void permute_locals(const int* perm, int n_new, bool rows = true, const RankJob* rank = nullptr);
   void migrate_compact();
   void compute_partner_tags();
   int select_locals(int mode, double bound, DevArray& list, int dim = 0);

@@ -1360,7 +1360,7 @@ void DemEngine::rebuild_begin()
 
 // Re-order (and possibly shrink to n_new) every per-atom array of the owned atoms: dst[i] = src[perm[i]].
 // The old-list rows (partner tags, slot counts, shear) travel with their atom through the B-side buffers.
-void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
+void DemEngine::permute_locals(const int* perm, int n_new, bool rows, const RankJob* rank)
 {
   order_version_++;
   hist_indirect_ = false;
@@ -1410,7 +1410,10 @@ void DemEngine::permute_locals(const int* perm, int n_new, bool rows)
     J.sb = wtouch_.as<unsigned char>();
     J.db = wtouch_alt_.as<unsigned char>();
   }
-  k_permute_all<<<nb, 256, 0, stream_>>>(J, perm, n_new, cap_);
+  if (rank)   // (the permutation is not there yet: this launch ranks the atoms inside their cells and writes it)
+    k_rank_permute<<<nb, 256, 0, stream_>>>(J, rank->keys, n_new, rank->first, rank->arrival, const_cast<int*>(perm), cap_);
+  else
+    k_permute_all<<<nb, 256, 0, stream_>>>(J, perm, n_new, cap_);
   for (int k = 0; k < 3; k++) std::swap(rec[k]->ptr, rec_alt[k]->ptr);
   for (int k = 0; k < 4; k++) std::swap(ints[k]->ptr, ints_alt[k]->ptr);
   for (int k = 0; k < J.nd; k++) std::swap(rows_a[k]->ptr, rows_alt[k]->ptr);
@@ -1471,9 +1474,18 @@ void DemEngine::rebuild_sort()
     exclusive_scan_i32(sort_tmp_, sort_tmp_bytes_, count, first, ne, stream_);
     k_key_place<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, count, first, perm_.as<int>());
     hist_clean_ = true;
-    k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), tag_.as<int>(),
-                                        perm_alt_.as<int>(), 0);
-    permute_locals(perm_alt_.as<int>(), nlocal_, /*rows=*/false);
+    // (rank and permutation in one launch: a launch less in a chain that small beds find bound by its launches -- 100 k loose
+    // bed +0.9 to +2.4 % whole run; the scattered stores cost the 1 M bed nothing, +0.1 to +1 %: profiles/r06_rank_permute_ab.txt)
+    const char* rp_env = getenv("SF_RANK_PERMUTE");
+    const bool fused_rank = rp_env ? atoi(rp_env) != 0 : true;
+    if (fused_rank) {
+      const RankJob rj{keys_.as<unsigned>(), first, perm_.as<int>()};
+      permute_locals(perm_alt_.as<int>(), nlocal_, /*rows=*/false, &rj);
+    } else {
+      k_key_rank<<<nb, 256, 0, stream_>>>(keys_.as<unsigned>(), nlocal_, first, perm_.as<int>(), tag_.as<int>(),
+                                          perm_alt_.as<int>(), 0);
+      permute_locals(perm_alt_.as<int>(), nlocal_, /*rows=*/false);
+    }
     mark_frozen();   // migrated / created atoms arrive without the mark; cheap, rebuild-time only
   } else {
     int bits = 1;

@@ -372,6 +372,42 @@ __global__ __launch_bounds__(256) void k_permute_all(PermuteJobs J, const int* p
   if (J.sb) J.db[i] = J.sb[p];
 }
 
+// k_key_rank and k_permute_all in one launch (beds whose rebuild chain is bound by the launches it takes): thread i ranks atom i
+// inside its cell by tag -- its place p in the new order -- and SCATTERS the atom's records and rows there (the atoms arrive
+// nearly sorted: p is close to i, the scattered stores of a wave cover nearly whole lines); perm[p] = i as k_key_rank writes it.
+__global__ __launch_bounds__(256) void k_rank_permute(PermuteJobs J, const unsigned* keys, int n, const int* first,
+                                                      const int* arrival, int* perm, size_t cap)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned b = keys[i];
+  const int s = first[b], e = first[b + 1];
+  const int* const tag = J.si[0];   // (the first int array of the job list is the tag array: DemEngine::permute_locals)
+  const int ti = tag[i];
+  int r = 0;
+  for (int k = s; k < e; k++) {
+    const int a = arrival[k], ta = tag[a];
+    r += (ta < ti || (ta == ti && a < i)) ? 1 : 0;
+  }
+  const int p = s + r;
+  perm[p] = i;
+  const double4 x = J.s4[0][i], v = J.s4[1][i], w = J.s4[2][i];
+  const int t1 = J.si[1][i], t2 = J.si[2][i], t3 = J.si[3][i];
+  J.d4[0][p] = x;
+  J.d4[1][p] = v;
+  J.d4[2][p] = w;
+  J.di[0][p] = ti;
+  J.di[1][p] = t1;
+  J.di[2][p] = t2;
+  J.di[3][p] = t3;
+  for (int k = 0; k < J.nd; k++) {
+    const double* src = J.sd[k];
+    double* dst = J.dd[k];
+    for (int q = 0; q < J.rd[k]; q++) dst[(size_t)q * cap + p] = src[(size_t)q * cap + i];
+  }
+  if (J.sb) J.db[p] = J.sb[i];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_gather_rows(T* dst, const T* src, const int* perm, int n, int rows,
                                                      size_t cap)

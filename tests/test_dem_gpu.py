@@ -366,7 +366,7 @@ def test_deterministic_rerun():
                                  {"SF_LPA": "1", "SF_NT_POLICY": "3"}, {"SF_LPA": "2"}, {"SF_LPA": "4"},
                                  {"SF_SCAN_MIN": "1"}, {"SF_ROCPRIM_SCAN": "1"},
                                  {"SF_HIST_IN_PLACE": "0"}, {"SF_HIST_IN_PLACE": "0", "SF_BUILD_LDS": "0"},
-                                 {"SF_BUILD_QUAD": "0"}])
+                                 {"SF_BUILD_QUAD": "0"}, {"SF_RANK_PERMUTE": "0"}])
 def test_kernel_variants_agree_with_oracle(env, monkeypatch):
     """The LDS-staged tile kernel (k_substep_lds), the plain / tiled orderings of the gathering kernel, its cache
     policies (non-temporal rows or not, chosen by system size in production), the lanes per atom and the scan of the
