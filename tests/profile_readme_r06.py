@@ -25,7 +25,7 @@ rows = [
      % (h["total_calibrated"] / 1e6, h["total_calibrated"] / h["algorithmic"], h["read_calibrated"] / 1e6, h["write"] / 1e6, h["tcc_miss_x_128B"] / 1e6)),
     ("list rebuild, packed bed (two-lane list build + sort + permutation)", "%.2f ms (round 5: 0.78)" % cfg["neighbor_rebuild_ms"]),
     ("loose bed (`fluidised_bed`: spacing 1.1 d, jitter 0.3 d; %d rebuilds in %d sub-steps)" % (f["neighbor_rebuilds_in_run"], 50 * f["steps"]),
-     "**%.2fe9 /s**, kernel %.1f µs (frac %.3f on its own bytes), **whole run %.3f**, rebuild %.2f ms (box 2: %.2fe9 /s, whole run **%.3f**, "
+     "**%.2fe9 /s**, kernel %.1f µs (frac %.3f on its own bytes), **whole run %.3f**, rebuild %.2f ms (box 2 over round 5's five steps: %.2fe9 /s, whole run **%.3f**, "
      "rebuild %.2f ms; round 5: 3.98e9, 0.266 / 0.246 on a slow box, 0.74 ms)"
      % (f["value"] / 1e9, f["mean_kernel_us"], f["roofline_frac"], f["roofline_frac_whole_run"], f["neighbor_rebuild_ms"], fx["value"] / 1e9,
         fx["roofline_frac_whole_run"], fx["neighbor_rebuild_ms"])),
@@ -34,7 +34,7 @@ rows = [
     ("`configs.C2` (10 080 grains, 32³ mesh, coupled)", "%.2fe8 /s, kernel %.1f µs (frac %.3f: launch-bound), %d coupled steps/s"
      % (c["C2"]["value"] / 1e8, c["C2"]["mean_kernel_us"], c["C2"]["roofline_frac"], round(c["C2"]["coupled_steps_per_s"]))),
     ("`configs.C3` (100 440-grain fluidised bed, 12×18×14 mesh, coupled; %d rebuilds in %d sub-steps)" % (c["C3"]["neighbor_rebuilds_in_run"], 50 * c["C3"]["steps"]),
-     "**%.2fe9 /s**, kernel %.1f µs (frac %.3f), **whole run %.3f** (box 2: %.3f; round 5: 2.01e9, 0.133), %d coupled steps/s"
+     "**%.2fe9 /s**, kernel %.1f µs (frac %.3f), **whole run %.3f** (box 2 over round 5's five steps: %.3f; round 5: 2.01e9, 0.133), %d coupled steps/s"
      % (c["C3"]["value"] / 1e9, c["C3"]["mean_kernel_us"], c["C3"]["roofline_frac"], c["C3"]["roofline_frac_whole_run"],
         cx["C3"]["roofline_frac_whole_run"], round(c["C3"]["coupled_steps_per_s"]))),
     ("`configs.C5` (500 k polydisperse d = 0.85–1.0 mm, hertzFix/history + lubricate/poly + fix cohesive)",
