@@ -1821,7 +1821,9 @@ void DemEngine::bin_and_build()
   // every fourth one, which only refreshes numbers no decision is near; the counters keep their values in between)
   if (nbuilds_ < 4 || (nbuilds_ & 3) == 0 || list_stats_near_a_threshold()) measure_list();
   max_neigh_used_ = h_flags_[F_MAXNEIGH];
-  park_rows_ = std::min(M_, max_neigh_used_ + 8);
+  // (SF_PARK_MARGIN: the tests make the rows too few on purpose -- the F_PARK_OVER path builds the list again)
+  static const int park_margin = getenv("SF_PARK_MARGIN") ? atoi(getenv("SF_PARK_MARGIN")) : 8;
+  park_rows_ = std::max(1, std::min(M_, max_neigh_used_ + park_margin));
   have_list_ = true;   // (xhold, the positions the skin/2 check refers to, was stored by k_build_neigh)
   nbuilds_++;
   if (xcd_auto_ && xcd_countdown_ == 0) xcd_countdown_ = 3;   // the third full launch on the new list is timed per XCD

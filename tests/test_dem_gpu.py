@@ -366,14 +366,17 @@ def test_deterministic_rerun():
                                  {"SF_LPA": "1", "SF_NT_POLICY": "3"}, {"SF_LPA": "2"}, {"SF_LPA": "4"},
                                  {"SF_SCAN_MIN": "1"}, {"SF_ROCPRIM_SCAN": "1"},
                                  {"SF_HIST_IN_PLACE": "0"}, {"SF_HIST_IN_PLACE": "0", "SF_BUILD_LDS": "0"},
-                                 {"SF_BUILD_QUAD": "0"}, {"SF_RANK_PERMUTE": "0"}])
+                                 {"SF_BUILD_QUAD": "0"}, {"SF_RANK_PERMUTE": "0"},
+                                 {"SF_PARK_MARGIN": "-6"}, {"SF_PARK_MARGIN": "-6", "SF_BUILD_QUAD": "0"}])
 def test_kernel_variants_agree_with_oracle(env, monkeypatch):
     """The LDS-staged tile kernel (k_substep_lds), the plain / tiled orderings of the gathering kernel, its cache
     policies (non-temporal rows or not, chosen by system size in production), the lanes per atom and the scan of the
     cell histograms (the engine's tile scan, used above 64 k cells in production, forced on for these small beds; or
     rocPRIM's; one workgroup below that in production), and the list build's three forms (old list read in place + parked
     candidates in LDS -- production on a single domain --, staged partner tags + LDS, staged + parked in memory) are speed
-    options only: every one must reproduce the oracle, through rebuilds too."""
+    options only: every one must reproduce the oracle, through rebuilds too.  SF_PARK_MARGIN=-6 gives the list build six
+    LDS parking rows fewer than the previous list's longest row: every rebuild overflows them and is built again with as many
+    rows as list slots (F_PARK_OVER)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     bed = _bed((6, 6, 6), periodic=True, seed=99, vmax=0.5)
