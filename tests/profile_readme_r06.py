@@ -44,7 +44,7 @@ rows = [
      % (c["C5_wide"]["value"] / 1e9, c["C5_wide"]["mean_kernel_us"], c["C5_wide"]["roofline_frac"], c["C5_wide"]["k_half"], c["C5_wide"]["longest_row"])),
     ("CPU baseline, oracle single thread, same bed", "%.2fe6 /s; coupled step %.3f steps/s; 16 independent processes: %.1fe7 /s"
      % (cb["value"] / 1e6, cb["coupled_steps_per_s"], b["cpu_baseline_all_cores"]["value"] / 1e7)),
-    ("GPU vs oracle on the whole bed after 50 sub-steps (`parity`)", "tags identical, max |Δx| %.1e d, v %.1e, ω %.1e, f %.1e relative"
+    ("GPU vs oracle on the whole bed after 50 sub-steps (`parity`)", "tags identical, max abs(Δx) %.1e d, v %.1e, ω %.1e, f %.1e relative"
      % (p["max_abs_dx_over_d"], p["max_rel_v"], p["max_rel_omega"], p["max_rel_f"])),
 ]
 tab = "| quantity | value |\n|---|---|\n" + "\n".join("| %s | %s |" % rw for rw in rows)
